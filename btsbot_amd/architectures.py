@@ -1,0 +1,453 @@
+"""Drop-in counterparts of the model classes in /root/reference/btsbot/architectures.py.
+
+Same class names, constructor argument (the config dict), forward keyword names
+(``image_input`` / ``metadata_input`` / ``input_data``), output shape ([B, 1] fp32 logits) and --
+the on-disk contract -- the same ``state_dict()`` keys, shapes and order, so
+``load_state_dict(torch.load("pytorch_model.bin"))`` (from_HF.py:74-79) works unchanged.
+
+What differs is underneath: there is no timm / cuDNN / MIOpen graph.  Every ``nn.Parameter`` is a
+view into one flat fp32 "master arena"; ``forward`` hands the arena and the input tensors to the
+hand-written gfx950 kernels in libbtsbot_hip.so through the C ABI of include/btsbot_hip.h.
+There is NO CPU fallback: calling a model whose tensors are not on a HIP device raises.
+
+Covered: ``mm_ConvNeXt`` (:125-171), ``ConvNeXt`` (:104-122), ``um_nn`` (:277-293),
+``frozen_fusion`` (:296-372) with ConvNeXt + um_nn branches; convnext_pico / convnext_nano
+backbones at 63x63.  ``MaxViT`` / ``mm_MaxViT`` / ``mm_cnn`` / ``um_cnn`` raise
+NotImplementedError (MaxViT is a later row, the VGG-like CNNs are out of scope).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import os.path as path
+import re
+import warnings
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+# timm model tables (convnext_pico / convnext_nano: conv_mlp=True, patch stem, LayerNorm2d)
+_CONVNEXT_TABLE = {
+    "convnext_pico": ((2, 2, 6, 2), (64, 128, 256, 512)),
+    "convnext_nano": ((2, 2, 8, 2), (80, 160, 320, 640)),
+}
+_DEFAULT_KIND = "convnext_nano.d1h_in1k"   # architectures.py:107,128
+MAX_CHUNK = 2048                            # alerts per internal workspace chunk
+
+
+def get_model_image_size(model_kind: str) -> int:
+    """architectures.py:10-22."""
+    if "maxvit" in model_kind.lower():
+        match = re.search(r"_(\d+)\.", model_kind)
+        if match:
+            return int(match.group(1))
+    return 224
+
+
+def _convnext_table(model_kind: str):
+    mk = model_kind.lower()
+    for name, tab in _CONVNEXT_TABLE.items():
+        if name in mk:
+            return tab
+    raise ValueError(
+        f"btsbot_amd: model_kind {model_kind!r} is not a supported ConvNeXt "
+        f"(have {sorted(_CONVNEXT_TABLE)})")
+
+
+def default_precision() -> str:
+    return os.environ.get("BTSBOT_AMD_PRECISION", "f32")
+
+
+class _Node(nn.Module):
+    """Bare container used to reproduce the reference's dotted state-dict key hierarchy."""
+
+
+class _HipModel(nn.Module):
+    """Shared machinery: parameter arena, state-dict key layout, C-ABI calls."""
+
+    _wiring: str = ""
+
+    # -- construction ------------------------------------------------------------------
+    def _setup(self, *, table, head_norm: bool, n_meta: int, meta_fc: Tuple[int, int],
+               comb_fc: Tuple[int, int], dropouts: Tuple[float, float],
+               key_map, precision: Optional[str]):
+        self._table = table
+        self._cfg_args = dict(
+            depths=table[0] if table else (1, 1, 1, 1), dims=table[1] if table else (0, 0, 0, 0),
+            head_norm=head_norm, n_meta=n_meta, meta_fc1=meta_fc[0], meta_fc2=meta_fc[1],
+            comb_fc1=comb_fc[0], comb_fc2=comb_fc[1], meta_dropout=dropouts[0],
+            comb_dropout=dropouts[1])
+        self._precision = precision or default_precision()
+        self._key_map = key_map
+        self._handle: Optional[_lib.Handle] = None
+        self._handle_device: Optional[torch.device] = None
+        self._packed_version = None
+        self._reserved = 0
+        self._debug = False
+        self._new_handle()
+        self._build_parameters()
+        self.reset_parameters()
+
+    def _new_handle(self):
+        if self._handle is not None:
+            self._handle.close()
+        cfg = _lib.make_config(self._wiring, self._precision, **self._cfg_args)
+        self._handle = _lib.Handle(cfg)
+        self._handle_device = None
+        self._packed_version = None
+        self._reserved = 0
+
+    def _build_parameters(self):
+        h = self._handle
+        self._table_rows = h.params()                      # (canonical, off, numel, shape, is_buf)
+        arena = torch.zeros(h.param_floats(), dtype=torch.float32)
+        object.__setattr__(self, "_arena", arena)          # plain attribute: not in state_dict
+        self._slots: List[tuple] = []      # (key, parent module, leaf name, off, numel, shape, is_buf)
+        for canon, off, numel, shape, is_buf in self._table_rows:
+            key = self._key_map(canon)
+            parent, leaf = self._descend(key)
+            view = arena[off:off + numel].view(shape)
+            if is_buf:
+                parent.register_buffer(leaf, view)
+            else:
+                parent.register_parameter(leaf, nn.Parameter(view))
+            self._slots.append((key, parent, leaf, off, numel, shape, is_buf))
+            if canon.endswith("running_var"):               # BatchNorm1d bookkeeping buffer
+                parent.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def _tensor_list(self):
+        """Current tensor object of every arena slot (buffers are replaced by nn.Module._apply)."""
+        return [getattr(parent, leaf) for _k, parent, leaf, *_ in self._slots]
+
+    def _descend(self, key: str):
+        parts = key.split(".")
+        node = self
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        return node, parts[-1]
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """timm-style init for the backbone (trunc-normal .02 weights, zero biases, LayerNorm 1/0,
+        layer-scale 1e-6), torch defaults for nn.Linear / nn.BatchNorm1d heads."""
+        for (canon, *_), t in zip(self._table_rows, self._tensor_list()):
+            leaf = canon.rsplit(".", 1)[-1]
+            is_head = canon.startswith(("meta.", "comb."))
+            if canon.endswith("gamma"):
+                t.fill_(1e-6)
+            elif leaf == "running_mean":
+                t.zero_()
+            elif leaf == "running_var":
+                t.fill_(1.0)
+            elif t.dim() == 1:
+                if leaf == "weight":
+                    t.fill_(1.0)                            # LayerNorm / BatchNorm scale
+                elif is_head and not canon.startswith("meta.0."):
+                    fan_in = self._fan_in(canon)
+                    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+                    t.uniform_(-bound, bound)               # nn.Linear bias default
+                else:
+                    t.zero_()
+            elif is_head:
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))  # nn.Linear weight default
+            else:
+                nn.init.trunc_normal_(t, std=0.02)
+
+    def _fan_in(self, bias_canon: str) -> int:
+        wname = bias_canon.rsplit(".", 1)[0] + ".weight"
+        for canon, _off, _n, shape, _b in self._table_rows:
+            if canon == wname:
+                return int(shape[1]) if len(shape) > 1 else 0
+        return 0
+
+    # -- device moves keep the single-arena invariant ----------------------------------------
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        tensors = self._tensor_list()
+        first = tensors[0]
+        if first.dtype != torch.float32:
+            raise TypeError("btsbot_amd models keep fp32 master parameters; choose the MFMA operand "
+                            "type with set_precision('bf16'|'f16'|'f32') instead of .half()/.bfloat16()")
+        arena = torch.zeros(self._arena.numel(), dtype=torch.float32, device=first.device)
+        with torch.no_grad():
+            for (key, parent, leaf, off, numel, shape, is_buf), t in zip(self._slots, tensors):
+                view = arena[off:off + numel].view(shape)
+                view.copy_(t.detach())
+                if is_buf:
+                    parent._buffers[leaf] = view
+                else:
+                    t.data = view
+        object.__setattr__(self, "_arena", arena)
+        self._packed_version = None
+        return self
+
+    # -- options ------------------------------------------------------------------------------
+    def set_precision(self, precision: str):
+        """'f32' (exact-fp32 MFMA, parity mode), 'bf16' or 'f16' (MFMA operand type)."""
+        if precision not in _lib.PRECISION:
+            raise ValueError(f"unknown precision {precision!r}")
+        if _lib.PRECISION[precision] != _lib.PRECISION[self._precision]:
+            self._precision = precision
+            self._new_handle()
+        return self
+
+    @property
+    def precision(self) -> str:
+        return self._precision
+
+    def mark_weights_dirty(self):
+        """Call after modifying parameters through ``.data`` (in-place ops on the parameters
+        themselves, ``load_state_dict`` and optimisers are tracked automatically)."""
+        self._packed_version = None
+
+    def set_debug_taps(self, on: bool = True):
+        self._debug = bool(on)
+        self._reserved = 0
+        _lib.check(_lib.lib().btsbot_set_debug(self._handle.ptr, int(on)), "btsbot_set_debug")
+
+    # -- execution ----------------------------------------------------------------------------
+    def _version(self):
+        return tuple(t._version for t in self._tensor_list())
+
+    def _prepare(self, device: torch.device, batch: int):
+        if device.type != "cuda":
+            raise RuntimeError(
+                "btsbot_amd: this model runs only on an AMD GPU through libbtsbot_hip.so "
+                f"(tensors are on {device}); there is no CPU fallback.  Move the model and its "
+                "inputs to 'cuda'.")
+        if self._arena.device != device:
+            raise RuntimeError(f"btsbot_amd: model parameters are on {self._arena.device} but the "
+                               f"input is on {device}")
+        L = _lib.lib()
+        if self._handle_device is not None and self._handle_device != device:
+            self._new_handle()
+            if self._debug:
+                L.btsbot_set_debug(self._handle.ptr, 1)
+        self._handle_device = device
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ver = self._version()
+        if ver != self._packed_version:
+            _lib.check(L.btsbot_pack_params(self._handle.ptr, C.c_void_p(self._arena.data_ptr()),
+                                            C.c_void_p(stream)), "btsbot_pack_params")
+            self._packed_version = ver
+        chunk = min(max(batch, 1), MAX_CHUNK)
+        if chunk > self._reserved:
+            _lib.check(L.btsbot_reserve(self._handle.ptr, chunk), "btsbot_reserve")
+            self._reserved = chunk
+        return L, stream
+
+    def _run(self, image: Optional[torch.Tensor], meta: Optional[torch.Tensor],
+             want_scores: bool = False):
+        ref = image if image is not None else meta
+        if ref is None:
+            raise ValueError("btsbot_amd: no input tensor")
+        batch = ref.shape[0]
+        dev = ref.device
+        if image is not None:
+            if image.dim() != 4 or tuple(image.shape[1:]) != (3, 63, 63):
+                raise ValueError(f"image input must be [B,3,63,63], got {tuple(image.shape)}")
+            image = image.to(torch.float32).contiguous()
+        if meta is not None:
+            n_meta = self._cfg_args["n_meta"]
+            if meta.dim() != 2 or meta.shape[1] != n_meta or meta.shape[0] != batch:
+                raise ValueError(f"metadata input must be [{batch},{n_meta}], got {tuple(meta.shape)}")
+            meta = meta.to(torch.float32).contiguous()
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "btsbot_amd: this model runs only on an AMD GPU through libbtsbot_hip.so "
+                f"(input is on {dev}); there is no CPU fallback.  Move the model and its inputs "
+                "to 'cuda'.")
+        if self.training:
+            raise NotImplementedError(
+                "btsbot_amd: the training-mode forward (BatchNorm batch statistics, dropout, "
+                "backward) is not built yet; call .eval() for inference")
+        with torch.cuda.device(dev):
+            L, stream = self._prepare(dev, batch)
+            logits = torch.empty(batch, dtype=torch.float32, device=dev)
+            scores = torch.empty(batch, dtype=torch.float32, device=dev) if want_scores else None
+            _lib.check(L.btsbot_forward(
+                self._handle.ptr,
+                C.c_void_p(image.data_ptr() if image is not None else 0),
+                C.c_void_p(meta.data_ptr() if meta is not None else 0),
+                C.c_void_p(logits.data_ptr()),
+                C.c_void_p(scores.data_ptr() if scores is not None else 0),
+                batch, 0, 0, C.c_void_p(stream)), "btsbot_forward")
+        logits = logits.view(batch, 1)
+        if want_scores:
+            return logits, scores.view(batch, 1)
+        return logits
+
+    def read_tap(self, name: str) -> torch.Tensor:
+        """fp32 NHWC copy of 'stem' / 'stage0'..'stage3' from the last forward chunk
+        (needs set_debug_taps(True) before the forward)."""
+        hw = {"stem": 15, "stage0": 15, "stage1": 7, "stage2": 3, "stage3": 1}[name]
+        ci = 0 if name == "stem" else int(name[-1])
+        c = self._cfg_args["dims"][ci]
+        dev = self._arena.device
+        buf = torch.empty(self._reserved * hw * hw * c, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            n = _lib.check(_lib.lib().btsbot_read_tap(
+                self._handle.ptr, name.encode(), C.c_void_p(buf.data_ptr()), buf.numel(),
+                C.c_void_p(stream)), "btsbot_read_tap")
+        return buf[:n].view(-1, hw * hw, c)
+
+
+def _backbone_key_map(bprefix: str, head_norm_key: str, meta_prefix: str, comb_keys):
+    def f(canon: str) -> str:
+        if canon.startswith("head_norm."):
+            return head_norm_key + canon[len("head_norm."):]
+        if canon.startswith("meta."):
+            return meta_prefix + canon[len("meta."):]
+        if canon.startswith("comb."):
+            idx, leaf = canon[len("comb."):].split(".")
+            return f"{comb_keys[int(idx)]}.{leaf}"
+        return bprefix + canon
+    return f
+
+
+def _warn_pretrained(config: dict):
+    if config.get("pretrained", True):
+        warnings.warn(
+            "btsbot_amd: config['pretrained'] is true, but pretrained timm/HF-hub backbones are not "
+            "fetched here (no timm, no network); parameters are randomly initialised until "
+            "load_state_dict() is called.", stacklevel=3)
+
+
+class mm_ConvNeXt(_HipModel):
+    """architectures.py:125-171 -- ConvNeXt image branch + GELU metadata branch + GELU fusion head."""
+    _wiring = "mm_ConvNeXt"
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        _warn_pretrained(config)
+        table = _convnext_table(config.get("model_kind", _DEFAULT_KIND))
+        self.convnext_feature_dim = table[1][-1]
+        ls = "LS" in config["train_data_version"]
+        self._setup(
+            table=table, head_norm=ls, n_meta=len(config.get("metadata_cols", [])),
+            meta_fc=(config["meta_fc1_neurons"], config["meta_fc2_neurons"]),
+            comb_fc=(config["comb_fc1_neurons"], config["comb_fc2_neurons"]),
+            dropouts=(config["meta_dropout"], config["comb_dropout"]),
+            key_map=_backbone_key_map("convnext_backbone.", "convnext_backbone.head.1.",
+                                      "metadata_branch.",
+                                      ["combined_head.0", "combined_head.2", "combined_head.5"]),
+            precision=precision or config.get("precision"))
+
+    def forward(self, image_input: torch.Tensor, metadata_input: torch.Tensor) -> torch.Tensor:
+        return self._run(image_input, metadata_input)
+
+
+class ConvNeXt(_HipModel):
+    """architectures.py:104-122 -- image-only ConvNeXt with a pooled, normalised MLP head."""
+    _wiring = "ConvNeXt"
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        _warn_pretrained(config)
+        table = _convnext_table(config.get("model_kind", _DEFAULT_KIND))
+        self._setup(
+            table=table, head_norm=True, n_meta=0, meta_fc=(0, 0),
+            comb_fc=(config["fc1_neurons"], config["fc2_neurons"]),
+            dropouts=(0.0, config["dropout"]),
+            key_map=_backbone_key_map("convnext.", "convnext.head.1.", "",
+                                      ["convnext.head.3", "convnext.head.5", "convnext.head.8"]),
+            precision=precision or config.get("precision"))
+
+    def forward(self, input_data: torch.Tensor) -> torch.Tensor:
+        return self._run(input_data, None)
+
+
+class um_nn(_HipModel):
+    """architectures.py:277-293 -- metadata-only MLP."""
+    _wiring = "um_nn"
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        self._setup(
+            table=None, head_norm=False, n_meta=len(config.get("metadata_cols", [])),
+            meta_fc=(config["meta_fc1_neurons"], config["meta_fc2_neurons"]), comb_fc=(0, 0),
+            dropouts=(config["meta_dropout"], 0.0),
+            key_map=_backbone_key_map("", "", "network.", ["network.6"]),
+            precision=precision or config.get("precision"))
+
+    def forward(self, input_data: torch.Tensor) -> torch.Tensor:
+        return self._run(None, input_data)
+
+
+class frozen_fusion(_HipModel):
+    """architectures.py:296-372 -- two trained uni-modal models with their heads removed
+    (ConvNeXt -> pool, LayerNorm2d, flatten; um_nn -> BN, Linear, ReLU, Dropout, Linear) feeding a
+    ReLU fusion head.  This is what the published "-metadata" HF checkpoints instantiate
+    (to_HF.py:142-162)."""
+    _wiring = "frozen_fusion"
+
+    @staticmethod
+    def _branch_config(config, which):
+        cfg = config.get(f"{which}_model_config", None)
+        if cfg is None:                                   # architectures.py:324-326
+            with open(path.join(config[f"{which}_model_dir"], "report.json"), "r") as f:
+                cfg = json.load(f)["train_config"]
+        return cfg
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        icfg = self._branch_config(config, "image")
+        mcfg = self._branch_config(config, "meta")
+        if icfg["model_name"] != "ConvNeXt" or mcfg["model_name"] != "um_nn":
+            raise NotImplementedError(
+                "btsbot_amd.frozen_fusion supports a ConvNeXt image branch and a um_nn metadata "
+                f"branch (got {icfg['model_name']} / {mcfg['model_name']})")
+        _warn_pretrained(icfg)
+        table = _convnext_table(icfg.get("model_kind", _DEFAULT_KIND))
+        self._setup(
+            table=table, head_norm=True, n_meta=len(mcfg.get("metadata_cols", [])),
+            meta_fc=(mcfg["meta_fc1_neurons"], mcfg["meta_fc2_neurons"]),
+            comb_fc=(config["comb_fc1_neurons"], config["comb_fc2_neurons"]),
+            dropouts=(mcfg["meta_dropout"], config["comb_dropout"]),
+            key_map=_backbone_key_map("image_branch.convnext.", "image_branch.convnext.head.1.",
+                                      "meta_branch.network.",
+                                      ["combined_head.0", "combined_head.2", "combined_head.5"]),
+            precision=precision or config.get("precision"))
+        if not config.get("skip_load_state", False):      # architectures.py:334-335
+            self._load_branch(path.join(config["image_model_dir"], "best_model.pth"),
+                              "image_branch.")
+            self._load_branch(path.join(config["meta_model_dir"], "best_model.pth"),
+                              "meta_branch.")
+
+    def _load_branch(self, file: str, prefix: str):
+        state = torch.load(file, map_location="cpu")
+        own = dict(self.state_dict())
+        picked = {}
+        for k, v in state.items():
+            k = k[len("module."):] if k.startswith("module.") else k
+            if prefix + k in own:
+                picked[prefix + k] = v
+        missing = [k for k in own if k.startswith(prefix) and k not in picked]
+        if missing:
+            raise RuntimeError(f"{file}: missing keys for {prefix}: {missing[:5]} ...")
+        self.load_state_dict(picked, strict=False)
+
+    def forward(self, image_input: torch.Tensor, metadata_input: torch.Tensor) -> torch.Tensor:
+        return self._run(image_input, metadata_input)
+
+
+def _not_built(name, why):
+    class _Missing(nn.Module):
+        def __init__(self, config=None, *a, **k):
+            raise NotImplementedError(f"btsbot_amd.{name}: {why}")
+    _Missing.__name__ = _Missing.__qualname__ = name
+    return _Missing
+
+
+MaxViT = _not_built("MaxViT", "the MaxViT image branch is a later row of SURVEY.md section 8")
+mm_MaxViT = _not_built("mm_MaxViT", "the MaxViT image branch is a later row of SURVEY.md section 8")
+mm_cnn = _not_built("mm_cnn", "legacy VGG-like CNN, out of scope (SURVEY.md section 2)")
+um_cnn = _not_built("um_cnn", "legacy VGG-like CNN, out of scope (SURVEY.md section 2)")

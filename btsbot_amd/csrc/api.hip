@@ -1,0 +1,557 @@
+// C ABI of libbtsbot_hip.so: handle, parameter table, weight packing and the forward schedule.
+// See include/btsbot_hip.h for the contract and the reference code each entry point replaces.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void btsbot_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* btsbot_last_error(void) { return g_err; }
+extern "C" int btsbot_abi_version(void) { return BTSBOT_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct ParamRec {
+  std::string name;
+  int64_t off, numel;
+  int ndim;
+  int shape[4];
+  int is_buffer;
+};
+
+struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
+  int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
+  size_t p_dw, p_fc1, p_fc2;
+};
+struct DownPk {
+  int64_t ln_w, ln_b, w, b;
+  size_t p_w;
+};
+
+constexpr int STAGE_HW[4] = {15, 7, 3, 1};
+
+}  // namespace
+
+struct btsbot_ctx {
+  btsbot_config cfg;
+  bool has_image, has_meta;
+  int n_comb;        // linear layers of the fusion MLP
+  int comb_dims[4];
+  int act;           // ACT_GELU / ACT_RELU of the heads
+  int meta_trailing_act;
+  std::vector<ParamRec> params;
+  int64_t total_floats = 0;
+
+  // master offsets
+  int64_t stem_w, stem_b, stem_lnw, stem_lnb, hn_w = -1, hn_b = -1;
+  std::vector<std::vector<BlockPk>> blocks;  // [stage][block]
+  DownPk down[4];
+  int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
+  int64_t comb_w[3], comb_b[3];
+  size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift;
+
+  // device memory
+  float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
+  unsigned char* extra = nullptr;   // transformed operands
+  size_t extra_bytes = 0;
+  bool packed = false;
+
+  unsigned char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int max_chunk = 0;
+  size_t o_x, o_x2, o_xn, o_h;      // workspace offsets
+  bool debug = false;
+  float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int last_chunk = 0;
+
+  int esz() const { return cfg.precision == BTSBOT_F32 ? 4 : 2; }
+};
+
+namespace {
+
+int64_t add_param(btsbot_ctx* h, const std::string& name, std::initializer_list<int> shape,
+                  int is_buffer = 0) {
+  ParamRec r;
+  r.name = name;
+  r.off = h->total_floats;
+  r.ndim = (int)shape.size();
+  r.numel = 1;
+  int i = 0;
+  for (int s : shape) {
+    r.shape[i++] = s;
+    r.numel *= s;
+  }
+  for (; i < 4; ++i) r.shape[i] = 1;
+  r.is_buffer = is_buffer;
+  // keep every tensor 16-byte aligned inside the arena so kernels can use vector loads
+  h->total_floats += (r.numel + 3) / 4 * 4;
+  h->params.push_back(r);
+  return r.off;
+}
+
+size_t bump(size_t& cur, size_t bytes) {
+  const size_t o = cur;
+  cur += (bytes + 255) / 256 * 256;
+  return o;
+}
+
+int build_tables(btsbot_ctx* h) {
+  const btsbot_config& c = h->cfg;
+  size_t cur = 0;
+  const int esz = h->esz();
+  char buf[96];
+  if (h->has_image) {
+    const int c0 = c.dims[0];
+    h->stem_w = add_param(h, "stem.0.weight", {c0, 3, 4, 4});
+    h->stem_b = add_param(h, "stem.0.bias", {c0});
+    h->stem_lnw = add_param(h, "stem.1.weight", {c0});
+    h->stem_lnb = add_param(h, "stem.1.bias", {c0});
+    h->blocks.resize(4);
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.dims[i];
+      if (i > 0) {
+        const int cin = c.dims[i - 1];
+        snprintf(buf, sizeof buf, "stages.%d.downsample.", i);
+        std::string p(buf);
+        h->down[i].ln_w = add_param(h, p + "0.weight", {cin});
+        h->down[i].ln_b = add_param(h, p + "0.bias", {cin});
+        h->down[i].w = add_param(h, p + "1.weight", {ch, cin, 2, 2});
+        h->down[i].b = add_param(h, p + "1.bias", {ch});
+        h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
+      }
+      for (int j = 0; j < c.depths[i]; ++j) {
+        snprintf(buf, sizeof buf, "stages.%d.blocks.%d.", i, j);
+        std::string p(buf);
+        BlockPk b;
+        b.gamma = add_param(h, p + "gamma", {ch});
+        b.dw_w = add_param(h, p + "conv_dw.weight", {ch, 1, 7, 7});
+        b.dw_b = add_param(h, p + "conv_dw.bias", {ch});
+        b.ln_w = add_param(h, p + "norm.weight", {ch});
+        b.ln_b = add_param(h, p + "norm.bias", {ch});
+        b.fc1_w = add_param(h, p + "mlp.fc1.weight", {4 * ch, ch, 1, 1});
+        b.fc1_b = add_param(h, p + "mlp.fc1.bias", {4 * ch});
+        b.fc2_w = add_param(h, p + "mlp.fc2.weight", {ch, 4 * ch, 1, 1});
+        b.fc2_b = add_param(h, p + "mlp.fc2.bias", {ch});
+        b.p_dw = bump(cur, (size_t)49 * ch * 4);
+        b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
+        b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
+        h->blocks[i].push_back(b);
+      }
+    }
+    if (c.head_norm) {
+      h->hn_w = add_param(h, "head_norm.weight", {c.dims[3]});
+      h->hn_b = add_param(h, "head_norm.bias", {c.dims[3]});
+    }
+  }
+  if (h->has_meta) {
+    h->bn_w = add_param(h, "meta.0.weight", {c.n_meta});
+    h->bn_b = add_param(h, "meta.0.bias", {c.n_meta});
+    h->bn_rm = add_param(h, "meta.0.running_mean", {c.n_meta}, 1);
+    h->bn_rv = add_param(h, "meta.0.running_var", {c.n_meta}, 1);
+    h->m1_w = add_param(h, "meta.1.weight", {c.meta_fc1, c.n_meta});
+    h->m1_b = add_param(h, "meta.1.bias", {c.meta_fc1});
+    h->m2_w = add_param(h, "meta.4.weight", {c.meta_fc2, c.meta_fc1});
+    h->m2_b = add_param(h, "meta.4.bias", {c.meta_fc2});
+    h->p_m1 = bump(cur, (size_t)c.meta_fc1 * c.n_meta * 4);
+    h->p_m2 = bump(cur, (size_t)c.meta_fc2 * c.meta_fc1 * 4);
+    h->p_bn_scale = bump(cur, (size_t)c.n_meta * 4);
+    h->p_bn_shift = bump(cur, (size_t)c.n_meta * 4);
+  }
+  for (int i = 0; i < h->n_comb; ++i) {
+    snprintf(buf, sizeof buf, "comb.%d.", i);
+    std::string p(buf);
+    h->comb_w[i] = add_param(h, p + "weight", {h->comb_dims[i + 1], h->comb_dims[i]});
+    h->comb_b[i] = add_param(h, p + "bias", {h->comb_dims[i + 1]});
+    h->p_comb[i] = bump(cur, (size_t)h->comb_dims[i + 1] * h->comb_dims[i] * 4);
+  }
+  h->extra_bytes = cur;
+  return BTSBOT_OK;
+}
+
+void ws_layout(const btsbot_ctx* h, int chunk, size_t* ox, size_t* ox2, size_t* oxn, size_t* oh,
+               size_t* total) {
+  const btsbot_config& c = h->cfg;
+  size_t cur = 0;
+  *ox = *ox2 = *oxn = *oh = 0;
+  if (h->has_image) {
+    size_t x_el = 0, xn_el = 0, h_el = 0;
+    for (int i = 0; i < 4; ++i) {
+      const size_t pc = (size_t)STAGE_HW[i] * STAGE_HW[i] * c.dims[i];
+      x_el = pc > x_el ? pc : x_el;
+      xn_el = pc > xn_el ? pc : xn_el;
+      h_el = 4 * pc > h_el ? 4 * pc : h_el;
+      if (i > 0) {  // patch matrix feeding the downsample GEMM
+        const size_t pe = (size_t)STAGE_HW[i] * STAGE_HW[i] * 4 * c.dims[i - 1];
+        xn_el = pe > xn_el ? pe : xn_el;
+      }
+    }
+    *ox = bump(cur, x_el * chunk * 4);
+    *ox2 = bump(cur, x_el * chunk * 4);
+    *oxn = bump(cur, xn_el * chunk * h->esz());
+    *oh = bump(cur, h_el * chunk * h->esz());
+  }
+  *total = cur > 256 ? cur : 256;
+}
+
+}  // namespace
+
+extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
+  if (cfg == nullptr || out == nullptr) {
+    btsbot_set_error("create: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (cfg->abi_version != BTSBOT_ABI_VERSION) {
+    btsbot_set_error("create: ABI version %d, library is %d", cfg->abi_version,
+                     BTSBOT_ABI_VERSION);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_F16 ||
+      cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_UM_NN) {
+    btsbot_set_error("create: bad precision %d or wiring %d", cfg->precision, cfg->wiring);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  btsbot_ctx* h = new btsbot_ctx();
+  h->cfg = *cfg;
+  const int w = cfg->wiring;
+  h->has_image = (w != BTSBOT_UM_NN);
+  h->has_meta = (w != BTSBOT_CONVNEXT);
+  h->act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_CONVNEXT) ? ACT_GELU : ACT_RELU;
+  h->meta_trailing_act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_UM_NN) ? 1 : 0;
+  if (h->has_image) {
+    if (cfg->image_size != 63) {
+      btsbot_set_error("create: kernels are specialised for 63x63 cutouts, got %d",
+                       cfg->image_size);
+      delete h;
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    const bool pico = cfg->dims[0] == 64 && cfg->dims[1] == 128 && cfg->dims[2] == 256 &&
+                      cfg->dims[3] == 512;
+    const bool nano = cfg->dims[0] == 80 && cfg->dims[1] == 160 && cfg->dims[2] == 320 &&
+                      cfg->dims[3] == 640;
+    if (!pico && !nano) {
+      btsbot_set_error("create: dims (%d,%d,%d,%d) are neither convnext_pico nor convnext_nano",
+                       cfg->dims[0], cfg->dims[1], cfg->dims[2], cfg->dims[3]);
+      delete h;
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < 4; ++i)
+      if (cfg->depths[i] < 1 || cfg->depths[i] > 64) {
+        btsbot_set_error("create: bad depth %d for stage %d", cfg->depths[i], i);
+        delete h;
+        return BTSBOT_ERR_INVALID_ARG;
+      }
+  }
+  if (h->has_meta && (cfg->n_meta < 1 || cfg->meta_fc1 < 1 || cfg->meta_fc2 < 1)) {
+    btsbot_set_error("create: metadata branch needs n_meta, meta_fc1, meta_fc2 > 0");
+    delete h;
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const int feat = h->has_image ? cfg->dims[3] : 0;
+  if (w == BTSBOT_UM_NN) {
+    h->n_comb = 1;
+    h->comb_dims[0] = cfg->meta_fc2;
+    h->comb_dims[1] = 1;
+  } else {
+    if (cfg->comb_fc1 < 1 || cfg->comb_fc2 < 1) {
+      btsbot_set_error("create: fusion head needs comb_fc1, comb_fc2 > 0");
+      delete h;
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    h->n_comb = 3;
+    h->comb_dims[0] = feat + (h->has_meta ? cfg->meta_fc2 : 0);
+    h->comb_dims[1] = cfg->comb_fc1;
+    h->comb_dims[2] = cfg->comb_fc2;
+    h->comb_dims[3] = 1;
+  }
+  build_tables(h);
+  *out = h;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_destroy(btsbot_handle h) {
+  if (h == nullptr) return BTSBOT_OK;
+  if (h->mirror) (void)hipFree(h->mirror);
+  if (h->extra) (void)hipFree(h->extra);
+  if (h->ws) (void)hipFree(h->ws);
+  for (float* t : h->taps)
+    if (t) (void)hipFree(t);
+  delete h;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_param_count(btsbot_handle h) { return h ? (int)h->params.size() : -1; }
+extern "C" int64_t btsbot_param_floats(btsbot_handle h) { return h ? h->total_floats : -1; }
+
+extern "C" int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_info* out) {
+  if (h == nullptr || out == nullptr || index < 0 || index >= (int)h->params.size()) {
+    btsbot_set_error("param_info_at: bad handle or index %d", index);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const ParamRec& r = h->params[index];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, r.name.c_str(), sizeof(out->name) - 1);
+  out->offset = r.off;
+  out->numel = r.numel;
+  out->ndim = r.ndim;
+  for (int i = 0; i < 4; ++i) out->shape[i] = r.shape[i];
+  out->is_buffer = r.is_buffer;
+  return BTSBOT_OK;
+}
+
+#define TRY(call)                   \
+  do {                              \
+    int _s = (call);                \
+    if (_s != BTSBOT_OK) return _s; \
+  } while (0)
+
+extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* stream) {
+  if (h == nullptr || master == nullptr) {
+    btsbot_set_error("pack_params: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const btsbot_config& c = h->cfg;
+  if (h->mirror == nullptr) {  // first pack on this handle: allocate the operand arenas
+    HIP_TRY(hipMalloc(&h->mirror, (size_t)h->total_floats * 4));
+    HIP_TRY(hipMalloc(&h->extra, h->extra_bytes > 0 ? h->extra_bytes : 256));
+  }
+  HIP_TRY(hipMemcpyAsync(h->mirror, master, (size_t)h->total_floats * 4, hipMemcpyDeviceToDevice,
+                         st));
+  const float* m = h->mirror;
+  if (h->has_image) {
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.dims[i];
+      if (i > 0)
+        TRY(launch_pack_down(c.precision, m + h->down[i].w, h->extra + h->down[i].p_w, ch,
+                             c.dims[i - 1], st));
+      for (const BlockPk& b : h->blocks[i]) {
+        TRY(launch_transpose_f32(m + b.dw_w, reinterpret_cast<float*>(h->extra + b.p_dw), ch, 49,
+                                 st));
+        TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
+        TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
+      }
+    }
+  }
+  if (h->has_meta) {
+    TRY(launch_transpose_f32(m + h->m1_w, reinterpret_cast<float*>(h->extra + h->p_m1), c.meta_fc1,
+                             c.n_meta, st));
+    TRY(launch_transpose_f32(m + h->m2_w, reinterpret_cast<float*>(h->extra + h->p_m2), c.meta_fc2,
+                             c.meta_fc1, st));
+    TRY(launch_bn_fold(m + h->bn_w, m + h->bn_b, m + h->bn_rm, m + h->bn_rv,
+                       reinterpret_cast<float*>(h->extra + h->p_bn_scale),
+                       reinterpret_cast<float*>(h->extra + h->p_bn_shift), c.n_meta, st));
+  }
+  for (int i = 0; i < h->n_comb; ++i)
+    TRY(launch_transpose_f32(m + h->comb_w[i], reinterpret_cast<float*>(h->extra + h->p_comb[i]),
+                             h->comb_dims[i + 1], h->comb_dims[i], st));
+  h->packed = true;
+  return BTSBOT_OK;
+}
+
+extern "C" int64_t btsbot_workspace_bytes(btsbot_handle h, int max_chunk) {
+  if (h == nullptr || max_chunk < 1) return -1;
+  size_t a, b, c, d, total;
+  ws_layout(h, max_chunk, &a, &b, &c, &d, &total);
+  return (int64_t)total;
+}
+
+extern "C" int btsbot_set_debug(btsbot_handle h, int on) {
+  if (h == nullptr) return BTSBOT_ERR_INVALID_ARG;
+  h->debug = on != 0;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
+  if (h == nullptr || max_chunk < 1) {
+    btsbot_set_error("reserve: bad argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  size_t total;
+  size_t ox, ox2, oxn, oh;
+  ws_layout(h, max_chunk, &ox, &ox2, &oxn, &oh, &total);
+  if (h->ws != nullptr && max_chunk <= h->max_chunk && (!h->debug || h->taps[0] != nullptr))
+    return BTSBOT_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  if (h->ws) (void)hipFree(h->ws);
+  h->ws = nullptr;
+  HIP_TRY(hipMalloc(&h->ws, total));
+  h->ws_bytes = total;
+  h->max_chunk = max_chunk;
+  h->o_x = ox;
+  h->o_x2 = ox2;
+  h->o_xn = oxn;
+  h->o_h = oh;
+  for (float*& t : h->taps) {
+    if (t) (void)hipFree(t);
+    t = nullptr;
+  }
+  if (h->debug && h->has_image) {
+    HIP_TRY(hipMalloc(&h->taps[0], (size_t)max_chunk * 225 * h->cfg.dims[0] * 4));
+    for (int i = 0; i < 4; ++i)
+      HIP_TRY(hipMalloc(&h->taps[i + 1],
+                        (size_t)max_chunk * STAGE_HW[i] * STAGE_HW[i] * h->cfg.dims[i] * 4));
+  }
+  return BTSBOT_OK;
+}
+
+static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, float* logits,
+                         float* scores, int nb, hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  float* x = reinterpret_cast<float*>(h->ws + h->o_x);
+  float* x2 = reinterpret_cast<float*>(h->ws + h->o_x2);
+  void* xn = h->ws + h->o_xn;
+  void* hb = h->ws + h->o_h;
+  if (h->has_image) {
+    TRY(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x, nb,
+                    c.dims[0], st));
+    if (h->debug)
+      HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)nb * 225 * c.dims[0] * 4,
+                             hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.dims[i], hw = STAGE_HW[i], rows = nb * hw * hw;
+      if (i > 0) {
+        const int cin = c.dims[i - 1];
+        TRY(launch_ln_patch(c.precision, x, m + h->down[i].ln_w, m + h->down[i].ln_b, xn, nb,
+                            STAGE_HW[i - 1], cin, st));
+        TRY(launch_gemm(c.precision, EPI_BIAS, xn, h->extra + h->down[i].p_w, m + h->down[i].b,
+                        nullptr, nullptr, x2, rows, ch, 4 * cin, st));
+        float* t = x;
+        x = x2;
+        x2 = t;
+      }
+      for (const BlockPk& b : h->blocks[i]) {
+        TRY(launch_dwconv_ln(c.precision, x, reinterpret_cast<const float*>(h->extra + b.p_dw),
+                             m + b.dw_b, m + b.ln_w, m + b.ln_b, xn, nb, hw, ch, st));
+        TRY(launch_gemm(c.precision, EPI_GELU, xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
+                        nullptr, hb, rows, 4 * ch, ch, st));
+        TRY(launch_gemm(c.precision, EPI_RESID, hb, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,
+                        x, x, rows, ch, 4 * ch, st));
+      }
+      if (h->debug)
+        HIP_TRY(hipMemcpyAsync(h->taps[i + 1], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice,
+                               st));
+    }
+  }
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.feat = h->has_image ? x : nullptr;
+  a.feat_dim = h->has_image ? c.dims[3] : 0;
+  a.hn_w = h->hn_w >= 0 ? m + h->hn_w : nullptr;
+  a.hn_b = h->hn_b >= 0 ? m + h->hn_b : nullptr;
+  if (h->has_meta) {
+    a.meta = meta;
+    a.n_meta = c.n_meta;
+    a.f1 = c.meta_fc1;
+    a.f2 = c.meta_fc2;
+    a.bn_scale = reinterpret_cast<const float*>(h->extra + h->p_bn_scale);
+    a.bn_shift = reinterpret_cast<const float*>(h->extra + h->p_bn_shift);
+    a.m1_wt = reinterpret_cast<const float*>(h->extra + h->p_m1);
+    a.m1_b = m + h->m1_b;
+    a.m2_wt = reinterpret_cast<const float*>(h->extra + h->p_m2);
+    a.m2_b = m + h->m2_b;
+    a.meta_act = h->act;
+    a.meta_trailing_act = h->meta_trailing_act;
+  }
+  a.n_layers = h->n_comb;
+  for (int i = 0; i <= h->n_comb; ++i) a.dims[i] = h->comb_dims[i];
+  for (int i = 0; i < h->n_comb; ++i) {
+    a.wt[i] = reinterpret_cast<const float*>(h->extra + h->p_comb[i]);
+    a.b[i] = m + h->comb_b[i];
+  }
+  a.comb_act = h->act;
+  a.logits = logits;
+  a.scores = scores;
+  a.B = nb;
+  TRY(launch_head(a, st));
+  h->last_chunk = nb;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const float* meta,
+                              float* logits, float* scores, int batch, int training,
+                              uint64_t dropout_seed, void* stream) {
+  (void)dropout_seed;
+  if (h == nullptr || logits == nullptr || batch < 0) {
+    btsbot_set_error("forward: NULL handle/logits or negative batch");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (!h->packed) {
+    btsbot_set_error("forward: btsbot_pack_params() has not been called");
+    return BTSBOT_ERR_STATE;
+  }
+  if ((h->has_image && triplets == nullptr) || (h->has_meta && meta == nullptr)) {
+    btsbot_set_error("forward: this wiring needs %s input",
+                     h->has_image && triplets == nullptr ? "image" : "metadata");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (training) {
+    btsbot_set_error("forward: training mode is not implemented in this build");
+    return BTSBOT_ERR_STATE;
+  }
+  if (batch == 0) return BTSBOT_OK;
+  if (h->ws == nullptr || h->max_chunk < 1) {
+    btsbot_set_error("forward: btsbot_reserve() has not been called");
+    return BTSBOT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int b0 = 0; b0 < batch; b0 += h->max_chunk) {
+    const int nb = batch - b0 < h->max_chunk ? batch - b0 : h->max_chunk;
+    TRY(forward_chunk(h, triplets ? triplets + (size_t)b0 * 3 * 63 * 63 : nullptr,
+                      meta ? meta + (size_t)b0 * h->cfg.n_meta : nullptr, logits + b0,
+                      scores ? scores + b0 : nullptr, nb, st));
+  }
+  return BTSBOT_OK;
+}
+
+extern "C" int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst,
+                                   int64_t capacity, void* stream) {
+  if (h == nullptr || name == nullptr || dst == nullptr) {
+    btsbot_set_error("read_tap: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (!h->debug || h->taps[0] == nullptr || !h->has_image) {
+    btsbot_set_error("read_tap: debug taps are off (btsbot_set_debug + btsbot_reserve first)");
+    return BTSBOT_ERR_STATE;
+  }
+  int idx = -1;
+  if (strcmp(name, "stem") == 0) idx = 0;
+  else if (strncmp(name, "stage", 5) == 0 && name[5] >= '0' && name[5] <= '3' && name[6] == 0)
+    idx = 1 + (name[5] - '0');
+  if (idx < 0) {
+    btsbot_set_error("read_tap: unknown tap '%s'", name);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const int st_i = idx == 0 ? 0 : idx - 1;
+  const int64_t n =
+      (int64_t)h->last_chunk * STAGE_HW[st_i] * STAGE_HW[st_i] * h->cfg.dims[st_i];
+  if (n > capacity) {
+    btsbot_set_error("read_tap: need %lld floats, capacity %lld", (long long)n,
+                     (long long)capacity);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  hipError_t e = hipMemcpyAsync(dst, h->taps[idx], (size_t)n * 4, hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) {
+    btsbot_set_error("read_tap: %s", hipGetErrorString(e));
+    return BTSBOT_ERR_HIP;
+  }
+  return n;
+}

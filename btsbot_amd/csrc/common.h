@@ -1,0 +1,136 @@
+// Shared device helpers and launcher prototypes for libbtsbot_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/btsbot_hip.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (no exception crosses the ABI)
+// ---------------------------------------------------------------------------------------
+void btsbot_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      btsbot_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                       __LINE__);                                                       \
+      return BTSBOT_ERR_HIP;                                                            \
+    }                                                                                   \
+  } while (0)
+
+#define LAUNCH_CHECK()                                                                  \
+  do {                                                                                  \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) {                                                             \
+      btsbot_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),       \
+                       __FILE__, __LINE__);                                             \
+      return BTSBOT_ERR_HIP;                                                            \
+    }                                                                                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// device math
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) {
+  // nn.GELU() default (exact erf form), architectures.py:35,149
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+// 64-lane butterfly sum; every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// sum within aligned groups of 16 lanes
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == ACT_GELU) return gelu_erf(x);
+  if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers (one per kernel family); all return btsbot_status
+// ---------------------------------------------------------------------------------------
+enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2 };
+
+// out = epi(X[M,K] . W[N,K]^T + bias[N]);  X, W are `prec`-typed, bias/gamma/resid fp32.
+//   EPI_GELU : out (prec-typed) [M,N] = gelu(acc + bias)
+//   EPI_RESID: out (fp32)       [M,N] = resid + gamma[n] * (acc + bias)   (in place allowed)
+//   EPI_BIAS : out (fp32)       [M,N] = acc + bias
+int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
+                const float* gamma, const float* resid, void* out, int M, int N, int K,
+                hipStream_t st);
+
+// stem: conv 4x4 s4 (+bias) + LayerNorm over C0.  img [B,3,63,63] fp32 -> out [B,225,C0] fp32.
+int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
+                const float* lnb, float* out, int B, int C0, hipStream_t st);
+
+// depthwise 7x7 p3 (+bias) + LayerNorm over C.  x [B,HW*HW,C] fp32 -> xn [B,HW*HW,C] prec-typed.
+// wdw is tap-major [49][C] fp32.
+int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bdw,
+                     const float* lnw, const float* lnb, void* xn, int B, int HW, int C,
+                     hipStream_t st);
+
+// downsample prologue: LayerNorm over Cin per pixel, then 2x2/s2 patch gather.
+// x [B,HW,HW,Cin] fp32 -> patches [B*(HW/2)^2, 4*Cin] prec-typed, k = (ky*2+kx)*Cin + c.
+int launch_ln_patch(int prec, const float* x, const float* lnw, const float* lnb, void* patches,
+                    int B, int HW, int Cin, hipStream_t st);
+
+struct HeadArgs {
+  // image feature part
+  const float* feat;  // [B, feat_dim] fp32 (final 1x1 map), or nullptr
+  int feat_dim;
+  const float* hn_w;  // head LayerNorm (nullptr -> none)
+  const float* hn_b;
+  // metadata part (BatchNorm folded to scale/shift; training: scale/shift of the batch stats)
+  const float* meta;  // [B, n_meta] or nullptr
+  int n_meta, f1, f2;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* m1_wt;  // [n_meta][f1]  (K-major)
+  const float* m1_b;
+  const float* m2_wt;  // [f1][f2]
+  const float* m2_b;
+  int meta_act, meta_trailing_act;
+  // combined MLP: up to 3 linear layers, act between them
+  int n_layers;
+  int dims[4];         // dims[0] = feat_dim + f2 (or f2 / feat_dim), ..., dims[n_layers] = 1
+  const float* wt[3];  // K-major [dims[i]][dims[i+1]]
+  const float* b[3];
+  int comb_act;
+  float* logits;
+  float* scores;  // may be nullptr
+  int B;
+};
+int launch_head(const HeadArgs& a, hipStream_t st);
+
+// parameter packing helpers
+int launch_cast(int prec, const float* src, void* dst, int64_t n, hipStream_t st);
+// src [R][Cc] fp32 -> dst [Cc][R] fp32
+int launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
+// downsample filter [Cout][Cin][2][2] fp32 -> [Cout][(ky*2+kx)*Cin + cin] prec-typed
+int launch_pack_down(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st);
+// BatchNorm1d eval fold: scale = w / sqrt(rv + eps), shift = b - rm * scale
+int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                   float* shift, int n, hipStream_t st);

@@ -1,0 +1,222 @@
+// Fused classifier heads (fp32): optional head LayerNorm on the 1x1 image feature, metadata branch
+// (BatchNorm1d folded to scale/shift -> Linear -> act -> Linear [-> act]), concat (image first, then
+// metadata), fusion MLP, logits + sigmoid scores -- one kernel, nothing but the logits leaves the CU.
+//
+// Reference wiring: /root/reference/btsbot/architectures.py:146-171 (mm_ConvNeXt, GELU),
+// :109-122 (ConvNeXt head), :282-293 (um_nn, ReLU), :299-313,358-372 (frozen_fusion, ReLU, metadata
+// branch without its trailing activation); sigmoid: inference_example.py:91.
+// Also the small parameter (re)packing kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int HG = 8;     // alerts per workgroup
+constexpr int HNT = 256;  // threads
+constexpr float HN_EPS = 1e-6f;
+
+// out[g][n] = act(bias[n] + sum_k in[g][k] * wt[k][n]) for the workgroup's HG alerts.
+// wt is K-major so consecutive threads (n) read consecutive addresses; in[][] is an LDS broadcast.
+__device__ __forceinline__ void dense(const float* in, int ldin, int K, const float* __restrict__ wt,
+                                      const float* __restrict__ bias, int N, int act, float* outp,
+                                      int ldout) {
+  for (int n = threadIdx.x; n < N; n += HNT) {
+    float acc[HG];
+    const float b = bias[n];
+#pragma unroll
+    for (int g = 0; g < HG; ++g) acc[g] = b;
+    for (int k = 0; k < K; ++k) {
+      const float wv = wt[(size_t)k * N + n];
+#pragma unroll
+      for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k], wv, acc[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < HG; ++g) outp[g * ldout + n] = apply_act(acc[g], act);
+  }
+}
+
+__global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int zd = a.dims[0];
+  int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
+  for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
+  float* z = smem;               // [HG][zd]
+  float* t0 = z + HG * zd;       // [HG][maxw]
+  float* t1 = t0 + HG * maxw;    // [HG][maxw]
+  const int b0 = blockIdx.x * HG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- image feature (+ head LayerNorm) -> z[:, 0:feat_dim]
+  if (a.feat_dim > 0) {
+    for (int g = wave; g < HG; g += HNT / 64) {
+      const int b = b0 + g;
+      const float* src = a.feat + (size_t)(b < a.B ? b : a.B - 1) * a.feat_dim;
+      if (a.hn_w != nullptr) {
+        float sum = 0.f;
+        for (int c = lane; c < a.feat_dim; c += 64) sum += src[c];
+        const float mean = wave_sum(sum) / a.feat_dim;
+        float sq = 0.f;
+        for (int c = lane; c < a.feat_dim; c += 64) {
+          const float d = src[c] - mean;
+          sq += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / a.feat_dim + HN_EPS);
+        for (int c = lane; c < a.feat_dim; c += 64)
+          z[g * zd + c] = (src[c] - mean) * rstd * a.hn_w[c] + a.hn_b[c];
+      } else {
+        for (int c = lane; c < a.feat_dim; c += 64) z[g * zd + c] = src[c];
+      }
+    }
+  }
+  // ---- metadata branch -> z[:, feat_dim : feat_dim + f2]
+  if (a.n_meta > 0) {
+    for (int i = tid; i < HG * a.n_meta; i += HNT) {
+      const int g = i / a.n_meta, j = i - g * a.n_meta;
+      const int b = b0 + g;
+      const float v = a.meta[(size_t)(b < a.B ? b : a.B - 1) * a.n_meta + j];
+      t0[g * maxw + j] = fmaf(v, a.bn_scale[j], a.bn_shift[j]);
+    }
+    __syncthreads();
+    dense(t0, maxw, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, maxw);
+    __syncthreads();
+    dense(t1, maxw, a.f1, a.m2_wt, a.m2_b, a.f2, a.meta_trailing_act ? a.meta_act : ACT_NONE,
+          z + a.feat_dim, zd);
+  }
+  __syncthreads();
+  // ---- fusion MLP
+  const float* in = z;
+  int ldin = zd;
+  float* bufs[2] = {t0, t1};
+  for (int i = 0; i < a.n_layers; ++i) {
+    float* o = bufs[i & 1];
+    dense(in, ldin, a.dims[i], a.wt[i], a.b[i], a.dims[i + 1],
+          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, maxw);
+    __syncthreads();
+    in = o;
+    ldin = maxw;
+  }
+  if (tid < HG && b0 + tid < a.B) {
+    const float zz = in[tid * ldin];
+    a.logits[b0 + tid] = zz;
+    if (a.scores != nullptr) a.scores[b0 + tid] = 1.0f / (1.0f + expf(-zz));
+  }
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ s, T* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = (T)s[i];
+}
+
+__global__ void transpose_kernel(const float* __restrict__ s, float* __restrict__ d, int R, int Cc) {
+  const int64_t n = (int64_t)R * Cc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);  // d[c][r]
+    d[i] = s[(int64_t)r * Cc + c];
+  }
+}
+
+template <typename T>
+__global__ void pack_down_kernel(const float* __restrict__ s, T* __restrict__ d, int Cout, int Cin) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // d[co][q][ci] <- s[co][ci][q],  q = ky*2 + kx
+    const int ci = (int)(i % Cin);
+    const int q = (int)((i / Cin) & 3);
+    const int co = (int)(i / (4 * (int64_t)Cin));
+    d[i] = (T)s[((int64_t)co * Cin + ci) * 4 + q];
+  }
+}
+
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv,
+                               float* scale, float* shift, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = w[i] / sqrtf(rv[i] + 1e-5f);
+    scale[i] = s;
+    shift[i] = b[i] - rm[i] * s;
+  }
+}
+
+inline int nblocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int launch_head(const HeadArgs& a, hipStream_t st) {
+  if (a.B <= 0) return BTSBOT_OK;
+  int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
+  for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
+  const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw) * sizeof(float);
+  if (lds > 64 * 1024) {
+    btsbot_set_error("head: layer widths too large for one workgroup (%zu bytes of LDS)", lds);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(head_kernel, dim3((a.B + HG - 1) / HG), dim3(HNT), lds, st, a);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_cast(int prec, const float* src, void* dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return BTSBOT_OK;
+  switch (prec) {
+    case BTSBOT_F32:
+      HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      return BTSBOT_OK;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<bf16_t*>(dst), n);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<f16_t*>(dst), n);
+      break;
+    default:
+      btsbot_set_error("cast: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(nblocks((int64_t)R * Cc)), dim3(256), 0, st, src, dst,
+                     R, Cc);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_pack_down(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(pack_down_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<float*>(dst), Cout, Cin);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(pack_down_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<bf16_t*>(dst), Cout, Cin);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(pack_down_kernel<f16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<f16_t*>(dst), Cout, Cin);
+      break;
+    default:
+      btsbot_set_error("pack_down: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                   float* shift, int n, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, b, rm, rv, scale,
+                     shift, n);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}

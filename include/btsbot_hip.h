@@ -1,0 +1,157 @@
+/*
+ * btsbot_hip.h -- C ABI of libbtsbot_hip.so: the MI355X (gfx950) implementation of BTSbot's
+ * classifier forward/backward hot path.
+ *
+ * The reference (nabeelre/BTSbot, /root/reference) has no FFI: the path sits behind Python
+ * nn.Modules (btsbot/architectures.py) driven by btsbot/train.py and btsbot/inference_example.py.
+ * Each entry point below names the reference code it stands in for; the Python host in
+ * btsbot_amd/ (same class names, kwargs and state-dict keys as the reference) binds these
+ * symbols with ctypes.  INTEGRATION.md shows the stub a BTSbot maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  int status: 0 = OK, <0 = error
+ *     (enum below); btsbot_last_error() returns a thread-local message.  No C++ exception
+ *     crosses the ABI.
+ *   - Every pointer is a BORROWED DEVICE pointer (hipMalloc'd / torch CUDA tensor) that must stay
+ *     valid until the work enqueued on `stream` has completed.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the legacy default stream).  All work is enqueued asynchronously.  Device
+ *     memory is allocated only by the first btsbot_pack_params() on a handle and by
+ *     btsbot_reserve(); forward / loss / optimiser calls never allocate, synchronise or copy to
+ *     the host -- so a caller may capture them into a hipGraph.
+ *   - One handle per GPU and per model replica; a handle is thread-compatible (one thread at a
+ *     time), matching "a single Python thread drives the model" (SURVEY.md section 8b).
+ *   - Tensors: triplets are [B,3,63,63] fp32 NCHW contiguous exactly as
+ *     inference_example.py:62-64 prepares them; metadata is [B,n_meta] fp32; logits/scores are
+ *     [B] fp32 (the reference's [B,1]).
+ */
+#ifndef BTSBOT_HIP_H
+#define BTSBOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTSBOT_ABI_VERSION 1
+
+enum btsbot_status {
+  BTSBOT_OK = 0,
+  BTSBOT_ERR_INVALID_ARG = -1,   /* bad config / NULL pointer / shape the kernels do not cover  */
+  BTSBOT_ERR_HIP = -2,           /* a HIP runtime call failed (message has hipGetErrorString)    */
+  BTSBOT_ERR_WORKSPACE = -3,     /* batch larger than the reserved workspace                     */
+  BTSBOT_ERR_UNKNOWN_PARAM = -4, /* parameter name not in the handle's table                     */
+  BTSBOT_ERR_STATE = -5          /* call order violated (e.g. backward without a training fwd)   */
+};
+
+/* which nn.Module of btsbot/architectures.py the handle reproduces */
+enum btsbot_wiring {
+  BTSBOT_MM_CONVNEXT = 0,   /* mm_ConvNeXt     architectures.py:125-171 (GELU heads)            */
+  BTSBOT_CONVNEXT = 1,      /* ConvNeXt        architectures.py:104-122 (image only)            */
+  BTSBOT_FROZEN_FUSION = 2, /* frozen_fusion   architectures.py:296-372 (ConvNeXt + um_nn, ReLU)*/
+  BTSBOT_UM_NN = 3          /* um_nn           architectures.py:277-293 (metadata only)         */
+};
+
+/* arithmetic type of the MFMA operands / staged activations (accumulation is always fp32;
+ * the residual stream, LayerNorm, GELU and the heads are fp32 in every mode) */
+enum btsbot_precision {
+  BTSBOT_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 fma chains -- the parity mode          */
+  BTSBOT_BF16 = 1, /* v_mfma_f32_16x16x32_bf16                                                   */
+  BTSBOT_F16 = 2   /* v_mfma_f32_16x16x32_f16 (same rate as bf16, 3 more mantissa bits)          */
+};
+
+typedef struct btsbot_config {
+  int32_t abi_version;   /* = BTSBOT_ABI_VERSION                                                 */
+  int32_t wiring;        /* enum btsbot_wiring                                                   */
+  int32_t precision;     /* enum btsbot_precision                                                */
+  /* timm ConvNeXt table (pico: depths 2,2,6,2 dims 64,128,256,512; nano: 2,2,8,2 / 80..640)     */
+  int32_t depths[4];
+  int32_t dims[4];
+  int32_t image_size;    /* 63 (the only size the kernels are specialised for)                   */
+  int32_t head_norm;     /* 1: pool + LayerNorm2d before flatten (ConvNeXt, frozen_fusion,
+                               mm_ConvNeXt on "LS" data); 0: flatten only (architectures.py:142) */
+  int32_t n_meta;        /* len(config["metadata_cols"]), 25 in prod_config.json:15-41           */
+  int32_t meta_fc1, meta_fc2;           /* metadata branch widths                                */
+  int32_t comb_fc1, comb_fc2;           /* fusion head widths (ConvNeXt: fc1_neurons/fc2_neurons)*/
+  float meta_dropout, comb_dropout;     /* training-mode dropout probabilities                   */
+} btsbot_config;
+
+typedef struct btsbot_ctx* btsbot_handle;
+
+/* One row of the handle's parameter table.  `name` is the canonical (prefix-free) name, e.g.
+ * "stages.1.blocks.0.mlp.fc1.weight", "head_norm.weight", "meta.0.running_mean",
+ * "comb.2.bias"; the Python host maps the reference's state-dict keys onto these
+ * (btsbot_amd/architectures.py).  `offset` is in floats into the master arena. */
+typedef struct btsbot_param_info {
+  char name[96];
+  int64_t offset;
+  int64_t numel;
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t is_buffer;     /* 1 for BatchNorm running_mean / running_var                           */
+} btsbot_param_info;
+
+const char* btsbot_last_error(void);
+int btsbot_abi_version(void);
+
+/* Replaces: model_type(config)   (from_HF.py:71-73, train.py:218-222).  Builds the parameter table
+ * only -- no HIP call, so it also works on a host without a GPU (the reference constructs on the
+ * CPU and then calls .to(device)). */
+int btsbot_create(const btsbot_config* cfg, btsbot_handle* out);
+int btsbot_destroy(btsbot_handle h);
+
+/* Parameter table: the fp32 "master arena" layout the caller allocates (one flat device buffer of
+ * btsbot_param_floats() floats; the Python host makes every nn.Parameter a view into it so that
+ * state_dict()/load_state_dict() keep the reference's keys, from_HF.py:74-79). */
+int btsbot_param_count(btsbot_handle h);
+int64_t btsbot_param_floats(btsbot_handle h);
+int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_info* out);
+
+/* Re-pack the master arena into the kernels' operand layouts (cast to the MFMA type, K-major
+ * 1x1 / 2x2 / 4x4 filters, tap-major depthwise filters, BatchNorm folded for eval).
+ * Replaces: load_state_dict (from_HF.py:74) / the implicit "weights are where cuDNN wants them".
+ * Must be called after every change of the master arena (load, optimiser step). */
+int btsbot_pack_params(btsbot_handle h, const float* master_arena, void* stream);
+
+/* Workspace: activations of one chunk of alerts.  reserve() (re)allocates for chunks of up to
+ * `max_chunk` alerts; forward() splits larger batches into chunks internally. */
+int64_t btsbot_workspace_bytes(btsbot_handle h, int max_chunk);
+int btsbot_reserve(btsbot_handle h, int max_chunk);
+
+/* Replaces: model(image_input=..., metadata_input=...) / model(input_data=...) followed by
+ * torch.sigmoid (architectures.py:166-171,121-122,292-293,367-372; inference_example.py:84-91).
+ * `triplets` may be NULL for BTSBOT_UM_NN, `meta` NULL for BTSBOT_CONVNEXT; `scores` may be NULL.
+ * training != 0 selects BatchNorm batch statistics + dropout (seeded by dropout_seed) and keeps
+ * the activations needed by btsbot_backward(). */
+int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* meta,
+                   float* logits, float* scores, int batch, int training,
+                   uint64_t dropout_seed, void* stream);
+
+/* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and
+ * stage outputs (call before btsbot_reserve()). */
+int btsbot_set_debug(btsbot_handle h, int on);
+
+/* Debug/validation tap: copy an intermediate of the LAST forward chunk to `dst` (fp32).
+ * name: "stem", "stage0".."stage3" (NHWC [chunk, P, C]).  Returns the element count or <0. */
+int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst, int64_t capacity,
+                        void* stream);
+
+/* Replaces: BCEWithLogitsLoss(pos_weight)(logits, labels) and its autograd
+ * (train.py:211-212,525-526).  labels are fp32 0/1.  loss_sum (1 float, caller-zeroed)
+ * accumulates sum_i l_i (divide by n_global for the mean); dlogits = d(mean loss)/dz over
+ * n_global alerts (n_global = global batch across ranks). */
+int btsbot_bce_fwd_bwd(const float* logits, const float* labels, float pos_weight,
+                       int batch, int n_global, float* loss_sum, float* dlogits, void* stream);
+
+/* Replaces: torch.optim.AdamW.step (train.py:242-246,527): decoupled weight decay, bias
+ * correction, eps outside the sqrt-correction exactly as torch (amsgrad off).  Flat arenas of
+ * n floats; `step` is 1-based. */
+int btsbot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTSBOT_HIP_H */
