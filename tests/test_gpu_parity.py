@@ -1,0 +1,188 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI by the
+btsbot_amd modules, against the CPU oracle and the committed reference-wrapper goldens.
+
+Tolerances (the reference's own notion of "same output" is rtol 1e-4 / atol 1e-5 on fp32 logits,
+/root/reference/btsbot/to_onnx.py:135-137; the north star asks for scores within 1e-4):
+  f32  mode: |dlogit| <= 1e-4 * max(1, max|logit|)  and  |dscore| <= 1e-5   (measured ~1e-5 / ~1e-6)
+  f16  mode: |dscore| <= 1e-3   (measured ~1.3e-4 with worst-case layer-scale gamma ~ 1)
+  bf16 mode: |dscore| <= 1e-2   (measured ~1.1e-3, same weights)
+Weights are seeded random with layer-scale gamma ~ 1 (a trained checkpoint has |gamma| << 1, which
+damps the low-precision error of every block); no trained checkpoint exists offline.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CONFIGS, seeded_state, build_model, run_model
+from btsbot_amd import _lib
+from btsbot_amd.synthetic import synthetic_batch
+from oracle import convnext_oracle as O   # checker only
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_SCORE = {"f32": 1e-5, "f16": 1e-3, "bf16": 1e-2}
+
+
+def _oracle(kind, cfg, sd, img, meta):
+    with torch.no_grad():
+        return O.forward(kind, sd, cfg, img, meta)
+
+
+def _check(out, ref, prec):
+    out = out.cpu()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert torch.isfinite(out).all()
+    ds = (torch.sigmoid(out) - torch.sigmoid(ref)).abs().max().item()
+    assert ds <= TOL_SCORE[prec], f"{prec}: max|dscore| {ds}"
+    if prec == "f32":
+        scale = max(1.0, ref.abs().max().item())
+        dl = (out - ref).abs().max().item()
+        assert dl <= 1e-4 * scale, f"f32: max|dlogit| {dl} (scale {scale})"
+    return ds
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+def test_forward_matches_oracle(cuda, name, prec):
+    kind, cfg = CONFIGS[name]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(39, seed=2)             # the example-data batch size
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    out = run_model(kind, m, img.to(cuda), meta.to(cuda))
+    _check(out, ref, prec)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_forward_matches_reference_wrapper_goldens(cuda, name):
+    """Committed logits of the reference's own nn.Modules on 8 bundled example alerts."""
+    kind, cfg = CONFIGS[name]
+    gold = np.load(os.path.join(GOLD, "ref_logits.npz"))
+    ex = np.load(os.path.join(GOLD, "example8.npz"))
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    img = torch.from_numpy(ex["triplets"]).to(cuda)
+    meta = torch.from_numpy(ex["metadata"]).to(cuda)
+    out = run_model(kind, m, img, meta)
+    _check(out, torch.from_numpy(gold[f"{name}/example8"]), "f32")
+
+
+def test_stage_activations_match_oracle(cuda):
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(5, seed=7)
+    taps = {}
+    with torch.no_grad():
+        O.mm_convnext_forward(sd, cfg, img, meta, taps=taps)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    m.set_debug_taps(True)
+    run_model(kind, m, img.to(cuda), meta.to(cuda))
+    for t in ("stem", "stage0", "stage1", "stage2", "stage3"):
+        got = m.read_tap(t).cpu()
+        ref = taps[t].permute(0, 2, 3, 1).reshape(got.shape)   # NCHW -> NHWC rows
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), t
+
+
+@pytest.mark.parametrize("batch", [1, 7, 8, 9, 64, 2049])
+def test_ragged_batches(cuda, batch):
+    """Batch sizes around the kernels' grouping factors (2/8 maps per workgroup, 8 alerts per head
+    workgroup, 128-row GEMM tiles) and one past the internal 2048-alert chunk."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(min(batch, 64), seed=9)
+    reps = (batch + img.shape[0] - 1) // img.shape[0]
+    img, meta = img.repeat(reps, 1, 1, 1)[:batch], meta.repeat(reps, 1)[:batch]
+    ref = _oracle(kind, cfg, sd, img[:64], meta[:64])
+    ref = ref.repeat(reps, 1)[:batch]
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    out = run_model(kind, m, img.to(cuda), meta.to(cuda))
+    _check(out, ref, "f32")
+
+
+def test_empty_batch(cuda):
+    kind, cfg = CONFIGS["mm_pico"]
+    m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "f32")
+    out = run_model(kind, m, torch.zeros(0, 3, 63, 63, device=cuda), torch.zeros(0, 25, device=cuda))
+    assert out.shape == (0, 1)
+
+
+def test_input_validation_and_layout(cuda):
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    img, meta, _ = synthetic_batch(4, seed=2)
+    with pytest.raises(ValueError):
+        m(image_input=img[:, :, :60, :60].to(cuda), metadata_input=meta.to(cuda))
+    with pytest.raises(ValueError):
+        m(image_input=img.to(cuda), metadata_input=meta[:, :24].to(cuda))
+    # a non-contiguous NHWC->NCHW view (what np.transpose gives before ascontiguousarray) and
+    # float64 inputs are accepted and give the same answer
+    ref = run_model(kind, m, img.to(cuda), meta.to(cuda))
+    nhwc = img.permute(0, 2, 3, 1).contiguous().to(cuda)
+    out = run_model(kind, m, nhwc.permute(0, 3, 1, 2).double(), meta.to(cuda).double())
+    assert torch.equal(out, ref)
+    # linearity-free sanity: alerts are independent -> permuting the batch permutes the logits
+    perm = torch.tensor([2, 0, 3, 1])
+    outp = run_model(kind, m, img[perm].to(cuda), meta[perm].to(cuda))
+    assert torch.equal(outp, ref[perm.to(cuda)])
+
+
+def test_weights_repacked_after_update(cuda):
+    kind, cfg = CONFIGS["um_nn"]
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    _, meta, _ = synthetic_batch(16, seed=2)
+    a = run_model(kind, m, None, meta.to(cuda))
+    with torch.no_grad():
+        m.network._modules["6"].bias.add_(1.5)
+    b = run_model(kind, m, None, meta.to(cuda))
+    assert torch.allclose(b, a + 1.5, atol=1e-4)
+
+
+def test_large_batch_properties(cuda):
+    """BASELINE.json full size (B=1024, bf16): alert independence -- the logits of a big batch
+    equal those of its halves run separately, bit for bit (no cross-alert term in eval mode)."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "bf16")
+    img, meta, _ = synthetic_batch(1024, seed=2)
+    img, meta = img.to(cuda), meta.to(cuda)
+    full = run_model(kind, m, img, meta)
+    lo = run_model(kind, m, img[:512].contiguous(), meta[:512].contiguous())
+    hi = run_model(kind, m, img[512:].contiguous(), meta[512:].contiguous())
+    assert torch.equal(full, torch.cat([lo, hi]))
+    assert torch.isfinite(full).all()
+
+
+def test_bce_kernel(cuda):
+    g = np.load(os.path.join(GOLD, "adamw_bce.npz"))
+    z = torch.from_numpy(g["z"]).to(cuda)
+    y = torch.from_numpy(g["y"]).to(cuda)
+    loss = torch.zeros(1, device=cuda)
+    dz = torch.empty_like(z)
+    import ctypes as C
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().btsbot_bce_fwd_bwd(C.c_void_p(z.data_ptr()), C.c_void_p(y.data_ptr()),
+                                             float(g["pos_weight"]), z.numel(), z.numel(),
+                                             C.c_void_p(loss.data_ptr()), C.c_void_p(dz.data_ptr()),
+                                             C.c_void_p(st)), "bce")
+    assert abs(loss.item() / z.numel() - float(g["loss"])) < 1e-5
+    assert np.allclose(dz.cpu().numpy(), g["dz"], atol=1e-7)
+
+
+def test_adamw_kernel(cuda):
+    g = np.load(os.path.join(GOLD, "adamw_bce.npz"))
+    p = torch.from_numpy(g["p0"]).to(cuda)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    import ctypes as C
+    st = torch.cuda.current_stream().cuda_stream
+    for s in range(3):
+        gr = torch.from_numpy(g["grads"][s]).to(cuda)
+        _lib.check(_lib.lib().btsbot_adamw_step(
+            C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(m.data_ptr()),
+            C.c_void_p(v.data_ptr()), p.numel(), 1e-4, 0.99, 0.99, 1e-8, 1e-2, s + 1,
+            C.c_void_p(st)), "adamw")
+        assert np.allclose(p.cpu().numpy(), g["traj"][s], rtol=2e-6, atol=1e-7)
