@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: alerts/sec of the BTSbot classifier hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per GPU).
+Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[1]: ConvNeXt-pico multi-modal (mm_ConvNeXt) bf16 inference on a
+batch of 1024 synthetic alerts per GPU (63x63x3 triplet + 25 metadata scalars each), inputs
+resident in HBM before the timed region.  One "step" = one forward of that batch through
+``model(image_input=..., metadata_input=...)`` -> logits (the C ABI also writes the sigmoid
+scores).  Alerts are independent, so N GPUs run N replicas on N different shards with no data-path
+collective: scaling is "weak", value = N * 1024 * K / max-over-ranks time.
+
+Extra objects on the line:
+  roofline      the pointwise-conv MFMA kernel (gemm_kernel<.., GELU>, fc1 of every block):
+                algorithmic FLOP per launch / mean launch time measured with HIP events on the
+                launch stream (a second, event-bracketed pass over the same K steps), against the
+                2.5 PFLOP/s dense bf16 MFMA peak.  `kernels` lists every kernel family the same way.
+  cpu_baseline  the CPU oracle (same ATen CPU ops the reference dispatches to) timed on this host,
+                rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import btsbot_amd  # noqa: E402
+from btsbot_amd.synthetic import METADATA_COLS, synthetic_batch  # noqa: E402
+
+METRIC = "alerts/sec (63×63×3 triplet + 25 meta) train+infer, 1/2/4/8 MI355X"
+PER_GPU_BATCH = 1024
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
+HBM_PEAK_GBS = 8000.0
+STAGE_P = (225, 49, 9, 1)
+
+CONFIG = dict(model_name="mm_ConvNeXt", model_kind="convnext_pico.d1_in1k", pretrained=False,
+              train_data_version="v11", metadata_cols=METADATA_COLS, meta_fc1_neurons=128,
+              meta_dropout=0.25, meta_fc2_neurons=128, comb_fc1_neurons=128, comb_fc2_neurons=32,
+              comb_dropout=0.2)
+
+
+def seeded_weights(model, seed=3):
+    """Random 'trained-like' weights written straight into the model (layer-scale ~1 so every block
+    contributes; there are no checkpoints offline)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if not v.is_floating_point():
+                continue
+            if k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.5)
+            elif k.endswith("gamma") or (v.dim() == 1 and k.endswith("weight")):
+                v.copy_(1.0 + 0.1 * torch.randn(v.shape, generator=g))
+            elif v.dim() == 1:
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+            else:
+                fan_in = v[0].numel()
+                v.copy_(torch.randn(v.shape, generator=g) / fan_in ** 0.5)
+    model.mark_weights_dirty()
+
+
+def family_work(batch, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512), esz=2):
+    """Algorithmic FLOP and compulsory HBM bytes per forward of `batch` alerts, per kernel family
+    (DESIGN.md 'Kernels')."""
+    w = {}
+    fc = sum(d * 2 * batch * p * c * 4 * c for d, p, c in zip(depths, STAGE_P, dims))
+    w["gemm_kernel<fc1,GELU>"] = dict(flop=fc, bytes=sum(
+        d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
+        for d, p, c in zip(depths, STAGE_P, dims)))
+    w["gemm_kernel<fc2,RESID>"] = dict(flop=fc, bytes=sum(
+        d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
+        for d, p, c in zip(depths, STAGE_P, dims)))
+    w["dwconv_ln_kernel"] = dict(
+        flop=sum(d * 2 * 49 * batch * p * c for d, p, c in zip(depths, STAGE_P, dims)),
+        bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in zip(depths, STAGE_P, dims)))
+    w["gemm_kernel<down,BIAS>"] = dict(
+        flop=sum(2 * batch * STAGE_P[i] * 4 * dims[i - 1] * dims[i] for i in (1, 2, 3)),
+        bytes=sum(batch * STAGE_P[i] * (4 * dims[i - 1] * esz + dims[i] * 4) for i in (1, 2, 3)))
+    w["ln_patch_kernel"] = dict(
+        flop=0, bytes=sum(batch * STAGE_P[i] * 4 * dims[i - 1] * (4 + esz) for i in (1, 2, 3)))
+    w["stem_kernel"] = dict(flop=2 * batch * 225 * 48 * dims[0],
+                            bytes=batch * (3 * 63 * 63 * 4 + 225 * dims[0] * 4))
+    w["head_kernel"] = dict(flop=2 * batch * (25 * 128 + 128 * 128 + 640 * 128 + 128 * 32 + 32),
+                            bytes=batch * (dims[3] * 4 + 25 * 4 + 8))
+    return w
+
+
+def cpu_baseline(sample_batch=256, budget_s=20.0):
+    """CPU oracle (kind 'port'): fp32, eval, no_grad, all host cores."""
+    from oracle import convnext_oracle as O   # CPU baseline leg only
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.random_state_dict(O.model_param_shapes("mm_ConvNeXt", CONFIG), seed=3)
+    img, meta, _ = synthetic_batch(sample_batch, seed=2)
+    with torch.no_grad():
+        for _ in range(2):
+            O.forward("mm_ConvNeXt", sd, CONFIG, img, meta)
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+            t0 = time.perf_counter()
+            O.forward("mm_ConvNeXt", sd, CONFIG, img, meta)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=round(sample_batch / med, 1), unit="alerts/s", cores=torch.get_num_threads(),
+                kind="port",
+                sample=f"{len(times)} forwards of {sample_batch} synthetic alerts (same model/weights, "
+                       f"fp32 torch-CPU oracle, median), ~{sum(times):.0f}s of CPU work")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="alerts per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = btsbot_amd.mm_ConvNeXt(CONFIG, precision=args.precision)
+    seeded_weights(model)
+    model = model.to(dev).eval()
+    # each rank gets its own shard of synthetic alerts (seed 2 + rank), resident in HBM
+    img, meta, _ = synthetic_batch(args.batch, seed=2 + rank)
+    img, meta = img.to(dev), meta.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(image_input=img, metadata_input=meta)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out).all()
+
+    # ---- roofline leg: same K steps, every launch bracketed by HIP events on the launch stream
+    model.set_profile(True)
+    for _ in range(args.steps):
+        step()
+    prof = model.collect_profile()
+    model.set_profile(False)
+
+    if rank == 0:
+        esz = 4 if args.precision == "f32" else 2
+        work = family_work(args.batch, esz=esz)
+        kernels = {}
+        for name, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            per_fwd_ms = ms / args.steps
+            wk = work[name]
+            kernels[name] = dict(
+                launches_per_step=n // args.steps, avg_launch_us=round(1e3 * ms / n, 2),
+                ms_per_step=round(per_fwd_ms, 4),
+                tflops=round(wk["flop"] / (per_fwd_ms * 1e-3) / 1e12, 2),
+                gbs=round(wk["bytes"] / (per_fwd_ms * 1e-3) / 1e9, 1))
+        dom = "gemm_kernel<fc1,GELU>"
+        ms, n = prof[dom]
+        flop_per_launch = work[dom]["flop"] * args.steps / n
+        achieved = flop_per_launch / (ms / n * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        total_alerts = args.batch * world * args.steps
+        line = {
+            "metric": METRIC,
+            "value": round(total_alerts / elapsed, 1),
+            "unit": "alerts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: ConvNeXt-pico multi-modal (mm_ConvNeXt) "
+                            f"{args.precision} inference, batch={args.batch} synthetic triplets per GPU, "
+                            "inputs resident in HBM, logits+scores out",
+                "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                "precision": args.precision, "weights": "seeded random, layer-scale ~1",
+                "parallelism": f"{world} independent replicas, batch-sharded, no collective",
+            },
+            "roofline": {
+                "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "flop_per_launch": flop_per_launch, "avg_launch_us": round(1e3 * ms / n, 2),
+                "launches_per_step": n // args.steps,
+            },
+            "kernels": kernels,
+            "flop_per_alert": 133701376 + 210000,
+            "whole_net_tflops": round((133701376 + 210000) * total_alerts / elapsed / 1e12, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

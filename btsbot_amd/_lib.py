@@ -22,6 +22,8 @@ SYMBOLS = [
     "btsbot_param_count", "btsbot_param_floats", "btsbot_param_info_at", "btsbot_pack_params",
     "btsbot_workspace_bytes", "btsbot_reserve", "btsbot_forward", "btsbot_set_debug",
     "btsbot_read_tap", "btsbot_bce_fwd_bwd", "btsbot_adamw_step",
+    "btsbot_set_profile", "btsbot_profile_categories", "btsbot_profile_category_name",
+    "btsbot_profile_collect",
 ]
 
 
@@ -87,6 +89,14 @@ def lib() -> C.CDLL:
     L.btsbot_set_debug.argtypes = [vp, i32]
     L.btsbot_read_tap.restype = i64
     L.btsbot_read_tap.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    L.btsbot_set_profile.restype = i32
+    L.btsbot_set_profile.argtypes = [vp, i32]
+    L.btsbot_profile_categories.restype = i32
+    L.btsbot_profile_categories.argtypes = []
+    L.btsbot_profile_category_name.restype = C.c_char_p
+    L.btsbot_profile_category_name.argtypes = [i32]
+    L.btsbot_profile_collect.restype = i32
+    L.btsbot_profile_collect.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     L.btsbot_bce_fwd_bwd.restype = i32
     L.btsbot_bce_fwd_bwd.argtypes = [vp, vp, f32, i32, i32, vp, vp, vp]
     L.btsbot_adamw_step.restype = i32

@@ -268,6 +268,9 @@ class _HipModel(nn.Module):
             raise NotImplementedError(
                 "btsbot_amd: the training-mode forward (BatchNorm batch statistics, dropout, "
                 "backward) is not built yet; call .eval() for inference")
+        if batch == 0:
+            empty = torch.empty(0, 1, dtype=torch.float32, device=dev)
+            return (empty, empty.clone()) if want_scores else empty
         with torch.cuda.device(dev):
             L, stream = self._prepare(dev, batch)
             logits = torch.empty(batch, dtype=torch.float32, device=dev)
@@ -283,6 +286,19 @@ class _HipModel(nn.Module):
         if want_scores:
             return logits, scores.view(batch, 1)
         return logits
+
+    def set_profile(self, on: bool = True):
+        """Bracket every kernel launch of forward() with HIP events (bench.py's roofline leg)."""
+        _lib.check(_lib.lib().btsbot_set_profile(self._handle.ptr, int(on)), "btsbot_set_profile")
+
+    def collect_profile(self) -> Dict[str, Tuple[float, int]]:
+        """{kernel family: (summed device ms, launches)} since the last collect."""
+        L = _lib.lib()
+        n = L.btsbot_profile_categories()
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(L.btsbot_profile_collect(self._handle.ptr, n, ms, cnt), "btsbot_profile_collect")
+        return {L.btsbot_profile_category_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n)}
 
     def read_tap(self, name: str) -> torch.Tensor:
         """fp32 NHWC copy of 'stem' / 'stage0'..'stage3' from the last forward chunk

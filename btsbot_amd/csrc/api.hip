@@ -47,6 +47,12 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, NCAT };
+const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
+                                     "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
+                                     "head_kernel"};
+constexpr size_t PROF_MAX_LAUNCHES = 8192;
+
 }  // namespace
 
 struct btsbot_ctx {
@@ -77,6 +83,12 @@ struct btsbot_ctx {
   size_t ws_bytes = 0;
   int max_chunk = 0;
   size_t o_x, o_x2, o_xn, o_h;      // workspace offsets
+  // per-kernel-family timing with HIP events on the launch stream (btsbot_set_profile)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs: [2i] before, [2i+1] after launch i
+  std::vector<int> prof_cat;
+  size_t prof_used = 0;
+
   bool debug = false;
   float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int last_chunk = 0;
@@ -292,6 +304,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->ws) (void)hipFree(h->ws);
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   delete h;
   return BTSBOT_OK;
 }
@@ -378,6 +391,45 @@ extern "C" int btsbot_set_debug(btsbot_handle h, int on) {
   return BTSBOT_OK;
 }
 
+extern "C" int btsbot_set_profile(btsbot_handle h, int on) {
+  if (h == nullptr) return BTSBOT_ERR_INVALID_ARG;
+  if (on && h->prof_ev.empty()) {
+    h->prof_ev.resize(2 * PROF_MAX_LAUNCHES);
+    h->prof_cat.resize(PROF_MAX_LAUNCHES);
+    for (hipEvent_t& e : h->prof_ev) HIP_TRY(hipEventCreate(&e));
+  }
+  h->prof_on = on != 0;
+  h->prof_used = 0;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_profile_categories(void) { return NCAT; }
+
+extern "C" const char* btsbot_profile_category_name(int cat) {
+  return cat >= 0 && cat < NCAT ? CAT_NAMES[cat] : "";
+}
+
+extern "C" int btsbot_profile_collect(btsbot_handle h, int n_cat, double* ms_sum,
+                                      int64_t* launches) {
+  if (h == nullptr || ms_sum == nullptr || launches == nullptr || n_cat < NCAT) {
+    btsbot_set_error("profile_collect: bad argument (need room for %d categories)", NCAT);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < n_cat; ++i) {
+    ms_sum[i] = 0.0;
+    launches[i] = 0;
+  }
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    HIP_TRY(hipEventSynchronize(h->prof_ev[2 * i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+    ms_sum[h->prof_cat[i]] += ms;
+    launches[h->prof_cat[i]] += 1;
+  }
+  h->prof_used = 0;
+  return BTSBOT_OK;
+}
+
 extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
   if (h == nullptr || max_chunk < 1) {
     btsbot_set_error("reserve: bad argument");
@@ -411,6 +463,19 @@ extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
   return BTSBOT_OK;
 }
 
+// run one launch, bracketed by HIP events on `st` when profiling is on
+template <typename F> static int timed(btsbot_ctx* h, int cat, hipStream_t st, F&& fn) {
+  const bool rec = h->prof_on && h->prof_used < PROF_MAX_LAUNCHES;
+  if (rec) HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_used], st));
+  const int s = fn();
+  if (s != BTSBOT_OK) return s;
+  if (rec) {
+    HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_used + 1], st));
+    h->prof_cat[h->prof_used++] = cat;
+  }
+  return BTSBOT_OK;
+}
+
 static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, float* logits,
                          float* scores, int nb, hipStream_t st) {
   const btsbot_config& c = h->cfg;
@@ -420,8 +485,10 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
   void* xn = h->ws + h->o_xn;
   void* hb = h->ws + h->o_h;
   if (h->has_image) {
-    TRY(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x, nb,
-                    c.dims[0], st));
+    TRY(timed(h, CAT_STEM, st, [&] {
+      return launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x, nb,
+                         c.dims[0], st);
+    }));
     if (h->debug)
       HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)nb * 225 * c.dims[0] * 4,
                              hipMemcpyDeviceToDevice, st));
@@ -429,21 +496,32 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
       const int ch = c.dims[i], hw = STAGE_HW[i], rows = nb * hw * hw;
       if (i > 0) {
         const int cin = c.dims[i - 1];
-        TRY(launch_ln_patch(c.precision, x, m + h->down[i].ln_w, m + h->down[i].ln_b, xn, nb,
-                            STAGE_HW[i - 1], cin, st));
-        TRY(launch_gemm(c.precision, EPI_BIAS, xn, h->extra + h->down[i].p_w, m + h->down[i].b,
-                        nullptr, nullptr, x2, rows, ch, 4 * cin, st));
+        TRY(timed(h, CAT_LNPATCH, st, [&] {
+          return launch_ln_patch(c.precision, x, m + h->down[i].ln_w, m + h->down[i].ln_b, xn, nb,
+                                 STAGE_HW[i - 1], cin, st);
+        }));
+        TRY(timed(h, CAT_DOWN, st, [&] {
+          return launch_gemm(c.precision, EPI_BIAS, xn, h->extra + h->down[i].p_w,
+                             m + h->down[i].b, nullptr, nullptr, x2, rows, ch, 4 * cin, st);
+        }));
         float* t = x;
         x = x2;
         x2 = t;
       }
       for (const BlockPk& b : h->blocks[i]) {
-        TRY(launch_dwconv_ln(c.precision, x, reinterpret_cast<const float*>(h->extra + b.p_dw),
-                             m + b.dw_b, m + b.ln_w, m + b.ln_b, xn, nb, hw, ch, st));
-        TRY(launch_gemm(c.precision, EPI_GELU, xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
-                        nullptr, hb, rows, 4 * ch, ch, st));
-        TRY(launch_gemm(c.precision, EPI_RESID, hb, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,
-                        x, x, rows, ch, 4 * ch, st));
+        TRY(timed(h, CAT_DWLN, st, [&] {
+          return launch_dwconv_ln(c.precision, x,
+                                  reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
+                                  m + b.ln_w, m + b.ln_b, xn, nb, hw, ch, st);
+        }));
+        TRY(timed(h, CAT_FC1, st, [&] {
+          return launch_gemm(c.precision, EPI_GELU, xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
+                             nullptr, hb, rows, 4 * ch, ch, st);
+        }));
+        TRY(timed(h, CAT_FC2, st, [&] {
+          return launch_gemm(c.precision, EPI_RESID, hb, h->extra + b.p_fc2, m + b.fc2_b,
+                             m + b.gamma, x, x, rows, ch, 4 * ch, st);
+        }));
       }
       if (h->debug)
         HIP_TRY(hipMemcpyAsync(h->taps[i + 1], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice,
@@ -480,7 +558,7 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
   a.logits = logits;
   a.scores = scores;
   a.B = nb;
-  TRY(launch_head(a, st));
+  TRY(timed(h, CAT_HEAD, st, [&] { return launch_head(a, st); }));
   h->last_chunk = nb;
   return BTSBOT_OK;
 }

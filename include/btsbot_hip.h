@@ -137,6 +137,15 @@ int btsbot_set_debug(btsbot_handle h, int on);
 int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst, int64_t capacity,
                         void* stream);
 
+/* Measurement aid with no reference counterpart (bench.py's roofline leg): when on, every kernel
+ * launch of forward() is bracketed by two HIP events recorded on the launch stream;
+ * profile_collect() waits for them and returns, per kernel family (profile_category_name), the
+ * summed device time in ms and the number of launches since the last collect. */
+int btsbot_set_profile(btsbot_handle h, int on);
+int btsbot_profile_categories(void);
+const char* btsbot_profile_category_name(int category);
+int btsbot_profile_collect(btsbot_handle h, int n_categories, double* ms_sum, int64_t* launches);
+
 /* Replaces: BCEWithLogitsLoss(pos_weight)(logits, labels) and its autograd
  * (train.py:211-212,525-526).  labels are fp32 0/1.  loss_sum (1 float, caller-zeroed)
  * accumulates sum_i l_i (divide by n_global for the mean); dlogits = d(mean loss)/dz over
