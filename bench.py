@@ -98,7 +98,13 @@ def family_work(batch, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512), esz=2):
 def cpu_baseline(sample_batch=256, budget_s=20.0):
     """CPU oracle (kind 'port'): fp32, eval, no_grad, all host cores."""
     from oracle import convnext_oracle as O   # CPU baseline leg only
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    # all host cores this process may use; capped at 64 torch intra-op threads, beyond which the
+    # 15x15..1x1 maps of a 256-alert sample only add synchronisation cost
+    torch.set_num_threads(max(1, min(ncores, 64)))
     sd = O.random_state_dict(O.model_param_shapes("mm_ConvNeXt", CONFIG), seed=3)
     img, meta, _ = synthetic_batch(sample_batch, seed=2)
     with torch.no_grad():

@@ -24,6 +24,7 @@ SYMBOLS = [
     "btsbot_read_tap", "btsbot_bce_fwd_bwd", "btsbot_adamw_step",
     "btsbot_set_profile", "btsbot_profile_categories", "btsbot_profile_category_name",
     "btsbot_profile_collect",
+    "btsbot_op_gemm", "btsbot_op_dwconv_ln", "btsbot_op_stem", "btsbot_op_ln_patch",
 ]
 
 
@@ -97,6 +98,14 @@ def lib() -> C.CDLL:
     L.btsbot_profile_category_name.argtypes = [i32]
     L.btsbot_profile_collect.restype = i32
     L.btsbot_profile_collect.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.btsbot_op_gemm.restype = i32
+    L.btsbot_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.btsbot_op_dwconv_ln.restype = i32
+    L.btsbot_op_dwconv_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.btsbot_op_stem.restype = i32
+    L.btsbot_op_stem.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.btsbot_op_ln_patch.restype = i32
+    L.btsbot_op_ln_patch.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     L.btsbot_bce_fwd_bwd.restype = i32
     L.btsbot_bce_fwd_bwd.argtypes = [vp, vp, f32, i32, i32, vp, vp, vp]
     L.btsbot_adamw_step.restype = i32

@@ -633,3 +633,49 @@ extern "C" int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst
   }
   return n;
 }
+
+// ---------------------------------------------------------------------------------------
+// op-level entry points
+// ---------------------------------------------------------------------------------------
+extern "C" int btsbot_op_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
+                              const float* gamma, const float* resid, void* out, int M, int N,
+                              int K, void* stream) {
+  if (X == nullptr || W == nullptr || bias == nullptr || out == nullptr || M < 0 || N < 1 ||
+      K < 1 || (epi == EPI_RESID && (gamma == nullptr || resid == nullptr))) {
+    btsbot_set_error("op_gemm: invalid argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return launch_gemm(prec, epi, X, W, bias, gamma, resid, out, M, N, K, (hipStream_t)stream);
+}
+
+extern "C" int btsbot_op_dwconv_ln(int prec, const float* x, const float* w, const float* bias,
+                                   const float* ln_w, const float* ln_b, void* xn, int B, int HW,
+                                   int C, void* stream) {
+  if (x == nullptr || w == nullptr || bias == nullptr || ln_w == nullptr || ln_b == nullptr ||
+      xn == nullptr || B < 0) {
+    btsbot_set_error("op_dwconv_ln: invalid argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return launch_dwconv_ln(prec, x, w, bias, ln_w, ln_b, xn, B, HW, C, (hipStream_t)stream);
+}
+
+extern "C" int btsbot_op_stem(const float* img, const float* w, const float* bias,
+                              const float* ln_w, const float* ln_b, float* out, int B, int C0,
+                              void* stream) {
+  if (img == nullptr || w == nullptr || bias == nullptr || ln_w == nullptr || ln_b == nullptr ||
+      out == nullptr || B < 0) {
+    btsbot_set_error("op_stem: invalid argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return launch_stem(img, w, bias, ln_w, ln_b, out, B, C0, (hipStream_t)stream);
+}
+
+extern "C" int btsbot_op_ln_patch(int prec, const float* x, const float* ln_w, const float* ln_b,
+                                  void* patches, int B, int HW, int Cin, void* stream) {
+  if (x == nullptr || ln_w == nullptr || ln_b == nullptr || patches == nullptr || B < 0 ||
+      HW < 2) {
+    btsbot_set_error("op_ln_patch: invalid argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return launch_ln_patch(prec, x, ln_w, ln_b, patches, B, HW, Cin, (hipStream_t)stream);
+}

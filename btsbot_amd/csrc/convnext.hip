@@ -206,19 +206,21 @@ __global__ __launch_bounds__(256) void dw1_ln_kernel(const float* __restrict__ x
 
 // ---------------------------------------------------------------------------------------
 // downsample prologue: LayerNorm(Cin) per input pixel, scattered into 2x2/s2 patch rows.
-// One wave per input pixel; odd last row/column of the map is never read (floor division).
+// 16 lanes per input pixel (4 pixels per wave), CPL = Cin/16 contiguous channels per lane; the odd
+// last row/column of the map is never read (floor division).
 // ---------------------------------------------------------------------------------------
-template <int CPT, typename T>
+template <int CPL, typename T>
 __global__ __launch_bounds__(256) void ln_patch_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb,
-                                                       T* __restrict__ patches, int B, int HW,
-                                                       int Cin) {
-  const int lane = threadIdx.x & 63;
+                                                       T* __restrict__ patches, int B, int HW) {
+  constexpr int Cin = CPL * 16;
+  const int sub = threadIdx.x & 15;
   const int HO = HW / 2;
   const long total = (long)B * HO * HO * 4;
-  const long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (id >= total) return;
+  long id = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = id < total;
+  if (!live) id = total - 1;
   const int q = (int)(id & 3);  // ky*2 + kx
   long rest = id >> 2;
   const int ox = (int)(rest % HO);
@@ -226,30 +228,34 @@ __global__ __launch_bounds__(256) void ln_patch_kernel(const float* __restrict__
   const int oy = (int)(rest % HO);
   const int b = (int)(rest / HO);
   const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
-  const float* src = x + (((size_t)b * HW + iy) * HW + ix) * Cin;
-  float v[CPT];
+  const float* src = x + (((size_t)b * HW + iy) * HW + ix) * Cin + sub * CPL;
+  float v[CPL];
   float sum = 0.f;
+  if (CPL % 4 == 0) {
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = lane + 64 * i;
-    v[i] = c < Cin ? src[c] : 0.f;
-    sum += v[i];
+    for (int i = 0; i < CPL; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(src + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = src[i];
   }
-  const float mean = wave_sum(sum) / Cin;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) sum += v[i];
+  const float mean = group16_sum(sum) * (1.0f / Cin);
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = lane + 64 * i;
-    const float d = c < Cin ? v[i] - mean : 0.f;
+  for (int i = 0; i < CPL; ++i) {
+    const float d = v[i] - mean;
     sq += d * d;
   }
-  const float rstd = rsqrtf(wave_sum(sq) / Cin + LN_EPS);
-  T* dst = patches + ((((size_t)b * HO + oy) * HO + ox) * 4 + q) * Cin;
+  const float rstd = rsqrtf(group16_sum(sq) * (1.0f / Cin) + LN_EPS);
+  if (!live) return;
+  T* dst = patches + ((((size_t)b * HO + oy) * HO + ox) * 4 + q) * Cin + sub * CPL;
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = lane + 64 * i;
-    if (c < Cin) dst[c] = (T)((v[i] - mean) * rstd * lnw[c] + lnb[c]);
-  }
+  for (int i = 0; i < CPL; ++i)
+    dst[i] = (T)((v[i] - mean) * rstd * lnw[sub * CPL + i] + lnb[sub * CPL + i]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -336,10 +342,10 @@ int launch_dw_typed(const float* x, const float* wdw, const float* bdw, const fl
   if (C == CC && HW == HH) return launch_dw_cfg<CC, HH, GG, WW, T>(x, wdw, bdw, lnw, lnb, xn, B, st)
   DW_CASE(64, 15, 1, 8);
   DW_CASE(128, 7, 2, 8);
-  DW_CASE(256, 3, 8, 8);
+  DW_CASE(256, 3, 2, 8);
   DW_CASE(80, 15, 1, 8);
   DW_CASE(160, 7, 2, 8);
-  DW_CASE(320, 3, 8, 10);
+  DW_CASE(320, 3, 2, 10);
 #undef DW_CASE
   if (HW == 1) {
     const int cpt = (C + 63) / 64;
@@ -364,24 +370,19 @@ template <typename T>
 int launch_lnp_typed(const float* x, const float* lnw, const float* lnb, void* patches, int B,
                      int HW, int Cin, hipStream_t st) {
   const int HO = HW / 2;
-  const long waves = (long)B * HO * HO * 4;
-  dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  const long pix = (long)B * HO * HO * 4;
+  dim3 grid((unsigned)((pix + 15) / 16)), blk(256);
   T* o = reinterpret_cast<T*>(patches);
-  const int cpt = (Cin + 63) / 64;
-  if (cpt <= 1)
-    hipLaunchKernelGGL((ln_patch_kernel<1, T>), grid, blk, 0, st, x, lnw, lnb, o, B, HW, Cin);
-  else if (cpt <= 2)
-    hipLaunchKernelGGL((ln_patch_kernel<2, T>), grid, blk, 0, st, x, lnw, lnb, o, B, HW, Cin);
-  else if (cpt <= 4)
-    hipLaunchKernelGGL((ln_patch_kernel<4, T>), grid, blk, 0, st, x, lnw, lnb, o, B, HW, Cin);
-  else if (cpt <= 5)
-    hipLaunchKernelGGL((ln_patch_kernel<5, T>), grid, blk, 0, st, x, lnw, lnb, o, B, HW, Cin);
-  else {
-    btsbot_set_error("ln_patch: Cin=%d too wide", Cin);
-    return BTSBOT_ERR_INVALID_ARG;
+#define LNP_CASE(CPL)                                                                          \
+  if (Cin == CPL * 16) {                                                                       \
+    hipLaunchKernelGGL((ln_patch_kernel<CPL, T>), grid, blk, 0, st, x, lnw, lnb, o, B, HW);    \
+    LAUNCH_CHECK();                                                                            \
+    return BTSBOT_OK;                                                                          \
   }
-  LAUNCH_CHECK();
-  return BTSBOT_OK;
+  LNP_CASE(4) LNP_CASE(8) LNP_CASE(16) LNP_CASE(5) LNP_CASE(10) LNP_CASE(20)
+#undef LNP_CASE
+  btsbot_set_error("ln_patch: no kernel for Cin=%d", Cin);
+  return BTSBOT_ERR_INVALID_ARG;
 }
 
 }  // namespace

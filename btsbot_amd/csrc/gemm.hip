@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
       if (EPI == EPI_GELU) {
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
-        v[0] = (T)gelu_erf(a[0] + bv.x);
-        v[1] = (T)gelu_erf(a[1] + bv.y);
-        v[2] = (T)gelu_erf(a[2] + bv.z);
-        v[3] = (T)gelu_erf(a[3] + bv.w);
+        v[0] = (T)gelu_for<T>(a[0] + bv.x);
+        v[1] = (T)gelu_for<T>(a[1] + bv.y);
+        v[2] = (T)gelu_for<T>(a[2] + bv.z);
+        v[3] = (T)gelu_for<T>(a[3] + bv.w);
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
       } else if (EPI == EPI_RESID) {
         const float4 r = *reinterpret_cast<const float4*>(resid + o);

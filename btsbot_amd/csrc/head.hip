@@ -16,21 +16,58 @@ constexpr float HN_EPS = 1e-6f;
 
 // out[g][n] = act(bias[n] + sum_k in[g][k] * wt[k][n]) for the workgroup's HG alerts.
 // wt is K-major so consecutive threads (n) read consecutive addresses; in[][] is an LDS broadcast.
+// The 256 threads cover min(N,256) neurons x KS slices of K (KS = 256 / N): every thread keeps 8
+// weight loads in flight (unrolled), partial sums meet in LDS (`part`, [KS][HG][N]).
 __device__ __forceinline__ void dense(const float* in, int ldin, int K, const float* __restrict__ wt,
                                       const float* __restrict__ bias, int N, int act, float* outp,
-                                      int ldout) {
-  for (int n = threadIdx.x; n < N; n += HNT) {
+                                      int ldout, float* part) {
+  int ks = 1;
+  while (ks * 2 * N <= HNT) ks *= 2;                 // power-of-two K slices
+  const int kchunk = (K + ks - 1) / ks;
+  for (int n0 = 0; n0 < N; n0 += HNT) {              // N > 256: several passes (ks == 1)
+    const int n = n0 + (threadIdx.x % (N < HNT ? N : HNT));
+    const int slice = N < HNT ? threadIdx.x / N : 0;
+    const bool live = n < N && slice < ks;
     float acc[HG];
-    const float b = bias[n];
 #pragma unroll
-    for (int g = 0; g < HG; ++g) acc[g] = b;
-    for (int k = 0; k < K; ++k) {
-      const float wv = wt[(size_t)k * N + n];
+    for (int g = 0; g < HG; ++g) acc[g] = 0.f;
+    if (live) {
+      const int k0 = slice * kchunk, k1 = min(K, k0 + kchunk);
+      int k = k0;
+      for (; k + 8 <= k1; k += 8) {
+        float wv[8];
 #pragma unroll
-      for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k], wv, acc[g]);
+        for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k + u], wv[u], acc[g]);
+      }
+      for (; k < k1; ++k) {
+        const float wv = wt[(size_t)k * N + n];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k], wv, acc[g]);
+      }
     }
+    if (ks == 1) {
+      if (live) {
+        const float b = bias[n];
 #pragma unroll
-    for (int g = 0; g < HG; ++g) outp[g * ldout + n] = apply_act(acc[g], act);
+        for (int g = 0; g < HG; ++g) outp[g * ldout + n] = apply_act(acc[g] + b, act);
+      }
+    } else {
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < HG; ++g) part[(slice * HG + g) * N + n] = acc[g];
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < HG * N; i += HNT) {
+        const int g = i / N, nn = i - g * N;
+        float t = bias[nn];
+        for (int s2 = 0; s2 < ks; ++s2) t += part[(s2 * HG + g) * N + nn];
+        outp[g * ldout + nn] = apply_act(t, act);
+      }
+    }
   }
 }
 
@@ -42,6 +79,7 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
   float* z = smem;               // [HG][zd]
   float* t0 = z + HG * zd;       // [HG][maxw]
   float* t1 = t0 + HG * maxw;    // [HG][maxw]
+  float* part = t1 + HG * maxw;  // [KS][HG][N], KS * N <= 256
   const int b0 = blockIdx.x * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -76,10 +114,10 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
       t0[g * maxw + j] = fmaf(v, a.bn_scale[j], a.bn_shift[j]);
     }
     __syncthreads();
-    dense(t0, maxw, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, maxw);
+    dense(t0, maxw, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, maxw, part);
     __syncthreads();
     dense(t1, maxw, a.f1, a.m2_wt, a.m2_b, a.f2, a.meta_trailing_act ? a.meta_act : ACT_NONE,
-          z + a.feat_dim, zd);
+          z + a.feat_dim, zd, part);
   }
   __syncthreads();
   // ---- fusion MLP
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
   for (int i = 0; i < a.n_layers; ++i) {
     float* o = bufs[i & 1];
     dense(in, ldin, a.dims[i], a.wt[i], a.b[i], a.dims[i + 1],
-          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, maxw);
+          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, maxw, part);
     __syncthreads();
     in = o;
     ldin = maxw;
@@ -151,7 +189,7 @@ int launch_head(const HeadArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
   for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
-  const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw) * sizeof(float);
+  const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw + HNT) * sizeof(float);
   if (lds > 64 * 1024) {
     btsbot_set_error("head: layer widths too large for one workgroup (%zu bytes of LDS)", lds);
     return BTSBOT_ERR_INVALID_ARG;

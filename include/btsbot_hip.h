@@ -137,6 +137,32 @@ int btsbot_set_debug(btsbot_handle h, int on);
 int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst, int64_t capacity,
                         void* stream);
 
+/* ---- op-level entry points (the ATen ops of SURVEY.md section 2.2 K1-K6, one kernel family each);
+ * forward() is a schedule of these.  `prec` is enum btsbot_precision: the type of the staged
+ * activations / filters (float, bf16 or f16 device arrays); fp32 everywhere else. ---- */
+
+/* K4/K5/K6: out = epi(X[M,K] . W[N,K]^T + bias[N]) on MFMA.  Replaces conv2d 1x1 (+gelu) /
+ * conv2d 1x1 + layer-scale + residual / conv2d 2x2 s2 on pre-gathered patches.
+ *   epi 0: out (prec) = gelu(acc + bias)         epi 1: out (f32) = resid + gamma * (acc + bias)
+ *   epi 2: out (f32) = acc + bias.   K % (16/sizeof(prec)) == 0, N % 4 == 0.                    */
+int btsbot_op_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
+                   const float* gamma, const float* resid, void* out, int M, int N, int K,
+                   void* stream);
+/* K2+K3: depthwise 7x7 p3 + bias + LayerNorm(C, eps 1e-6).  x [B,HW,HW,C] f32 NHWC ->
+ * xn [B,HW,HW,C] (prec).  w_tap_major is [49][C] f32.  (C,HW) in {(64,15),(128,7),(256,3),(512,1),
+ * (80,15),(160,7),(320,3),(640,1)}. */
+int btsbot_op_dwconv_ln(int prec, const float* x, const float* w_tap_major, const float* bias,
+                        const float* ln_w, const float* ln_b, void* xn, int B, int HW, int C,
+                        void* stream);
+/* K1: conv2d 4x4 s4 + bias + LayerNorm(C0).  img [B,3,63,63] f32 -> out [B,225,C0] f32 NHWC;
+ * w is [C0][3][4][4] as PyTorch stores it.  C0 in {64, 80}. */
+int btsbot_op_stem(const float* img, const float* w, const float* bias, const float* ln_w,
+                   const float* ln_b, float* out, int B, int C0, void* stream);
+/* K6 prologue: LayerNorm(Cin) + 2x2/s2 patch gather.  x [B,HW,HW,Cin] f32 ->
+ * patches [B*(HW/2)^2, 4*Cin] (prec), k = (ky*2+kx)*Cin + c. */
+int btsbot_op_ln_patch(int prec, const float* x, const float* ln_w, const float* ln_b,
+                       void* patches, int B, int HW, int Cin, void* stream);
+
 /* Measurement aid with no reference counterpart (bench.py's roofline leg): when on, every kernel
  * launch of forward() is bracketed by two HIP events recorded on the launch stream;
  * profile_collect() waits for them and returns, per kernel family (profile_category_name), the
