@@ -13,7 +13,8 @@ scores).  Alerts are independent, so N GPUs run N replicas on N different shards
 collective: scaling is "weak", value = N * 1024 * K / max-over-ranks time.
 
 Extra objects on the line:
-  roofline      the pointwise-conv MFMA kernel (gemm_kernel<.., GELU>, fc1 of every block):
+  roofline      the pointwise-conv MFMA kernel family with the largest device time (the fused
+                fc1->GELU->fc2 kernel of stages 0-1, or the fc1 / fc2 GEMMs of stages 2-3):
                 algorithmic FLOP per launch / mean launch time measured with HIP events on the
                 launch stream (a second, event-bracketed pass over the same K steps), against the
                 2.5 PFLOP/s dense bf16 MFMA peak.  `kernels` lists every kernel family the same way.
@@ -69,20 +70,30 @@ def seeded_weights(model, seed=3):
     model.mark_weights_dirty()
 
 
-def family_work(batch, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512), esz=2):
+def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512)):
     """Algorithmic FLOP and compulsory HBM bytes per forward of `batch` alerts, per kernel family
-    (DESIGN.md 'Kernels')."""
+    (DESIGN.md 'Kernels').  In the 16-bit modes the blocks of the stages with
+    C in {64,128} run the fused MLP kernel, the others the fc1 / fc2 GEMM pair."""
+    esz = 4 if precision == "f32" else 2
+    st = list(zip(depths, STAGE_P, dims))
+    fused = [precision != "f32" and c in (64, 128) for _, _, c in st]
+    pw = lambda d, p, c: d * 2 * batch * p * c * 4 * c          # one of the two 1x1 convs
     w = {}
-    fc = sum(d * 2 * batch * p * c * 4 * c for d, p, c in zip(depths, STAGE_P, dims))
-    w["gemm_kernel<fc1,GELU>"] = dict(flop=fc, bytes=sum(
-        d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
-        for d, p, c in zip(depths, STAGE_P, dims)))
-    w["gemm_kernel<fc2,RESID>"] = dict(flop=fc, bytes=sum(
-        d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
-        for d, p, c in zip(depths, STAGE_P, dims)))
+    w["fused_mlp_kernel"] = dict(
+        flop=sum(2 * pw(d, p, c) for (d, p, c), f in zip(st, fused) if f),
+        bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
+                  for (d, p, c), f in zip(st, fused) if f))
+    w["gemm_kernel<fc1,GELU>"] = dict(
+        flop=sum(pw(d, p, c) for (d, p, c), f in zip(st, fused) if not f),
+        bytes=sum(d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
+                  for (d, p, c), f in zip(st, fused) if not f))
+    w["gemm_kernel<fc2,RESID>"] = dict(
+        flop=sum(pw(d, p, c) for (d, p, c), f in zip(st, fused) if not f),
+        bytes=sum(d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
+                  for (d, p, c), f in zip(st, fused) if not f))
     w["dwconv_ln_kernel"] = dict(
-        flop=sum(d * 2 * 49 * batch * p * c for d, p, c in zip(depths, STAGE_P, dims)),
-        bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in zip(depths, STAGE_P, dims)))
+        flop=sum(d * 2 * 49 * batch * p * c for d, p, c in st),
+        bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in st))
     w["gemm_kernel<down,BIAS>"] = dict(
         flop=sum(2 * batch * STAGE_P[i] * 4 * dims[i - 1] * dims[i] for i in (1, 2, 3)),
         bytes=sum(batch * STAGE_P[i] * (4 * dims[i - 1] * esz + dims[i] * 4) for i in (1, 2, 3)))
@@ -93,6 +104,9 @@ def family_work(batch, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512), esz=2):
     w["head_kernel"] = dict(flop=2 * batch * (25 * 128 + 128 * 128 + 640 * 128 + 128 * 32 + 32),
                             bytes=batch * (dims[3] * 4 + 25 * 4 + 8))
     return w
+
+
+POINTWISE = ("fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
 
 
 def cpu_baseline(sample_batch=256, budget_s=20.0):
@@ -189,8 +203,7 @@ def main():
     model.set_profile(False)
 
     if rank == 0:
-        esz = 4 if args.precision == "f32" else 2
-        work = family_work(args.batch, esz=esz)
+        work = family_work(args.batch, args.precision)
         kernels = {}
         for name, (ms, n) in prof.items():
             if n == 0:
@@ -202,7 +215,8 @@ def main():
                 ms_per_step=round(per_fwd_ms, 4),
                 tflops=round(wk["flop"] / (per_fwd_ms * 1e-3) / 1e12, 2),
                 gbs=round(wk["bytes"] / (per_fwd_ms * 1e-3) / 1e9, 1))
-        dom = "gemm_kernel<fc1,GELU>"
+        # the pointwise-conv kernel family that takes the most device time
+        dom = max((k for k in POINTWISE if prof.get(k, (0, 0))[1] > 0), key=lambda k: prof[k][0])
         ms, n = prof[dom]
         flop_per_launch = work[dom]["flop"] * args.steps / n
         achieved = flop_per_launch / (ms / n * 1e-3) / 1e12

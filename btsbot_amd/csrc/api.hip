@@ -1,6 +1,7 @@
 // C ABI of libbtsbot_hip.so: handle, parameter table, weight packing and the forward schedule.
 // See include/btsbot_hip.h for the contract and the reference code each entry point replaces.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -38,7 +39,8 @@ struct ParamRec {
 
 struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
-  size_t p_dw, p_fc1, p_fc2;
+  size_t p_dw, p_fc1, p_fc2, p_fused;
+  bool fused;
 };
 struct DownPk {
   int64_t ln_w, ln_b, w, b;
@@ -47,10 +49,10 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, NCAT };
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
-                                     "head_kernel"};
+                                     "head_kernel", "fused_mlp_kernel"};
 constexpr size_t PROF_MAX_LAUNCHES = 8192;
 
 }  // namespace
@@ -89,6 +91,7 @@ struct btsbot_ctx {
   std::vector<int> prof_cat;
   size_t prof_used = 0;
 
+  bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
   bool debug = false;
   float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int last_chunk = 0;
@@ -164,6 +167,8 @@ int build_tables(btsbot_ctx* h) {
         b.p_dw = bump(cur, (size_t)49 * ch * 4);
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
+        b.fused = fused_mlp_supported(c.precision, ch);
+        b.p_fused = b.fused ? bump(cur, fused_mlp_packed_bytes(ch)) : 0;
         h->blocks[i].push_back(b);
       }
     }
@@ -293,6 +298,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->comb_dims[3] = 1;
   }
   build_tables(h);
+  const char* nf = getenv("BTSBOT_AMD_NO_FUSED_MLP");
+  h->use_fused = !(nf != nullptr && nf[0] == '1');
   *out = h;
   return BTSBOT_OK;
 }
@@ -359,6 +366,9 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                                  st));
         TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
+        if (b.fused)
+          TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
+                                    h->extra + b.p_fused, st));
       }
     }
   }
@@ -514,6 +524,13 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
                                   reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                   m + b.ln_w, m + b.ln_b, xn, nb, hw, ch, st);
         }));
+        if (b.fused && h->use_fused) {
+          TRY(timed(h, CAT_FUSED, st, [&] {
+            return launch_fused_mlp(c.precision, ch, xn, h->extra + b.p_fused, m + b.fc1_b,
+                                    m + b.fc2_b, m + b.gamma, x, rows, st);
+          }));
+          continue;
+        }
         TRY(timed(h, CAT_FC1, st, [&] {
           return launch_gemm(c.precision, EPI_GELU, xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
                              nullptr, hb, rows, 4 * ch, ch, st);

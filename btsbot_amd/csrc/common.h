@@ -112,6 +112,14 @@ int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bd
 int launch_ln_patch(int prec, const float* x, const float* lnw, const float* lnb, void* patches,
                     int B, int HW, int Cin, hipStream_t st);
 
+// fused fc1 -> GELU -> fc2 -> layer-scale -> residual (fused_mlp.hip); 16-bit modes, C in {64,128}
+bool fused_mlp_supported(int prec, int C);
+size_t fused_mlp_packed_bytes(int C);
+int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, void* dst,
+                          hipStream_t st);
+int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
+                     const float* b2, const float* gamma, float* x, int M, hipStream_t st);
+
 struct HeadArgs {
   // image feature part
   const float* feat;  // [B, feat_dim] fp32 (final 1x1 map), or nullptr
