@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int XCH = TM * 8 / 256, WCH = TN * 8 / 256;
   constexpr int KSTEPS = 128 / MM::KSTEP_BYTES;
-  static_assert(WM * WN == 4 && XCH >= 1 && WCH >= 1, "tile/wave layout");
+  static_assert(WM * WN == 4 && XCH >= 1 && WCH >= 1 && MI >= 1 && NI >= 1, "tile/wave layout");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[(TM + TN) * LDS_STRIDE];
   unsigned char* Xs = smem;
@@ -171,22 +171,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
   }
 }
 
+template <typename T, int TM, int TN, int WM, int WN, int EPI>
+int launch_tile(const T* x, const T* w, const float* bias, const float* gamma, const float* resid,
+                void* out, int M, int N, int K, hipStream_t st) {
+  dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_kernel<T, TM, TN, WM, WN, EPI>), grid, dim3(256), 0, st, x, w, bias,
+                     gamma, resid, out, M, N, K);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// Tile choice: the largest tile that still gives the 256 CUs a few workgroups each.  The skinny
+// late-stage GEMMs (M = 1024..9216) would run on 32..144 CUs with 128x128 tiles and are
+// latency-bound there; 64x64 tiles trade LDS traffic per MFMA for 4x the workgroups.
 template <typename T, int EPI>
 int launch_typed(const void* X, const void* W, const float* bias, const float* gamma,
                  const float* resid, void* out, int M, int N, int K, hipStream_t st) {
   const T* x = reinterpret_cast<const T*>(X);
   const T* w = reinterpret_cast<const T*>(W);
-  if (N >= 128) {
-    dim3 grid((M + 127) / 128, (N + 127) / 128);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, EPI>), grid, dim3(256), 0, st, x, w, bias,
-                       gamma, resid, out, M, N, K);
-  } else {
-    dim3 grid((M + 127) / 128, (N + 63) / 64);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 4, 1, EPI>), grid, dim3(256), 0, st, x, w, bias,
-                       gamma, resid, out, M, N, K);
-  }
-  LAUNCH_CHECK();
-  return BTSBOT_OK;
+  const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long wg12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+  if (N >= 128 && wg128 >= 512)
+    return launch_tile<T, 128, 128, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
+  if (wg12864 >= 512 || N < 64)
+    return launch_tile<T, 128, 64, 4, 1, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
+  return launch_tile<T, 64, 64, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
 }
 
 template <typename T>
