@@ -97,6 +97,12 @@ int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bi
                 const float* gamma, const float* resid, void* out, int M, int N, int K,
                 hipStream_t st);
 
+// pipelined LDS-DMA variant for the 16-bit modes (gemm2.hip); launch_gemm dispatches to it
+bool gemm2_supported(int prec, int M, int N, int K);
+int launch_gemm2(int prec, int epi, const void* X, const void* W, const float* bias,
+                 const float* gamma, const float* resid, void* out, int M, int N, int K,
+                 hipStream_t st);
+
 // stem: conv 4x4 s4 (+bias) + LayerNorm over C0.  img [B,3,63,63] fp32 -> out [B,225,C0] fp32.
 int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
                 const float* lnb, float* out, int B, int C0, hipStream_t st);

@@ -13,6 +13,8 @@
 // operand and the activation rows the B operand, so each lane ends up with 4 CONSECUTIVE output
 // channels of one pixel (C/D layout: col = lane&15 -> pixel, row = 4*(lane>>4)+r -> channel) and
 // the epilogue writes 8/16-byte vectors.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -225,6 +227,12 @@ int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bi
     btsbot_set_error("launch_gemm: grid too large (M=%d N=%d)", M, N);
     return BTSBOT_ERR_INVALID_ARG;
   }
+  static const bool v1_only = [] {
+    const char* e = getenv("BTSBOT_AMD_GEMM_V1");   // A/B switch for timing
+    return e != nullptr && e[0] == '1';
+  }();
+  if (!v1_only && gemm2_supported(prec, M, N, K))
+    return launch_gemm2(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   switch (prec) {
     case BTSBOT_F32: return launch_epi<float>(epi, X, W, bias, gamma, resid, out, M, N, K, st);
     case BTSBOT_BF16: return launch_epi<bf16_t>(epi, X, W, bias, gamma, resid, out, M, N, K, st);

@@ -1,0 +1,236 @@
+// Pipelined MFMA GEMM for the 16-bit modes (gfx950), same contract as gemm.hip:
+//
+//   out[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] ),   K % 64 == 0
+//
+// What is different from gemm.hip (which stays as the fp32 / ragged-K path):
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a
+//     3-slot ring; two k-tiles are in flight while one is consumed, ONE raw s_barrier per k-tile,
+//     counted s_waitcnt vmcnt (never 0 in the loop);
+//   * the LDS image is linear (what LDS-DMA requires); bank conflicts are removed by an XOR swizzle
+//     applied to the per-lane SOURCE address and again on the fragment read:
+//         16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7);
+//   * the epilogue is staged through the (then idle) ring so that HBM sees whole rows: 16-byte
+//     vectors, 256..512 contiguous bytes per output row instead of 8-byte pieces.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T> struct Mma2;
+template <> struct Mma2<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma2<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
+                                                    const T* __restrict__ W,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ gamma,
+                                                    const float* resid, void* out, int M, int N,
+                                                    int K) {
+  using MM = Mma2<T>;
+  using frag = typename MM::frag;
+  constexpr int ROWB = 128;                       // bytes per staged row (64 elements)
+  constexpr int SLOT = (TM + TN) * ROWB;          // one ring slot
+  constexpr int WTM = TM / WM, WTN = TN / WN;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int XB = TM / 8 / 4, WB = TN / 8 / 4; // 8-row blocks per wave per tile
+  constexpr int LPT = XB + WB;                    // LDS-DMA instructions per thread per k-tile
+  using OT = typename std::conditional<EPI == EPI_GELU, T, float>::type;
+  constexpr int OPITCH = TN * (int)sizeof(OT) + 16;  // epilogue staging row pitch
+  static_assert(TM * OPITCH <= 3 * SLOT, "epilogue tile must fit in the ring");
+  static_assert(WM * WN == 4 && XB >= 1 && WB >= 1, "tile/wave layout");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+
+  // ---- per-lane source pointers of this wave's LDS-DMA pieces (k advances by 128 B per tile)
+  const int prow = lane >> 3, ppos = lane & 7;
+  const unsigned char* src[LPT];
+  int dsto[LPT];  // wave-uniform LDS byte offset of each 1-KiB piece inside a slot
+#pragma unroll
+  for (int i = 0; i < XB; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    const int gr = min(m0 + row, M - 1);
+    src[i] = reinterpret_cast<const unsigned char*>(X + (size_t)gr * K) +
+             ((ppos ^ ((row >> 1) & 7)) << 4);
+    dsto[i] = (wave + 4 * i) * 8 * ROWB;
+  }
+#pragma unroll
+  for (int i = 0; i < WB; ++i) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    const int gr = min(n0 + row, N - 1);
+    src[XB + i] = reinterpret_cast<const unsigned char*>(W + (size_t)gr * K) +
+                  ((ppos ^ ((row >> 1) & 7)) << 4);
+    dsto[XB + i] = TM * ROWB + (wave + 4 * i) * 8 * ROWB;
+  }
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)kt * ROWB),
+                                       (lptr_t)(smem + slot * SLOT + dsto[i]), 16, 0, 0);
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  const int lrow = lane & 15, lq = lane >> 4;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed for this wave once at most one younger tile is outstanding
+    if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // ... for every wave; and everyone is done reading slot (kt-1)%3
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    const unsigned char* xs = smem + (kt % 3) * SLOT;
+    const unsigned char* ws = xs + TM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag bfr[MI], afr[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int r = wm * WTM + mi * 16 + lrow;
+        bfr[mi] = *reinterpret_cast<const frag*>(xs + r * ROWB +
+                                                 (((ks * 4 + lq) ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int r = wn * WTN + ni * 16 + lrow;
+        afr[ni] = *reinterpret_cast<const frag*>(ws + r * ROWB +
+                                                 (((ks * 4 + lq) ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MM::run(afr[ni], bfr[mi], acc[ni][mi]);
+    }
+  }
+  __syncthreads();  // ring is idle from here on (no LDS-DMA in flight: last wait was vmcnt(0))
+
+  // ---- epilogue stage 1: registers -> LDS tile [TM][TN] of OT (lane owns 4 consecutive n)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int nl = wn * WTN + ni * 16 + lq * 4;
+    const int n = min(n0 + nl, N - 4);
+    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+    float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_RESID) gv = *reinterpret_cast<const float4*>(gamma + n);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ml = wm * WTM + mi * 16 + lrow;
+      const f32x4 a = acc[ni][mi];
+      unsigned char* dst = smem + ml * OPITCH + nl * (int)sizeof(OT);
+      if (EPI == EPI_GELU) {
+        typedef T __attribute__((ext_vector_type(4))) T4;
+        T4 v;
+        v[0] = (T)gelu_fast(a[0] + bv.x);
+        v[1] = (T)gelu_fast(a[1] + bv.y);
+        v[2] = (T)gelu_fast(a[2] + bv.z);
+        v[3] = (T)gelu_fast(a[3] + bv.w);
+        *reinterpret_cast<T4*>(dst) = v;
+      } else {
+        *reinterpret_cast<float4*>(dst) =
+            make_float4(gv.x * (a[0] + bv.x), gv.y * (a[1] + bv.y), gv.z * (a[2] + bv.z),
+                        gv.w * (a[3] + bv.w));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue stage 2: whole rows LDS -> HBM, 16 bytes per lane
+  constexpr int CPR = TN * (int)sizeof(OT) / 16;   // 16-byte chunks per row
+  constexpr int EPC = 16 / (int)sizeof(OT);        // elements per chunk
+  for (int i = tid; i < TM * CPR; i += 256) {
+    const int ml = i / CPR, ch = i - ml * CPR;
+    const int m = m0 + ml, n = n0 + ch * EPC;
+    if (m >= M || n >= N) continue;
+    uint4 v = *reinterpret_cast<const uint4*>(smem + ml * OPITCH + ch * 16);
+    const size_t o = (size_t)m * N + n;
+    if (EPI == EPI_RESID) {
+      const float4 r = *reinterpret_cast<const float4*>(resid + o);
+      float4 f = *reinterpret_cast<float4*>(&v);
+      f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = f;
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<OT*>(out) + o) = v;
+    }
+  }
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int EPI>
+int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
+                 const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+  constexpr size_t lds = 3 * (size_t)(TM + TN) * 128;
+  auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, bias, gamma, resid, out, M, N, K);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+template <typename T, int EPI>
+int launch_typed2(const void* X, const void* W, const float* bias, const float* gamma,
+                  const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+  const T* x = reinterpret_cast<const T*>(X);
+  const T* w = reinterpret_cast<const T*>(W);
+  const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (N >= 128 && wg128 >= 256)
+    return launch_tile2<T, 128, 128, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
+  return launch_tile2<T, 64, 64, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
+}
+
+template <typename T>
+int launch_epi2(int epi, const void* X, const void* W, const float* bias, const float* gamma,
+                const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+  switch (epi) {
+    case EPI_GELU: return launch_typed2<T, EPI_GELU>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_RESID: return launch_typed2<T, EPI_RESID>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_BIAS: return launch_typed2<T, EPI_BIAS>(X, W, bias, gamma, resid, out, M, N, K, st);
+  }
+  btsbot_set_error("launch_gemm2: bad epilogue %d", epi);
+  return BTSBOT_ERR_INVALID_ARG;
+}
+
+}  // namespace
+
+bool gemm2_supported(int prec, int M, int N, int K) {
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && K % 64 == 0 && N % 64 == 0 && N >= 64 &&
+         M >= 1;
+}
+
+int launch_gemm2(int prec, int epi, const void* X, const void* W, const float* bias,
+                 const float* gamma, const float* resid, void* out, int M, int N, int K,
+                 hipStream_t st) {
+  if (prec == BTSBOT_BF16)
+    return launch_epi2<bf16_t>(epi, X, W, bias, gamma, resid, out, M, N, K, st);
+  return launch_epi2<f16_t>(epi, X, W, bias, gamma, resid, out, M, N, K, st);
+}
