@@ -4,8 +4,9 @@
 //
 // What is different from gemm.hip (which stays as the fp32 / ragged-K path):
 //   * operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a
-//     3-slot ring; two k-tiles are in flight while one is consumed, ONE raw s_barrier per k-tile,
-//     counted s_waitcnt vmcnt (never 0 in the loop);
+//     2- or 3-slot ring (128x128 tiles: 2 slots = 64 KB so two workgroups share a CU; 64x64 tiles:
+//     3 slots, two k-tiles in flight while one is consumed), ONE raw s_barrier per k-tile, counted
+//     s_waitcnt vmcnt;
 //   * the LDS image is linear (what LDS-DMA requires); bank conflicts are removed by an XOR swizzle
 //     applied to the per-lane SOURCE address and again on the fragment read:
 //         16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7);
@@ -38,7 +39,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int EPI>
+template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
 __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
                                                     const T* __restrict__ W,
                                                     const float* __restrict__ bias,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   constexpr int LPT = XB + WB;                    // LDS-DMA instructions per thread per k-tile
   using OT = typename std::conditional<EPI == EPI_GELU, T, float>::type;
   constexpr int OPITCH = TN * (int)sizeof(OT) + 16;  // epilogue staging row pitch
-  static_assert(TM * OPITCH <= 3 * SLOT, "epilogue tile must fit in the ring");
+    static_assert(NSLOT == 2 || NSLOT == 3, "ring depth");
   static_assert(WM * WN == 4 && XB >= 1 && WB >= 1, "tile/wave layout");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,14 +100,15 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
 
   const int nk = K / 64;
   const int lrow = lane & 15, lq = lane >> 4;
+  // NSLOT-1 k-tiles are in flight while one is consumed
   issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  if (NSLOT == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed for this wave once at most one younger tile is outstanding
-    if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // ... for every wave; and everyone is done reading slot (kt-1)%3
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-    const unsigned char* xs = smem + (kt % 3) * SLOT;
+    // tile kt has landed for this wave once only the younger tiles are outstanding
+    if (NSLOT == 3 && kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // ... for every wave; and everyone is done reading tile kt-1
+    if (kt + NSLOT - 1 < nk) issue(kt + NSLOT - 1, (kt + NSLOT - 1) % NSLOT);
+    const unsigned char* xs = smem + (kt % NSLOT) * SLOT;
     const unsigned char* ws = xs + TM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -180,11 +182,13 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   }
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int EPI>
+template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
 int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                  const float* resid, void* out, int M, int N, int K, hipStream_t st) {
-  constexpr size_t lds = 3 * (size_t)(TM + TN) * 128;
-  auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI>;
+  constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
+  constexpr size_t otile = (size_t)TM * (TN * (EPI == EPI_GELU ? sizeof(T) : sizeof(float)) + 16);
+  constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
+  auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -204,8 +208,8 @@ int launch_typed2(const void* X, const void* W, const float* bias, const float* 
   const T* w = reinterpret_cast<const T*>(W);
   const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (N >= 128 && wg128 >= 256)
-    return launch_tile2<T, 128, 128, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
-  return launch_tile2<T, 64, 64, 2, 2, EPI>(x, w, bias, gamma, resid, out, M, N, K, st);
+    return launch_tile2<T, 128, 128, 2, 2, EPI, 2>(x, w, bias, gamma, resid, out, M, N, K, st);
+  return launch_tile2<T, 64, 64, 2, 2, EPI, 3>(x, w, bias, gamma, resid, out, M, N, K, st);
 }
 
 template <typename T>

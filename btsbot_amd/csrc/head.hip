@@ -14,15 +14,16 @@ constexpr int HG = 8;     // alerts per workgroup
 constexpr int HNT = 256;  // threads
 constexpr float HN_EPS = 1e-6f;
 
-// out[g][n] = act(bias[n] + sum_k in[g][k] * wt[k][n]) for the workgroup's HG alerts.
-// wt is K-major so consecutive threads (n) read consecutive addresses; in[][] is an LDS broadcast.
-// The 256 threads cover min(N,256) neurons x KS slices of K (KS = 256 / N): every thread keeps 8
-// weight loads in flight (unrolled), partial sums meet in LDS (`part`, [KS][HG][N]).
-__device__ __forceinline__ void dense(const float* in, int ldin, int K, const float* __restrict__ wt,
+// Activations of the workgroup's HG alerts live in LDS k-major: v[k][g] (8 alerts = two float4),
+// so one thread reads all alerts of a k with two ds_read_b128 broadcasts.
+// out[n][g] = act(bias[n] + sum_k in[k][g] * wt[k][n]); wt is K-major so consecutive threads (n)
+// read consecutive addresses.  The 256 threads cover min(N,256) neurons x KS slices of K
+// (KS = 256 / N); each keeps 8 weight loads in flight; partial sums meet in LDS (`part`).
+__device__ __forceinline__ void dense(const float* in, int K, const float* __restrict__ wt,
                                       const float* __restrict__ bias, int N, int act, float* outp,
-                                      int ldout, float* part) {
+                                      float* part) {
   int ks = 1;
-  while (ks * 2 * N <= HNT) ks *= 2;                 // power-of-two K slices
+  while (ks * 2 * N <= HNT) ks *= 2;
   const int kchunk = (K + ks - 1) / ks;
   for (int n0 = 0; n0 < N; n0 += HNT) {              // N > 256: several passes (ks == 1)
     const int n = n0 + (threadIdx.x % (N < HNT ? N : HNT));
@@ -39,51 +40,57 @@ __device__ __forceinline__ void dense(const float* in, int ldin, int K, const fl
 #pragma unroll
         for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k + u], wv[u], acc[g]);
+        for (int u = 0; u < 8; ++u) {
+          const float4 a0 = *reinterpret_cast<const float4*>(in + (k + u) * HG);
+          const float4 a1 = *reinterpret_cast<const float4*>(in + (k + u) * HG + 4);
+          acc[0] = fmaf(a0.x, wv[u], acc[0]); acc[1] = fmaf(a0.y, wv[u], acc[1]);
+          acc[2] = fmaf(a0.z, wv[u], acc[2]); acc[3] = fmaf(a0.w, wv[u], acc[3]);
+          acc[4] = fmaf(a1.x, wv[u], acc[4]); acc[5] = fmaf(a1.y, wv[u], acc[5]);
+          acc[6] = fmaf(a1.z, wv[u], acc[6]); acc[7] = fmaf(a1.w, wv[u], acc[7]);
+        }
       }
       for (; k < k1; ++k) {
         const float wv = wt[(size_t)k * N + n];
 #pragma unroll
-        for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[g * ldin + k], wv, acc[g]);
+        for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[k * HG + g], wv, acc[g]);
       }
     }
     if (ks == 1) {
       if (live) {
         const float b = bias[n];
 #pragma unroll
-        for (int g = 0; g < HG; ++g) outp[g * ldout + n] = apply_act(acc[g] + b, act);
+        for (int g = 0; g < HG; ++g) outp[n * HG + g] = apply_act(acc[g] + b, act);
       }
     } else {
       if (live) {
 #pragma unroll
-        for (int g = 0; g < HG; ++g) part[(slice * HG + g) * N + n] = acc[g];
+        for (int g = 0; g < HG; ++g) part[(slice * N + n) * HG + g] = acc[g];
       }
       __syncthreads();
       for (int i = threadIdx.x; i < HG * N; i += HNT) {
-        const int g = i / N, nn = i - g * N;
+        const int nn = i / HG;
         float t = bias[nn];
-        for (int s2 = 0; s2 < ks; ++s2) t += part[(s2 * HG + g) * N + nn];
-        outp[g * ldout + nn] = apply_act(t, act);
+        for (int s2 = 0; s2 < ks; ++s2) t += part[s2 * N * HG + i];
+        outp[i] = apply_act(t, act);
       }
     }
   }
 }
 
 __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
+  static_assert(HG == 8, "dense() reads the 8 alerts of a k as two float4");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int zd = a.dims[0];
   int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
   for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
-  float* z = smem;               // [HG][zd]
-  float* t0 = z + HG * zd;       // [HG][maxw]
-  float* t1 = t0 + HG * maxw;    // [HG][maxw]
-  float* part = t1 + HG * maxw;  // [KS][HG][N], KS * N <= 256
+  float* z = smem;               // [zd][HG]
+  float* t0 = z + HG * zd;       // [maxw][HG]
+  float* t1 = t0 + HG * maxw;    // [maxw][HG]
+  float* part = t1 + HG * maxw;  // [KS][N][HG], KS * N <= 256
   const int b0 = blockIdx.x * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // ---- image feature (+ head LayerNorm) -> z[:, 0:feat_dim]
+  // ---- image feature (+ head LayerNorm) -> z[0:feat_dim][g]
   if (a.feat_dim > 0) {
     for (int g = wave; g < HG; g += HNT / 64) {
       const int b = b0 + g;
@@ -99,41 +106,39 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
         }
         const float rstd = rsqrtf(wave_sum(sq) / a.feat_dim + HN_EPS);
         for (int c = lane; c < a.feat_dim; c += 64)
-          z[g * zd + c] = (src[c] - mean) * rstd * a.hn_w[c] + a.hn_b[c];
+          z[c * HG + g] = (src[c] - mean) * rstd * a.hn_w[c] + a.hn_b[c];
       } else {
-        for (int c = lane; c < a.feat_dim; c += 64) z[g * zd + c] = src[c];
+        for (int c = lane; c < a.feat_dim; c += 64) z[c * HG + g] = src[c];
       }
     }
   }
-  // ---- metadata branch -> z[:, feat_dim : feat_dim + f2]
+  // ---- metadata branch -> z[feat_dim : feat_dim + f2][g]
   if (a.n_meta > 0) {
     for (int i = tid; i < HG * a.n_meta; i += HNT) {
       const int g = i / a.n_meta, j = i - g * a.n_meta;
       const int b = b0 + g;
       const float v = a.meta[(size_t)(b < a.B ? b : a.B - 1) * a.n_meta + j];
-      t0[g * maxw + j] = fmaf(v, a.bn_scale[j], a.bn_shift[j]);
+      t0[j * HG + g] = fmaf(v, a.bn_scale[j], a.bn_shift[j]);
     }
     __syncthreads();
-    dense(t0, maxw, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, maxw, part);
+    dense(t0, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, part);
     __syncthreads();
-    dense(t1, maxw, a.f1, a.m2_wt, a.m2_b, a.f2, a.meta_trailing_act ? a.meta_act : ACT_NONE,
-          z + a.feat_dim, zd, part);
+    dense(t1, a.f1, a.m2_wt, a.m2_b, a.f2, a.meta_trailing_act ? a.meta_act : ACT_NONE,
+          z + a.feat_dim * HG, part);
   }
   __syncthreads();
   // ---- fusion MLP
   const float* in = z;
-  int ldin = zd;
   float* bufs[2] = {t0, t1};
   for (int i = 0; i < a.n_layers; ++i) {
     float* o = bufs[i & 1];
-    dense(in, ldin, a.dims[i], a.wt[i], a.b[i], a.dims[i + 1],
-          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, maxw, part);
+    dense(in, a.dims[i], a.wt[i], a.b[i], a.dims[i + 1],
+          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, part);
     __syncthreads();
     in = o;
-    ldin = maxw;
   }
   if (tid < HG && b0 + tid < a.B) {
-    const float zz = in[tid * ldin];
+    const float zz = in[tid];
     a.logits[b0 + tid] = zz;
     if (a.scores != nullptr) a.scores[b0 + tid] = 1.0f / (1.0f + expf(-zz));
   }
