@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "stage0.h"
 
 // ---------------------------------------------------------------------------------------
 // errors
@@ -49,10 +50,10 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, NCAT };
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
-                                     "head_kernel", "fused_mlp_kernel"};
+                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel"};
 constexpr size_t PROF_MAX_LAUNCHES = 8192;
 
 }  // namespace
@@ -73,7 +74,8 @@ struct btsbot_ctx {
   DownPk down[4];
   int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
   int64_t comb_w[3], comb_b[3];
-  size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift;
+  size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift, p_stem16 = 0;
+  bool stage0 = false;     // stem + stage 0 + first downsample as one kernel
 
   // device memory
   float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
@@ -92,6 +94,7 @@ struct btsbot_ctx {
   size_t prof_used = 0;
 
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
+  bool use_stage0 = true;  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
   bool debug = false;
   float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int last_chunk = 0;
@@ -138,6 +141,8 @@ int build_tables(btsbot_ctx* h) {
     h->stem_b = add_param(h, "stem.0.bias", {c0});
     h->stem_lnw = add_param(h, "stem.1.weight", {c0});
     h->stem_lnb = add_param(h, "stem.1.bias", {c0});
+    h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
+    if (h->stage0) h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
@@ -300,6 +305,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   build_tables(h);
   const char* nf = getenv("BTSBOT_AMD_NO_FUSED_MLP");
   h->use_fused = !(nf != nullptr && nf[0] == '1');
+  const char* ns = getenv("BTSBOT_AMD_NO_STAGE0");
+  h->use_stage0 = !(ns != nullptr && ns[0] == '1');
   *out = h;
   return BTSBOT_OK;
 }
@@ -356,6 +363,9 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                          st));
   const float* m = h->mirror;
   if (h->has_image) {
+    if (h->stage0)
+      TRY(launch_cast(c.precision, m + h->stem_w, h->extra + h->p_stem16, (int64_t)c.dims[0] * 48,
+                      st));
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
       if (i > 0)
@@ -495,16 +505,47 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
   void* xn = h->ws + h->o_xn;
   void* hb = h->ws + h->o_h;
   if (h->has_image) {
-    TRY(timed(h, CAT_STEM, st, [&] {
-      return launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x, nb,
-                         c.dims[0], st);
-    }));
-    if (h->debug)
-      HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)nb * 225 * c.dims[0] * 4,
-                             hipMemcpyDeviceToDevice, st));
-    for (int i = 0; i < 4; ++i) {
+    const bool s0 = h->stage0 && h->use_stage0;
+    if (s0) {
+      Stage0Args a;
+      memset(&a, 0, sizeof(a));
+      a.img = img;
+      a.stem_w = h->extra + h->p_stem16;
+      a.stem_b = m + h->stem_b;
+      a.stem_lnw = m + h->stem_lnw;
+      a.stem_lnb = m + h->stem_lnb;
+      for (int j = 0; j < 2; ++j) {
+        const BlockPk& b = h->blocks[0][j];
+        a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+        a.blk[j].dw_b = m + b.dw_b;
+        a.blk[j].ln_w = m + b.ln_w;
+        a.blk[j].ln_b = m + b.ln_b;
+        a.blk[j].wpk = h->extra + b.p_fused;
+        a.blk[j].b1 = m + b.fc1_b;
+        a.blk[j].b2 = m + b.fc2_b;
+        a.blk[j].gamma = m + b.gamma;
+      }
+      a.ds_lnw = m + h->down[1].ln_w;
+      a.ds_lnb = m + h->down[1].ln_b;
+      a.ds_w = h->extra + h->down[1].p_w;
+      a.ds_b = m + h->down[1].b;
+      a.out = x;
+      a.tap_stem = h->debug ? h->taps[0] : nullptr;
+      a.tap_stage = h->debug ? h->taps[1] : nullptr;
+      a.B = nb;
+      TRY(timed(h, CAT_STAGE0, st, [&] { return launch_stage0(c.precision, a, st); }));
+    } else {
+      TRY(timed(h, CAT_STEM, st, [&] {
+        return launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x,
+                           nb, c.dims[0], st);
+      }));
+      if (h->debug)
+        HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)nb * 225 * c.dims[0] * 4,
+                               hipMemcpyDeviceToDevice, st));
+    }
+    for (int i = s0 ? 1 : 0; i < 4; ++i) {
       const int ch = c.dims[i], hw = STAGE_HW[i], rows = nb * hw * hw;
-      if (i > 0) {
+      if (i > 0 && !(s0 && i == 1)) {
         const int cin = c.dims[i - 1];
         TRY(timed(h, CAT_LNPATCH, st, [&] {
           return launch_ln_patch(c.precision, x, m + h->down[i].ln_w, m + h->down[i].ln_b, xn, nb,
@@ -542,7 +583,7 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
       }
       if (h->debug)
         HIP_TRY(hipMemcpyAsync(h->taps[i + 1], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice,
-                               st));
+                               st));   // (stage 0's tap is written by the megakernel when fused)
     }
   }
   HeadArgs a;

@@ -126,6 +126,11 @@ int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, voi
 int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
                      const float* b2, const float* gamma, float* x, int M, hipStream_t st);
 
+// stage-0 megakernel (stage0.hip): stem + 2 blocks + downsample in one launch, 16-bit modes, C0 = 64
+struct Stage0Args;
+bool stage0_supported(int prec, int c0);
+int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
+
 struct HeadArgs {
   // image feature part
   const float* feat;  // [B, feat_dim] fp32 (final 1x1 map), or nullptr

@@ -116,8 +116,8 @@ __global__ __launch_bounds__(NW * 64) void dwconv_ln_kernel(
             if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[ky * 7 + kx], acc[xx]);
           }
         }
-        // keep hipcc from hoisting all 7 rows' LDS reads to the top (105 live registers -> spills)
-        __builtin_amdgcn_sched_barrier(0);
+        // compiler fence: keeps hipcc from hoisting all 7 rows' LDS reads (105 live registers)
+        asm volatile("" ::: "memory");
       }
     }
     // ---- LayerNorm over C for each of the row's HW pixels

@@ -35,10 +35,18 @@ __device__ __forceinline__ void dense(const float* in, int K, const float* __res
     if (live) {
       const int k0 = slice * kchunk, k1 = min(K, k0 + kchunk);
       int k = k0;
-      for (; k + 8 <= k1; k += 8) {
-        float wv[8];
+      // groups of 8 k: the next group's weights are in flight while this group is consumed
+      float wv[8], wn[8];
+      const int ngrp = (k1 - k0) / 8;
+      if (ngrp > 0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
+      }
+      for (int gi = 0; gi < ngrp; ++gi, k += 8) {
+        if (gi + 1 < ngrp) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wn[u] = wt[(size_t)(k + 8 + u) * N + n];
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const float4 a0 = *reinterpret_cast<const float4*>(in + (k + u) * HG);
@@ -48,6 +56,8 @@ __device__ __forceinline__ void dense(const float* in, int K, const float* __res
           acc[4] = fmaf(a1.x, wv[u], acc[4]); acc[5] = fmaf(a1.y, wv[u], acc[5]);
           acc[6] = fmaf(a1.z, wv[u], acc[6]); acc[7] = fmaf(a1.w, wv[u], acc[7]);
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = wn[u];
       }
       for (; k < k1; ++k) {
         const float wv = wt[(size_t)k * N + n];

@@ -1,0 +1,30 @@
+// Argument block of the stage-0 megakernel (stage0.hip).
+#pragma once
+
+struct Stage0Blk {
+  const float* dw_w;   // [49][64] tap-major
+  const float* dw_b;
+  const float* ln_w;
+  const float* ln_b;
+  const unsigned char* wpk;   // fused_mlp packed image (FusedGeom<64>)
+  const float* b1;
+  const float* b2;
+  const float* gamma;
+};
+struct Stage0Args {
+  const float* img;       // [B][3][63][63]
+  const void* stem_w;     // [64][48] 16-bit
+  const float* stem_b;
+  const float* stem_lnw;
+  const float* stem_lnb;
+  Stage0Blk blk[2];
+  const float* ds_lnw;
+  const float* ds_lnb;
+  const void* ds_w;       // [128][256] 16-bit, k = (ky*2+kx)*64 + c
+  const float* ds_b;
+  float* out;             // [B][49][128] f32
+  float* tap_stem;        // optional [B][225][64] f32 copies (validation)
+  float* tap_stage;
+  int B;
+};
+
