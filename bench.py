@@ -76,37 +76,49 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     C in {64,128} run the fused MLP kernel, the others the fc1 / fc2 GEMM pair."""
     esz = 4 if precision == "f32" else 2
     st = list(zip(depths, STAGE_P, dims))
-    fused = [precision != "f32" and c in (64, 128) for _, _, c in st]
+    s0 = precision != "f32" and dims[0] == 64 and depths[0] == 2      # stage-0 megakernel
+    fused = [precision != "f32" and c in (64, 128) and not (s0 and i == 0)
+             for i, (_, _, c) in enumerate(st)]
     pw = lambda d, p, c: d * 2 * batch * p * c * 4 * c          # one of the two 1x1 convs
     w = {}
+    stem_flop = 2 * batch * 225 * 48 * dims[0]
+    down_flop = lambda i: 2 * batch * STAGE_P[i] * 4 * dims[i - 1] * dims[i]
+    # MFMA-executed algorithmic FLOP only (stem, 2 x (fc1 + fc2), downsample); the depthwise conv
+    # (2 x 2*49*225*64 FLOP per alert, VALU) is not counted against the MFMA roofline
+    w["stage0_kernel"] = dict(
+        flop=(stem_flop + 2 * pw(*st[0]) + down_flop(1)) if s0 else 0,
+        bytes=batch * (3 * 63 * 63 * 4 + 49 * dims[1] * 4))
     w["fused_mlp_kernel"] = dict(
         flop=sum(2 * pw(d, p, c) for (d, p, c), f in zip(st, fused) if f),
         bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
                   for (d, p, c), f in zip(st, fused) if f))
+    unf = [not f and not (s0 and i == 0) for i, f in enumerate(fused)]
     w["gemm_kernel<fc1,GELU>"] = dict(
-        flop=sum(pw(d, p, c) for (d, p, c), f in zip(st, fused) if not f),
+        flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
         bytes=sum(d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
-                  for (d, p, c), f in zip(st, fused) if not f))
+                  for (d, p, c), u in zip(st, unf) if u))
     w["gemm_kernel<fc2,RESID>"] = dict(
-        flop=sum(pw(d, p, c) for (d, p, c), f in zip(st, fused) if not f),
+        flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
         bytes=sum(d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
-                  for (d, p, c), f in zip(st, fused) if not f))
+                  for (d, p, c), u in zip(st, unf) if u))
+    dwst = [(d, p, c) for i, (d, p, c) in enumerate(st) if not (s0 and i == 0)]
     w["dwconv_ln_kernel"] = dict(
-        flop=sum(d * 2 * 49 * batch * p * c for d, p, c in st),
-        bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in st))
+        flop=sum(d * 2 * 49 * batch * p * c for d, p, c in dwst),
+        bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in dwst))
+    dn = [i for i in (1, 2, 3) if not (s0 and i == 1)]
     w["gemm_kernel<down,BIAS>"] = dict(
-        flop=sum(2 * batch * STAGE_P[i] * 4 * dims[i - 1] * dims[i] for i in (1, 2, 3)),
-        bytes=sum(batch * STAGE_P[i] * (4 * dims[i - 1] * esz + dims[i] * 4) for i in (1, 2, 3)))
+        flop=sum(down_flop(i) for i in dn),
+        bytes=sum(batch * STAGE_P[i] * (4 * dims[i - 1] * esz + dims[i] * 4) for i in dn))
     w["ln_patch_kernel"] = dict(
-        flop=0, bytes=sum(batch * STAGE_P[i] * 4 * dims[i - 1] * (4 + esz) for i in (1, 2, 3)))
-    w["stem_kernel"] = dict(flop=2 * batch * 225 * 48 * dims[0],
+        flop=0, bytes=sum(batch * STAGE_P[i] * 4 * dims[i - 1] * (4 + esz) for i in dn))
+    w["stem_kernel"] = dict(flop=stem_flop,
                             bytes=batch * (3 * 63 * 63 * 4 + 225 * dims[0] * 4))
     w["head_kernel"] = dict(flop=2 * batch * (25 * 128 + 128 * 128 + 640 * 128 + 128 * 32 + 32),
                             bytes=batch * (dims[3] * 4 + 25 * 4 + 8))
     return w
 
 
-POINTWISE = ("fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
+POINTWISE = ("stage0_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
 
 
 def cpu_baseline(sample_batch=256, budget_s=20.0):
