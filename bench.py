@@ -205,7 +205,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    assert torch.isfinite(out).all()
+    if not os.environ.get("BTSBOT_AMD_S0_DIAG"):
+        assert torch.isfinite(out).all()
 
     # ---- roofline leg: same K steps, every launch bracketed by HIP events on the launch stream
     model.set_profile(True)

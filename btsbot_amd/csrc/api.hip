@@ -533,6 +533,10 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
       a.tap_stem = h->debug ? h->taps[0] : nullptr;
       a.tap_stage = h->debug ? h->taps[1] : nullptr;
       a.B = nb;
+      {
+        const char* dg = getenv("BTSBOT_AMD_S0_DIAG");
+        a.diag = dg != nullptr ? atoi(dg) : 0;
+      }
       TRY(timed(h, CAT_STAGE0, st, [&] { return launch_stage0(c.precision, a, st); }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {

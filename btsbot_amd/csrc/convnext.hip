@@ -116,8 +116,6 @@ __global__ __launch_bounds__(NW * 64) void dwconv_ln_kernel(
             if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[ky * 7 + kx], acc[xx]);
           }
         }
-        // compiler fence: keeps hipcc from hoisting all 7 rows' LDS reads (105 live registers)
-        asm volatile("" ::: "memory");
       }
     }
     // ---- LayerNorm over C for each of the row's HW pixels

@@ -26,5 +26,7 @@ struct Stage0Args {
   float* tap_stem;        // optional [B][225][64] f32 copies (validation)
   float* tap_stage;
   int B;
+  int diag;               // timing diagnostics only (BTSBOT_AMD_S0_DIAG): bit0 skip depthwise FMAs,
+                          // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
 };
 

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         x[ct][4 * qd + 3] = bv.w;
       }
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {     // k-step = input channel: k = ci*16 + ky*4 + kx
+    for (int ci = 0; ci < ((a.diag & 16) ? 0 : 3); ++ci) {     // k-step = input channel: k = ci*16 + ky*4 + kx
       const float* r0 = src + (ci * 63 + 4 * py + 2 * h) * 63 + 4 * px;
       const f4u v0 = *reinterpret_cast<const f4u*>(r0);
       const f4u v1 = *reinterpret_cast<const f4u*>(r0 + 63);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
     __syncthreads();   // map0 complete; previous block's filter / fc1-bias reads finished
     if (tid < 256) b1s[tid] = b1v;
     // ---- the block's pointwise filters: 76 x 1 KiB LDS-DMA pieces, wave w takes w, w+8, ...
-    for (int pc2 = wave; pc2 < WBYTES / 1024; pc2 += 8)
+    for (int pc2 = wave; pc2 < ((a.diag & 4) ? 0 : WBYTES / 1024); pc2 += 8)
       __builtin_amdgcn_global_load_lds((gptr_t)(bk.wpk + (size_t)pc2 * 1024 + lane * 16),
                                        (lptr_t)(wring + pc2 * 1024), 16, 0, 0);
 
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = (i < HW) ? bias : 0.f;
-        if (valid) {
+        if (valid && !(a.diag & 1)) {
 #pragma unroll
           for (int ky = 0; ky < 7; ++ky) {
             const int iy = y + ky - 3;
@@ -256,8 +256,6 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
                 const int ix = xx + kx - 3;
                 if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[ky * 7 + kx], acc[xx]);
               }
-            // compiler fence: keeps hipcc from hoisting all 7 rows' LDS reads (105 live registers)
-            asm volatile("" ::: "memory");
           }
         }
         // LN over the 64 channels (= the 64 lanes) of each of the row's 15 pixels; two-pass
@@ -315,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
 #pragma unroll 1
-      for (int sub = 0; sub < NSUB; ++sub) {
+      for (int sub = 0; sub < ((a.diag & 2) ? 0 : NSUB); ++sub) {
         const unsigned char* w1s = wring + sub * SUBBYTES;
         const unsigned char* w2s = w1s + 32 * W1ROW;
         f32x16 hacc;
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         }
         frag hf[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
+        for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)((a.diag & 8) ? hacc[r] : gelu_fast(hacc[r]));
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
     }
     const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(cot * 32 + lr) * 256 + h * 8;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < ((a.diag & 32) ? 0 : 16); ++ks) {
       const int q = ks >> 2;
       const int pin = (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
       const frag bf = *reinterpret_cast<const frag*>(map0 + pin * PITCH + (ks & 3) * 32 + h * 16);
