@@ -25,6 +25,7 @@ SYMBOLS = [
     "btsbot_set_profile", "btsbot_profile_categories", "btsbot_profile_category_name",
     "btsbot_profile_collect",
     "btsbot_op_gemm", "btsbot_op_dwconv_ln", "btsbot_op_stem", "btsbot_op_ln_patch",
+    "btsbot_reserve_train", "btsbot_forward_train", "btsbot_backward",
 ]
 
 
@@ -106,6 +107,12 @@ def lib() -> C.CDLL:
     L.btsbot_op_stem.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.btsbot_op_ln_patch.restype = i32
     L.btsbot_op_ln_patch.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.btsbot_reserve_train.restype = i32
+    L.btsbot_reserve_train.argtypes = [vp, i32]
+    L.btsbot_forward_train.restype = i32
+    L.btsbot_forward_train.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.btsbot_backward.restype = i32
+    L.btsbot_backward.argtypes = [vp, vp, vp, i32, i32, vp]
     L.btsbot_bce_fwd_bwd.restype = i32
     L.btsbot_bce_fwd_bwd.argtypes = [vp, vp, f32, i32, i32, vp, vp, vp]
     L.btsbot_adamw_step.restype = i32

@@ -101,6 +101,7 @@ class _HipModel(nn.Module):
         self._handle_device = None
         self._packed_version = None
         self._reserved = 0
+        self._reserved_train = 0
 
     def _build_parameters(self):
         h = self._handle
@@ -243,13 +244,11 @@ class _HipModel(nn.Module):
             self._reserved = chunk
         return L, stream
 
-    def _run(self, image: Optional[torch.Tensor], meta: Optional[torch.Tensor],
-             want_scores: bool = False):
+    def _check_inputs(self, image, meta):
         ref = image if image is not None else meta
         if ref is None:
             raise ValueError("btsbot_amd: no input tensor")
-        batch = ref.shape[0]
-        dev = ref.device
+        batch, dev = ref.shape[0], ref.device
         if image is not None:
             if image.dim() != 4 or tuple(image.shape[1:]) != (3, 63, 63):
                 raise ValueError(f"image input must be [B,3,63,63], got {tuple(image.shape)}")
@@ -264,10 +263,13 @@ class _HipModel(nn.Module):
                 "btsbot_amd: this model runs only on an AMD GPU through libbtsbot_hip.so "
                 f"(input is on {dev}); there is no CPU fallback.  Move the model and its inputs "
                 "to 'cuda'.")
+        return image, meta, batch, dev
+
+    def _run(self, image: Optional[torch.Tensor], meta: Optional[torch.Tensor],
+             want_scores: bool = False):
+        image, meta, batch, dev = self._check_inputs(image, meta)
         if self.training:
-            raise NotImplementedError(
-                "btsbot_amd: the training-mode forward (BatchNorm batch statistics, dropout, "
-                "backward) is not built yet; call .eval() for inference")
+            return self._run_train(image, meta)
         if batch == 0:
             empty = torch.empty(0, 1, dtype=torch.float32, device=dev)
             return (empty, empty.clone()) if want_scores else empty
@@ -286,6 +288,93 @@ class _HipModel(nn.Module):
         if want_scores:
             return logits, scores.view(batch, 1)
         return logits
+
+    # -- training mode ------------------------------------------------------------------------
+    def _slot_groups(self):
+        """(comb, meta, image) lists of (tensor, off, numel, shape) over the arena slots."""
+        comb, meta, image = [], [], []
+        for (canon, *_), (key, parent, leaf, off, numel, shape, is_buf), t in zip(
+                self._table_rows, self._slots, self._tensor_list()):
+            if is_buf:
+                continue
+            dest = comb if canon.startswith("comb.") else meta if canon.startswith("meta.") else image
+            dest.append((t, off, numel, shape))
+        return comb, meta, image
+
+    def _dropout_masks(self, batch: int, dev):
+        """uint8 keep-masks [B, meta_fc1] and [B, comb_fc2] drawn from torch's device RNG (or the
+        ones a test planted in ``_forced_masks``)."""
+        forced = getattr(self, "_forced_masks", None)
+        a = self._cfg_args
+        out = []
+        for name, width, p in (("meta", a["meta_fc1"], a["meta_dropout"]),
+                               ("comb", a["comb_fc2"], a["comb_dropout"])):
+            if width <= 0 or p <= 0.0:
+                out.append(None)
+            elif forced is not None and name in forced:
+                out.append(forced[name].to(device=dev, dtype=torch.uint8).contiguous())
+            else:
+                out.append((torch.rand(batch, width, device=dev) >= p).to(torch.uint8))
+        return out
+
+    def _run_train(self, image, meta):
+        """model.train() forward: BatchNorm batch statistics (+ running-stat update), dropout,
+        activations cached for backward.  Differentiable w.r.t. the fusion head and the metadata
+        branch; a trainable ConvNeXt branch is refused (not built yet)."""
+        comb, metag, imageg = self._slot_groups()
+        grad_on = torch.is_grad_enabled()
+        if grad_on and any(t.requires_grad for t, *_ in imageg):
+            raise NotImplementedError(
+                "btsbot_amd: backward through the ConvNeXt image branch is not built yet; freeze it "
+                "(requires_grad_(False)) as frozen_fusion training does (train.py:224-232), or run "
+                "under torch.no_grad()")
+        trainable = [g for g in comb + metag if g[0].requires_grad] if grad_on else []
+        ref = image if image is not None else meta
+        batch, dev = ref.shape[0], ref.device
+        if batch < 1:
+            raise ValueError("btsbot_amd: training-mode forward needs a non-empty batch")
+        masks = self._dropout_masks(batch, dev)
+        if not trainable:
+            return self._forward_train_raw(image, meta, masks)
+        return _TrainFn.apply(self, image, meta, masks, trainable, *[g[0] for g in trainable])
+
+    def _forward_train_raw(self, image, meta, masks):
+        ref = image if image is not None else meta
+        batch, dev = ref.shape[0], ref.device
+        with torch.cuda.device(dev):
+            L, stream = self._prepare(dev, batch)
+            if batch > getattr(self, "_reserved_train", 0):
+                _lib.check(L.btsbot_reserve_train(self._handle.ptr, batch), "btsbot_reserve_train")
+                self._reserved_train = batch
+            logits = torch.empty(batch, dtype=torch.float32, device=dev)
+            self._live_masks = masks          # must outlive btsbot_backward
+            _lib.check(L.btsbot_forward_train(
+                self._handle.ptr,
+                C.c_void_p(image.data_ptr() if image is not None else 0),
+                C.c_void_p(meta.data_ptr() if meta is not None else 0),
+                C.c_void_p(logits.data_ptr()), C.c_void_p(0), batch,
+                C.c_void_p(masks[0].data_ptr() if masks[0] is not None else 0),
+                C.c_void_p(masks[1].data_ptr() if masks[1] is not None else 0),
+                C.c_void_p(self._arena.data_ptr()), C.c_void_p(stream)), "btsbot_forward_train")
+        # the kernel updated running_mean / running_var inside the arena
+        for mod in self.modules():
+            if "num_batches_tracked" in mod._buffers:
+                mod._buffers["num_batches_tracked"] += 1
+        self._packed_version = None
+        return logits.view(batch, 1)
+
+    def _backward_raw(self, dlogits: torch.Tensor, need_meta: bool) -> torch.Tensor:
+        """d(loss)/d(param) into the flat gradient arena (master-arena layout); returns the arena."""
+        dev = self._arena.device
+        if getattr(self, "_grad_arena", None) is None or self._grad_arena.device != dev:
+            object.__setattr__(self, "_grad_arena", torch.zeros_like(self._arena))
+        dl = dlogits.reshape(-1).to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.lib().btsbot_backward(
+                self._handle.ptr, C.c_void_p(dl.data_ptr()), C.c_void_p(self._grad_arena.data_ptr()),
+                int(need_meta), 0, C.c_void_p(stream)), "btsbot_backward")
+        return self._grad_arena
 
     def set_profile(self, on: bool = True):
         """Bracket every kernel launch of forward() with HIP events (bench.py's roofline leg)."""
@@ -314,6 +403,26 @@ class _HipModel(nn.Module):
                 self._handle.ptr, name.encode(), C.c_void_p(buf.data_ptr()), buf.numel(),
                 C.c_void_p(stream)), "btsbot_read_tap")
         return buf[:n].view(-1, hw * hw, c)
+
+
+class _TrainFn(torch.autograd.Function):
+    """Autograd node around btsbot_forward_train / btsbot_backward (train.py:510,526)."""
+
+    @staticmethod
+    def forward(ctx, model, image, meta, masks, trainable, *params):
+        ctx.model = model
+        ctx.trainable = trainable
+        return model._forward_train_raw(image, meta, masks)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, trainable = ctx.model, ctx.trainable
+        _comb, metag, _img = model._slot_groups()
+        meta_ids = {id(t) for t, *_ in metag}
+        need_meta = any(id(t) in meta_ids for t, *_ in trainable)
+        arena = model._backward_raw(dlogits, need_meta)
+        grads = [arena[off:off + numel].view(shape).clone() for _t, off, numel, shape in trainable]
+        return (None, None, None, None, None, *grads)
 
 
 def _backbone_key_map(bprefix: str, head_norm_key: str, meta_prefix: str, comb_keys):

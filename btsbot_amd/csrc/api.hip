@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ctx.h"
 #include "stage0.h"
 
 // ---------------------------------------------------------------------------------------
@@ -24,83 +25,6 @@ void btsbot_set_error(const char* fmt, ...) {
 
 extern "C" const char* btsbot_last_error(void) { return g_err; }
 extern "C" int btsbot_abi_version(void) { return BTSBOT_ABI_VERSION; }
-
-// ---------------------------------------------------------------------------------------
-// handle
-// ---------------------------------------------------------------------------------------
-namespace {
-
-struct ParamRec {
-  std::string name;
-  int64_t off, numel;
-  int ndim;
-  int shape[4];
-  int is_buffer;
-};
-
-struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
-  int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
-  size_t p_dw, p_fc1, p_fc2, p_fused;
-  bool fused;
-};
-struct DownPk {
-  int64_t ln_w, ln_b, w, b;
-  size_t p_w;
-};
-
-constexpr int STAGE_HW[4] = {15, 7, 3, 1};
-
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, NCAT };
-const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
-                                     "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
-                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel"};
-constexpr size_t PROF_MAX_LAUNCHES = 8192;
-
-}  // namespace
-
-struct btsbot_ctx {
-  btsbot_config cfg;
-  bool has_image, has_meta;
-  int n_comb;        // linear layers of the fusion MLP
-  int comb_dims[4];
-  int act;           // ACT_GELU / ACT_RELU of the heads
-  int meta_trailing_act;
-  std::vector<ParamRec> params;
-  int64_t total_floats = 0;
-
-  // master offsets
-  int64_t stem_w, stem_b, stem_lnw, stem_lnb, hn_w = -1, hn_b = -1;
-  std::vector<std::vector<BlockPk>> blocks;  // [stage][block]
-  DownPk down[4];
-  int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
-  int64_t comb_w[3], comb_b[3];
-  size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift, p_stem16 = 0;
-  bool stage0 = false;     // stem + stage 0 + first downsample as one kernel
-
-  // device memory
-  float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
-  unsigned char* extra = nullptr;   // transformed operands
-  size_t extra_bytes = 0;
-  bool packed = false;
-
-  unsigned char* ws = nullptr;
-  size_t ws_bytes = 0;
-  int max_chunk = 0;
-  size_t o_x, o_x2, o_xn, o_h;      // workspace offsets
-  // per-kernel-family timing with HIP events on the launch stream (btsbot_set_profile)
-  bool prof_on = false;
-  std::vector<hipEvent_t> prof_ev;   // pairs: [2i] before, [2i+1] after launch i
-  std::vector<int> prof_cat;
-  size_t prof_used = 0;
-
-  bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
-  bool use_stage0 = true;  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
-  bool debug = false;
-  float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int last_chunk = 0;
-
-  int esz() const { return cfg.precision == BTSBOT_F32 ? 4 : 2; }
-};
 
 namespace {
 
@@ -316,6 +240,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->mirror) (void)hipFree(h->mirror);
   if (h->extra) (void)hipFree(h->extra);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->tcache) (void)hipFree(h->tcache);
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -496,8 +421,9 @@ template <typename F> static int timed(btsbot_ctx* h, int cat, hipStream_t st, F
   return BTSBOT_OK;
 }
 
-static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, float* logits,
-                         float* scores, int nb, hipStream_t st) {
+// image branch of one chunk; *feat_out = [nb][dims[3]] fp32 features inside the workspace
+static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st,
+                          float** feat_out) {
   const btsbot_config& c = h->cfg;
   const float* m = h->mirror;
   float* x = reinterpret_cast<float*>(h->ws + h->o_x);
@@ -590,6 +516,16 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
                                st));   // (stage 0's tap is written by the megakernel when fused)
     }
   }
+  *feat_out = x;
+  return BTSBOT_OK;
+}
+
+static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, float* logits,
+                         float* scores, int nb, hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  float* x = nullptr;
+  if (h->has_image) TRY(backbone_chunk(h, img, nb, st, &x));
   HeadArgs a;
   memset(&a, 0, sizeof(a));
   a.feat = h->has_image ? x : nullptr;
@@ -643,7 +579,8 @@ extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const floa
     return BTSBOT_ERR_INVALID_ARG;
   }
   if (training) {
-    btsbot_set_error("forward: training mode is not implemented in this build");
+    btsbot_set_error("forward: for training mode call btsbot_forward_train() (explicit dropout "
+                     "keep-masks, BatchNorm batch statistics)");
     return BTSBOT_ERR_STATE;
   }
   if (batch == 0) return BTSBOT_OK;
@@ -659,6 +596,104 @@ extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const floa
                       scores ? scores + b0 : nullptr, nb, st));
   }
   return BTSBOT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// training: forward with batch statistics + dropout, backward of the heads
+// ---------------------------------------------------------------------------------------
+size_t train_cache_floats(const btsbot_ctx* h, int M);
+float* train_cache_feat(btsbot_ctx* h, float* cache, int M);
+int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* logits,
+                       float* scores, int M, const uint8_t* meta_mask, const uint8_t* comb_mask,
+                       float* master, hipStream_t st);
+int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
+                        int need_meta, const uint8_t* meta_mask, const uint8_t* comb_mask,
+                        hipStream_t st);
+
+extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch) {
+  if (h == nullptr || max_batch < 1) {
+    btsbot_set_error("reserve_train: bad argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (h->tcache != nullptr && max_batch <= h->tcache_batch) return BTSBOT_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  if (h->tcache) (void)hipFree(h->tcache);
+  h->tcache = nullptr;
+  HIP_TRY(hipMalloc(&h->tcache, train_cache_floats(h, max_batch) * sizeof(float)));
+  h->tcache_batch = max_batch;
+  h->train_batch = 0;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, const float* meta,
+                                    float* logits, float* scores, int batch,
+                                    const uint8_t* meta_mask, const uint8_t* comb_mask,
+                                    float* master_arena, void* stream) {
+  if (h == nullptr || logits == nullptr || batch < 1) {
+    btsbot_set_error("forward_train: NULL handle/logits or empty batch");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (!h->packed || h->ws == nullptr || h->tcache == nullptr || batch > h->tcache_batch) {
+    btsbot_set_error("forward_train: pack_params / reserve / reserve_train(%d) first", batch);
+    return BTSBOT_ERR_STATE;
+  }
+  if ((h->has_image && triplets == nullptr) || (h->has_meta && meta == nullptr)) {
+    btsbot_set_error("forward_train: missing input for this wiring");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const btsbot_config& c = h->cfg;
+  if (h->has_meta && ((c.meta_dropout > 0.f && meta_mask == nullptr) || c.meta_dropout >= 1.f)) {
+    btsbot_set_error("forward_train: metadata dropout %.3f needs a keep-mask", c.meta_dropout);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (h->n_comb > 1 && ((c.comb_dropout > 0.f && comb_mask == nullptr) || c.comb_dropout >= 1.f)) {
+    btsbot_set_error("forward_train: head dropout %.3f needs a keep-mask", c.comb_dropout);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (h->has_meta && (c.n_meta > 768 || c.meta_fc1 > 768 || c.meta_fc2 > 768)) {
+    btsbot_set_error("forward_train: metadata widths above 768 are not supported");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (h->has_image) {
+    // The image branch has no train/eval difference (no BatchNorm, no dropout, drop-path 0):
+    // same kernels as inference, chunk by chunk; features are collected in the training cache.
+    float* feat = train_cache_feat(h, h->tcache, batch);
+    const int F = c.dims[3];
+    for (int b0 = 0; b0 < batch; b0 += h->max_chunk) {
+      const int nb = batch - b0 < h->max_chunk ? batch - b0 : h->max_chunk;
+      float* x = nullptr;
+      TRY(backbone_chunk(h, triplets + (size_t)b0 * 3 * 63 * 63, nb, st, &x));
+      HIP_TRY(hipMemcpyAsync(feat + (size_t)b0 * F, x, (size_t)nb * F * sizeof(float),
+                             hipMemcpyDeviceToDevice, st));
+    }
+  }
+  TRY(head_train_forward(h, h->tcache, meta, logits, scores, batch, meta_mask, comb_mask,
+                         master_arena, st));
+  h->train_batch = batch;
+  h->t_meta_mask = meta_mask;
+  h->t_comb_mask = comb_mask;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena,
+                               int need_meta_grads, int need_image_grads, void* stream) {
+  if (h == nullptr || dlogits == nullptr || grad_arena == nullptr) {
+    btsbot_set_error("backward: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (h->train_batch < 1) {
+    btsbot_set_error("backward: no training-mode forward has been run on this handle");
+    return BTSBOT_ERR_STATE;
+  }
+  if (need_image_grads && h->has_image) {
+    btsbot_set_error("backward: gradients of the ConvNeXt image branch are not built yet "
+                     "(train with the branch frozen, as frozen_fusion does: train.py:224-232)");
+    return BTSBOT_ERR_STATE;
+  }
+  return head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch,
+                             need_meta_grads, h->t_meta_mask, h->t_comb_mask,
+                             (hipStream_t)stream);
 }
 
 extern "C" int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst,

@@ -1,0 +1,83 @@
+// Internal: the handle behind btsbot_handle (shared by api.hip and head_train.hip).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct ParamRec {
+  std::string name;
+  int64_t off, numel;
+  int ndim;
+  int shape[4];
+  int is_buffer;
+};
+
+struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
+  int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
+  size_t p_dw, p_fc1, p_fc2, p_fused;
+  bool fused;
+};
+struct DownPk {
+  int64_t ln_w, ln_b, w, b;
+  size_t p_w;
+};
+
+constexpr int STAGE_HW[4] = {15, 7, 3, 1};
+
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, NCAT };
+const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
+                                     "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
+                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel"};
+constexpr size_t PROF_MAX_LAUNCHES = 8192;
+
+struct btsbot_ctx {
+  btsbot_config cfg;
+  bool has_image, has_meta;
+  int n_comb;        // linear layers of the fusion MLP
+  int comb_dims[4];
+  int act;           // ACT_GELU / ACT_RELU of the heads
+  int meta_trailing_act;
+  std::vector<ParamRec> params;
+  int64_t total_floats = 0;
+
+  // master offsets
+  int64_t stem_w, stem_b, stem_lnw, stem_lnb, hn_w = -1, hn_b = -1;
+  std::vector<std::vector<BlockPk>> blocks;  // [stage][block]
+  DownPk down[4];
+  int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
+  int64_t comb_w[3], comb_b[3];
+  size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift, p_stem16 = 0;
+  bool stage0 = false;     // stem + stage 0 + first downsample as one kernel
+
+  // device memory
+  float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
+  unsigned char* extra = nullptr;   // transformed operands
+  size_t extra_bytes = 0;
+  bool packed = false;
+
+  unsigned char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int max_chunk = 0;
+  size_t o_x, o_x2, o_xn, o_h;      // workspace offsets
+  // per-kernel-family timing with HIP events on the launch stream (btsbot_set_profile)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs: [2i] before, [2i+1] after launch i
+  std::vector<int> prof_cat;
+  size_t prof_used = 0;
+
+  bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
+  bool use_stage0 = true;  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
+  // training cache (head_train.hip): activations of the last training-mode forward
+  float* tcache = nullptr;
+  int tcache_batch = 0, train_batch = 0;
+  const uint8_t* t_meta_mask = nullptr;
+  const uint8_t* t_comb_mask = nullptr;
+
+  bool debug = false;
+  float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int last_chunk = 0;
+
+  int esz() const { return cfg.precision == BTSBOT_F32 ? 4 : 2; }
+};
+

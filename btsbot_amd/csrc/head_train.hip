@@ -1,0 +1,380 @@
+// Training-mode heads (fp32): forward with BatchNorm1d batch statistics + dropout, and the backward
+// pass of the fusion head and the metadata branch.
+//
+// Reference: the nn.Sequential heads of /root/reference/btsbot/architectures.py:146-164 (mm_ConvNeXt),
+// :282-290 (um_nn), :358-365 (frozen_fusion) under model.train(), and loss.backward() at
+// /root/reference/btsbot/train.py:525-526.  For frozen_fusion only `combined_head` has
+// requires_grad (train.py:224-232) -- but its frozen branches still run in train mode, so the
+// metadata BatchNorm uses batch statistics and keeps updating its running stats; reproduced here.
+//
+// Sizes are tiny (B x {25,128,128,640,128,32,1}); kernels are plain fp32 tiles, one launch per
+// layer, deterministic summation order (no atomics).
+#include "ctx.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, HN_EPS = 1e-6f;
+
+__device__ __forceinline__ float act_fwd(float x, int act) { return apply_act(x, act); }
+__device__ __forceinline__ float act_bwd(float x, int act) {
+  if (act == ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == ACT_GELU) {  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+  }
+  return 1.f;
+}
+
+// out_pre[m][n] = bias[n] + sum_k in[m*ldi + k] * wt[k*N + n];  out_act = dropout(act(pre))
+__global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ in, int ldi,
+                                                      const float* __restrict__ wt,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ pre, float* outa, int ldo,
+                                                      int M, int N, int K, int act,
+                                                      const uint8_t* __restrict__ mask,
+                                                      float keep_scale) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * N) return;
+  const int m = idx / N, n = idx - m * N;
+  float acc = bias[n];
+  const float* ip = in + (size_t)m * ldi;
+  for (int k = 0; k < K; ++k) acc = fmaf(ip[k], wt[(size_t)k * N + n], acc);
+  if (pre != nullptr) pre[idx] = acc;
+  float v = act_fwd(acc, act);
+  if (mask != nullptr) v = mask[idx] ? v * keep_scale : 0.f;
+  outa[(size_t)m * ldo + n] = v;
+}
+
+// dpre[m][n] = dout[m*ldd + n] * act'(pre[m][n]) * mask * keep_scale     (in place allowed)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, int ldd,
+                                                      const float* __restrict__ pre, float* dpre,
+                                                      int M, int N, int act,
+                                                      const uint8_t* __restrict__ mask,
+                                                      float keep_scale) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * N) return;
+  const int m = idx / N, n = idx - m * N;
+  float d = dout[(size_t)m * ldd + n];
+  if (mask != nullptr) d = mask[idx] ? d * keep_scale : 0.f;
+  dpre[idx] = d * act_bwd(pre[idx], act);
+}
+
+// din[m*ldi + k] = sum_n dpre[m][n] * w[n][k]      (w in its natural [N][K] layout)
+__global__ __launch_bounds__(256) void lin_bwd_in_kernel(const float* __restrict__ dpre,
+                                                         const float* __restrict__ w, float* din,
+                                                         int ldi, int M, int N, int K) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * K) return;
+  const int m = idx / K, k = idx - m * K;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc = fmaf(dpre[(size_t)m * N + n], w[(size_t)n * K + k], acc);
+  din[(size_t)m * ldi + k] = acc;
+}
+
+// dw[n][k] = sum_m dpre[m][n] * in[m*ldi + k];  db[n] = sum_m dpre[m][n]   (fixed order over m)
+__global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dpre,
+                                                        const float* __restrict__ in, int ldi,
+                                                        float* __restrict__ dw,
+                                                        float* __restrict__ db, int M, int N,
+                                                        int K) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * (K + 1)) return;
+  const int n = idx / (K + 1), k = idx - n * (K + 1);
+  float acc = 0.f;
+  if (k < K) {
+    for (int m = 0; m < M; ++m) acc = fmaf(dpre[(size_t)m * N + n], in[(size_t)m * ldi + k], acc);
+    dw[(size_t)n * K + k] = acc;
+  } else {
+    for (int m = 0; m < M; ++m) acc += dpre[(size_t)m * N + n];
+    db[n] = acc;
+  }
+}
+
+// BatchNorm1d, training: one workgroup per feature j.  Biased variance normalises, unbiased
+// variance goes into running_var (torch semantics), momentum 0.1.
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ x, int M,
+                                                           int n, const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           float* run_mean, float* run_var,
+                                                           float* __restrict__ xhat,
+                                                           float* __restrict__ out,
+                                                           float* __restrict__ rstd_out) {
+  __shared__ float sh[8];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int m = tid; m < M; m += 256) s += x[(size_t)m * n + j];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) sh[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / M;
+  __syncthreads();
+  float q = 0.f;
+  for (int m = tid; m < M; m += 256) {
+    const float d = x[(size_t)m * n + j] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) sh[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float ss = sh[4] + sh[5] + sh[6] + sh[7];
+  const float var = ss / M;
+  const float rstd = rsqrtf(var + BN_EPS);
+  for (int m = tid; m < M; m += 256) {
+    const float xh = (x[(size_t)m * n + j] - mean) * rstd;
+    xhat[(size_t)m * n + j] = xh;
+    out[(size_t)m * n + j] = xh * w[j] + b[j];
+  }
+  if (tid == 0) {
+    rstd_out[j] = rstd;
+    if (run_mean != nullptr) {
+      run_mean[j] = (1.f - BN_MOM) * run_mean[j] + BN_MOM * mean;
+      run_var[j] = (1.f - BN_MOM) * run_var[j] + BN_MOM * (M > 1 ? ss / (M - 1) : var);
+    }
+  }
+}
+
+// dx = (w * rstd / M) * (M*dy - sum(dy) - xhat * sum(dy*xhat));  dw = sum(dy*xhat);  db = sum(dy)
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ dy, int M,
+                                                           int n, const float* __restrict__ w,
+                                                           const float* __restrict__ xhat,
+                                                           const float* __restrict__ rstd,
+                                                           float* __restrict__ dw,
+                                                           float* __restrict__ db) {
+  __shared__ float sh[8];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int m = tid; m < M; m += 256) {
+    const float d = dy[(size_t)m * n + j];
+    s += d;
+    q += d * xhat[(size_t)m * n + j];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((tid & 63) == 0) {
+    sh[tid >> 6] = s;
+    sh[4 + (tid >> 6)] = q;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    db[j] = sh[0] + sh[1] + sh[2] + sh[3];
+    dw[j] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+  (void)w;
+  (void)rstd;   // dx of the metadata INPUT is never needed (the inputs are data)
+}
+
+// rows of feat -> (optional LayerNorm) -> z[:, 0:F]
+__global__ __launch_bounds__(256) void feat_rows_kernel(const float* __restrict__ feat, int F,
+                                                        const float* __restrict__ hw,
+                                                        const float* __restrict__ hb, float* z,
+                                                        int ldz, int M) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* src = feat + (size_t)m * F;
+  float mean = 0.f, rstd = 1.f;
+  if (hw != nullptr) {
+    float s = 0.f;
+    for (int c = lane; c < F; c += 64) s += src[c];
+    mean = wave_sum(s) / F;
+    float q = 0.f;
+    for (int c = lane; c < F; c += 64) {
+      const float d = src[c] - mean;
+      q += d * d;
+    }
+    rstd = rsqrtf(wave_sum(q) / F + HN_EPS);
+  }
+  for (int c = lane; c < F; c += 64)
+    z[(size_t)m * ldz + c] = hw != nullptr ? (src[c] - mean) * rstd * hw[c] + hb[c] : src[c];
+}
+
+__global__ void logits_kernel(const float* __restrict__ in, float* logits, float* scores, int M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float z = in[i];
+  logits[i] = z;
+  if (scores != nullptr) scores[i] = 1.0f / (1.0f + expf(-z));
+}
+
+inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// cache layout (floats) for a batch of M alerts
+// ---------------------------------------------------------------------------------------
+size_t train_cache_floats(const btsbot_ctx* h, int M) {
+  const btsbot_config& c = h->cfg;
+  const size_t F = h->has_image ? c.dims[3] : 0;
+  size_t n = 0;
+  n += (size_t)M * F;                                   // raw backbone features
+  if (h->has_meta) n += (size_t)M * (2 * c.n_meta + 2 * c.meta_fc1 + c.meta_fc2) + c.n_meta;
+  n += (size_t)M * h->comb_dims[0];                     // z
+  for (int i = 0; i < h->n_comb; ++i) n += 2 * (size_t)M * h->comb_dims[i + 1];   // pre + act
+  n += 2 * (size_t)M * 768;                             // backward scratch (d-buffers)
+  return n + 1024;
+}
+
+struct TrainPtrs {
+  float *feat, *xhat, *x1, *bn_rstd, *a1, *h1, *a2, *z, *pre[3], *actv[3], *d0, *d1;
+};
+
+static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
+  const btsbot_config& c = h->cfg;
+  const size_t F = h->has_image ? c.dims[3] : 0;
+  TrainPtrs p;
+  float* cur = base;
+  auto take = [&](size_t n) {
+    float* r = cur;
+    cur += (n + 3) / 4 * 4;
+    return r;
+  };
+  p.feat = take((size_t)M * F);
+  p.xhat = p.x1 = p.bn_rstd = p.a1 = p.h1 = p.a2 = nullptr;
+  if (h->has_meta) {
+    p.xhat = take((size_t)M * c.n_meta);
+    p.x1 = take((size_t)M * c.n_meta);
+    p.bn_rstd = take(c.n_meta);
+    p.a1 = take((size_t)M * c.meta_fc1);
+    p.h1 = take((size_t)M * c.meta_fc1);
+    p.a2 = take((size_t)M * c.meta_fc2);
+  }
+  p.z = take((size_t)M * h->comb_dims[0]);
+  for (int i = 0; i < 3; ++i) p.pre[i] = p.actv[i] = nullptr;
+  for (int i = 0; i < h->n_comb; ++i) {
+    p.pre[i] = take((size_t)M * h->comb_dims[i + 1]);
+    p.actv[i] = take((size_t)M * h->comb_dims[i + 1]);
+  }
+  p.d0 = take((size_t)M * 768);
+  p.d1 = take((size_t)M * 768);
+  return p;
+}
+
+// Forward of the heads in training mode.  feat: [M][F] backbone features (already in the cache).
+int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* logits,
+                       float* scores, int M, const uint8_t* meta_mask, const uint8_t* comb_mask,
+                       float* master, hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  TrainPtrs p = carve(h, cache, M);
+  const int F = h->has_image ? c.dims[3] : 0;
+  const int zd = h->comb_dims[0];
+  for (int i = 1; i <= h->n_comb; ++i)
+    if (h->comb_dims[i] > 768 || zd > 4096) {
+      btsbot_set_error("train: head widths exceed the training scratch (768)");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+  if (h->has_image) {
+    hipLaunchKernelGGL(feat_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, p.feat, F,
+                       h->hn_w >= 0 ? m + h->hn_w : nullptr, h->hn_b >= 0 ? m + h->hn_b : nullptr,
+                       p.z, zd, M);
+    LAUNCH_CHECK();
+  }
+  if (h->has_meta) {
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.n_meta), dim3(256), 0, st, meta, M, c.n_meta,
+                       m + h->bn_w, m + h->bn_b, master ? master + h->bn_rm : nullptr,
+                       master ? master + h->bn_rv : nullptr, p.xhat, p.x1, p.bn_rstd);
+    LAUNCH_CHECK();
+    const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
+    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, p.x1, c.n_meta,
+                       reinterpret_cast<const float*>(h->extra + h->p_m1), m + h->m1_b, p.a1, p.h1,
+                       c.meta_fc1, M, c.meta_fc1, c.n_meta, h->act,
+                       c.meta_dropout > 0.f ? meta_mask : nullptr, ks1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, p.h1,
+                       c.meta_fc1, reinterpret_cast<const float*>(h->extra + h->p_m2), m + h->m2_b,
+                       p.a2, p.z + F, zd, M, c.meta_fc2, c.meta_fc1,
+                       h->meta_trailing_act ? h->act : ACT_NONE, nullptr, 1.f);
+    LAUNCH_CHECK();
+  }
+  const float* in = p.z;
+  int ldi = zd;
+  const float ksc = c.comb_dropout < 1.f ? 1.f / (1.f - c.comb_dropout) : 0.f;
+  for (int i = 0; i < h->n_comb; ++i) {
+    const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
+    const bool last = i + 1 == h->n_comb;
+    // Dropout sits after the activation of the layer BEFORE the final Linear (architectures.py:162)
+    const bool drop = !last && i + 2 == h->n_comb && c.comb_dropout > 0.f;
+    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * N), dim3(256), 0, st, in, ldi,
+                       reinterpret_cast<const float*>(h->extra + h->p_comb[i]), m + h->comb_b[i],
+                       p.pre[i], p.actv[i], N, M, N, K, last ? ACT_NONE : h->act,
+                       drop ? comb_mask : nullptr, ksc);
+    LAUNCH_CHECK();
+    in = p.actv[i];
+    ldi = N;
+  }
+  hipLaunchKernelGGL(logits_kernel, g1(M), dim3(256), 0, st, in, logits, scores, M);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// Backward of the heads.  Writes d(loss)/d(param) for the fusion head (always) and the metadata
+// branch (need_meta) into `grads` (master-arena layout).
+int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
+                        int need_meta, const uint8_t* meta_mask, const uint8_t* comb_mask,
+                        hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  TrainPtrs p = carve(h, cache, M);
+  const int F = h->has_image ? c.dims[3] : 0;
+  const int zd = h->comb_dims[0];
+  const float ksc = c.comb_dropout < 1.f ? 1.f / (1.f - c.comb_dropout) : 0.f;
+  // fusion head, last layer first; dcur = gradient w.r.t. the layer's (pre-activation) output
+  const float* dcur = dlogits;
+  float* bufs[2] = {p.d0, p.d1};
+  for (int i = h->n_comb - 1; i >= 0; --i) {
+    const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
+    const float* in = i == 0 ? p.z : p.actv[i - 1];
+    const int ldi = i == 0 ? zd : K;
+    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)N * (K + 1)), dim3(256), 0, st, dcur, in, ldi,
+                       grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
+    LAUNCH_CHECK();
+    if (i == 0 && !(need_meta && h->has_meta)) break;   // d(z) only feeds the metadata branch
+    float* din = bufs[i & 1];
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dcur, m + h->comb_w[i],
+                       din, K, M, N, K);
+    LAUNCH_CHECK();
+    if (i > 0) {   // through dropout + activation of layer i-1
+      const bool drop = i + 1 == h->n_comb && c.comb_dropout > 0.f;
+      hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * K), dim3(256), 0, st, din, K, p.pre[i - 1],
+                         din, M, K, h->act, drop ? comb_mask : nullptr, ksc);
+      LAUNCH_CHECK();
+    }
+    dcur = din;
+  }
+  if (need_meta && h->has_meta) {
+    // dcur = d(z) [M][zd]; the metadata features are its columns F .. F+f2
+    const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
+    float* da2 = p.d1 == dcur ? p.d0 : p.d1;   // scratch not holding dcur
+    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, dcur + F, zd,
+                       p.a2, da2, M, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE, nullptr,
+                       1.f);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)c.meta_fc2 * (c.meta_fc1 + 1)), dim3(256), 0, st,
+                       da2, p.h1, c.meta_fc1, grads + h->m2_w, grads + h->m2_b, M, c.meta_fc2,
+                       c.meta_fc1);
+    LAUNCH_CHECK();
+    float* dh1 = const_cast<float*>(dcur);     // d(z) is dead once da2 exists
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, da2,
+                       m + h->m2_w, dh1, c.meta_fc1, M, c.meta_fc2, c.meta_fc1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, dh1, c.meta_fc1,
+                       p.a1, dh1, M, c.meta_fc1, h->act, c.meta_dropout > 0.f ? meta_mask : nullptr,
+                       ks1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)c.meta_fc1 * (c.n_meta + 1)), dim3(256), 0, st,
+                       dh1, p.x1, c.n_meta, grads + h->m1_w, grads + h->m1_b, M, c.meta_fc1,
+                       c.n_meta);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.n_meta), dim3(256), 0, st, dh1,
+                       m + h->m1_w, da2, c.n_meta, M, c.meta_fc1, c.n_meta);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.n_meta), dim3(256), 0, st, da2, M, c.n_meta,
+                       m + h->bn_w, p.xhat, p.bn_rstd, grads + h->bn_w, grads + h->bn_b);
+    LAUNCH_CHECK();
+  }
+  return BTSBOT_OK;
+}
+
+float* train_cache_feat(btsbot_ctx* h, float* cache, int M) { return carve(h, cache, M).feat; }

@@ -1,0 +1,133 @@
+"""Training step of the classifier on MI355X: the hot loop of /root/reference/btsbot/train.py:481-566
+(zero_grad -> forward -> BCEWithLogitsLoss(pos_weight) -> backward -> AdamW.step) plus the optimiser
+and schedule set-up of train.py:242-260, without autograd, host syncs or DataParallel.
+
+    trainer = Trainer(model, lr=1e-4, betas=(0.99, 0.99), pos_weight=w)   # model.train() already
+    for images, meta, labels in batches:                                    # device tensors
+        loss = trainer.step(images, meta, labels)        # returns a device scalar, no .item()
+    trainer.scheduler_step()                                                # once per epoch
+
+What is trained follows ``requires_grad`` exactly as the reference does (train.py:224-236): for
+``frozen_fusion`` only ``combined_head``; for ``um_nn`` everything.  A trainable ConvNeXt branch is
+refused until its backward kernels exist.  With torch.distributed initialised, every rank passes its
+own shard and the flat gradient arena is all-reduced once per step (parallel.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib, parallel
+
+
+def lr_schedule(lr: float, epochs: int, warmup_epochs: int) -> Sequence[float]:
+    """Learning rate of epoch 0..epochs-1 under train.py:249-260's
+    SequentialLR[LinearLR(0.01 -> 1 over warmup), CosineAnnealingLR(T_max=max(1, epochs-warmup),
+    eta_min=0.01*lr)], stepped once per epoch -- produced by torch's own schedulers so that
+    version quirks (warmup 0 leaves the LR at 0.01*lr on torch 2.10) are reproduced, not guessed."""
+    import warnings
+    prm = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([prm], lr=lr)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sched = torch.optim.lr_scheduler.SequentialLR(
+            opt,
+            schedulers=[
+                torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, total_iters=warmup_epochs),
+                torch.optim.lr_scheduler.CosineAnnealingLR(
+                    opt, T_max=max(1, epochs - warmup_epochs), eta_min=lr * 0.01),
+            ],
+            milestones=[warmup_epochs])
+        out = []
+        for _ in range(epochs):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+    return out
+
+
+class Trainer:
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, pos_weight: float = 1.0, epochs: int = 1,
+                 warmup_epochs: int = 0, group=None):
+        self.model = model
+        self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.pos_weight = float(pos_weight)
+        self.group = group
+        self.lrs = list(lr_schedule(lr, max(1, epochs), warmup_epochs))
+        self.epoch = 0
+        self.t = 0                                   # AdamW step count
+        comb, meta, image = model._slot_groups()
+        if any(t.requires_grad for t, *_ in image):
+            raise NotImplementedError(
+                "btsbot_amd.train: a trainable ConvNeXt image branch is not supported yet; freeze it "
+                "as train.py:224-232 does for frozen_fusion")
+        self.need_meta = any(t.requires_grad for t, *_ in meta)
+        # contiguous arena ranges of the trainable tensors (padding between tensors has zero grad)
+        slots = sorted((off, off + numel) for t, off, numel, _s in comb + meta if t.requires_grad)
+        self.ranges = []
+        for lo, hi in slots:
+            hi = (hi + 3) // 4 * 4
+            if self.ranges and lo <= self.ranges[-1][1]:
+                self.ranges[-1][1] = max(hi, self.ranges[-1][1])
+            else:
+                self.ranges.append([lo, hi])
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    @property
+    def lr(self) -> float:
+        return self.lrs[min(self.epoch, len(self.lrs) - 1)]
+
+    def scheduler_step(self):
+        """train.py:332 -- once per epoch."""
+        self.epoch += 1
+
+    def step(self, images: Optional[torch.Tensor], meta: Optional[torch.Tensor],
+             labels: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
+        """One optimisation step on this rank's shard; returns sum_i loss_i / global_batch as a
+        device scalar (the rank's contribution to the global mean loss)."""
+        m = self.model
+        if not m.training:
+            raise RuntimeError("Trainer.step: put the model in train mode first (model.train())")
+        images, meta, batch, dev = m._check_inputs(images, meta)
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        n_global = int(global_batch) if global_batch is not None else batch * world
+        with torch.no_grad():
+            masks = m._dropout_masks(batch, dev)
+            logits = m._forward_train_raw(images, meta, masks).reshape(-1)
+            y = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            dl = torch.empty_like(logits)
+            L = _lib.lib()
+            with torch.cuda.device(dev):
+                st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(L.btsbot_bce_fwd_bwd(C.c_void_p(logits.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                self.pos_weight, batch, n_global,
+                                                C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()),
+                                                st), "btsbot_bce_fwd_bwd")
+            grads = m._backward_raw(dl, self.need_meta)
+            if self.exp_avg is None:
+                self.exp_avg = torch.zeros_like(m._arena)
+                self.exp_avg_sq = torch.zeros_like(m._arena)
+            if world > 1:
+                # one exchange per step: the trainable slice of the flat gradient arena
+                lo, hi = self.ranges[0][0], self.ranges[-1][1]
+                parallel.allreduce_mean_(grads[lo:hi], self.group)
+            self.t += 1
+            with torch.cuda.device(dev):
+                st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for lo, hi in self.ranges:
+                    _lib.check(L.btsbot_adamw_step(
+                        C.c_void_p(m._arena[lo:hi].data_ptr()), C.c_void_p(grads[lo:hi].data_ptr()),
+                        C.c_void_p(self.exp_avg[lo:hi].data_ptr()),
+                        C.c_void_p(self.exp_avg_sq[lo:hi].data_ptr()), hi - lo, self.lr,
+                        self.betas[0], self.betas[1], self.eps, self.wd, self.t, st),
+                        "btsbot_adamw_step")
+            m.mark_weights_dirty()
+            self.last_logits = logits
+        return loss[0] / n_global

@@ -128,6 +128,28 @@ int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* met
                    float* logits, float* scores, int batch, int training,
                    uint64_t dropout_seed, void* stream);
 
+/* Training-mode forward: replaces model(...) under model.train() (train.py:510).  The image branch
+ * is identical to inference (ConvNeXt has no BatchNorm / dropout, drop-path 0); the metadata
+ * BatchNorm1d uses the statistics of THIS batch and, when master_arena is non-NULL, updates
+ * running_mean / running_var there (momentum 0.1, unbiased variance), exactly as nn.BatchNorm1d --
+ * also when the branch is frozen (frozen_fusion keeps its branches in train mode).  Dropout is
+ * applied with caller-supplied keep-masks (uint8 [batch][meta_fc1] and [batch][comb_fc2]; 1 = keep,
+ * scaled by 1/(1-p)); the masks must stay valid until btsbot_backward() has run.  Activations are
+ * kept in a cache sized by btsbot_reserve_train(max_batch) (whole batch, no chunking, because of the
+ * batch statistics). */
+int btsbot_reserve_train(btsbot_handle h, int max_batch);
+int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const float* meta,
+                         float* logits, float* scores, int batch, const uint8_t* meta_keep_mask,
+                         const uint8_t* comb_keep_mask, float* master_arena, void* stream);
+
+/* Replaces loss.backward() (train.py:526) for the parameters of the fusion head (always) and the
+ * metadata branch (need_meta_grads): writes d(loss)/d(param) into grad_arena, which has the master
+ * arena's layout (other entries are left untouched).  dlogits = d(loss)/d(logits) [batch], e.g. from
+ * btsbot_bce_fwd_bwd.  need_image_grads != 0 (a trainable ConvNeXt branch) is refused in this build
+ * with BTSBOT_ERR_STATE. */
+int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, int need_meta_grads,
+                    int need_image_grads, void* stream);
+
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and
  * stage outputs (call before btsbot_reserve()). */
 int btsbot_set_debug(btsbot_handle h, int on);

@@ -1,0 +1,153 @@
+"""GPU parity of the training path (heads): training-mode forward (BatchNorm batch statistics,
+dropout with planted keep-masks), backward, BCE, AdamW -- against torch autograd through the CPU
+oracle.  Tolerances: fp32 arithmetic on both sides, different summation order -> 1e-4 relative
+to the largest entry of each tensor."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CONFIGS, seeded_state, build_model
+from btsbot_amd.synthetic import synthetic_batch
+from btsbot_amd.train import Trainer, lr_schedule
+from oracle import convnext_oracle as O   # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(cfg_kind, cfg, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    if cfg_kind == "frozen_fusion":
+        f1, p1 = cfg["meta_model_config"]["meta_fc1_neurons"], cfg["meta_model_config"]["meta_dropout"]
+        c2, p2 = cfg["comb_fc2_neurons"], cfg["comb_dropout"]
+    elif cfg_kind == "um_nn":
+        f1, p1, c2, p2 = cfg["meta_fc1_neurons"], cfg["meta_dropout"], 0, 0.0
+    else:
+        f1, p1 = cfg["meta_fc1_neurons"], cfg["meta_dropout"]
+        c2, p2 = cfg["comb_fc2_neurons"], cfg["comb_dropout"]
+    m = {"meta": (torch.rand(batch, f1, generator=g) >= p1).float()}
+    if c2:
+        m["comb"] = (torch.rand(batch, c2, generator=g) >= p2).float()
+    return m
+
+
+def _close(a, b, what, rtol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _oracle_train(kind, cfg, sd, img, meta, labels, masks, pos_weight, trainable):
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    logits = O.forward(kind, sd, cfg, img, meta, training=True, masks=masks)
+    loss = O.bce_with_logits(logits, labels.float().unsqueeze(1), pos_weight)
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: sd[k].grad for k in trainable}, sd
+
+
+@pytest.mark.parametrize("name", ["frozen_fusion", "um_nn", "mm_pico"])
+def test_training_forward_and_head_gradients(cuda, name):
+    kind, cfg = CONFIGS[name]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, labels = synthetic_batch(48, seed=4)
+    masks = _masks(kind, cfg, 48, seed=9)
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    if kind == "frozen_fusion":                      # train.py:224-232
+        for p in m.image_branch.parameters():
+            p.requires_grad_(False)
+        for p in m.meta_branch.parameters():
+            p.requires_grad_(False)
+    elif kind == "mm_ConvNeXt":                      # image branch frozen (its backward is not built)
+        for p in m.convnext_backbone.parameters():
+            p.requires_grad_(False)
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert trainable
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    gi = img.to(cuda) if kind != "um_nn" else None
+    gm = meta.to(cuda)
+    if kind == "um_nn":
+        logits = m(input_data=gm)
+    else:
+        logits = m(image_input=gi, metadata_input=gm)
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+        logits, labels.to(cuda).float().unsqueeze(1))
+    loss.backward()
+
+    ref_logits, ref_loss, ref_grads, ref_sd = _oracle_train(kind, cfg, sd, img, meta, labels, masks,
+                                                            2.0, trainable)
+    _close(logits, ref_logits, "training-mode logits")
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item()))
+    got = dict(m.named_parameters())
+    for k in trainable:
+        assert got[k].grad is not None, k
+        _close(got[k].grad, ref_grads[k], f"grad {k}", rtol=2e-4)
+    for k, p in m.named_parameters():
+        if k not in trainable:
+            assert p.grad is None
+    # BatchNorm1d running statistics were updated from this batch (also when the branch is frozen)
+    out_sd = m.state_dict()
+    for k in out_sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(out_sd[k], ref_sd[k], k, rtol=1e-5)
+        if k.endswith("num_batches_tracked"):
+            assert int(out_sd[k]) == int(sd[k]) + 1
+
+
+def test_trainable_image_branch_is_refused(cuda):
+    kind, cfg = CONFIGS["mm_pico"]
+    m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "f32").train()
+    img, meta, _ = synthetic_batch(4, seed=4)
+    with pytest.raises(NotImplementedError, match="image branch"):
+        m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    with torch.no_grad():                             # fine without gradients
+        out = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    assert out.shape == (4, 1)
+
+
+@pytest.mark.parametrize("name", ["um_nn", "frozen_fusion"])
+def test_trainer_matches_torch_adamw_loop(cuda, name):
+    """3 steps of Trainer.step (HIP forward/BCE/backward/AdamW) vs the reference recipe on the CPU:
+    oracle forward + BCEWithLogitsLoss(pos_weight) + torch.optim.AdamW(lr, betas=(.99,.99)),
+    train.py:211-212,242-246,498-527.  Dropout off so both sides see the same network."""
+    kind, cfg = CONFIGS[name]
+    cfg = copy.deepcopy(cfg)
+    if kind == "um_nn":
+        cfg["meta_dropout"] = 0.0
+    else:
+        cfg["comb_dropout"] = 0.0
+        cfg["meta_model_config"]["meta_dropout"] = 0.0
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    if kind == "frozen_fusion":
+        for p in list(m.image_branch.parameters()) + list(m.meta_branch.parameters()):
+            p.requires_grad_(False)
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    tr = Trainer(m, lr=1e-3, betas=(0.99, 0.99), pos_weight=1.5)
+
+    ref = {k: v.clone() for k, v in sd.items()}
+    params = [ref[k].requires_grad_(True) for k in trainable]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.99, 0.99))
+    for step in range(3):
+        img, meta, labels = synthetic_batch(32, seed=20 + step)
+        loss = tr.step(img.to(cuda) if kind != "um_nn" else None, meta.to(cuda), labels.to(cuda))
+        opt.zero_grad()
+        logits = O.forward(kind, ref, cfg, img, meta, training=True)
+        rl = O.bce_with_logits(logits, labels.float().unsqueeze(1), 1.5)
+        rl.backward()
+        opt.step()
+        assert abs(loss.item() - rl.item()) <= 2e-5 * max(1.0, abs(rl.item())), step
+    out = m.state_dict()
+    for k in trainable:
+        _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-4)
+
+
+def test_lr_schedule_matches_golden():
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lr_sequences.json")))
+    for key, seq in gold.items():
+        w, e = map(int, key.split(","))
+        assert np.allclose(lr_schedule(1e-4, e, w), seq, rtol=1e-9)
