@@ -126,11 +126,14 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
         for p in list(m.image_branch.parameters()) + list(m.meta_branch.parameters()):
             p.requires_grad_(False)
     trainable = [k for k, p in m.named_parameters() if p.requires_grad]
-    tr = Trainer(m, lr=1e-3, betas=(0.99, 0.99), pos_weight=1.5)
+    tr = Trainer(m, lr=1e-3, betas=(0.99, 0.99), pos_weight=1.5, epochs=8, warmup_epochs=2)
+    tr.scheduler_step()
+    tr.scheduler_step()                              # epoch 2 of (warmup 2, epochs 8): full lr
+    assert abs(tr.lr - 1e-3) < 1e-12
 
     ref = {k: v.clone() for k, v in sd.items()}
     params = [ref[k].requires_grad_(True) for k in trainable]
-    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.99, 0.99))
+    opt = torch.optim.AdamW(params, lr=tr.lr, betas=(0.99, 0.99))
     for step in range(3):
         img, meta, labels = synthetic_batch(32, seed=20 + step)
         loss = tr.step(img.to(cuda) if kind != "um_nn" else None, meta.to(cuda), labels.to(cuda))
@@ -142,7 +145,9 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
         assert abs(loss.item() - rl.item()) <= 2e-5 * max(1.0, abs(rl.item())), step
     out = m.state_dict()
     for k in trainable:
-        _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-4)
+        _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-5)
+        # the UPDATE itself (3 steps of ~lr each), not just the (dominant) initial value
+        _close(out[k].cpu() - sd[k], ref[k].detach() - sd[k], f"update of {k}", rtol=2e-2)
 
 
 def test_lr_schedule_matches_golden():
