@@ -167,6 +167,72 @@ __global__ __launch_bounds__(NW * 64) void dwconv_ln_kernel(
   }
 }
 
+// 3x3 maps (stage 2): every output sees at most the central 5x5 taps and all 9 inputs.  One
+// workgroup per alert, lane = channel, all 9 outputs of a channel in one thread; LayerNorm needs the
+// C-wide sums of 9 pixels: wave butterflies, then one LDS exchange across the C/64 waves.
+template <int C, typename T>
+__global__ __launch_bounds__(C) void dw3_ln_kernel(const float* __restrict__ x,
+                                                   const float* __restrict__ wdw,
+                                                   const float* __restrict__ bdw,
+                                                   const float* __restrict__ lnw,
+                                                   const float* __restrict__ lnb,
+                                                   T* __restrict__ xn, int B) {
+  constexpr int NW = C / 64;
+  __shared__ float red[2][NW][9];
+  const int c = threadIdx.x, wave = c >> 6;
+  const int a = blockIdx.x;
+  const float* src = x + (size_t)a * 9 * C + c;
+  float in[9];
+#pragma unroll
+  for (int p = 0; p < 9; ++p) in[p] = src[p * C];
+  float acc[9];
+  const float bias = bdw[c];
+#pragma unroll
+  for (int p = 0; p < 9; ++p) acc[p] = bias;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const float w = wdw[((dy + 3) * 7 + dx + 3) * C + c];
+#pragma unroll
+      for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 3; ++ox) {
+          const int iy = oy + dy, ix = ox + dx;
+          if (iy >= 0 && iy < 3 && ix >= 0 && ix < 3)
+            acc[oy * 3 + ox] = fmaf(in[iy * 3 + ix], w, acc[oy * 3 + ox]);
+        }
+    }
+  float mean[9], rstd[9];
+#pragma unroll
+  for (int p = 0; p < 9; ++p) {
+    const float s = wave_sum(acc[p]);
+    if ((c & 63) == 0) red[0][wave][p] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 9; ++p) {
+    float t = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) t += red[0][w2][p];
+    mean[p] = t * (1.0f / C);
+    const float d = acc[p] - mean[p];
+    const float q = wave_sum(d * d);
+    if ((c & 63) == 0) red[1][wave][p] = q;
+  }
+  __syncthreads();
+  const float g = lnw[c], bb = lnb[c];
+  T* dst = xn + (size_t)a * 9 * C + c;
+#pragma unroll
+  for (int p = 0; p < 9; ++p) {
+    float t = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) t += red[1][w2][p];
+    rstd[p] = rsqrtf(t * (1.0f / C) + LN_EPS);
+    dst[p * C] = (T)((acc[p] - mean[p]) * rstd[p] * g + bb);
+  }
+}
+
 // 1x1 map (last stage): the 7x7 filter only ever sees its centre tap.  One wave per alert.
 template <int CPT, typename T>
 __global__ __launch_bounds__(256) void dw1_ln_kernel(const float* __restrict__ x,
@@ -340,10 +406,17 @@ int launch_dw_typed(const float* x, const float* wdw, const float* bdw, const fl
   if (C == CC && HW == HH) return launch_dw_cfg<CC, HH, GG, WW, T>(x, wdw, bdw, lnw, lnb, xn, B, st)
   DW_CASE(64, 15, 1, 8);
   DW_CASE(128, 7, 2, 8);
-  DW_CASE(256, 3, 2, 8);
+  if (HW == 3 && (C == 256 || C == 320)) {
+    T* o = reinterpret_cast<T*>(xn);
+    if (C == 256)
+      hipLaunchKernelGGL((dw3_ln_kernel<256, T>), dim3(B), dim3(256), 0, st, x, wdw, bdw, lnw, lnb, o, B);
+    else
+      hipLaunchKernelGGL((dw3_ln_kernel<320, T>), dim3(B), dim3(320), 0, st, x, wdw, bdw, lnw, lnb, o, B);
+    LAUNCH_CHECK();
+    return BTSBOT_OK;
+  }
   DW_CASE(80, 15, 1, 8);
   DW_CASE(160, 7, 2, 8);
-  DW_CASE(320, 3, 2, 10);
 #undef DW_CASE
   if (HW == 1) {
     const int cpt = (C + 63) / 64;

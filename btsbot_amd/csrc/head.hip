@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int HG = 8;     // alerts per workgroup
-constexpr int HNT = 256;  // threads
+constexpr int HNT = 512;  // threads
 constexpr float HN_EPS = 1e-6f;
 
 // Activations of the workgroup's HG alerts live in LDS k-major: v[k][g] (8 alerts = two float4),
@@ -35,20 +35,21 @@ __device__ __forceinline__ void dense(const float* in, int K, const float* __res
     if (live) {
       const int k0 = slice * kchunk, k1 = min(K, k0 + kchunk);
       int k = k0;
-      // groups of 8 k: the next group's weights are in flight while this group is consumed
-      float wv[8], wn[8];
-      const int ngrp = (k1 - k0) / 8;
+      // groups of 16 k: the next group's weights are in flight while this group is consumed
+      constexpr int GK = 16;
+      float wv[GK], wn[GK];
+      const int ngrp = (k1 - k0) / GK;
       if (ngrp > 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
+        for (int u = 0; u < GK; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
       }
-      for (int gi = 0; gi < ngrp; ++gi, k += 8) {
+      for (int gi = 0; gi < ngrp; ++gi, k += GK) {
         if (gi + 1 < ngrp) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) wn[u] = wt[(size_t)(k + 8 + u) * N + n];
+          for (int u = 0; u < GK; ++u) wn[u] = wt[(size_t)(k + GK + u) * N + n];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GK; ++u) {
           const float4 a0 = *reinterpret_cast<const float4*>(in + (k + u) * HG);
           const float4 a1 = *reinterpret_cast<const float4*>(in + (k + u) * HG + 4);
           acc[0] = fmaf(a0.x, wv[u], acc[0]); acc[1] = fmaf(a0.y, wv[u], acc[1]);
@@ -57,7 +58,7 @@ __device__ __forceinline__ void dense(const float* in, int K, const float* __res
           acc[6] = fmaf(a1.z, wv[u], acc[6]); acc[7] = fmaf(a1.w, wv[u], acc[7]);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = wn[u];
+        for (int u = 0; u < GK; ++u) wv[u] = wn[u];
       }
       for (; k < k1; ++k) {
         const float wv = wt[(size_t)k * N + n];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
   float* z = smem;               // [zd][HG]
   float* t0 = z + HG * zd;       // [maxw][HG]
   float* t1 = t0 + HG * maxw;    // [maxw][HG]
-  float* part = t1 + HG * maxw;  // [KS][N][HG], KS * N <= 256
+  float* part = t1 + HG * maxw;  // [KS][N][HG], KS * N <= HNT
   const int b0 = blockIdx.x * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
