@@ -11,66 +11,72 @@
 namespace {
 
 constexpr int HG = 8;     // alerts per workgroup
-constexpr int HNT = 512;  // threads
+constexpr int HNT = 1024;  // threads
 constexpr float HN_EPS = 1e-6f;
 
 // Activations of the workgroup's HG alerts live in LDS k-major: v[k][g] (8 alerts = two float4),
 // so one thread reads all alerts of a k with two ds_read_b128 broadcasts.
 // out[n][g] = act(bias[n] + sum_k in[k][g] * wt[k][n]); wt is K-major so consecutive threads (n)
-// read consecutive addresses.  The 256 threads cover min(N,256) neurons x KS slices of K
-// (KS = 256 / N); each keeps 8 weight loads in flight; partial sums meet in LDS (`part`).
+// read consecutive addresses.  The HNT threads cover min(N,HNT) neurons x KS slices of K
+// (KS = HNT / N).  The head is a chain of small dependent layers, i.e. latency-bound: every thread
+// keeps TWO groups of 16 weight loads in flight (a slice of <= 32 k issues all its loads before
+// the first FMA), partial sums meet in LDS (`part`), biases are fetched before the K loop.
 __device__ __forceinline__ void dense(const float* in, int K, const float* __restrict__ wt,
                                       const float* __restrict__ bias, int N, int act, float* outp,
                                       float* part) {
+  constexpr int GK = 16;
   int ks = 1;
   while (ks * 2 * N <= HNT) ks *= 2;
   const int kchunk = (K + ks - 1) / ks;
-  for (int n0 = 0; n0 < N; n0 += HNT) {              // N > 256: several passes (ks == 1)
+  for (int n0 = 0; n0 < N; n0 += HNT) {              // N > HNT: several passes (ks == 1)
     const int n = n0 + (threadIdx.x % (N < HNT ? N : HNT));
     const int slice = N < HNT ? threadIdx.x / N : 0;
     const bool live = n < N && slice < ks;
+    // bias of the output this thread finalises after the K loop
+    const int fin = threadIdx.x;                      // ks > 1: element index into [N][HG]
+    const float bfin = ks == 1 ? (live ? bias[n] : 0.f) : (fin < HG * N ? bias[fin / HG] : 0.f);
     float acc[HG];
 #pragma unroll
     for (int g = 0; g < HG; ++g) acc[g] = 0.f;
     if (live) {
       const int k0 = slice * kchunk, k1 = min(K, k0 + kchunk);
-      int k = k0;
-      // groups of 16 k: the next group's weights are in flight while this group is consumed
-      constexpr int GK = 16;
-      float wv[GK], wn[GK];
-      const int ngrp = (k1 - k0) / GK;
+      const int ngrp = k1 > k0 ? (k1 - k0 + GK - 1) / GK : 0;
+      float wa[GK], wb[GK];
       if (ngrp > 0) {
 #pragma unroll
-        for (int u = 0; u < GK; ++u) wv[u] = wt[(size_t)(k + u) * N + n];
+        for (int u = 0; u < GK; ++u) wa[u] = k0 + u < k1 ? wt[(size_t)(k0 + u) * N + n] : 0.f;
       }
-      for (int gi = 0; gi < ngrp; ++gi, k += GK) {
-        if (gi + 1 < ngrp) {
+      if (ngrp > 1) {
 #pragma unroll
-          for (int u = 0; u < GK; ++u) wn[u] = wt[(size_t)(k + GK + u) * N + n];
-        }
+        for (int u = 0; u < GK; ++u)
+          wb[u] = k0 + GK + u < k1 ? wt[(size_t)(k0 + GK + u) * N + n] : 0.f;
+      }
+      for (int gi = 0; gi < ngrp; ++gi) {
+        const int kb = k0 + gi * GK;
 #pragma unroll
         for (int u = 0; u < GK; ++u) {
-          const float4 a0 = *reinterpret_cast<const float4*>(in + (k + u) * HG);
-          const float4 a1 = *reinterpret_cast<const float4*>(in + (k + u) * HG + 4);
-          acc[0] = fmaf(a0.x, wv[u], acc[0]); acc[1] = fmaf(a0.y, wv[u], acc[1]);
-          acc[2] = fmaf(a0.z, wv[u], acc[2]); acc[3] = fmaf(a0.w, wv[u], acc[3]);
-          acc[4] = fmaf(a1.x, wv[u], acc[4]); acc[5] = fmaf(a1.y, wv[u], acc[5]);
-          acc[6] = fmaf(a1.z, wv[u], acc[6]); acc[7] = fmaf(a1.w, wv[u], acc[7]);
+          const int kk = min(kb + u, k1 - 1);         // padded taps carry weight 0
+          const float4 a0 = *reinterpret_cast<const float4*>(in + kk * HG);
+          const float4 a1 = *reinterpret_cast<const float4*>(in + kk * HG + 4);
+          const float w = wa[u];
+          acc[0] = fmaf(a0.x, w, acc[0]); acc[1] = fmaf(a0.y, w, acc[1]);
+          acc[2] = fmaf(a0.z, w, acc[2]); acc[3] = fmaf(a0.w, w, acc[3]);
+          acc[4] = fmaf(a1.x, w, acc[4]); acc[5] = fmaf(a1.y, w, acc[5]);
+          acc[6] = fmaf(a1.z, w, acc[6]); acc[7] = fmaf(a1.w, w, acc[7]);
         }
 #pragma unroll
-        for (int u = 0; u < GK; ++u) wv[u] = wn[u];
-      }
-      for (; k < k1; ++k) {
-        const float wv = wt[(size_t)k * N + n];
+        for (int u = 0; u < GK; ++u) wa[u] = wb[u];
+        if (gi + 2 < ngrp) {
+          const int kn = k0 + (gi + 2) * GK;
 #pragma unroll
-        for (int g = 0; g < HG; ++g) acc[g] = fmaf(in[k * HG + g], wv, acc[g]);
+          for (int u = 0; u < GK; ++u) wb[u] = kn + u < k1 ? wt[(size_t)(kn + u) * N + n] : 0.f;
+        }
       }
     }
     if (ks == 1) {
       if (live) {
-        const float b = bias[n];
 #pragma unroll
-        for (int g = 0; g < HG; ++g) outp[n * HG + g] = apply_act(acc[g] + b, act);
+        for (int g = 0; g < HG; ++g) outp[n * HG + g] = apply_act(acc[g] + bfin, act);
       }
     } else {
       if (live) {
@@ -78,9 +84,8 @@ __device__ __forceinline__ void dense(const float* in, int K, const float* __res
         for (int g = 0; g < HG; ++g) part[(slice * N + n) * HG + g] = acc[g];
       }
       __syncthreads();
-      for (int i = threadIdx.x; i < HG * N; i += HNT) {
-        const int nn = i / HG;
-        float t = bias[nn];
+      for (int i = fin; i < HG * N; i += HNT) {
+        float t = i == fin ? bfin : bias[i / HG];
         for (int s2 = 0; s2 < ks; ++s2) t += part[s2 * N * HG + i];
         outp[i] = apply_act(t, act);
       }
@@ -107,17 +112,27 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
       const int b = b0 + g;
       const float* src = a.feat + (size_t)(b < a.B ? b : a.B - 1) * a.feat_dim;
       if (a.hn_w != nullptr) {
+        float v[12];                                   // feat_dim <= 768: one load per value
         float sum = 0.f;
-        for (int c = lane; c < a.feat_dim; c += 64) sum += src[c];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int c = lane + 64 * i;
+          v[i] = c < a.feat_dim ? src[c] : 0.f;
+          sum += v[i];
+        }
         const float mean = wave_sum(sum) / a.feat_dim;
         float sq = 0.f;
-        for (int c = lane; c < a.feat_dim; c += 64) {
-          const float d = src[c] - mean;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const float d = lane + 64 * i < a.feat_dim ? v[i] - mean : 0.f;
           sq += d * d;
         }
         const float rstd = rsqrtf(wave_sum(sq) / a.feat_dim + HN_EPS);
-        for (int c = lane; c < a.feat_dim; c += 64)
-          z[c * HG + g] = (src[c] - mean) * rstd * a.hn_w[c] + a.hn_b[c];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int c = lane + 64 * i;
+          if (c < a.feat_dim) z[c * HG + g] = (v[i] - mean) * rstd * a.hn_w[c] + a.hn_b[c];
+        }
       } else {
         for (int c = lane; c < a.feat_dim; c += 64) z[c * HG + g] = src[c];
       }
@@ -206,6 +221,10 @@ int launch_head(const HeadArgs& a, hipStream_t st) {
   int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
   for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
   const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw + HNT) * sizeof(float);
+  if (a.feat_dim > 768) {
+    btsbot_set_error("head: feature width %d above 768", a.feat_dim);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (lds > 64 * 1024) {
     btsbot_set_error("head: layer widths too large for one workgroup (%zu bytes of LDS)", lds);
     return BTSBOT_ERR_INVALID_ARG;
