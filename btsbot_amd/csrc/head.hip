@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int HG = 8;     // alerts per workgroup
-constexpr int HNT = 1024;  // threads
+constexpr int HNT = 512;   // threads (1024 would cap VGPRs at 128 and spill)
 constexpr float HN_EPS = 1e-6f;
 
 // Activations of the workgroup's HG alerts live in LDS k-major: v[k][g] (8 alerts = two float4),
