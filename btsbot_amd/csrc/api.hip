@@ -67,6 +67,7 @@ int build_tables(btsbot_ctx* h) {
     h->stem_lnb = add_param(h, "stem.1.bias", {c0});
     h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
     if (h->stage0) h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);
+    h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
@@ -231,6 +232,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_fused = !(nf != nullptr && nf[0] == '1');
   const char* ns = getenv("BTSBOT_AMD_NO_STAGE0");
   h->use_stage0 = !(ns != nullptr && ns[0] == '1');
+  const char* n1 = getenv("BTSBOT_AMD_NO_STAGE1");
+  h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
   *out = h;
   return BTSBOT_OK;
 }
@@ -473,9 +476,11 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)nb * 225 * c.dims[0] * 4,
                                hipMemcpyDeviceToDevice, st));
     }
+    const bool s1 = h->stage1 && h->use_stage1;
+    bool down_done = s0;      // the previous stage's kernel already applied stage i's downsample
     for (int i = s0 ? 1 : 0; i < 4; ++i) {
       const int ch = c.dims[i], hw = STAGE_HW[i], rows = nb * hw * hw;
-      if (i > 0 && !(s0 && i == 1)) {
+      if (i > 0 && !down_done) {
         const int cin = c.dims[i - 1];
         TRY(timed(h, CAT_LNPATCH, st, [&] {
           return launch_ln_patch(c.precision, x, m + h->down[i].ln_w, m + h->down[i].ln_b, xn, nb,
@@ -488,6 +493,36 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         float* t = x;
         x = x2;
         x2 = t;
+      }
+      down_done = false;
+      if (i == 1 && s1) {
+        Stage1Args a;
+        memset(&a, 0, sizeof(a));
+        a.x_in = x;
+        for (int j = 0; j < 2; ++j) {
+          const BlockPk& b = h->blocks[1][j];
+          a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+          a.blk[j].dw_b = m + b.dw_b;
+          a.blk[j].ln_w = m + b.ln_w;
+          a.blk[j].ln_b = m + b.ln_b;
+          a.blk[j].wpk = h->extra + b.p_fused;
+          a.blk[j].b1 = m + b.fc1_b;
+          a.blk[j].b2 = m + b.fc2_b;
+          a.blk[j].gamma = m + b.gamma;
+        }
+        a.ds_lnw = m + h->down[2].ln_w;
+        a.ds_lnb = m + h->down[2].ln_b;
+        a.ds_w = h->extra + h->down[2].p_w;
+        a.ds_b = m + h->down[2].b;
+        a.out = x2;
+        a.tap_stage = h->debug ? h->taps[2] : nullptr;
+        a.B = nb;
+        TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1(c.precision, a, st); }));
+        float* t = x;
+        x = x2;
+        x2 = t;
+        down_done = true;
+        continue;
       }
       for (const BlockPk& b : h->blocks[i]) {
         TRY(timed(h, CAT_DWLN, st, [&] {
@@ -556,6 +591,10 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
   a.logits = logits;
   a.scores = scores;
   a.B = nb;
+  {
+    const char* dg = getenv("BTSBOT_AMD_HEAD_DIAG");
+    a.diag = dg != nullptr ? atoi(dg) : 0;
+  }
   TRY(timed(h, CAT_HEAD, st, [&] { return launch_head(a, st); }));
   h->last_chunk = nb;
   return BTSBOT_OK;

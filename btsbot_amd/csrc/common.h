@@ -131,6 +131,10 @@ struct Stage0Args;
 bool stage0_supported(int prec, int c0);
 int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
 
+struct Stage1Args;
+bool stage1_supported(int prec, int c1, int c2);
+int launch_stage1(int prec, const Stage1Args& a, hipStream_t st);
+
 struct HeadArgs {
   // image feature part
   const float* feat;  // [B, feat_dim] fp32 (final 1x1 map), or nullptr
@@ -156,6 +160,8 @@ struct HeadArgs {
   float* logits;
   float* scores;  // may be nullptr
   int B;
+  int diag;       // timing diagnostics (BTSBOT_AMD_HEAD_DIAG): 1 skip feature LN, 2 skip metadata
+                  // branch, 4 skip fusion layer 0, 8 skip fusion layers 1.., 16 skip all K loops
 };
 int launch_head(const HeadArgs& a, hipStream_t st);
 

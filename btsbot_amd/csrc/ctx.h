@@ -25,10 +25,10 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, NCAT };
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
-                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel"};
+                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel", "stage1_kernel"};
 constexpr size_t PROF_MAX_LAUNCHES = 8192;
 
 struct btsbot_ctx {
@@ -67,7 +67,9 @@ struct btsbot_ctx {
   size_t prof_used = 0;
 
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
-  bool use_stage0 = true;  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
+  bool stage1 = false;     // stage 1 + second downsample as one kernel
+  bool use_stage0 = true;
+  bool use_stage1 = true;  // BTSBOT_AMD_NO_STAGE1=1 likewise for stage 1  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
   // training cache (head_train.hip): activations of the last training-mode forward
   float* tcache = nullptr;
   int tcache_batch = 0, train_batch = 0;

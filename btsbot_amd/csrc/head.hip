@@ -13,84 +13,100 @@ namespace {
 constexpr int HG = 8;     // alerts per workgroup
 constexpr int HNT = 512;   // threads (1024 would cap VGPRs at 128 and spill)
 constexpr float HN_EPS = 1e-6f;
+constexpr int PARTN = 2048;   // cross-slice scratch: KS * N <= PARTN rows of HG floats (64 KB)
 
 // Activations of the workgroup's HG alerts live in LDS k-major: v[k][g] (8 alerts = two float4),
 // so one thread reads all alerts of a k with two ds_read_b128 broadcasts.
-// out[n][g] = act(bias[n] + sum_k in[k][g] * wt[k][n]); wt is K-major so consecutive threads (n)
-// read consecutive addresses.  The HNT threads cover min(N,HNT) neurons x KS slices of K
-// (KS = HNT / N).  The head is a chain of small dependent layers, i.e. latency-bound: every thread
-// keeps TWO groups of 16 weight loads in flight (a slice of <= 32 k issues all its loads before
-// the first FMA), partial sums meet in LDS (`part`), biases are fetched before the K loop.
-__device__ __forceinline__ void dense(const float* in, int K, const float* __restrict__ wt,
-                                      const float* __restrict__ bias, int N, int act, float* outp,
-                                      float* part) {
-  constexpr int GK = 16;
+// out[n][g] = act(bias[n] + sum_k in[k][g] * wt[k][n]); wt is K-major.  The head is a chain of small
+// dependent layers, i.e. latency-bound, so the layout aims at few dependent memory round trips:
+//   * a thread owns NPT = 4 consecutive neurons (one float4 weight load per k) of one K slice;
+//     the HNT threads cover N/4 quads x KS slices, KS <= 16 so the cross-slice sum stays short;
+//   * two groups of 8 k are in flight per thread (a slice of <= 16 k issues every load up front);
+//   * partial sums meet in LDS (`part`), biases are fetched before the K loop.
+// N not a multiple of 4 (the final N = 1 layer) takes the scalar path with the same structure.
+template <int NPT>
+__device__ __forceinline__ void dense_t(const float* in, int K, const float* __restrict__ wt,
+                                        const float* __restrict__ bias, int N, int act, float* outp,
+                                        float* part) {
+  constexpr int GK = 8;
+  typedef float __attribute__((ext_vector_type(NPT))) wvec;
+  const int nq = N / NPT;                              // neuron groups
   int ks = 1;
-  while (ks * 2 * N <= HNT) ks *= 2;
+  while (ks * 2 * nq <= HNT && ks * 2 * N <= PARTN && ks < 16 && K / (ks * 2) >= 8) ks *= 2;
   const int kchunk = (K + ks - 1) / ks;
-  for (int n0 = 0; n0 < N; n0 += HNT) {              // N > HNT: several passes (ks == 1)
-    const int n = n0 + (threadIdx.x % (N < HNT ? N : HNT));
-    const int slice = N < HNT ? threadIdx.x / N : 0;
-    const bool live = n < N && slice < ks;
-    // bias of the output this thread finalises after the K loop
-    const int fin = threadIdx.x;                      // ks > 1: element index into [N][HG]
-    const float bfin = ks == 1 ? (live ? bias[n] : 0.f) : (fin < HG * N ? bias[fin / HG] : 0.f);
-    float acc[HG];
+  for (int q0 = 0; q0 < nq; q0 += HNT) {               // nq > HNT: several passes (ks == 1)
+    const int q = q0 + (threadIdx.x % (nq < HNT ? nq : HNT));
+    const int slice = nq < HNT ? threadIdx.x / nq : 0;
+    const bool live = q < nq && slice < ks;
+    const int fin = threadIdx.x;                       // element of [N][HG] finalised by this thread
+    const float bfin = fin < HG * N ? bias[fin / HG] : 0.f;
+    float acc[NPT][HG];
 #pragma unroll
-    for (int g = 0; g < HG; ++g) acc[g] = 0.f;
+    for (int j = 0; j < NPT; ++j)
+#pragma unroll
+      for (int g = 0; g < HG; ++g) acc[j][g] = 0.f;
     if (live) {
       const int k0 = slice * kchunk, k1 = min(K, k0 + kchunk);
       const int ngrp = k1 > k0 ? (k1 - k0 + GK - 1) / GK : 0;
-      float wa[GK], wb[GK];
+      const float* wp = wt + (size_t)q * NPT;
+      wvec wa[GK], wb[GK];
+      auto ld = [&](int kk) {
+        return kk < k1 ? *reinterpret_cast<const wvec*>(wp + (size_t)kk * N) : wvec(0.f);
+      };
       if (ngrp > 0) {
 #pragma unroll
-        for (int u = 0; u < GK; ++u) wa[u] = k0 + u < k1 ? wt[(size_t)(k0 + u) * N + n] : 0.f;
+        for (int u = 0; u < GK; ++u) wa[u] = ld(k0 + u);
       }
       if (ngrp > 1) {
 #pragma unroll
-        for (int u = 0; u < GK; ++u)
-          wb[u] = k0 + GK + u < k1 ? wt[(size_t)(k0 + GK + u) * N + n] : 0.f;
+        for (int u = 0; u < GK; ++u) wb[u] = ld(k0 + GK + u);
       }
       for (int gi = 0; gi < ngrp; ++gi) {
         const int kb = k0 + gi * GK;
 #pragma unroll
         for (int u = 0; u < GK; ++u) {
-          const int kk = min(kb + u, k1 - 1);         // padded taps carry weight 0
+          const int kk = min(kb + u, k1 - 1);          // padded taps carry weight 0
           const float4 a0 = *reinterpret_cast<const float4*>(in + kk * HG);
           const float4 a1 = *reinterpret_cast<const float4*>(in + kk * HG + 4);
-          const float w = wa[u];
-          acc[0] = fmaf(a0.x, w, acc[0]); acc[1] = fmaf(a0.y, w, acc[1]);
-          acc[2] = fmaf(a0.z, w, acc[2]); acc[3] = fmaf(a0.w, w, acc[3]);
-          acc[4] = fmaf(a1.x, w, acc[4]); acc[5] = fmaf(a1.y, w, acc[5]);
-          acc[6] = fmaf(a1.z, w, acc[6]); acc[7] = fmaf(a1.w, w, acc[7]);
+#pragma unroll
+          for (int j = 0; j < NPT; ++j) {
+            const float w = wa[u][j];
+            acc[j][0] = fmaf(a0.x, w, acc[j][0]); acc[j][1] = fmaf(a0.y, w, acc[j][1]);
+            acc[j][2] = fmaf(a0.z, w, acc[j][2]); acc[j][3] = fmaf(a0.w, w, acc[j][3]);
+            acc[j][4] = fmaf(a1.x, w, acc[j][4]); acc[j][5] = fmaf(a1.y, w, acc[j][5]);
+            acc[j][6] = fmaf(a1.z, w, acc[j][6]); acc[j][7] = fmaf(a1.w, w, acc[j][7]);
+          }
         }
 #pragma unroll
         for (int u = 0; u < GK; ++u) wa[u] = wb[u];
         if (gi + 2 < ngrp) {
           const int kn = k0 + (gi + 2) * GK;
 #pragma unroll
-          for (int u = 0; u < GK; ++u) wb[u] = kn + u < k1 ? wt[(size_t)(kn + u) * N + n] : 0.f;
+          for (int u = 0; u < GK; ++u) wb[u] = ld(kn + u);
         }
       }
+#pragma unroll
+      for (int j = 0; j < NPT; ++j)
+#pragma unroll
+        for (int g = 0; g < HG; ++g) part[((size_t)slice * N + q * NPT + j) * HG + g] = acc[j][g];
     }
-    if (ks == 1) {
-      if (live) {
-#pragma unroll
-        for (int g = 0; g < HG; ++g) outp[n * HG + g] = apply_act(acc[g] + bfin, act);
-      }
-    } else {
-      if (live) {
-#pragma unroll
-        for (int g = 0; g < HG; ++g) part[(slice * N + n) * HG + g] = acc[g];
-      }
-      __syncthreads();
-      for (int i = fin; i < HG * N; i += HNT) {
-        float t = i == fin ? bfin : bias[i / HG];
-        for (int s2 = 0; s2 < ks; ++s2) t += part[s2 * N * HG + i];
-        outp[i] = apply_act(t, act);
-      }
+    __syncthreads();
+    for (int i = fin; i < HG * N; i += HNT) {
+      float t = i == fin ? bfin : bias[i / HG];
+      for (int s2 = 0; s2 < ks; ++s2) t += part[s2 * N * HG + i];
+      outp[i] = apply_act(t, act);
     }
   }
+}
+
+__device__ __forceinline__ void dense(const float* in, int K, const float* __restrict__ wt,
+                                      const float* __restrict__ bias, int N, int act, float* outp,
+                                      float* part, bool skipk = false) {
+  if (skipk) K = 0;
+  if ((N & 3) == 0)
+    dense_t<4>(in, K, wt, bias, N, act, outp, part);
+  else
+    dense_t<1>(in, K, wt, bias, N, act, outp, part);
 }
 
 __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
@@ -102,12 +118,12 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
   float* z = smem;               // [zd][HG]
   float* t0 = z + HG * zd;       // [maxw][HG]
   float* t1 = t0 + HG * maxw;    // [maxw][HG]
-  float* part = t1 + HG * maxw;  // [KS][N][HG], KS * N <= HNT
+  float* part = t1 + HG * maxw;  // [KS][N][HG], KS * N <= PARTN
   const int b0 = blockIdx.x * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- image feature (+ head LayerNorm) -> z[0:feat_dim][g]
-  if (a.feat_dim > 0) {
+  if (a.feat_dim > 0 && !(a.diag & 1)) {
     for (int g = wave; g < HG; g += HNT / 64) {
       const int b = b0 + g;
       const float* src = a.feat + (size_t)(b < a.B ? b : a.B - 1) * a.feat_dim;
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
     }
   }
   // ---- metadata branch -> z[feat_dim : feat_dim + f2][g]
-  if (a.n_meta > 0) {
+  if (a.n_meta > 0 && !(a.diag & 2)) {
     for (int i = tid; i < HG * a.n_meta; i += HNT) {
       const int g = i / a.n_meta, j = i - g * a.n_meta;
       const int b = b0 + g;
@@ -147,10 +163,10 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
       t0[j * HG + g] = fmaf(v, a.bn_scale[j], a.bn_shift[j]);
     }
     __syncthreads();
-    dense(t0, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, part);
+    dense(t0, a.n_meta, a.m1_wt, a.m1_b, a.f1, a.meta_act, t1, part, a.diag & 16);
     __syncthreads();
     dense(t1, a.f1, a.m2_wt, a.m2_b, a.f2, a.meta_trailing_act ? a.meta_act : ACT_NONE,
-          z + a.feat_dim * HG, part);
+          z + a.feat_dim * HG, part, a.diag & 16);
   }
   __syncthreads();
   // ---- fusion MLP
@@ -158,8 +174,9 @@ __global__ __launch_bounds__(HNT) void head_kernel(HeadArgs a) {
   float* bufs[2] = {t0, t1};
   for (int i = 0; i < a.n_layers; ++i) {
     float* o = bufs[i & 1];
+    if ((i == 0 && (a.diag & 4)) || (i > 0 && (a.diag & 8))) { in = o; continue; }
     dense(in, a.dims[i], a.wt[i], a.b[i], a.dims[i + 1],
-          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, part);
+          i + 1 < a.n_layers ? a.comb_act : ACT_NONE, o, part, a.diag & 16);
     __syncthreads();
     in = o;
   }
@@ -220,14 +237,20 @@ int launch_head(const HeadArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   int maxw = a.f1 > a.n_meta ? a.f1 : a.n_meta;
   for (int i = 1; i <= a.n_layers; ++i) maxw = a.dims[i] > maxw ? a.dims[i] : maxw;
-  const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw + HNT) * sizeof(float);
+  const size_t lds = (size_t)HG * (a.dims[0] + 2 * maxw + PARTN) * sizeof(float);
   if (a.feat_dim > 768) {
     btsbot_set_error("head: feature width %d above 768", a.feat_dim);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (lds > 64 * 1024) {
+  if (lds > 150 * 1024) {
     btsbot_set_error("head: layer widths too large for one workgroup (%zu bytes of LDS)", lds);
     return BTSBOT_ERR_INVALID_ARG;
+  }
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr = lds;
   }
   hipLaunchKernelGGL(head_kernel, dim3((a.B + HG - 1) / HG), dim3(HNT), lds, st, a);
   LAUNCH_CHECK();

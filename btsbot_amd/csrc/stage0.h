@@ -30,3 +30,16 @@ struct Stage0Args {
                           // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
 };
 
+
+// Argument block of the stage-1 megakernel (stage1.hip): 4 alerts per workgroup, C = 128.
+struct Stage1Args {
+  const float* x_in;      // [B][49][128] f32 (stage-0 output after its downsample)
+  Stage0Blk blk[2];       // dw_w is [49][128]; wpk is the FusedGeom<128> image
+  const float* ds_lnw;
+  const float* ds_lnb;
+  const void* ds_w;       // [256][512] 16-bit, k = (ky*2+kx)*128 + c
+  const float* ds_b;
+  float* out;             // [B][9][256] f32
+  float* tap_stage;       // optional [B][49][128] f32 copy of the stage output (validation)
+  int B;
+};
