@@ -77,7 +77,9 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     esz = 4 if precision == "f32" else 2
     st = list(zip(depths, STAGE_P, dims))
     s0 = precision != "f32" and dims[0] == 64 and depths[0] == 2      # stage-0 megakernel
-    fused = [precision != "f32" and c in (64, 128) and not (s0 and i == 0)
+    s1 = precision != "f32" and dims[1] == 128 and dims[2] == 256 and depths[1] == 2   # stage-1
+    mega = [s0, s1, False, False]
+    fused = [precision != "f32" and c in (64, 128) and not mega[i]
              for i, (_, _, c) in enumerate(st)]
     pw = lambda d, p, c: d * 2 * batch * p * c * 4 * c          # one of the two 1x1 convs
     w = {}
@@ -88,11 +90,14 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     w["stage0_kernel"] = dict(
         flop=(stem_flop + 2 * pw(*st[0]) + down_flop(1)) if s0 else 0,
         bytes=batch * (3 * 63 * 63 * 4 + 49 * dims[1] * 4))
+    w["stage1_kernel"] = dict(
+        flop=(2 * pw(*st[1]) + down_flop(2)) if s1 else 0,
+        bytes=batch * (49 * dims[1] * 4 + 9 * dims[2] * 4))
     w["fused_mlp_kernel"] = dict(
         flop=sum(2 * pw(d, p, c) for (d, p, c), f in zip(st, fused) if f),
         bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
                   for (d, p, c), f in zip(st, fused) if f))
-    unf = [not f and not (s0 and i == 0) for i, f in enumerate(fused)]
+    unf = [not f and not mega[i] for i, f in enumerate(fused)]
     w["gemm_kernel<fc1,GELU>"] = dict(
         flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
         bytes=sum(d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
@@ -101,11 +106,11 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
         flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
         bytes=sum(d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
                   for (d, p, c), u in zip(st, unf) if u))
-    dwst = [(d, p, c) for i, (d, p, c) in enumerate(st) if not (s0 and i == 0)]
+    dwst = [(d, p, c) for i, (d, p, c) in enumerate(st) if not mega[i]]
     w["dwconv_ln_kernel"] = dict(
         flop=sum(d * 2 * 49 * batch * p * c for d, p, c in dwst),
         bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in dwst))
-    dn = [i for i in (1, 2, 3) if not (s0 and i == 1)]
+    dn = [i for i in (1, 2, 3) if not mega[i - 1]]
     w["gemm_kernel<down,BIAS>"] = dict(
         flop=sum(down_flop(i) for i in dn),
         bytes=sum(batch * STAGE_P[i] * (4 * dims[i - 1] * esz + dims[i] * 4) for i in dn))
@@ -118,7 +123,7 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     return w
 
 
-POINTWISE = ("stage0_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
+POINTWISE = ("stage0_kernel", "stage1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
 
 
 def cpu_baseline(sample_batch=256, budget_s=20.0):
