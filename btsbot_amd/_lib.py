@@ -25,7 +25,7 @@ SYMBOLS = [
     "btsbot_set_profile", "btsbot_profile_categories", "btsbot_profile_category_name",
     "btsbot_profile_collect",
     "btsbot_op_gemm", "btsbot_op_dwconv_ln", "btsbot_op_stem", "btsbot_op_ln_patch",
-    "btsbot_reserve_train", "btsbot_forward_train", "btsbot_backward",
+    "btsbot_reserve_train", "btsbot_forward_train", "btsbot_backward", "btsbot_debug_stamps",
 ]
 
 
@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.btsbot_op_stem.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.btsbot_op_ln_patch.restype = i32
     L.btsbot_op_ln_patch.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.btsbot_debug_stamps.restype = i32
+    L.btsbot_debug_stamps.argtypes = [vp, vp]
     L.btsbot_reserve_train.restype = i32
     L.btsbot_reserve_train.argtypes = [vp, i32]
     L.btsbot_forward_train.restype = i32

@@ -333,6 +333,12 @@ extern "C" int64_t btsbot_workspace_bytes(btsbot_handle h, int max_chunk) {
   return (int64_t)total;
 }
 
+extern "C" int btsbot_debug_stamps(btsbot_handle h, unsigned long long* device_buffer32) {
+  if (h == nullptr) return BTSBOT_ERR_INVALID_ARG;
+  h->stamps = device_buffer32;
+  return BTSBOT_OK;
+}
+
 extern "C" int btsbot_set_debug(btsbot_handle h, int on) {
   if (h == nullptr) return BTSBOT_ERR_INVALID_ARG;
   h->debug = on != 0;
@@ -466,6 +472,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         const char* dg = getenv("BTSBOT_AMD_S0_DIAG");
         a.diag = dg != nullptr ? atoi(dg) : 0;
       }
+      a.stamps = h->stamps;
       TRY(timed(h, CAT_STAGE0, st, [&] { return launch_stage0(c.precision, a, st); }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
@@ -517,6 +524,11 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.out = x2;
         a.tap_stage = h->debug ? h->taps[2] : nullptr;
         a.B = nb;
+        {
+          const char* dg = getenv("BTSBOT_AMD_S0_DIAG");
+          a.diag = dg != nullptr ? atoi(dg) : 0;
+        }
+        a.stamps = h->stamps ? h->stamps + 16 : nullptr;
         TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1(c.precision, a, st); }));
         float* t = x;
         x = x2;

@@ -76,6 +76,7 @@ struct btsbot_ctx {
   const uint8_t* t_meta_mask = nullptr;
   const uint8_t* t_comb_mask = nullptr;
 
+  unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1
   bool debug = false;
   float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int last_chunk = 0;

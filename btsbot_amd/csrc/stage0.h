@@ -26,6 +26,7 @@ struct Stage0Args {
   float* tap_stem;        // optional [B][225][64] f32 copies (validation)
   float* tap_stage;
   int B;
+  unsigned long long* stamps;   // optional: workgroup 0 / thread 0 writes s_memtime at phase ends
   int diag;               // timing diagnostics only (BTSBOT_AMD_S0_DIAG): bit0 skip depthwise FMAs,
                           // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
 };
@@ -42,4 +43,6 @@ struct Stage1Args {
   float* out;             // [B][9][256] f32
   float* tap_stage;       // optional [B][49][128] f32 copy of the stage output (validation)
   int B;
+  unsigned long long* stamps;   // optional phase timestamps (workgroup 0, thread 0)
+  int diag;               // timing diagnostics, same bits as Stage0Args::diag
 };

@@ -51,6 +51,12 @@ constexpr int NSUB = 8;
 constexpr int WBYTES = NSUB * SUBBYTES;           // 77824: the whole block's pointwise filters
 constexpr float LN_EPS = 1e-6f;
 
+// diagnostic builds of the timeline: workgroup 0, thread 0 stores the shader clock
+#define STAMP(i)                                                                  \
+  do {                                                                            \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+  } while (0)
+
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 
 __device__ __forceinline__ float swap_add32(float a, float b) {
@@ -77,7 +83,8 @@ __device__ __forceinline__ int chan(int ct, int r, int h) { return ct * 32 + (r 
 // LayerNorm over the 64 channels of this lane's pixel, held as x[2][16] in this lane and its
 // partner lane^32; affine with w/b; result in place.
 __device__ __forceinline__ void ln_regs(f32x16 (&x)[CT], const float* __restrict__ w,
-                                        const float* __restrict__ b, int h, f32x16 (&y)[CT]) {
+                                        const float* __restrict__ b, int h, f32x16 (&y)[CT],
+                                        bool noload = false) {
   float s = 0.f;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -100,8 +107,8 @@ __device__ __forceinline__ void ln_regs(f32x16 (&x)[CT], const float* __restrict
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int c = ct * 32 + 8 * qd + 4 * h;
-      const float4 wv = *reinterpret_cast<const float4*>(w + c);
-      const float4 bv = *reinterpret_cast<const float4*>(b + c);
+      const float4 wv = noload ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(w + c);
+      const float4 bv = noload ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(b + c);
       y[ct][4 * qd + 0] = (x[ct][4 * qd + 0] - mean) * rstd * wv.x + bv.x;
       y[ct][4 * qd + 1] = (x[ct][4 * qd + 1] - mean) * rstd * wv.y + bv.y;
       y[ct][4 * qd + 2] = (x[ct][4 * qd + 2] - mean) * rstd * wv.z + bv.z;
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
   const int pc = live ? p : 0;
   const int py = pc / HW, px = pc - py * HW;
 
+  STAMP(0);
   // rows 225..255 of both images are padding: keep them finite
   for (int i = tid; i < (256 - P) * PITCH / 4; i += 512) {
     reinterpret_cast<unsigned*>(map0 + P * PITCH)[i] = 0u;
@@ -195,12 +203,13 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         x[ct] = S0M<T>::run(af, bf, x[ct]);
       }
     }
-    ln_regs(x, a.stem_lnw, a.stem_lnb, h, x);
+    ln_regs(x, a.stem_lnw, a.stem_lnb, h, x, a.diag & 64);
     regs_to_map<T>(x, map0, p, h);
     if (a.tap_stem != nullptr && live)
       regs_to_tap(x, a.tap_stem + ((size_t)alert * P + p) * C, h);
   }
 
+  STAMP(1);   // stem done
   // ============================ two ConvNeXt blocks ========================================
   // Depthwise filters (lane = channel: 49 taps + bias + LN affine) are fetched one block AHEAD with
   // ordinary loads, so that no ordinary load is outstanding while the pointwise filters' LDS-DMA
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
   float w[49], dwbias, lng, lnb2, b1v;
   {
 #pragma unroll
-    for (int t = 0; t < 49; ++t) w[t] = a.blk[0].dw_w[t * C + lane];
+    for (int t = 0; t < 49; ++t) w[t] = (a.diag & 64) ? 0.01f : a.blk[0].dw_w[t * C + lane];
     dwbias = a.blk[0].dw_b[lane];
     lng = a.blk[0].ln_w[lane];
     lnb2 = a.blk[0].ln_b[lane];
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
 #pragma unroll
     for (int t = 0; t < 49; ++t) asm volatile("" ::"v"(w[t]));
     asm volatile("" ::"v"(dwbias), "v"(lng), "v"(lnb2), "v"(b1v));
+    STAMP(2 + 5 * j);   // filters touched
     __syncthreads();   // map0 complete; previous block's filter / fc1-bias reads finished
     if (tid < 256) b1s[tid] = b1v;
     // ---- the block's pointwise filters: 76 x 1 KiB LDS-DMA pieces, wave w takes w, w+8, ...
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
       __builtin_amdgcn_global_load_lds((gptr_t)(bk.wpk + (size_t)pc2 * 1024 + lane * 16),
                                        (lptr_t)(wring + pc2 * 1024), 16, 0, 0);
 
+    STAMP(3 + 5 * j);   // DMA issued
     // ---- depthwise 7x7 + bias + LN: lane = channel, wave = map row, 2 rounds of 8 rows
     {
       const int c = lane;
@@ -290,17 +301,19 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         }
       }
     }
+    STAMP(4 + 5 * j);   // depthwise done
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's filter pieces have landed
     __syncthreads();                                    // map1 + filters complete for everyone
     if (j == 0) {   // next block's depthwise filters: in flight under the MLP (no DMA pending now)
 #pragma unroll
-      for (int t = 0; t < 49; ++t) w[t] = a.blk[1].dw_w[t * C + lane];
+      for (int t = 0; t < 49; ++t) w[t] = (a.diag & 64) ? 0.01f : a.blk[1].dw_w[t * C + lane];
       dwbias = a.blk[1].dw_b[lane];
       lng = a.blk[1].ln_w[lane];
       lnb2 = a.blk[1].ln_b[lane];
       b1v = a.blk[1].b1[tid & 255];
     }
 
+    STAMP(5 + 5 * j);   // DMA landed + barrier
     // ---- fc1 -> GELU -> fc2 (register-chained, see fused_mlp.hip), then x += gamma*(y + b2)
     {
       frag xf[4];
@@ -347,8 +360,8 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const int c = ct * 32 + 8 * qd + 4 * h;
-          const float4 bv = *reinterpret_cast<const float4*>(bk.b2 + c);
-          const float4 gv = *reinterpret_cast<const float4*>(bk.gamma + c);
+          const float4 bv = (a.diag & 64) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bk.b2 + c);
+          const float4 gv = (a.diag & 64) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(bk.gamma + c);
           x[ct][4 * qd + 0] += gv.x * (yacc[ct][4 * qd + 0] + bv.x);
           x[ct][4 * qd + 1] += gv.y * (yacc[ct][4 * qd + 1] + bv.y);
           x[ct][4 * qd + 2] += gv.z * (yacc[ct][4 * qd + 2] + bv.z);
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         }
       if (j == 0) regs_to_map<T>(x, map0, p, h);   // next block's depthwise input
     }
+    STAMP(6 + 5 * j);   // MLP done
   }
   if (a.tap_stage != nullptr && live)
     regs_to_tap(x, a.tap_stage + ((size_t)alert * P + p) * C, h);
@@ -363,9 +377,10 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
   // ============================ downsample: LN + conv 2x2 s2 (64 -> 128) ====================
   {
     f32x16 xn[CT];
-    ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn);
+    ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn, a.diag & 64);
     regs_to_map<T>(xn, map0, p, h);   // map0: last read by block 1's depthwise phase
     __syncthreads();
+    STAMP(12);   // downsample LN done
     // wave -> (pixel tile pt of the 49 outputs, 32-channel output tile cot); K = 4 taps x 64 ch
     const int pt = wave & 1, cot = wave >> 1;
     const int o = pt * 32 + lr;
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
         *reinterpret_cast<float4*>(dst + 8 * qd) =
             make_float4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
     }
+    STAMP(13);   // end
   }
 }
 

@@ -48,6 +48,12 @@ constexpr int SUBS = 2, NCHUNK = 8;
 constexpr int CHUNKB = SUBS * SUBBYTES;            // 37888 = 37 x 1 KiB
 constexpr int PIECES = CHUNKB / 1024;
 constexpr float LN_EPS = 1e-6f;
+
+// diagnostic builds of the timeline: workgroup 0, thread 0 stores the shader clock
+#define STAMP(i)                                                                  \
+  do {                                                                            \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+  } while (0)
 static_assert(CHUNKB % 1024 == 0, "chunk must be whole LDS-DMA pieces");
 
 __device__ __forceinline__ float swap_add32(float a, float b) {
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
   const bool live = p < nal * P;
   const int pc = live ? p : 0;
 
+  STAMP(0);
   // ---- stage input -> registers (accumulator layout) and the 16-bit map image
   f32x16 x[CT];
   {
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
     regs_to_map<T>(x, map, p, h);
   }
 
+  STAMP(1);   // input loaded
   const int chunk = wave & 1;                        // channel half owned in the depthwise phase
   const int cdw = chunk * 64 + lane;
 #pragma unroll 1
@@ -166,13 +174,16 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
 #pragma unroll
     for (int t = 0; t < 49; ++t) asm volatile("" ::"v"(w[t]));
     asm volatile("" ::"v"(dwbias), "v"(lng), "v"(lnb2), "v"(b1v));
+    STAMP(2 + 5 * j);   // filters touched
     __syncthreads();            // map complete; previous block's ring / b1s reads finished
     b1s[tid] = b1v;
     // chunk 0 of the pointwise filters -> ring slot 0, in flight under the depthwise phase
-    for (int pc2 = wave; pc2 < PIECES; pc2 += 8)
+    const int npieces = (a.diag & 4) ? 0 : PIECES;
+    for (int pc2 = wave; pc2 < npieces; pc2 += 8)
       __builtin_amdgcn_global_load_lds((gptr_t)(bk.wpk + (size_t)pc2 * 1024 + lane * 16),
                                        (lptr_t)(ring + pc2 * 1024), 16, 0, 0);
 
+    STAMP(3 + 5 * j);   // DMA issued
     // ---- depthwise 7x7 + bias + LN: 56 (alert, row, channel-half) items over 8 waves = 7 rounds;
     //      LN outputs wait in registers (xnv) until every wave is done reading the image
     typedef T T8 __attribute__((ext_vector_type(8)));
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
           const int iy = y + ky - 3;
-          if (iy < 0 || iy >= HW) continue;
+          if (iy < 0 || iy >= HW || (a.diag & 1)) continue;
           const T* row = mi + ((g * HW + iy) * HW) * (PITCH / 2) + cdw;
           float in[HW];
 #pragma unroll
@@ -238,7 +249,9 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
         for (int xx = 0; xx < HW; ++xx) dst[xx * (PITCH / 2)] = xnv[rd][xx];
       }
     }
+    STAMP(4 + 5 * j);   // depthwise done
     __syncthreads();            // LN image complete
+    STAMP(5 + 5 * j);
 
     // ---- fc1 -> GELU -> fc2 over 8 chunks of 64 hidden units (ring), then x += gamma*(y + b2)
     {
@@ -256,13 +269,13 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk ch landed
         __syncthreads();        // ... everyone's; and everyone is done with chunk ch-1's slot
         if (ch + 1 < NCHUNK)
-          for (int pc2 = wave; pc2 < PIECES; pc2 += 8)
+          for (int pc2 = wave; pc2 < npieces; pc2 += 8)
             __builtin_amdgcn_global_load_lds(
                 (gptr_t)(bk.wpk + (size_t)(ch + 1) * CHUNKB + (size_t)pc2 * 1024 + lane * 16),
                 (lptr_t)(ring + ((ch + 1) & 1) * CHUNKB + pc2 * 1024), 16, 0, 0);
         const unsigned char* cb = ring + (ch & 1) * CHUNKB;
 #pragma unroll 1
-        for (int sub = 0; sub < SUBS; ++sub) {
+        for (int sub = 0; sub < ((a.diag & 2) ? 0 : SUBS); ++sub) {
           const unsigned char* w1s = cb + sub * SUBBYTES;
           const unsigned char* w2s = w1s + 32 * W1ROW;
           f32x16 hacc;
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
           }
           frag hf[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
+          for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)((a.diag & 8) ? hacc[r] : gelu_fast(hacc[r]));
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -307,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
       // the LN image was last read (xf) before the first chunk barrier: free to overwrite
       if (j == 0) regs_to_map<T>(x, map, p, h);
     }
+    STAMP(6 + 5 * j);   // MLP done
   }
   if (a.tap_stage != nullptr && live) {
     float* tp = a.tap_stage + ((size_t)a0 * P + p) * C;
@@ -324,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
     ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn);
     regs_to_map<T>(xn, map, p, h);
     __syncthreads();
+    STAMP(12);
     const int pt = wave & 1;                         // output-pixel tile (36 -> 2 tiles of 32)
     const int o = pt * 32 + lr;
     const bool olive = o < nal * PO;
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
       }
       const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(cot * 32 + lr) * (4 * C) + h * 8;
 #pragma unroll 8
-      for (int ks = 0; ks < 32; ++ks) {
+      for (int ks = 0; ks < ((a.diag & 32) ? 0 : 32); ++ks) {
         const int q = ks >> 3;                       // tap (ky*2 + kx): 8 k-steps of 16 channels each
         const int pin = g * P + (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
         const frag bf = *reinterpret_cast<const frag*>(map + pin * PITCH + (ks & 7) * 32 + h * 16);
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
               make_float4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
       }
     }
+    STAMP(13);
   }
 }
 

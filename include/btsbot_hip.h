@@ -154,6 +154,10 @@ int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, in
  * stage outputs (call before btsbot_reserve()). */
 int btsbot_set_debug(btsbot_handle h, int on);
 
+/* Developer aid: when non-NULL, workgroup 0 of the stage megakernels stores the shader clock at its
+ * phase boundaries into device_buffer32[0..31] (uint64). */
+int btsbot_debug_stamps(btsbot_handle h, unsigned long long* device_buffer32);
+
 /* Debug/validation tap: copy an intermediate of the LAST forward chunk to `dst` (fp32).
  * name: "stem", "stage0".."stage3" (NHWC [chunk, P, C]).  Returns the element count or <0. */
 int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst, int64_t capacity,

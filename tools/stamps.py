@@ -1,0 +1,27 @@
+"""Developer diagnostic: in-kernel phase timeline (shader clock) of workgroup 0 of the megakernels."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from helpers import CONFIGS, seeded_state, build_model, run_model
+from btsbot_amd import _lib
+from btsbot_amd.synthetic import synthetic_batch
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+kind, cfg = CONFIGS["mm_pico"]
+m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), dev, "bf16")
+img, meta, _ = synthetic_batch(B, seed=2)
+img, meta = img.to(dev), meta.to(dev)
+for _ in range(3):
+    run_model(kind, m, img, meta)
+buf = torch.zeros(32, dtype=torch.int64, device=dev)
+_lib.check(_lib.lib().btsbot_debug_stamps(m._handle.ptr, C.c_void_p(buf.data_ptr())), "stamps")
+run_model(kind, m, img, meta)
+torch.cuda.synchronize()
+t = buf.cpu().tolist()
+names = ["start", "stem/input", "b0 filters touched", "b0 DMA issued", "b0 depthwise done", "b0 DMA landed", "b0 MLP done",
+         "b1 filters touched", "b1 DMA issued", "b1 depthwise done", "b1 DMA landed", "b1 MLP done", "ds LN done", "end"]
+for base, tag in ((0, "stage0"), (16, "stage1")):
+    print(tag, "total cycles", t[base + 13] - t[base])
+    for i in range(1, 14):
+        print(f"   {names[i]:22s} +{t[base + i] - t[base + i - 1]:8d}")
