@@ -329,6 +329,17 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
       for (int sub = 0; sub < ((a.diag & 2) ? 0 : NSUB); ++sub) {
         const unsigned char* w1s = wring + sub * SUBBYTES;
         const unsigned char* w2s = w1s + 32 * W1ROW;
+        // all 8 filter fragments of this sub-chunk are requested up front (explicit arrays: hipcc
+        // otherwise reuses one register quad and serialises ds_read -> wait -> MFMA per fragment)
+        frag a1[4], a2[CT][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          a1[ks] = *reinterpret_cast<const frag*>(w1s + lr * W1ROW + ks * 32 + h * 16);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + (ct * 32 + lr) * W2ROW + s2 * 32 + h * 16);
         f32x16 hacc;
         const float* bp = b1s + sub * 32 + 4 * h;
 #pragma unroll
@@ -340,20 +351,14 @@ __global__ __launch_bounds__(512, 2) void stage0_kernel(Stage0Args a) {
           hacc[4 * qd + 3] = bv.w;
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const frag af = *reinterpret_cast<const frag*>(w1s + lr * W1ROW + ks * 32 + h * 16);
-          hacc = S0M<T>::run(af, xf[ks], hacc);
-        }
+        for (int ks = 0; ks < 4; ++ks) hacc = S0M<T>::run(a1[ks], xf[ks], hacc);
         frag hf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)((a.diag & 8) ? hacc[r] : gelu_fast(hacc[r]));
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const frag af = *reinterpret_cast<const frag*>(w2s + (ct * 32 + lr) * W2ROW + s2 * 32 + h * 16);
-            yacc[ct] = S0M<T>::run(af, hf[s2], yacc[ct]);
-          }
+          for (int s2 = 0; s2 < 2; ++s2) yacc[ct] = S0M<T>::run(a2[ct][s2], hf[s2], yacc[ct]);
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)

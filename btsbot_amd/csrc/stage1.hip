@@ -264,15 +264,24 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
+      // Ring: chunk ch+1 travels global -> registers (ordinary, non-blocking loads issued before the
+      // MFMAs of chunk ch) -> LDS slot (ch+1)&1 after them; ONE barrier per chunk.  (LDS-DMA here
+      // stalled the issuing wave for the whole transfer: ~4.4k cycles per 37 KB chunk.)
+      constexpr int SPT = (CHUNKB / 16 + 511) / 512;     // 16-byte pieces per thread per chunk
+      uint4 stg[SPT];
 #pragma unroll 1
       for (int ch = 0; ch < NCHUNK; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk ch landed
-        __syncthreads();        // ... everyone's; and everyone is done with chunk ch-1's slot
-        if (ch + 1 < NCHUNK)
-          for (int pc2 = wave; pc2 < npieces; pc2 += 8)
-            __builtin_amdgcn_global_load_lds(
-                (gptr_t)(bk.wpk + (size_t)(ch + 1) * CHUNKB + (size_t)pc2 * 1024 + lane * 16),
-                (lptr_t)(ring + ((ch + 1) & 1) * CHUNKB + pc2 * 1024), 16, 0, 0);
+        if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 came by LDS-DMA
+        __syncthreads();        // chunk ch is in its slot for everyone; slot (ch+1)&1 is free
+        {   // (the fetch after the last chunk wraps to chunk 0: redundant, harmless, branch-free)
+          const uint4* srcp =
+              reinterpret_cast<const uint4*>(bk.wpk + (size_t)((ch + 1) & (NCHUNK - 1)) * CHUNKB);
+#pragma unroll
+          for (int i = 0; i < SPT; ++i) {
+            const int q = tid + i * 512;
+            stg[i] = srcp[q < CHUNKB / 16 ? q : CHUNKB / 16 - 1];
+          }
+        }
         const unsigned char* cb = ring + (ch & 1) * CHUNKB;
 #pragma unroll 1
         for (int sub = 0; sub < ((a.diag & 2) ? 0 : SUBS); ++sub) {
@@ -303,6 +312,14 @@ __global__ __launch_bounds__(512, 2) void stage1_kernel(Stage1Args a) {
               const frag af = *reinterpret_cast<const frag*>(w2s + (ct * 32 + lr) * W2ROW + s2 * 32 + h * 16);
               yacc[ct] = S1M<T>::run(af, hf[s2], yacc[ct]);
             }
+        }
+        {
+          uint4* dstp = reinterpret_cast<uint4*>(ring + ((ch + 1) & 1) * CHUNKB);
+#pragma unroll
+          for (int i = 0; i < SPT; ++i) {
+            const int q = tid + i * 512;
+            if (i < SPT - 1 || q < CHUNKB / 16) dstp[q] = stg[i];
+          }
         }
       }
 #pragma unroll
