@@ -110,9 +110,9 @@ def lib() -> C.CDLL:
     L.btsbot_debug_stamps.restype = i32
     L.btsbot_debug_stamps.argtypes = [vp, vp]
     L.btsbot_reserve_train.restype = i32
-    L.btsbot_reserve_train.argtypes = [vp, i32]
+    L.btsbot_reserve_train.argtypes = [vp, i32, i32]
     L.btsbot_forward_train.restype = i32
-    L.btsbot_forward_train.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.btsbot_forward_train.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp]
     L.btsbot_backward.restype = i32
     L.btsbot_backward.argtypes = [vp, vp, vp, i32, i32, vp]
     L.btsbot_bce_fwd_bwd.restype = i32

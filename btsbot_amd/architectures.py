@@ -102,6 +102,7 @@ class _HipModel(nn.Module):
         self._packed_version = None
         self._reserved = 0
         self._reserved_train = 0
+        self._reserved_image = False
 
     def _build_parameters(self):
         h = self._handle
@@ -319,16 +320,12 @@ class _HipModel(nn.Module):
 
     def _run_train(self, image, meta):
         """model.train() forward: BatchNorm batch statistics (+ running-stat update), dropout,
-        activations cached for backward.  Differentiable w.r.t. the fusion head and the metadata
-        branch; a trainable ConvNeXt branch is refused (not built yet)."""
+        activations cached for backward.  Differentiable w.r.t. every parameter that has
+        requires_grad (fusion head, metadata branch, ConvNeXt image branch)."""
         comb, metag, imageg = self._slot_groups()
         grad_on = torch.is_grad_enabled()
-        if grad_on and any(t.requires_grad for t, *_ in imageg):
-            raise NotImplementedError(
-                "btsbot_amd: backward through the ConvNeXt image branch is not built yet; freeze it "
-                "(requires_grad_(False)) as frozen_fusion training does (train.py:224-232), or run "
-                "under torch.no_grad()")
-        trainable = [g for g in comb + metag if g[0].requires_grad] if grad_on else []
+        trainable = [g for g in imageg + metag + comb if g[0].requires_grad] if grad_on else []
+        keep_image = grad_on and any(t.requires_grad for t, *_ in imageg)
         ref = image if image is not None else meta
         batch, dev = ref.shape[0], ref.device
         if batch < 1:
@@ -336,16 +333,25 @@ class _HipModel(nn.Module):
         masks = self._dropout_masks(batch, dev)
         if not trainable:
             return self._forward_train_raw(image, meta, masks)
-        return _TrainFn.apply(self, image, meta, masks, trainable, *[g[0] for g in trainable])
+        return _TrainFn.apply(self, image, meta, masks, (trainable, keep_image),
+                              *[g[0] for g in trainable])
 
-    def _forward_train_raw(self, image, meta, masks):
+    def _forward_train_raw(self, image, meta, masks, keep_image: bool = False):
         ref = image if image is not None else meta
         batch, dev = ref.shape[0], ref.device
         with torch.cuda.device(dev):
             L, stream = self._prepare(dev, batch)
-            if batch > getattr(self, "_reserved_train", 0):
-                _lib.check(L.btsbot_reserve_train(self._handle.ptr, batch), "btsbot_reserve_train")
-                self._reserved_train = batch
+            if batch > self._reserved_train or (keep_image and not self._reserved_image):
+                _lib.check(L.btsbot_reserve_train(self._handle.ptr, max(batch, self._reserved_train),
+                                                  int(keep_image or self._reserved_image)),
+                           "btsbot_reserve_train")
+                self._reserved_train = max(batch, self._reserved_train)
+                if keep_image and not self._reserved_image:
+                    self._reserved_image = True
+                    # the dgrad operand images are packed from now on
+                    _lib.check(L.btsbot_pack_params(self._handle.ptr,
+                                                    C.c_void_p(self._arena.data_ptr()),
+                                                    C.c_void_p(stream)), "btsbot_pack_params")
             logits = torch.empty(batch, dtype=torch.float32, device=dev)
             self._live_masks = masks          # must outlive btsbot_backward
             _lib.check(L.btsbot_forward_train(
@@ -355,7 +361,8 @@ class _HipModel(nn.Module):
                 C.c_void_p(logits.data_ptr()), C.c_void_p(0), batch,
                 C.c_void_p(masks[0].data_ptr() if masks[0] is not None else 0),
                 C.c_void_p(masks[1].data_ptr() if masks[1] is not None else 0),
-                C.c_void_p(self._arena.data_ptr()), C.c_void_p(stream)), "btsbot_forward_train")
+                C.c_void_p(self._arena.data_ptr()), int(keep_image), C.c_void_p(stream)),
+                "btsbot_forward_train")
         # the kernel updated running_mean / running_var inside the arena
         for mod in self.modules():
             if "num_batches_tracked" in mod._buffers:
@@ -363,7 +370,8 @@ class _HipModel(nn.Module):
         self._packed_version = None
         return logits.view(batch, 1)
 
-    def _backward_raw(self, dlogits: torch.Tensor, need_meta: bool) -> torch.Tensor:
+    def _backward_raw(self, dlogits: torch.Tensor, need_meta: bool,
+                      need_image: bool = False) -> torch.Tensor:
         """d(loss)/d(param) into the flat gradient arena (master-arena layout); returns the arena."""
         dev = self._arena.device
         if getattr(self, "_grad_arena", None) is None or self._grad_arena.device != dev:
@@ -373,7 +381,7 @@ class _HipModel(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.lib().btsbot_backward(
                 self._handle.ptr, C.c_void_p(dl.data_ptr()), C.c_void_p(self._grad_arena.data_ptr()),
-                int(need_meta), 0, C.c_void_p(stream)), "btsbot_backward")
+                int(need_meta), int(need_image), C.c_void_p(stream)), "btsbot_backward")
         return self._grad_arena
 
     def set_profile(self, on: bool = True):
@@ -409,10 +417,12 @@ class _TrainFn(torch.autograd.Function):
     """Autograd node around btsbot_forward_train / btsbot_backward (train.py:510,526)."""
 
     @staticmethod
-    def forward(ctx, model, image, meta, masks, trainable, *params):
+    def forward(ctx, model, image, meta, masks, plan, *params):
+        trainable, keep_image = plan
         ctx.model = model
         ctx.trainable = trainable
-        return model._forward_train_raw(image, meta, masks)
+        ctx.keep_image = keep_image
+        return model._forward_train_raw(image, meta, masks, keep_image)
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -420,7 +430,7 @@ class _TrainFn(torch.autograd.Function):
         _comb, metag, _img = model._slot_groups()
         meta_ids = {id(t) for t, *_ in metag}
         need_meta = any(id(t) in meta_ids for t, *_ in trainable)
-        arena = model._backward_raw(dlogits, need_meta)
+        arena = model._backward_raw(dlogits, need_meta, ctx.keep_image)
         grads = [arena[off:off + numel].view(shape).clone() for _t, off, numel, shape in trainable]
         return (None, None, None, None, None, *grads)
 

@@ -66,7 +66,7 @@ int build_tables(btsbot_ctx* h) {
     h->stem_lnw = add_param(h, "stem.1.weight", {c0});
     h->stem_lnb = add_param(h, "stem.1.bias", {c0});
     h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
-    if (h->stage0) h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);
+    h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
     h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
@@ -80,6 +80,7 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].w = add_param(h, p + "1.weight", {ch, cin, 2, 2});
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
+        h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
       }
       for (int j = 0; j < c.depths[i]; ++j) {
         snprintf(buf, sizeof buf, "stages.%d.blocks.%d.", i, j);
@@ -97,6 +98,8 @@ int build_tables(btsbot_ctx* h) {
         b.p_dw = bump(cur, (size_t)49 * ch * 4);
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
+        b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
+        b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
         b.fused = fused_mlp_supported(c.precision, ch);
         b.p_fused = b.fused ? bump(cur, fused_mlp_packed_bytes(ch)) : 0;
         h->blocks[i].push_back(b);
@@ -107,6 +110,7 @@ int build_tables(btsbot_ctx* h) {
       h->hn_b = add_param(h, "head_norm.bias", {c.dims[3]});
     }
   }
+  h->img_floats = h->total_floats;
   if (h->has_meta) {
     h->bn_w = add_param(h, "meta.0.weight", {c.n_meta});
     h->bn_b = add_param(h, "meta.0.bias", {c.n_meta});
@@ -244,6 +248,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->extra) (void)hipFree(h->extra);
   if (h->ws) (void)hipFree(h->ws);
   if (h->tcache) (void)hipFree(h->tcache);
+  if (h->bbcache) (void)hipFree(h->bbcache);
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -291,19 +296,27 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                          st));
   const float* m = h->mirror;
   if (h->has_image) {
-    if (h->stage0)
+    if (h->stage0 || h->train_packs)
       TRY(launch_cast(c.precision, m + h->stem_w, h->extra + h->p_stem16, (int64_t)c.dims[0] * 48,
                       st));
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
-      if (i > 0)
+      if (i > 0) {
         TRY(launch_pack_down(c.precision, m + h->down[i].w, h->extra + h->down[i].p_w, ch,
                              c.dims[i - 1], st));
+        if (h->train_packs)
+          TRY(launch_pack_down_t(c.precision, m + h->down[i].w, h->extra + h->down[i].p_wt, ch,
+                                 c.dims[i - 1], st));
+      }
       for (const BlockPk& b : h->blocks[i]) {
         TRY(launch_transpose_f32(m + b.dw_w, reinterpret_cast<float*>(h->extra + b.p_dw), ch, 49,
                                  st));
         TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
+        if (h->train_packs) {   // W1^T [C][4C] and W2^T [4C][C] for the dgrad GEMMs
+          TRY(launch_transpose_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1t, 4 * ch, ch, st));
+          TRY(launch_transpose_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2t, ch, 4 * ch, st));
+        }
         if (b.fused)
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
                                     h->extra + b.p_fused, st));
@@ -653,25 +666,44 @@ extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const floa
 // training: forward with batch statistics + dropout, backward of the heads
 // ---------------------------------------------------------------------------------------
 size_t train_cache_floats(const btsbot_ctx* h, int M);
+size_t bb_cache_bytes(const btsbot_ctx* h, int B);
+int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t st, float** feat_out);
+int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads,
+                            int B, hipStream_t st);
 float* train_cache_feat(btsbot_ctx* h, float* cache, int M);
 int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* logits,
                        float* scores, int M, const uint8_t* meta_mask, const uint8_t* comb_mask,
                        float* master, hipStream_t st);
 int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
-                        int need_meta, const uint8_t* meta_mask, const uint8_t* comb_mask,
-                        hipStream_t st);
+                        int need_meta, int need_image, float** dfeat_out,
+                        const uint8_t* meta_mask, const uint8_t* comb_mask, hipStream_t st);
 
-extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch) {
+extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_image_grads) {
   if (h == nullptr || max_batch < 1) {
     btsbot_set_error("reserve_train: bad argument");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (h->tcache != nullptr && max_batch <= h->tcache_batch) return BTSBOT_OK;
+  const bool want_bb = with_image_grads && h->has_image;
+  if (h->tcache != nullptr && max_batch <= h->tcache_batch &&
+      (!want_bb || (h->bbcache != nullptr && max_batch <= h->bbcache_batch)))
+    return BTSBOT_OK;
   HIP_TRY(hipDeviceSynchronize());
-  if (h->tcache) (void)hipFree(h->tcache);
-  h->tcache = nullptr;
-  HIP_TRY(hipMalloc(&h->tcache, train_cache_floats(h, max_batch) * sizeof(float)));
-  h->tcache_batch = max_batch;
+  if (h->tcache == nullptr || max_batch > h->tcache_batch) {
+    if (h->tcache) (void)hipFree(h->tcache);
+    h->tcache = nullptr;
+    HIP_TRY(hipMalloc(&h->tcache, train_cache_floats(h, max_batch) * sizeof(float)));
+    h->tcache_batch = max_batch;
+  }
+  if (want_bb && (h->bbcache == nullptr || max_batch > h->bbcache_batch)) {
+    if (h->bbcache) (void)hipFree(h->bbcache);
+    h->bbcache = nullptr;
+    HIP_TRY(hipMalloc(&h->bbcache, bb_cache_bytes(h, max_batch)));
+    h->bbcache_batch = max_batch;
+    if (!h->train_packs) {      // the dgrad transposes must be packed too from now on
+      h->train_packs = true;
+      h->packed = false;
+    }
+  }
   h->train_batch = 0;
   return BTSBOT_OK;
 }
@@ -679,7 +711,8 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch) {
 extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, const float* meta,
                                     float* logits, float* scores, int batch,
                                     const uint8_t* meta_mask, const uint8_t* comb_mask,
-                                    float* master_arena, void* stream) {
+                                    float* master_arena, int keep_image_activations,
+                                    void* stream) {
   if (h == nullptr || logits == nullptr || batch < 1) {
     btsbot_set_error("forward_train: NULL handle/logits or empty batch");
     return BTSBOT_ERR_INVALID_ARG;
@@ -706,7 +739,19 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
     return BTSBOT_ERR_INVALID_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (h->has_image) {
+  h->bb_saved = false;
+  h->t_img = triplets;
+  if (h->has_image && keep_image_activations) {
+    if (h->bbcache == nullptr || batch > h->bbcache_batch) {
+      btsbot_set_error("forward_train: reserve_train(%d, with_image_grads=1) first", batch);
+      return BTSBOT_ERR_STATE;
+    }
+    float* feat = nullptr;
+    TRY(backbone_train_forward(h, triplets, batch, st, &feat));
+    HIP_TRY(hipMemcpyAsync(train_cache_feat(h, h->tcache, batch), feat,
+                           (size_t)batch * c.dims[3] * sizeof(float), hipMemcpyDeviceToDevice,
+                           st));
+  } else if (h->has_image) {
     // The image branch has no train/eval difference (no BatchNorm, no dropout, drop-path 0):
     // same kernels as inference, chunk by chunk; features are collected in the training cache.
     float* feat = train_cache_feat(h, h->tcache, batch);
@@ -737,14 +782,20 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     btsbot_set_error("backward: no training-mode forward has been run on this handle");
     return BTSBOT_ERR_STATE;
   }
-  if (need_image_grads && h->has_image) {
-    btsbot_set_error("backward: gradients of the ConvNeXt image branch are not built yet "
-                     "(train with the branch frozen, as frozen_fusion does: train.py:224-232)");
+  hipStream_t st = (hipStream_t)stream;
+  const int need_img = need_image_grads && h->has_image;
+  if (need_img && !h->bb_saved) {
+    btsbot_set_error("backward: image-branch gradients need forward_train(keep_image_activations=1)");
     return BTSBOT_ERR_STATE;
   }
-  return head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch,
-                             need_meta_grads, h->t_meta_mask, h->t_comb_mask,
-                             (hipStream_t)stream);
+  if (need_img)   // image-branch gradients are accumulated with atomics
+    HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
+  float* dfeat = nullptr;
+  TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
+                          need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));
+  if (need_img)
+    TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));
+  return BTSBOT_OK;
 }
 
 extern "C" int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst,

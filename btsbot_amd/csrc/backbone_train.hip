@@ -1,0 +1,207 @@
+// Training-mode schedule of the ConvNeXt image branch: a forward that keeps what the backward
+// needs, and the backward itself (kernels in backward.hip / gemm.hip / convnext.hip).
+//
+// Replaces, for the timm backbone reached at /root/reference/btsbot/architectures.py:108,132, what
+// torch autograd does between model(...) (train.py:510) and loss.backward() (train.py:526).
+// The image branch has no BatchNorm and no dropout (drop-path 0): its training forward computes the
+// same function as inference, only unfused (per-op kernels) with per-block buffers:
+//     kept per block : x_in (fp32), xn = LN(dwconv(x_in)) (operand type), a = fc1 pre-activation,
+//                      h = gelu(a)
+//     kept per stage : the stage output (input of the next downsample), the 2x2 patch matrix
+// Everything else (depthwise output, LN statistics, stem conv output) is recomputed in the backward.
+#include <string.h>
+
+#include "ctx.h"
+
+namespace {
+
+struct BlkBuf {
+  float* xin;
+  void* xn;
+  void* a;
+  void* h;
+};
+
+struct BBCache {
+  float* xs[4];             // stage outputs [B*P_i*C_i] fp32
+  void* patches[4];         // [B*P_i][4*C_{i-1}] operand type (i >= 1)
+  std::vector<std::vector<BlkBuf>> blk;
+  // backward scratch
+  float *dyA, *dyB, *dC;    // fp32 [max rows*C]
+  void *dyT, *da;           // operand type [max rows*C], [max rows*4C]
+  float *G, *S;             // fp32 [max C*4C], [max 4C]
+  float* dpat;              // fp32 [max rows*4Cin]
+  void* stem_patches;       // [B*225][48] operand type
+  float* stem_pre;          // [B*225][C0] fp32
+  size_t total;
+};
+
+size_t al(size_t n) { return (n + 255) / 256 * 256; }
+
+// carve the cache for a batch of B alerts; base == nullptr only measures
+BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
+  const btsbot_config& c = h->cfg;
+  const size_t esz = h->esz();
+  BBCache k;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char* p = base ? base + cur : nullptr;
+    cur += al(bytes);
+    return p;
+  };
+  size_t maxrc = 0, maxr4c = 0, maxc4c = 0, maxpat = 0;
+  k.blk.resize(4);
+  for (int i = 0; i < 4; ++i) {
+    const size_t rows = (size_t)B * STAGE_HW[i] * STAGE_HW[i], ch = c.dims[i];
+    k.xs[i] = reinterpret_cast<float*>(take(rows * ch * 4));
+    k.patches[i] = i > 0 ? take(rows * 4 * c.dims[i - 1] * esz) : nullptr;
+    if (i > 0 && rows * 4 * c.dims[i - 1] > maxpat) maxpat = rows * 4 * c.dims[i - 1];
+    for (int j = 0; j < c.depths[i]; ++j) {
+      BlkBuf b;
+      b.xin = reinterpret_cast<float*>(take(rows * ch * 4));
+      b.xn = take(rows * ch * esz);
+      b.a = take(rows * 4 * ch * esz);
+      b.h = take(rows * 4 * ch * esz);
+      k.blk[i].push_back(b);
+    }
+    if (rows * ch > maxrc) maxrc = rows * ch;
+    if (rows * 4 * ch > maxr4c) maxr4c = rows * 4 * ch;
+    if (4 * ch * ch > maxc4c) maxc4c = 4 * ch * ch;
+    if (i > 0 && 4 * ch * c.dims[i - 1] > maxc4c) maxc4c = 4 * ch * c.dims[i - 1];
+  }
+  k.dyA = reinterpret_cast<float*>(take(maxrc * 4));
+  k.dyB = reinterpret_cast<float*>(take(maxrc * 4));
+  k.dC = reinterpret_cast<float*>(take(maxrc * 4));
+  k.dyT = take(maxrc * esz);
+  k.da = take(maxr4c * esz);
+  k.G = reinterpret_cast<float*>(take(maxc4c * 4));
+  k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));
+  k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
+  k.stem_patches = take((size_t)B * 225 * 48 * esz);
+  k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
+  k.total = cur;
+  return k;
+}
+
+#define TRYB(call)                  \
+  do {                              \
+    int _s = (call);                \
+    if (_s != BTSBOT_OK) return _s; \
+  } while (0)
+
+}  // namespace
+
+size_t bb_cache_bytes(const btsbot_ctx* h, int B) { return carve_bb(h, nullptr, B).total; }
+
+// training forward of the image branch for the whole batch; *feat_out = [B][dims[3]] fp32
+int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t st,
+                           float** feat_out) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  BBCache k = carve_bb(h, h->bbcache, B);
+  TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, k.xs[0], B,
+                   c.dims[0], st));
+  for (int i = 0; i < 4; ++i) {
+    const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
+    if (i > 0) {
+      const int cin = c.dims[i - 1];
+      TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
+                           k.patches[i], B, STAGE_HW[i - 1], cin, st));
+      TRYB(launch_gemm(c.precision, EPI_BIAS, k.patches[i], h->extra + h->down[i].p_w,
+                       m + h->down[i].b, nullptr, nullptr, k.xs[i], rows, ch, 4 * cin, st));
+    }
+    for (size_t j = 0; j < h->blocks[i].size(); ++j) {
+      const BlockPk& b = h->blocks[i][j];
+      const BlkBuf& s = k.blk[i][j];
+      HIP_TRY(hipMemcpyAsync(s.xin, k.xs[i], (size_t)rows * ch * 4, hipMemcpyDeviceToDevice, st));
+      TRYB(launch_dwconv_ln(c.precision, k.xs[i], reinterpret_cast<const float*>(h->extra + b.p_dw),
+                            m + b.dw_b, m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, st));
+      TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
+                       reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, st));
+      TRYB(launch_gemm(c.precision, EPI_RESID, s.h, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,
+                       k.xs[i], k.xs[i], rows, ch, 4 * ch, st));
+    }
+  }
+  *feat_out = k.xs[3];
+  h->bb_saved = true;
+  return BTSBOT_OK;
+}
+
+// backward of the image branch.  dfeat: [B][dims[3]] fp32 gradient w.r.t. the branch output
+// (before the head LayerNorm, which the caller has already differentiated).  Gradients are
+// ACCUMULATED (atomics) into `grads` (master-arena layout): the caller zeroes the image-branch
+// range first.
+int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads,
+                            int B, hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  const int prec = c.precision;
+  const size_t esz = h->esz();
+  BBCache k = carve_bb(h, h->bbcache, B);
+  float* dy = k.dyA;
+  float* dxn = k.dyB;
+  HIP_TRY(hipMemcpyAsync(dy, dfeat, (size_t)B * c.dims[3] * 4, hipMemcpyDeviceToDevice, st));
+  for (int i = 3; i >= 0; --i) {
+    const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
+    for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
+      const BlockPk& b = h->blocks[i][j];
+      const BlkBuf& s = k.blk[i][j];
+      const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
+      // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
+      HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)ch * 4, st));
+      HIP_TRY(hipMemsetAsync(k.G, 0, (size_t)ch * H * 4, st));
+      TRYB(launch_colsum(BTSBOT_F32, dy, k.S, rows, ch, st));
+      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
+      TRYB(launch_wgrad(prec, k.dyT, s.h, k.G, rows, ch, H, H, st));
+      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
+                            grads + b.fc2_b, grads + b.gamma, ch, H, st));
+      // ---- da = ((gamma (.) dy) W2) * gelu'(a)
+      TRYB(launch_scale_cast(prec, dy, m + b.gamma, k.dyT, (long)rows * ch, ch, st));
+      TRYB(launch_gemm(prec, EPI_DGELU, k.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
+                       reinterpret_cast<const float*>(s.a), k.da, rows, H, ch, st));
+      // ---- fc1:  dW1 += da^T xn,  db1 += colsum(da),  dxn = da W1
+      TRYB(launch_wgrad(prec, k.da, s.xn, grads + b.fc1_w, rows, H, ch, ch, st));
+      TRYB(launch_colsum(prec, k.da, grads + b.fc1_b, rows, H, st));
+      TRYB(launch_gemm(prec, EPI_PLAIN, k.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
+                       rows, ch, H, st));
+      // ---- LayerNorm backward on the recomputed depthwise output d = dwconv(x_in) + bias
+      TRYB(launch_dw_plain(s.xin, wdw, 0, m + b.dw_b, nullptr, k.dC, B, hw, ch, st));
+      TRYB(launch_ln_bwd(k.dC, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
+      // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
+      TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, B, hw, ch, st));
+      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st));
+    }
+    if (i > 0) {
+      // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
+      const int cin = c.dims[i - 1], hwp = STAGE_HW[i - 1];
+      const long prow = (long)B * hwp * hwp;
+      TRYB(launch_colsum(BTSBOT_F32, dy, grads + h->down[i].b, rows, ch, st));
+      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
+      HIP_TRY(hipMemsetAsync(k.G, 0, (size_t)ch * 4 * cin * 4, st));
+      TRYB(launch_wgrad(prec, k.dyT, k.patches[i], k.G, rows, ch, 4 * cin, 4 * cin, st));
+      TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));
+      TRYB(launch_gemm(prec, EPI_PLAIN, k.dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
+                       nullptr, k.dpat, rows, 4 * cin, ch, st));
+      TRYB(launch_unpatch(k.dpat, dxn, B, hwp, cin, st));
+      // LN backward per input pixel (x_prev = stage i-1 output); result is the new dy
+      TRYB(launch_ln_bwd(k.xs[i - 1], dxn, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
+                         grads + h->down[i].ln_b, prow, cin, st));
+    }
+  }
+  // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]
+  {
+    const int c0 = c.dims[0], rows = B * 225;
+    const void* ws16 = prec == BTSBOT_F32 ? static_cast<const void*>(m + h->stem_w)
+                                          : static_cast<const void*>(h->extra + h->p_stem16);
+    TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, st));
+    TRYB(launch_gemm(prec, EPI_BIAS, k.stem_patches, ws16, m + h->stem_b, nullptr, nullptr,
+                     k.stem_pre, rows, c0, 48, st));
+    TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
+                       grads + h->stem_lnb, rows, c0, st));
+    TRYB(launch_colsum(BTSBOT_F32, dxn, grads + h->stem_b, rows, c0, st));
+    TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT, (long)rows * c0, c0, st));
+    TRYB(launch_wgrad(prec, k.dyT, k.stem_patches, grads + h->stem_w, rows, c0, 48, 48, st));
+  }
+  (void)esz;
+  return BTSBOT_OK;
+}

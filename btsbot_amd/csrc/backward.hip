@@ -1,0 +1,572 @@
+// Backward kernels of the ConvNeXt image branch (gfx950).  Replaces the autograd graph that
+// loss.backward() walks at /root/reference/btsbot/train.py:526 for timm's ConvNeXt blocks:
+//
+//   y = x + gamma * fc2(gelu(fc1(LN(dwconv(x)))))
+//
+// Given dy: G = dy^T h (wgrad GEMM) -> dW2 = gamma (.) G, dgamma = <W2, G> + b2 * colsum(dy);
+// dh = (gamma (.) dy) W2, da = dh * gelu'(a) (dgrad GEMM epilogue); dW1 = da^T xn; dxn = da W1;
+// LayerNorm backward on the recomputed depthwise output; depthwise dgrad = the same depthwise
+// kernel with the 7x7 filter flipped; depthwise wgrad = per-tap correlation reduced over pixels
+// and alerts.  Reductions over the batch use fp32 atomics into the (pre-zeroed) gradient arena.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-6f;
+
+template <typename T> struct Mw;
+template <> struct Mw<float> {
+  using frag = float;
+  static constexpr int KR = 4;   // reduction depth per MFMA
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mw<bf16_t> {
+  using frag = bf16x8;
+  static constexpr int KR = 32;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mw<f16_t> {
+  using frag = f16x8;
+  static constexpr int KR = 32;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// wgrad: out[n][k] += sum_m D[m][n] * A[m][k]   (D: [M][N], A: [M][K], both row-major, type T)
+// Workgroup = 64x64 output tile x one slice of M; 4 waves in 2x2, each a 32x32 sub-tile.
+// Both operands are "reduction-major" in memory, so fragments are gathered from row-major LDS
+// tiles with strided 16-bit reads (lane (i, g) takes rows 8g..8g+7 of column i).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ D,
+                                                    const T* __restrict__ A,
+                                                    float* __restrict__ out, int M, int N, int K,
+                                                    int ldo, int mslice) {
+  using MM = Mw<T>;
+  using frag = typename MM::frag;
+  constexpr int TM = 64;                 // rows of the reduction dimension per LDS tile
+  constexpr int PITCH = 64 + 8;          // elements per LDS row (padded)
+  __shared__ T Ds[TM * PITCH];
+  __shared__ T As[TM * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * mslice, mend = min(M, mbeg + mslice);
+  const int li = lane & 15, lg = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int m0 = mbeg; m0 < mend; m0 += TM) {
+    // stage [64 m][64 n] of D and [64 m][64 k] of A (zero-filled at the edges)
+    for (int i = tid; i < TM * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const int m = m0 + r;
+      Ds[r * PITCH + c] = (m < mend && n0 + c < N) ? D[(size_t)m * N + n0 + c] : (T)0.f;
+      As[r * PITCH + c] = (m < mend && k0 + c < K) ? A[(size_t)m * K + k0 + c] : (T)0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ms = 0; ms < TM; ms += MM::KR) {
+      frag af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int cn = wn * 32 + t * 16 + li, ck = wk * 32 + t * 16 + li;
+        if constexpr (MM::KR == 32) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            af[t][e] = Ds[(ms + 8 * lg + e) * PITCH + cn];
+            bf[t][e] = As[(ms + 8 * lg + e) * PITCH + ck];
+          }
+        } else {
+          af[t] = Ds[(ms + lg) * PITCH + cn];
+          bf[t] = As[(ms + lg) * PITCH + ck];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MM::run(af[i], bf[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane&15 -> k, row = 4*(lane>>4)+r -> n
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 32 + i * 16 + lg * 4 + r;
+        const int k = k0 + wk * 32 + j * 16 + li;
+        if (n < N && k < K) atomicAdd(out + (size_t)n * ldo + k, acc[i][j][r]);
+      }
+}
+
+// out[n] += sum_m in[m][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* out, int M,
+                                                     int N, int mslice) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int mbeg = blockIdx.y * mslice, mend = min(M, mbeg + mslice);
+  float s = 0.f;
+  for (int m = mbeg; m < mend; ++m) s += (float)in[(size_t)m * N + n];
+  atomicAdd(out + n, s);
+}
+
+// out[m][c] = (T)(in[m][c] * scale[c])   (scale may be null)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ in,
+                                                         const float* __restrict__ scale,
+                                                         T* __restrict__ out, long n, int C) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (T)(in[i] * (scale != nullptr ? scale[i % C] : 1.f));
+}
+
+// fc2 weight/scale gradients from G = dy^T h:  dW2[c][k] = gamma[c] G[c][k];
+// dgamma[c] = sum_k W2[c][k] G[c][k] + b2[c] S[c];  db2[c] = gamma[c] S[c]    (S = colsum(dy))
+__global__ __launch_bounds__(256) void fc2_grads_kernel(const float* __restrict__ G,
+                                                        const float* __restrict__ S,
+                                                        const float* __restrict__ w2,
+                                                        const float* __restrict__ b2,
+                                                        const float* __restrict__ gamma,
+                                                        float* dW2, float* db2, float* dgamma,
+                                                        int C, int H) {
+  const int c = blockIdx.x;
+  const float g = gamma[c];
+  float part = 0.f;
+  for (int k = threadIdx.x; k < H; k += 256) {
+    const float gv = G[(size_t)c * H + k];
+    dW2[(size_t)c * H + k] = g * gv;
+    part += w2[(size_t)c * H + k] * gv;
+  }
+  part = wave_sum(part);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dgamma[c] = sh[0] + sh[1] + sh[2] + sh[3] + b2[c] * S[c];
+    db2[c] = g * S[c];
+  }
+}
+
+// LayerNorm backward over the C channels of each row.  One wave per row (grid-stride).
+//   xhat = (d - mean) * rstd;  t = dxn * g;  dd = rstd * (t - mean(t) - xhat * mean(t * xhat))
+//   dg += dxn * xhat;  dbeta += dxn
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d,
+                                                     const float* __restrict__ dxn,
+                                                     const float* __restrict__ g, float* dd,
+                                                     float* dg, float* dbeta, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+  float gl[CPT], adg[CPT], adb[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = lane + 64 * i;
+    gl[i] = c < C ? g[c] : 0.f;
+    adg[i] = adb[i] = 0.f;
+  }
+  for (long r = w0; r < rows; r += nw) {
+    float v[CPT], t[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? d[r * C + c] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? v[i] - mean : 0.f;
+      q += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + LN_EPS);
+    float st = 0.f, stx = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      const float dx = c < C ? dxn[r * C + c] : 0.f;
+      v[i] *= rstd;                     // xhat
+      t[i] = dx * gl[i];
+      st += t[i];
+      stx += t[i] * v[i];
+      adg[i] += dx * v[i];
+      adb[i] += dx;
+    }
+    st = wave_sum(st) / C;
+    stx = wave_sum(stx) / C;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) dd[r * C + c] = rstd * (t[i] - st - v[i] * stx);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) {
+      atomicAdd(dg + c, adg[i]);
+      atomicAdd(dbeta + c, adb[i]);
+    }
+  }
+}
+
+// Depthwise 7x7 p3 without LayerNorm, fp32 in / fp32 out, one workgroup per alert, thread =
+// channel (grid-stride over channels), whole map in LDS.  out = conv(x, w) [+ bias] [+ addend].
+// With the taps flipped (w'[t] = w[48 - t]) this is the gradient w.r.t. the conv input.
+template <int HW>
+__global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ w, int flip,
+                                                       const float* __restrict__ bias,
+                                                       const float* addend, float* out, int C) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [HW*HW][C]
+  constexpr int P = HW * HW;
+  const size_t base = (size_t)blockIdx.x * P * C;
+  for (int i = threadIdx.x; i < P * C; i += 256) xs[i] = x[base + i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wv[49];
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wv[t] = w[(flip ? 48 - t : t) * C + c];
+    const float b = bias != nullptr ? bias[c] : 0.f;
+    for (int y = 0; y < HW; ++y) {
+      float acc[HW];
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) acc[xx] = b;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int iy = y + ky - 3;
+        if (iy < 0 || iy >= HW) continue;
+        float in[HW];
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) {
+            const int ix = xx + kx - 3;
+            if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], wv[ky * 7 + kx], acc[xx]);
+          }
+      }
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) {
+        const size_t o = base + (size_t)(y * HW + xx) * C + c;
+        out[o] = acc[xx] + (addend != nullptr ? addend[o] : 0.f);
+      }
+    }
+  }
+}
+
+// Depthwise filter gradient: dw[t][c] += sum_{alerts,pixels} dd[p][c] * x[p + delta_t][c];
+// dbias[c] += sum dd.  Workgroup = GA alerts (sequentially), thread = channel.
+template <int HW>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ dd, float* dw,
+                                                       float* dbias, int B, int C, int ga) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [P][C], ds [P][C]
+  constexpr int P = HW * HW;
+  float* xs = sm;
+  float* ds = sm + P * C;
+  const int a0 = blockIdx.x * ga, a1 = min(B, a0 + ga);
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    float acc[49], ab = 0.f;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+    for (int a = a0; a < a1; ++a) {
+      __syncthreads();
+      const size_t base = (size_t)a * P * C;
+      for (int i = threadIdx.x; i < P * C; i += 256) {
+        xs[i] = x[base + i];
+        ds[i] = dd[base + i];
+      }
+      __syncthreads();
+      if (c < C) {
+        for (int y = 0; y < HW; ++y) {
+          float g[HW];
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) {
+            g[xx] = ds[(y * HW + xx) * C + c];
+            ab += g[xx];
+          }
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky) {
+            const int iy = y + ky - 3;
+            if (iy < 0 || iy >= HW) continue;
+            float in[HW];
+#pragma unroll
+            for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+              for (int xx = 0; xx < HW; ++xx) {
+                const int ix = xx + kx - 3;
+                if (ix >= 0 && ix < HW) acc[ky * 7 + kx] = fmaf(g[xx], in[ix], acc[ky * 7 + kx]);
+              }
+          }
+        }
+      }
+    }
+    if (c < C) {
+#pragma unroll
+      for (int t = 0; t < 49; ++t) atomicAdd(dw + (size_t)c * 49 + t, acc[t]);   // [C][1][7][7]
+      atomicAdd(dbias + c, ab);
+    }
+  }
+}
+
+// downsample backward glue: for every INPUT pixel of [B][HW][HW][Cin]: if it lies in a 2x2/s2
+// patch, gather its slice of dpatches ([B*HO*HO][4*Cin], k = q*Cin + c) into dxn, else dxn = 0.
+__global__ __launch_bounds__(256) void unpatch_kernel(const float* __restrict__ dpatches,
+                                                      float* __restrict__ dxn, int B, int HW,
+                                                      int Cin) {
+  const int HO = HW / 2;
+  const long n = (long)B * HW * HW * Cin;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cin);
+    long r = i / Cin;
+    const int ix = (int)(r % HW);
+    r /= HW;
+    const int iy = (int)(r % HW);
+    const int b = (int)(r / HW);
+    float v = 0.f;
+    if (iy < 2 * HO && ix < 2 * HO) {
+      const int oy = iy >> 1, ox = ix >> 1, q = (iy & 1) * 2 + (ix & 1);
+      v = dpatches[(((size_t)b * HO + oy) * HO + ox) * 4 * Cin + q * Cin + c];
+    }
+    dxn[i] = v;
+  }
+}
+
+// im2col of the stem: img [B][3][63][63] f32 -> patches [B*225][48] (T), k = ci*16 + ky*4 + kx
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img,
+                                                          T* __restrict__ patches, int B) {
+  const long n = (long)B * 225 * 48;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % 48);
+    const long r = i / 48;
+    const int p = (int)(r % 225), b = (int)(r / 225);
+    const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+    const int py = p / 15, px = p - py * 15;
+    patches[i] = (T)img[((size_t)b * 3 + ci) * 3969 + (4 * py + ky) * 63 + 4 * px + kx];
+  }
+}
+
+inline int gridn(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+template <typename T>
+int wgrad_t(const void* D, const void* A, float* out, int M, int N, int K, int ldo,
+            hipStream_t st) {
+  // slices of the reduction: enough workgroups to fill the chip, at least 512 rows each
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int nsl = (1024 + tiles - 1) / tiles;
+  if (nsl > (M + 511) / 512) nsl = (M + 511) / 512;
+  if (nsl < 1) nsl = 1;
+  int mslice = ((M + nsl - 1) / nsl + 63) / 64 * 64;
+  nsl = (M + mslice - 1) / mslice;
+  dim3 grid((N + 63) / 64, (K + 63) / 64, nsl);
+  hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(D),
+                     reinterpret_cast<const T*>(A), out, M, N, K, ldo, mslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+template <typename T>
+int colsum_t(const void* in, float* out, int M, int N, hipStream_t st) {
+  int nsl = (M + 1023) / 1024;
+  if (nsl > 256) nsl = 256;
+  const int mslice = (M + nsl - 1) / nsl;
+  dim3 grid((N + 255) / 256, (M + mslice - 1) / mslice);
+  hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(in), out,
+                     M, N, mslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+}  // namespace
+
+#define BY_PREC(prec, CALL_F32, CALL_BF16, CALL_F16)            \
+  switch (prec) {                                               \
+    case BTSBOT_F32: return CALL_F32;                           \
+    case BTSBOT_BF16: return CALL_BF16;                         \
+    case BTSBOT_F16: return CALL_F16;                           \
+  }                                                             \
+  btsbot_set_error("backward: bad precision %d", prec);         \
+  return BTSBOT_ERR_INVALID_ARG;
+
+int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
+                 hipStream_t st) {
+  if (M <= 0) return BTSBOT_OK;
+  BY_PREC(prec, wgrad_t<float>(D, A, out, M, N, K, ldo, st),
+          wgrad_t<bf16_t>(D, A, out, M, N, K, ldo, st), wgrad_t<f16_t>(D, A, out, M, N, K, ldo, st))
+}
+
+int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st) {
+  if (M <= 0) return BTSBOT_OK;
+  BY_PREC(prec, colsum_t<float>(in, out, M, N, st), colsum_t<bf16_t>(in, out, M, N, st),
+          colsum_t<f16_t>(in, out, M, N, st))
+}
+
+int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
+                      hipStream_t st) {
+  if (n <= 0) return BTSBOT_OK;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(scale_cast_kernel<float>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
+                         reinterpret_cast<float*>(out), n, C);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
+                         reinterpret_cast<bf16_t*>(out), n, C);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(scale_cast_kernel<f16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
+                         reinterpret_cast<f16_t*>(out), n, C);
+      break;
+    default:
+      btsbot_set_error("scale_cast: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_fc2_grads(const float* G, const float* S, const float* w2, const float* b2,
+                     const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(fc2_grads_kernel, dim3(C), dim3(256), 0, st, G, S, w2, b2, gamma, dW2, db2,
+                     dgamma, C, H);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
+                  float* dbeta, long rows, int C, hipStream_t st) {
+  if (rows <= 0) return BTSBOT_OK;
+  long blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const int cpt = (C + 63) / 64;
+#define LNB(CPT)                                                                                \
+  hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
+                     dd, dg, dbeta, rows, C)
+  if (cpt <= 1) LNB(1);
+  else if (cpt <= 2) LNB(2);
+  else if (cpt <= 4) LNB(4);
+  else if (cpt <= 5) LNB(5);
+  else if (cpt <= 8) LNB(8);
+  else if (cpt <= 10) LNB(10);
+  else {
+    btsbot_set_error("ln_bwd: C=%d too wide", C);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+#undef LNB
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
+                    const float* addend, float* out, int B, int HW, int C, hipStream_t st) {
+  if (B <= 0) return BTSBOT_OK;
+  const size_t lds = (size_t)HW * HW * C * sizeof(float);
+#define DWP(H)                                                                                 \
+  {                                                                                            \
+    static size_t attr = 0;                                                                    \
+    if (lds > attr) {                                                                          \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_plain_kernel<H>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+      attr = lds;                                                                              \
+    }                                                                                          \
+    hipLaunchKernelGGL((dw_plain_kernel<H>), dim3(B), dim3(256), lds, st, x, w, flip, bias,    \
+                       addend, out, C);                                                        \
+  }
+  if (HW == 15) DWP(15)
+  else if (HW == 7) DWP(7)
+  else if (HW == 3) DWP(3)
+  else if (HW == 1) DWP(1)
+  else {
+    btsbot_set_error("dw_plain: no kernel for HW=%d", HW);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+#undef DWP
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, int B, int HW, int C,
+                    hipStream_t st) {
+  if (B <= 0) return BTSBOT_OK;
+  const size_t lds = 2 * (size_t)HW * HW * C * sizeof(float);
+  const int ga = B >= 1024 ? 4 : 1;
+  const int grid = (B + ga - 1) / ga;
+#define DWW(H)                                                                                 \
+  {                                                                                            \
+    static size_t attr = 0;                                                                    \
+    if (lds > attr) {                                                                          \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dw_wgrad_kernel<H>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+      attr = lds;                                                                              \
+    }                                                                                          \
+    hipLaunchKernelGGL((dw_wgrad_kernel<H>), dim3(grid), dim3(256), lds, st, x, dd, dw, dbias, \
+                       B, C, ga);                                                              \
+  }
+  if (HW == 15) DWW(15)
+  else if (HW == 7) DWW(7)
+  else if (HW == 3) DWW(3)
+  else if (HW == 1) DWW(1)
+  else {
+    btsbot_set_error("dw_wgrad: no kernel for HW=%d", HW);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+#undef DWW
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st) {
+  const long n = (long)B * HW * HW * Cin;
+  if (n <= 0) return BTSBOT_OK;
+  hipLaunchKernelGGL(unpatch_kernel, dim3(gridn(n)), dim3(256), 0, st, dpatches, dxn, B, HW, Cin);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st) {
+  const long n = (long)B * 225 * 48;
+  if (n <= 0) return BTSBOT_OK;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(gridn(n)), dim3(256), 0, st, img,
+                         reinterpret_cast<float*>(patches), B);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, st, img,
+                         reinterpret_cast<bf16_t*>(patches), B);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(stem_im2col_kernel<f16_t>, dim3(gridn(n)), dim3(256), 0, st, img,
+                         reinterpret_cast<f16_t*>(patches), B);
+      break;
+    default:
+      btsbot_set_error("stem_im2col: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}

@@ -60,6 +60,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x) { return gelu_fast(x); }
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 
+// d/dx of the exact erf GELU: Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
@@ -87,12 +94,16 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 // ---------------------------------------------------------------------------------------
 // launchers (one per kernel family); all return btsbot_status
 // ---------------------------------------------------------------------------------------
-enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2 };
+enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2, EPI_GELU_SAVE = 3, EPI_DGELU = 4, EPI_PLAIN = 5 };
 
 // out = epi(X[M,K] . W[N,K]^T + bias[N]);  X, W are `prec`-typed, bias/gamma/resid fp32.
 //   EPI_GELU : out (prec-typed) [M,N] = gelu(acc + bias)
 //   EPI_RESID: out (fp32)       [M,N] = resid + gamma[n] * (acc + bias)   (in place allowed)
 //   EPI_BIAS : out (fp32)       [M,N] = acc + bias
+// training-only epilogues (register-staged kernel; `resid` carries a prec-typed aux pointer):
+//   EPI_GELU_SAVE: aux [M,N] = acc + bias (pre-activation, written), out = gelu(aux)
+//   EPI_DGELU    : out (prec-typed) = acc * gelu'(aux[m][n])            (aux read, no bias)
+//   EPI_PLAIN    : out (fp32) = acc
 int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
                 const float* gamma, const float* resid, void* out, int M, int N, int K,
                 hipStream_t st);
@@ -130,6 +141,29 @@ int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const flo
 struct Stage0Args;
 bool stage0_supported(int prec, int c0);
 int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
+
+// backward kernels (backward.hip)
+int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
+                 hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
+int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
+int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
+                      hipStream_t st);
+int launch_fc2_grads(const float* G, const float* S, const float* w2, const float* b2,
+                     const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
+                     hipStream_t st);
+int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
+                  float* dbeta, long rows, int C, hipStream_t st);
+int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
+                    const float* addend, float* out, int B, int HW, int C, hipStream_t st);
+int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, int B, int HW, int C,
+                    hipStream_t st);
+int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
+int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
+// src fp32 [R][Cc] -> dst prec-typed [Cc][R]
+int launch_transpose_cast(int prec, const float* src, void* dst, int R, int Cc, hipStream_t st);
+int launch_pack_down_t(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st);
+// Gd [Cout][4][Cin] (q-major patches order) accumulated into dst [Cout][Cin][4] (master layout)
+int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st);
 
 struct Stage1Args;
 bool stage1_supported(int prec, int c1, int c2);

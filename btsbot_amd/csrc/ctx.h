@@ -16,11 +16,12 @@ struct ParamRec {
 struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
+  size_t p_fc1t, p_fc2t;   // transposes for the dgrad GEMMs: W1^T [C][4C], (W2)^T [4C][C]
   bool fused;
 };
 struct DownPk {
   int64_t ln_w, ln_b, w, b;
-  size_t p_w;
+  size_t p_w, p_wt;        // p_wt: [4*Cin][Cout] transpose of the packed filter (dgrad)
 };
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
@@ -70,6 +71,13 @@ struct btsbot_ctx {
   bool stage1 = false;     // stage 1 + second downsample as one kernel
   bool use_stage0 = true;
   bool use_stage1 = true;  // BTSBOT_AMD_NO_STAGE1=1 likewise for stage 1  // BTSBOT_AMD_NO_STAGE0=1 keeps the per-op schedule for stage 0
+  // image-branch training cache (backbone_train.hip)
+  unsigned char* bbcache = nullptr;
+  int bbcache_batch = 0;
+  int64_t img_floats = 0;     // master-arena floats [0, img_floats) belong to the image branch
+  const float* t_img = nullptr;   // triplets of the last training forward (stem backward re-reads them)
+  bool train_packs = false;   // also pack the dgrad transposes (set by btsbot_reserve_train)
+  bool bb_saved = false;      // the last training forward kept the image-branch activations
   // training cache (head_train.hip): activations of the last training-mode forward
   float* tcache = nullptr;
   int tcache_batch = 0, train_batch = 0;

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
     if (n >= N) continue;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != EPI_DGELU && EPI != EPI_PLAIN) bv = *reinterpret_cast<const float4*>(bias + n);
     float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == EPI_RESID) gv = *reinterpret_cast<const float4*>(gamma + n);
 #pragma unroll
@@ -149,7 +150,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
       if (m >= M) continue;
       const f32x4 a = acc[ni][mi];
       const size_t o = (size_t)m * N + n;
-      if (EPI == EPI_GELU) {
+      if (EPI == EPI_GELU_SAVE) {
+        typedef T __attribute__((ext_vector_type(4))) T4;
+        T4 pre, v;
+        pre[0] = (T)(a[0] + bv.x);
+        pre[1] = (T)(a[1] + bv.y);
+        pre[2] = (T)(a[2] + bv.z);
+        pre[3] = (T)(a[3] + bv.w);
+        // the saved pre-activation is what the backward differentiates: take GELU of the ROUNDED value
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)gelu_for<T>((float)pre[e]);
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(const_cast<float*>(resid)) + o) = pre;
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
+      } else if (EPI == EPI_DGELU) {
+        typedef T __attribute__((ext_vector_type(4))) T4;
+        const T4 pre = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
+        T4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)(a[e] * gelu_grad((float)pre[e]));
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
+      } else if (EPI == EPI_GELU) {
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
         v[0] = (T)gelu_for<T>(a[0] + bv.x);
@@ -207,6 +227,10 @@ int launch_epi(int epi, const void* X, const void* W, const float* bias, const f
     case EPI_GELU: return launch_typed<T, EPI_GELU>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_RESID: return launch_typed<T, EPI_RESID>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_BIAS: return launch_typed<T, EPI_BIAS>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_GELU_SAVE:
+      return launch_typed<T, EPI_GELU_SAVE>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_DGELU: return launch_typed<T, EPI_DGELU>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_PLAIN: return launch_typed<T, EPI_PLAIN>(X, W, bias, gamma, resid, out, M, N, K, st);
   }
   btsbot_set_error("launch_gemm: bad epilogue %d", epi);
   return BTSBOT_ERR_INVALID_ARG;
@@ -231,7 +255,7 @@ int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bi
     const char* e = getenv("BTSBOT_AMD_GEMM_V1");   // A/B switch for timing
     return e != nullptr && e[0] == '1';
   }();
-  if (!v1_only && gemm2_supported(prec, M, N, K))
+  if (!v1_only && epi <= EPI_BIAS && gemm2_supported(prec, M, N, K))
     return launch_gemm2(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   switch (prec) {
     case BTSBOT_F32: return launch_epi<float>(epi, X, W, bias, gamma, resid, out, M, N, K, st);

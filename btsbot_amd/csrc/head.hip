@@ -216,6 +216,41 @@ __global__ void pack_down_kernel(const float* __restrict__ s, T* __restrict__ d,
   }
 }
 
+template <typename T>
+__global__ void transpose_cast_kernel(const float* __restrict__ s, T* __restrict__ d, int R, int Cc) {
+  const int64_t n = (int64_t)R * Cc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);  // d[c][r]
+    d[i] = (T)s[(int64_t)r * Cc + c];
+  }
+}
+
+// downsample filter [Cout][Cin][2][2] fp32 -> [(q*Cin + ci)][Cout] (the dgrad GEMM's "W" operand)
+template <typename T>
+__global__ void pack_down_t_kernel(const float* __restrict__ s, T* __restrict__ d, int Cout, int Cin) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int k = (int)(i / Cout);          // q*Cin + ci
+    const int q = k / Cin, ci = k - q * Cin;
+    d[i] = (T)s[((int64_t)co * Cin + ci) * 4 + q];
+  }
+}
+
+__global__ void unpack_down_grad_kernel(const float* __restrict__ g, float* __restrict__ d, int Cout,
+                                        int Cin) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);
+    const int ci = (int)((i >> 2) % Cin);
+    const int co = (int)(i / (4 * (int64_t)Cin));
+    d[i] = g[((int64_t)co * 4 + q) * Cin + ci];      // d[co][ci][q] = g[co][q][ci]
+  }
+}
+
 __global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv,
                                float* scale, float* shift, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,6 +348,59 @@ int launch_bn_fold(const float* w, const float* b, const float* rm, const float*
                    float* shift, int n, hipStream_t st) {
   hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, b, rm, rv, scale,
                      shift, n);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_transpose_cast(int prec, const float* src, void* dst, int R, int Cc, hipStream_t st) {
+  const int64_t n = (int64_t)R * Cc;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<float*>(dst), R, Cc);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<bf16_t*>(dst), R, Cc);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<f16_t*>(dst), R, Cc);
+      break;
+    default:
+      btsbot_set_error("transpose_cast: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_down_grad_kernel, dim3(nblocks((int64_t)Cout * Cin * 4)), dim3(256), 0,
+                     st, Gd, dst, Cout, Cin);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_pack_down_t(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(pack_down_t_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<float*>(dst), Cout, Cin);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(pack_down_t_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<bf16_t*>(dst), Cout, Cin);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(pack_down_t_kernel<f16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
+                         reinterpret_cast<f16_t*>(dst), Cout, Cin);
+      break;
+    default:
+      btsbot_set_error("pack_down_t: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

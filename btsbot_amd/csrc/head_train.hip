@@ -11,6 +11,12 @@
 // layer, deterministic summation order (no atomics).
 #include "ctx.h"
 
+#define TRY_RET(call)               \
+  do {                              \
+    int _s = (call);                \
+    if (_s != BTSBOT_OK) return _s; \
+  } while (0)
+
 namespace {
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, HN_EPS = 1e-6f;
@@ -212,12 +218,12 @@ size_t train_cache_floats(const btsbot_ctx* h, int M) {
   if (h->has_meta) n += (size_t)M * (2 * c.n_meta + 2 * c.meta_fc1 + c.meta_fc2) + c.n_meta;
   n += (size_t)M * h->comb_dims[0];                     // z
   for (int i = 0; i < h->n_comb; ++i) n += 2 * (size_t)M * h->comb_dims[i + 1];   // pre + act
-  n += 2 * (size_t)M * 768;                             // backward scratch (d-buffers)
+  n += 3 * (size_t)M * 768;                             // backward scratch (d-buffers)
   return n + 1024;
 }
 
 struct TrainPtrs {
-  float *feat, *xhat, *x1, *bn_rstd, *a1, *h1, *a2, *z, *pre[3], *actv[3], *d0, *d1;
+  float *feat, *xhat, *x1, *bn_rstd, *a1, *h1, *a2, *z, *pre[3], *actv[3], *d0, *d1, *dm;
 };
 
 static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
@@ -248,6 +254,7 @@ static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
   }
   p.d0 = take((size_t)M * 768);
   p.d1 = take((size_t)M * 768);
+  p.dm = take((size_t)M * 768);
   return p;
 }
 
@@ -312,8 +319,8 @@ int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* lo
 // Backward of the heads.  Writes d(loss)/d(param) for the fusion head (always) and the metadata
 // branch (need_meta) into `grads` (master-arena layout).
 int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
-                        int need_meta, const uint8_t* meta_mask, const uint8_t* comb_mask,
-                        hipStream_t st) {
+                        int need_meta, int need_image, float** dfeat_out,
+                        const uint8_t* meta_mask, const uint8_t* comb_mask, hipStream_t st) {
   const btsbot_config& c = h->cfg;
   const float* m = h->mirror;
   TrainPtrs p = carve(h, cache, M);
@@ -330,7 +337,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
     hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)N * (K + 1)), dim3(256), 0, st, dcur, in, ldi,
                        grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
     LAUNCH_CHECK();
-    if (i == 0 && !(need_meta && h->has_meta)) break;   // d(z) only feeds the metadata branch
+    if (i == 0 && !(need_meta && h->has_meta) && !need_image) break;   // nobody needs d(z)
     float* din = bufs[i & 1];
     hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dcur, m + h->comb_w[i],
                        din, K, M, N, K);
@@ -343,10 +350,21 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
     }
     dcur = din;
   }
+  if (need_image && h->has_image) {
+    // d(z)[:, 0:F] is the gradient of the (head-normalised) image feature; pull it out of the
+    // concat layout before the metadata backward recycles that buffer, then undo the head LN
+    float* dfeat = p.d1 == dcur ? p.d0 : p.d1;
+    HIP_TRY(hipMemcpy2DAsync(dfeat, (size_t)F * 4, dcur, (size_t)zd * 4, (size_t)F * 4, M,
+                             hipMemcpyDeviceToDevice, st));
+    if (h->hn_w >= 0)
+      TRY_RET(launch_ln_bwd(p.feat, dfeat, m + h->hn_w, dfeat, grads + h->hn_w, grads + h->hn_b, M,
+                            F, st));
+    *dfeat_out = dfeat;
+  }
   if (need_meta && h->has_meta) {
     // dcur = d(z) [M][zd]; the metadata features are its columns F .. F+f2
     const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
-    float* da2 = p.d1 == dcur ? p.d0 : p.d1;   // scratch not holding dcur
+    float* da2 = p.dm;                         // scratch holding neither d(z) nor d(feat)
     hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, dcur + F, zd,
                        p.a2, da2, M, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE, nullptr,
                        1.f);

@@ -8,8 +8,7 @@ and schedule set-up of train.py:242-260, without autograd, host syncs or DataPar
     trainer.scheduler_step()                                                # once per epoch
 
 What is trained follows ``requires_grad`` exactly as the reference does (train.py:224-236): for
-``frozen_fusion`` only ``combined_head``; for ``um_nn`` everything.  A trainable ConvNeXt branch is
-refused until its backward kernels exist.  With torch.distributed initialised, every rank passes its
+``frozen_fusion`` only ``combined_head``; otherwise everything, ConvNeXt image branch included.  With torch.distributed initialised, every rank passes its
 own shard and the flat gradient arena is all-reduced once per step (parallel.py).
 """
 from __future__ import annotations
@@ -61,13 +60,11 @@ class Trainer:
         self.epoch = 0
         self.t = 0                                   # AdamW step count
         comb, meta, image = model._slot_groups()
-        if any(t.requires_grad for t, *_ in image):
-            raise NotImplementedError(
-                "btsbot_amd.train: a trainable ConvNeXt image branch is not supported yet; freeze it "
-                "as train.py:224-232 does for frozen_fusion")
+        self.need_image = any(t.requires_grad for t, *_ in image)
         self.need_meta = any(t.requires_grad for t, *_ in meta)
         # contiguous arena ranges of the trainable tensors (padding between tensors has zero grad)
-        slots = sorted((off, off + numel) for t, off, numel, _s in comb + meta if t.requires_grad)
+        slots = sorted((off, off + numel) for t, off, numel, _s in image + meta + comb
+                       if t.requires_grad)
         self.ranges = []
         for lo, hi in slots:
             hi = (hi + 3) // 4 * 4
@@ -99,7 +96,7 @@ class Trainer:
         n_global = int(global_batch) if global_batch is not None else batch * world
         with torch.no_grad():
             masks = m._dropout_masks(batch, dev)
-            logits = m._forward_train_raw(images, meta, masks).reshape(-1)
+            logits = m._forward_train_raw(images, meta, masks, self.need_image).reshape(-1)
             y = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
             loss = torch.zeros(1, dtype=torch.float32, device=dev)
             dl = torch.empty_like(logits)
@@ -110,7 +107,7 @@ class Trainer:
                                                 self.pos_weight, batch, n_global,
                                                 C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()),
                                                 st), "btsbot_bce_fwd_bwd")
-            grads = m._backward_raw(dl, self.need_meta)
+            grads = m._backward_raw(dl, self.need_meta, self.need_image)
             if self.exp_avg is None:
                 self.exp_avg = torch.zeros_like(m._arena)
                 self.exp_avg_sq = torch.zeros_like(m._arena)

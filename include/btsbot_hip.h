@@ -135,18 +135,23 @@ int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* met
  * also when the branch is frozen (frozen_fusion keeps its branches in train mode).  Dropout is
  * applied with caller-supplied keep-masks (uint8 [batch][meta_fc1] and [batch][comb_fc2]; 1 = keep,
  * scaled by 1/(1-p)); the masks must stay valid until btsbot_backward() has run.  Activations are
- * kept in a cache sized by btsbot_reserve_train(max_batch) (whole batch, no chunking, because of the
- * batch statistics). */
-int btsbot_reserve_train(btsbot_handle h, int max_batch);
+ * kept in a cache sized by btsbot_reserve_train(max_batch, with_image_grads) (whole batch, no
+ * chunking, because of the batch statistics).  keep_image_activations != 0 runs the image branch
+ * through the per-op training schedule that keeps, per block, x_in / LN output / fc1 pre-activation /
+ * hidden activation (about 1.2 MB per alert) for a later btsbot_backward(need_image_grads=1);
+ * otherwise the image branch runs the fused inference kernels. */
+int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_image_grads);
 int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const float* meta,
                          float* logits, float* scores, int batch, const uint8_t* meta_keep_mask,
-                         const uint8_t* comb_keep_mask, float* master_arena, void* stream);
+                         const uint8_t* comb_keep_mask, float* master_arena,
+                         int keep_image_activations, void* stream);
 
 /* Replaces loss.backward() (train.py:526) for the parameters of the fusion head (always) and the
  * metadata branch (need_meta_grads): writes d(loss)/d(param) into grad_arena, which has the master
  * arena's layout (other entries are left untouched).  dlogits = d(loss)/d(logits) [batch], e.g. from
- * btsbot_bce_fwd_bwd.  need_image_grads != 0 (a trainable ConvNeXt branch) is refused in this build
- * with BTSBOT_ERR_STATE. */
+ * btsbot_bce_fwd_bwd.  need_image_grads != 0 also differentiates the ConvNeXt image branch (stem,
+ * every block, downsamples, head LayerNorm); those gradients are reduced over the batch with fp32
+ * atomics, so their last bits vary from run to run. */
 int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, int need_meta_grads,
                     int need_image_grads, void* stream);
 

@@ -61,8 +61,8 @@ def test_training_forward_and_head_gradients(cuda, name):
             p.requires_grad_(False)
         for p in m.meta_branch.parameters():
             p.requires_grad_(False)
-    elif kind == "mm_ConvNeXt":                      # image branch frozen (its backward is not built)
-        for p in m.convnext_backbone.parameters():
+    elif kind == "mm_ConvNeXt":                      # image branch frozen in THIS test; the
+        for p in m.convnext_backbone.parameters():   # full backward has its own test below
             p.requires_grad_(False)
     trainable = [k for k, p in m.named_parameters() if p.requires_grad]
     assert trainable
@@ -97,15 +97,44 @@ def test_training_forward_and_head_gradients(cuda, name):
             assert int(out_sd[k]) == int(sd[k]) + 1
 
 
-def test_trainable_image_branch_is_refused(cuda):
-    kind, cfg = CONFIGS["mm_pico"]
-    m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "f32").train()
-    img, meta, _ = synthetic_batch(4, seed=4)
-    with pytest.raises(NotImplementedError, match="image branch"):
-        m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
-    with torch.no_grad():                             # fine without gradients
-        out = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
-    assert out.shape == (4, 1)
+@pytest.mark.parametrize("name", ["mm_pico", "convnext", "mm_nano_ls"])
+def test_full_backward_matches_autograd(cuda, name):
+    """Every parameter trainable (train.py:233-236): gradients of the whole model -- stem, every
+    ConvNeXt block (layer-scale, depthwise, LayerNorm, fc1, fc2), downsamples, head LayerNorm,
+    metadata branch, fusion head -- against torch autograd through the fp32 CPU oracle.
+    fp32 mode; batch reductions use fp32 atomics, hence the 5e-4 relative bound."""
+    kind, cfg = CONFIGS[name]
+    sd = seeded_state(kind, cfg, seed=3)
+    B = 6
+    img, meta, labels = synthetic_batch(B, seed=4)
+    masks = _masks(kind, cfg, B, seed=9) if kind != "ConvNeXt" else \
+        {"comb": (torch.rand(B, cfg["fc2_neurons"], generator=torch.Generator().manual_seed(9))
+                  >= cfg["dropout"]).float()}
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    trainable = [k for k, p in m.named_parameters()]
+    if kind == "ConvNeXt":
+        logits = m(input_data=img.to(cuda))
+        omasks = {"head": masks["comb"]}
+    else:
+        logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+        omasks = masks
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+        logits, labels.to(cuda).float().unsqueeze(1))
+    loss.backward()
+    ref_logits, ref_loss, ref_grads, _ = _oracle_train(kind, cfg, sd, img, meta, labels, omasks, 2.0,
+                                                       trainable)
+    _close(logits, ref_logits, "training-mode logits")
+    got = dict(m.named_parameters())
+    worst = 0.0
+    for k in trainable:
+        assert got[k].grad is not None, k
+        a, b = got[k].grad.cpu().double(), ref_grads[k].double()
+        scale = max(b.abs().max().item(), 1e-7)
+        err = (a - b).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err <= 5e-4, f"grad {k}: rel err {err:.3e} (scale {scale:.3e})"
+    print(f"{name}: worst relative gradient error {worst:.2e} over {len(trainable)} tensors")
 
 
 @pytest.mark.parametrize("name", ["um_nn", "frozen_fusion"])
