@@ -422,6 +422,7 @@ class _TrainFn(torch.autograd.Function):
         ctx.model = model
         ctx.trainable = trainable
         ctx.keep_image = keep_image
+        ctx.inputs = (image, meta, masks)   # the C side re-reads them in backward: keep them alive
         return model._forward_train_raw(image, meta, masks, keep_image)
 
     @staticmethod
