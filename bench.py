@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="alerts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
+    ap.add_argument("--train-batch", type=int, default=256, help="alerts per GPU per training step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +223,44 @@ def main():
     prof = model.collect_profile()
     model.set_profile(False)
 
+    # ---- training leg (BASELINE.json configs[2]): mm_ConvNeXt, every parameter trainable,
+    #      BCE(pos_weight) + backward + one all-reduce of the flat gradient arena + AdamW per step
+    train = None
+    if args.train_steps > 0:
+        from btsbot_amd.train import Trainer
+        del out
+        tcfg = dict(CONFIG, meta_dropout=0.25, comb_dropout=0.2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tm = btsbot_amd.mm_ConvNeXt(tcfg, precision=args.precision)
+        seeded_weights(tm)
+        tm = tm.to(dev).train()
+        timg, tmeta, tlab = synthetic_batch(args.train_batch, seed=100 + rank)
+        timg, tmeta, tlab = timg.to(dev), tmeta.to(dev), tlab.to(dev)
+        tr = Trainer(tm, lr=1e-4, betas=(0.99, 0.99), pos_weight=1.0, epochs=8, warmup_epochs=2)
+        for _ in range(2):
+            tr.step(timg, tmeta, tlab)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tloss = tr.step(timg, tmeta, tlab)
+        fence()
+        tel = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([tel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tel = t.item()
+        train = {
+            "workload": "BASELINE.json configs[2]: mm_ConvNeXt-pico training step (BCE pos_weight + "
+                        "backward + AdamW), every parameter trainable, one RCCL all-reduce of the "
+                        "flat gradient arena per step",
+            "value": round(args.train_batch * world * args.train_steps / tel, 1), "unit": "alerts/s",
+            "per_gpu_batch": args.train_batch, "global_batch": args.train_batch * world,
+            "steps": args.train_steps, "ms_per_step": round(1e3 * tel / args.train_steps, 3),
+            "loss_finite": bool(torch.isfinite(tloss).item()),
+        }
+        del tm, tr
+
     if rank == 0:
         work = family_work(args.batch, args.precision)
         kernels = {}
@@ -271,6 +312,8 @@ def main():
             "flop_per_alert": 133701376 + 210000,
             "whole_net_tflops": round((133701376 + 210000) * total_alerts / elapsed / 1e12, 2),
         }
+        if train is not None:
+            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -137,7 +137,7 @@ def test_full_backward_matches_autograd(cuda, name):
     print(f"{name}: worst relative gradient error {worst:.2e} over {len(trainable)} tensors")
 
 
-@pytest.mark.parametrize("name", ["um_nn", "frozen_fusion"])
+@pytest.mark.parametrize("name", ["um_nn", "frozen_fusion", "mm_pico"])
 def test_trainer_matches_torch_adamw_loop(cuda, name):
     """3 steps of Trainer.step (HIP forward/BCE/backward/AdamW) vs the reference recipe on the CPU:
     oracle forward + BCEWithLogitsLoss(pos_weight) + torch.optim.AdamW(lr, betas=(.99,.99)),
@@ -146,6 +146,8 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
     cfg = copy.deepcopy(cfg)
     if kind == "um_nn":
         cfg["meta_dropout"] = 0.0
+    elif kind == "mm_ConvNeXt":                      # every parameter trainable, image branch too
+        cfg["meta_dropout"] = cfg["comb_dropout"] = 0.0
     else:
         cfg["comb_dropout"] = 0.0
         cfg["meta_model_config"]["meta_dropout"] = 0.0
@@ -164,7 +166,7 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
     params = [ref[k].requires_grad_(True) for k in trainable]
     opt = torch.optim.AdamW(params, lr=tr.lr, betas=(0.99, 0.99))
     for step in range(3):
-        img, meta, labels = synthetic_batch(32, seed=20 + step)
+        img, meta, labels = synthetic_batch(32 if kind != "mm_ConvNeXt" else 8, seed=20 + step)
         loss = tr.step(img.to(cuda) if kind != "um_nn" else None, meta.to(cuda), labels.to(cuda))
         opt.zero_grad()
         logits = O.forward(kind, ref, cfg, img, meta, training=True)
@@ -176,7 +178,10 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
     for k in trainable:
         _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-5)
         # the UPDATE itself (3 steps of ~lr each), not just the (dominant) initial value
-        _close(out[k].cpu() - sd[k], ref[k].detach() - sd[k], f"update of {k}", rtol=2e-2)
+        # (Adam's first steps are ~ lr * sign(g): entries with |g| near 0 are ill-conditioned, so the
+        # update is compared relative to lr, not to itself)
+        upd_err = ((out[k].cpu() - sd[k]) - (ref[k].detach() - sd[k])).abs().max().item()
+        assert upd_err <= 0.05 * 3 * 1e-3, f"update of {k}: {upd_err:.3e}"
 
 
 def test_lr_schedule_matches_golden():
