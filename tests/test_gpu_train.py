@@ -176,7 +176,7 @@ def test_trainer_matches_torch_adamw_loop(cuda, name):
         assert abs(loss.item() - rl.item()) <= 2e-5 * max(1.0, abs(rl.item())), step
     out = m.state_dict()
     for k in trainable:
-        _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-5)
+        _close(out[k], ref[k], f"param {k} after 3 steps", rtol=2e-4)
         # the UPDATE itself (3 steps of ~lr each), not just the (dominant) initial value
         # (Adam's first steps are ~ lr * sign(g): entries with |g| near 0 are ill-conditioned, so the
         # update is compared relative to lr, not to itself)
