@@ -31,6 +31,7 @@ struct BBCache {
   void *dyT, *da;           // operand type [max rows*C], [max rows*4C]
   float *G, *S;             // fp32 [max C*4C], [max 4C]
   float* dpat;              // fp32 [max rows*4Cin]
+  float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
   void* stem_patches;       // [B*225][48] operand type
   float* stem_pre;          // [B*225][C0] fp32
   size_t total;
@@ -77,6 +78,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
+  k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
   k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
   k.total = cur;
@@ -168,7 +170,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_dw_plain(s.xin, wdw, 0, m + b.dw_b, nullptr, k.dC, B, hw, ch, st));
       TRYB(launch_ln_bwd(k.dC, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
       // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
-      TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, B, hw, ch, st));
+      TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
       TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st));
     }
     if (i > 0) {

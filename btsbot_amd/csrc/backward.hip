@@ -111,16 +111,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ D,
       }
 }
 
-// out[n] += sum_m in[m][n]
+// out[n] += sum_m in[m][n].  Block = 64 columns x 4 row groups over one slice of M; the row groups
+// meet in LDS so that every column costs ONE atomic per block (same-address atomics serialise).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* out, int M,
                                                      int N, int mslice) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
   const int mbeg = blockIdx.y * mslice, mend = min(M, mbeg + mslice);
-  float s = 0.f;
-  for (int m = mbeg; m < mend; ++m) s += (float)in[(size_t)m * N + n];
-  atomicAdd(out + n, s);
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int m = mbeg + rg;
+    for (; m + 4 < mend; m += 8) {
+      s0 += (float)in[(size_t)m * N + n];
+      s1 += (float)in[(size_t)(m + 4) * N + n];
+    }
+    if (m < mend) s0 += (float)in[(size_t)m * N + n];
+  }
+  sh[rg][cl] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && n < N) atomicAdd(out + n, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
 }
 
 // out[m][c] = (T)(in[m][c] * scale[c])   (scale may be null)
@@ -214,13 +225,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       if (c < C) dd[r * C + c] = rstd * (t[i] - st - v[i] * stx);
     }
   }
+  // the block's 4 waves meet in LDS: one atomic per channel per block
+  __shared__ float sh[2][4][CPT * 64];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = lane + 64 * i;
-    if (c < C) {
-      atomicAdd(dg + c, adg[i]);
-      atomicAdd(dbeta + c, adb[i]);
-    }
+    sh[0][wv][lane + 64 * i] = adg[i];
+    sh[1][wv][lane + 64 * i] = adb[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
+    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
   }
 }
 
@@ -270,8 +286,10 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
   }
 }
 
-// Depthwise filter gradient: dw[t][c] += sum_{alerts,pixels} dd[p][c] * x[p + delta_t][c];
-// dbias[c] += sum dd.  Workgroup = GA alerts (sequentially), thread = channel.
+// Depthwise filter gradient: sum_{alerts,pixels} dd[p][c] * x[p + delta_t][c] per tap, and sum dd
+// for the bias.  Workgroup = GA alerts (sequentially), thread = channel; every workgroup writes ONE
+// partial row [C*49 | C] which launch_dw_wgrad then column-sums into the gradient arena (the filter
+// and its bias are adjacent there) -- no same-address atomic storm.
 template <int HW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ dd, float* dw,
@@ -320,10 +338,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         }
       }
     }
-    if (c < C) {
+    if (c < C) {   // this workgroup's partial row: [C][49] filter taps, then [C] biases
+      float* row = dw + (size_t)blockIdx.x * 50 * C;
 #pragma unroll
-      for (int t = 0; t < 49; ++t) atomicAdd(dw + (size_t)c * 49 + t, acc[t]);   // [C][1][7][7]
-      atomicAdd(dbias + c, ab);
+      for (int t = 0; t < 49; ++t) row[(size_t)c * 49 + t] = acc[t];
+      row[(size_t)49 * C + c] = ab;
     }
   }
 }
@@ -390,10 +409,13 @@ int wgrad_t(const void* D, const void* A, float* out, int M, int N, int K, int l
 
 template <typename T>
 int colsum_t(const void* in, float* out, int M, int N, hipStream_t st) {
-  int nsl = (M + 1023) / 1024;
-  if (nsl > 256) nsl = 256;
+  const int nb = (N + 63) / 64;
+  int nsl = (768 + nb - 1) / nb;                 // ~768 blocks in flight
+  if (nsl > 64) nsl = 64;                        // ... but at most 64 atomics per column
+  if (nsl > (M + 63) / 64) nsl = (M + 63) / 64;
+  if (nsl < 1) nsl = 1;
   const int mslice = (M + nsl - 1) / nsl;
-  dim3 grid((N + 255) / 256, (M + mslice - 1) / mslice);
+  dim3 grid(nb, (M + mslice - 1) / mslice);
   hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(in), out,
                      M, N, mslice);
   LAUNCH_CHECK();
@@ -461,7 +483,7 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
                   float* dbeta, long rows, int C, hipStream_t st) {
   if (rows <= 0) return BTSBOT_OK;
   long blocks = (rows + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;     // <= 512 same-address atomics per channel
   const int cpt = (C + 63) / 64;
 #define LNB(CPT)                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
@@ -509,11 +531,16 @@ int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
   return BTSBOT_OK;
 }
 
-int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, int B, int HW, int C,
-                    hipStream_t st) {
+int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, float* partials,
+                    int B, int HW, int C, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
+  if (dbias != dw + (size_t)49 * C) {
+    btsbot_set_error("dw_wgrad: filter and bias gradients must be adjacent in the arena");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   const size_t lds = 2 * (size_t)HW * HW * C * sizeof(float);
-  const int ga = B >= 1024 ? 4 : 1;
+  int ga = (B + 255) / 256;            // <= 256 workgroups => <= 256 atomics per filter tap
+  if (ga < 1) ga = 1;
   const int grid = (B + ga - 1) / ga;
 #define DWW(H)                                                                                 \
   {                                                                                            \
@@ -523,8 +550,8 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, in
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
       attr = lds;                                                                              \
     }                                                                                          \
-    hipLaunchKernelGGL((dw_wgrad_kernel<H>), dim3(grid), dim3(256), lds, st, x, dd, dw, dbias, \
-                       B, C, ga);                                                              \
+    hipLaunchKernelGGL((dw_wgrad_kernel<H>), dim3(grid), dim3(256), lds, st, x, dd, partials,  \
+                       dbias, B, C, ga);                                                       \
   }
   if (HW == 15) DWW(15)
   else if (HW == 7) DWW(7)
@@ -536,7 +563,7 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, in
   }
 #undef DWW
   LAUNCH_CHECK();
-  return BTSBOT_OK;
+  return colsum_t<float>(partials, dw, grid, 50 * C, st);
 }
 
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st) {

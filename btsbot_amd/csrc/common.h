@@ -155,8 +155,8 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
                   float* dbeta, long rows, int C, hipStream_t st);
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
                     const float* addend, float* out, int B, int HW, int C, hipStream_t st);
-int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, int B, int HW, int C,
-                    hipStream_t st);
+int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, float* partials,
+                    int B, int HW, int C, hipStream_t st);   // partials: >= 256 * 50 * C floats
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
