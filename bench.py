@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
-    ap.add_argument("--train-batch", type=int, default=256, help="alerts per GPU per training step")
+    ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
