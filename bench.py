@@ -304,7 +304,8 @@ def main():
             },
             "roofline": {
                 "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": pmc_traffic(dom, args),
                 "flop_per_launch": flop_per_launch, "avg_launch_us": round(1e3 * ms / n, 2),
                 "launches_per_step": n // args.steps,
             },
@@ -320,6 +321,24 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, args):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/r*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same command, FETCH_SIZE doubled per the gfx950 calibration in tools/pmc_calib).  PMC counters
+    cannot be sampled from inside this process, so the figure is only reported for the workload the
+    summary was collected on (default precision and batch); otherwise null."""
+    import glob
+    if args.precision != "bf16" or args.batch != PER_GPU_BATCH:
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        ks = json.load(f)["kernels"]
+    hits = [v for v in ks.values() if v["family"] == kernel]
+    return hits[0]["traffic_bytes"] if len(hits) == 1 else None
 
 
 if __name__ == "__main__":

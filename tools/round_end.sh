@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round-end measurement recipe (run on the MI355X box through gpurun from the repo root).
+# Writes everything under gpurun_out/final/; copy what should be judged into profiles/.
+set -u
+O=gpurun_out/final; mkdir -p $O
+export TMPDIR=/tmp
+python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+( time python bench.py ) > $O/bench_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --train-steps 0 > $O/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 > $O/pmc_write.log 2>&1
+find $O -name "*.csv" | head -50
+tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -2; tail -5 $O/bench_default.log
