@@ -313,9 +313,11 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                                  st));
         TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
-        if (h->train_packs) {   // W1^T [C][4C] and W2^T [4C][C] for the dgrad GEMMs
-          TRY(launch_transpose_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1t, 4 * ch, ch, st));
-          TRY(launch_transpose_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2t, ch, 4 * ch, st));
+        if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
+          TRY(launch_transpose_cast(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch,
+                                    ch, st));
+          TRY(launch_transpose_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch,
+                                    4 * ch, st));
         }
         if (b.fused)
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
@@ -486,6 +488,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.diag = dg != nullptr ? atoi(dg) : 0;
       }
       a.stamps = h->stamps;
+      a.wgt = h->stamps ? h->stamps + 32 : nullptr;
       TRY(timed(h, CAT_STAGE0, st, [&] { return launch_stage0(c.precision, a, st); }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
@@ -542,6 +545,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.diag = dg != nullptr ? atoi(dg) : 0;
         }
         a.stamps = h->stamps ? h->stamps + 16 : nullptr;
+        a.wgt = h->stamps ? h->stamps + 32 + 2 * 4096 : nullptr;
         TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1(c.precision, a, st); }));
         float* t = x;
         x = x2;

@@ -75,8 +75,8 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.dC = reinterpret_cast<float*>(take(maxrc * 4));
   k.dyT = take(maxrc * esz);
   k.da = take(maxr4c * esz);
-  k.G = reinterpret_cast<float*>(take(maxc4c * 4));
-  k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));
+  k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
+  k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
   k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
@@ -133,6 +133,14 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
 // (before the head LayerNorm, which the caller has already differentiated).  Gradients are
 // ACCUMULATED (atomics) into `grads` (master-arena layout): the caller zeroes the image-branch
 // range first.
+// out[n][k] += sum_m D[m][n] A[m][k] and cs[n] += sum_m D[m][n]; D and A in the mode's operand type
+static int wgrad_cs(int prec, const void* D, const void* A, float* out, float* cs, int M, int N,
+                    int K, int ldo, hipStream_t st) {
+  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st);
+  const int rc = launch_wgrad(prec, D, A, out, M, N, K, ldo, st);
+  return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
+}
+
 int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads,
                             int B, hipStream_t st) {
   const btsbot_config& c = h->cfg;
@@ -150,20 +158,16 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
       // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
-      HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)ch * 4, st));
-      HIP_TRY(hipMemsetAsync(k.G, 0, (size_t)ch * H * 4, st));
-      TRYB(launch_colsum(BTSBOT_F32, dy, k.S, rows, ch, st));
+      HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + (size_t)ch * H) - k.S) * 4, st));
       TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
-      TRYB(launch_wgrad(prec, k.dyT, s.h, k.G, rows, ch, H, H, st));
+      TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, st));
-      // ---- da = ((gamma (.) dy) W2) * gelu'(a)
-      TRYB(launch_scale_cast(prec, dy, m + b.gamma, k.dyT, (long)rows * ch, ch, st));
+      // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, k.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), k.da, rows, H, ch, st));
       // ---- fc1:  dW1 += da^T xn,  db1 += colsum(da),  dxn = da W1
-      TRYB(launch_wgrad(prec, k.da, s.xn, grads + b.fc1_w, rows, H, ch, ch, st));
-      TRYB(launch_colsum(prec, k.da, grads + b.fc1_b, rows, H, st));
+      TRYB(wgrad_cs(prec, k.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, st));
       TRYB(launch_gemm(prec, EPI_PLAIN, k.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
       // ---- LayerNorm backward on the recomputed depthwise output d = dwconv(x_in) + bias
@@ -177,10 +181,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
       const int cin = c.dims[i - 1], hwp = STAGE_HW[i - 1];
       const long prow = (long)B * hwp * hwp;
-      TRYB(launch_colsum(BTSBOT_F32, dy, grads + h->down[i].b, rows, ch, st));
       TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
       HIP_TRY(hipMemsetAsync(k.G, 0, (size_t)ch * 4 * cin * 4, st));
-      TRYB(launch_wgrad(prec, k.dyT, k.patches[i], k.G, rows, ch, 4 * cin, 4 * cin, st));
+      TRYB(wgrad_cs(prec, k.dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin,
+                    st));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));
       TRYB(launch_gemm(prec, EPI_PLAIN, k.dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
@@ -200,9 +204,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                      k.stem_pre, rows, c0, 48, st));
     TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
                        grads + h->stem_lnb, rows, c0, st));
-    TRYB(launch_colsum(BTSBOT_F32, dxn, grads + h->stem_b, rows, c0, st));
     TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT, (long)rows * c0, c0, st));
-    TRYB(launch_wgrad(prec, k.dyT, k.stem_patches, grads + h->stem_w, rows, c0, 48, 48, st));
+    TRYB(wgrad_cs(prec, k.dyT, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
+                  st));
   }
   (void)esz;
   return BTSBOT_OK;

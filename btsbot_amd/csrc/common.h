@@ -145,6 +145,8 @@ int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
 // backward kernels (backward.hip)
 int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
+int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
+                   int K, int ldo, hipStream_t st);   // wgrad.hip: 16-bit modes, colsum optional
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
                       hipStream_t st);
@@ -160,7 +162,8 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, fl
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
-int launch_transpose_cast(int prec, const float* src, void* dst, int R, int Cc, hipStream_t st);
+int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,
+                          hipStream_t st);
 int launch_pack_down_t(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st);
 // Gd [Cout][4][Cin] (q-major patches order) accumulated into dst [Cout][Cin][4] (master layout)
 int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st);

@@ -16,7 +16,7 @@ struct ParamRec {
 struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
-  size_t p_fc1t, p_fc2t;   // transposes for the dgrad GEMMs: W1^T [C][4C], (W2)^T [4C][C]
+  size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
 };
 struct DownPk {

@@ -217,12 +217,13 @@ __global__ void pack_down_kernel(const float* __restrict__ s, T* __restrict__ d,
 }
 
 template <typename T>
-__global__ void transpose_cast_kernel(const float* __restrict__ s, T* __restrict__ d, int R, int Cc) {
+__global__ void transpose_cast_kernel(const float* __restrict__ s, const float* __restrict__ rowscale,
+                                      T* __restrict__ d, int R, int Cc) {
   const int64_t n = (int64_t)R * Cc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);  // d[c][r]
-    d[i] = (T)s[(int64_t)r * Cc + c];
+    d[i] = (T)(s[(int64_t)r * Cc + c] * (rowscale != nullptr ? rowscale[r] : 1.f));
   }
 }
 
@@ -352,20 +353,22 @@ int launch_bn_fold(const float* w, const float* b, const float* rm, const float*
   return BTSBOT_OK;
 }
 
-int launch_transpose_cast(int prec, const float* src, void* dst, int R, int Cc, hipStream_t st) {
+// dst[c][r] = src[r][c] * (rowscale ? rowscale[r] : 1)
+int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,
+                          hipStream_t st) {
   const int64_t n = (int64_t)R * Cc;
   switch (prec) {
     case BTSBOT_F32:
       hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src,
-                         reinterpret_cast<float*>(dst), R, Cc);
+                         rowscale, reinterpret_cast<float*>(dst), R, Cc);
       break;
     case BTSBOT_BF16:
       hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
-                         reinterpret_cast<bf16_t*>(dst), R, Cc);
+                         rowscale, reinterpret_cast<bf16_t*>(dst), R, Cc);
       break;
     case BTSBOT_F16:
       hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, dim3(nblocks(n)), dim3(256), 0, st, src,
-                         reinterpret_cast<f16_t*>(dst), R, Cc);
+                         rowscale, reinterpret_cast<f16_t*>(dst), R, Cc);
       break;
     default:
       btsbot_set_error("transpose_cast: bad precision %d", prec);

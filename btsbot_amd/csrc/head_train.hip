@@ -78,22 +78,44 @@ __global__ __launch_bounds__(256) void lin_bwd_in_kernel(const float* __restrict
   din[(size_t)m * ldi + k] = acc;
 }
 
-// dw[n][k] = sum_m dpre[m][n] * in[m*ldi + k];  db[n] = sum_m dpre[m][n]   (fixed order over m)
+// dw[n][k] = sum_m dpre[m][n] * in[m*ldi + k];  db[n] = sum_m dpre[m][n]
+// Workgroup = 16 consecutive outputs x 16 interleaved slices of m; the slices meet in LDS in a fixed
+// order, so the result is deterministic (no atomics).
 __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dpre,
                                                         const float* __restrict__ in, int ldi,
                                                         float* __restrict__ dw,
                                                         float* __restrict__ db, int M, int N,
                                                         int K) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= N * (K + 1)) return;
-  const int n = idx / (K + 1), k = idx - n * (K + 1);
-  float acc = 0.f;
-  if (k < K) {
-    for (int m = 0; m < M; ++m) acc = fmaf(dpre[(size_t)m * N + n], in[(size_t)m * ldi + k], acc);
-    dw[(size_t)n * K + k] = acc;
-  } else {
-    for (int m = 0; m < M; ++m) acc += dpre[(size_t)m * N + n];
-    db[n] = acc;
+  __shared__ float sh[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;
+  const bool live = idx < N * (K + 1);
+  const int n = live ? idx / (K + 1) : 0, k = live ? idx - n * (K + 1) : 0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (live) {
+    const float* dp = dpre + n;
+    if (k < K) {
+      const float* ip = in + k;
+      int m = g;
+      for (; m + 48 < M; m += 64) {
+        a0 = fmaf(dp[(size_t)m * N], ip[(size_t)m * ldi], a0);
+        a1 = fmaf(dp[(size_t)(m + 16) * N], ip[(size_t)(m + 16) * ldi], a1);
+        a2 = fmaf(dp[(size_t)(m + 32) * N], ip[(size_t)(m + 32) * ldi], a2);
+        a3 = fmaf(dp[(size_t)(m + 48) * N], ip[(size_t)(m + 48) * ldi], a3);
+      }
+      for (; m < M; m += 16) a0 = fmaf(dp[(size_t)m * N], ip[(size_t)m * ldi], a0);
+    } else {
+      for (int m = g; m < M; m += 16) a0 += dp[(size_t)m * N];
+    }
+  }
+  sh[g][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16 && live) {
+    float s = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) s += sh[gg][o];
+    if (k < K) dw[(size_t)n * K + k] = s;
+    else db[n] = s;
   }
 }
 
@@ -334,7 +356,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
     const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
     const float* in = i == 0 ? p.z : p.actv[i - 1];
     const int ldi = i == 0 ? zd : K;
-    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)N * (K + 1)), dim3(256), 0, st, dcur, in, ldi,
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, st, dcur, in, ldi,
                        grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
     LAUNCH_CHECK();
     if (i == 0 && !(need_meta && h->has_meta) && !need_image) break;   // nobody needs d(z)
@@ -369,7 +391,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
                        p.a2, da2, M, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE, nullptr,
                        1.f);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)c.meta_fc2 * (c.meta_fc1 + 1)), dim3(256), 0, st,
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc2 * (c.meta_fc1 + 1) + 15) / 16), dim3(256), 0, st,
                        da2, p.h1, c.meta_fc1, grads + h->m2_w, grads + h->m2_b, M, c.meta_fc2,
                        c.meta_fc1);
     LAUNCH_CHECK();
@@ -381,7 +403,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
                        p.a1, dh1, M, c.meta_fc1, h->act, c.meta_dropout > 0.f ? meta_mask : nullptr,
                        ks1);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, g1((long)c.meta_fc1 * (c.n_meta + 1)), dim3(256), 0, st,
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc1 * (c.n_meta + 1) + 15) / 16), dim3(256), 0, st,
                        dh1, p.x1, c.n_meta, grads + h->m1_w, grads + h->m1_b, M, c.meta_fc1,
                        c.n_meta);
     LAUNCH_CHECK();

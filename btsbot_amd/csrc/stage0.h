@@ -27,6 +27,7 @@ struct Stage0Args {
   float* tap_stage;
   int B;
   unsigned long long* stamps;   // optional: workgroup 0 / thread 0 writes s_memtime at phase ends
+  unsigned long long* wgt;      // optional: every workgroup's start / end (100 MHz wall clock), [grid][2]
   int diag;               // timing diagnostics only (BTSBOT_AMD_S0_DIAG): bit0 skip depthwise FMAs,
                           // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
 };
@@ -44,5 +45,6 @@ struct Stage1Args {
   float* tap_stage;       // optional [B][49][128] f32 copy of the stage output (validation)
   int B;
   unsigned long long* stamps;   // optional phase timestamps (workgroup 0, thread 0)
+  unsigned long long* wgt;      // optional per-workgroup start / end, [grid][2]
   int diag;               // timing diagnostics, same bits as Stage0Args::diag
 };

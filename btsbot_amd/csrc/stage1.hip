@@ -53,6 +53,8 @@ constexpr float LN_EPS = 1e-6f;
 #define STAMP(i)                                                                  \
   do {                                                                            \
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+    if (a.wgt != nullptr && threadIdx.x == 0 && ((i) == 0 || (i) == 13))           \
+      a.wgt[2 * blockIdx.x + ((i) == 13)] = wall_clock64();                        \
   } while (0)
 static_assert(CHUNKB % 1024 == 0, "chunk must be whole LDS-DMA pieces");
 

@@ -1,0 +1,227 @@
+// Filter-gradient GEMM of the 1x1 convolutions, 16-bit operands (gfx950):
+//
+//   out[n][k] += sum_m D[m][n] * A[m][k]        colsum[n] += sum_m D[m][n]   (optional)
+//
+// D = gradient w.r.t. the layer output [M pixels][N], A = the layer input [M][K]; both are stored
+// pixel-major, i.e. with the REDUCTION index outermost -- the opposite of what an MFMA operand
+// wants.  The tiles are therefore staged row-major (16-byte global loads -> ds_write_b128) and
+// read back with ds_read_b64_tr_b16, gfx950's transposing LDS read: two reads hand a lane its
+// eight reduction-consecutive values of one output row/column (cdna_hip_programming.md T10).
+// Rows are padded by 64 bytes so the four rows a 32-lane half touches fall on disjoint banks.
+//
+// Workgroup = TN x TK output tile x one slice of M, 4 waves in 2 x 2, v_mfma_f32_32x32x16.
+// Global loads of tile t+1 are in flight while tile t is multiplied (register-staged double
+// buffer, one barrier per 32-row tile).  Slices meet in the output through fp32 atomics.
+// Replaces (with backward.hip) what autograd does for nn.Linear / 1x1 Conv2d weight gradients at
+// /root/reference/btsbot/train.py:526.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <typename T> struct W2M;
+template <> struct W2M<bf16_t> {
+  static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float tofloat(unsigned short v) {
+    return __builtin_bit_cast(float, (unsigned)v << 16);
+  }
+};
+template <> struct W2M<f16_t> {
+  static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float tofloat(unsigned short v) {
+    return (float)__builtin_bit_cast(f16_t, v);
+  }
+};
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// lane's 8 reduction-consecutive elements (rows r0 + 8h .. +7) of column c0 + (lane & 31)
+__device__ __forceinline__ s16x8 tr_frag(const unsigned char* tile, int pitchb, int r0, int c0,
+                                         int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const unsigned char* a = tile + (r0 + 8 * h + q) * pitchb + (c0 + 16 * g1 + 4 * p) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 4 * pitchb));
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int TM = 32;   // reduction rows per LDS tile
+
+template <typename T, int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
+                                                     const T* __restrict__ A,
+                                                     float* __restrict__ out,
+                                                     float* __restrict__ colsum, int M, int N,
+                                                     int K, int ldo, int mslice) {
+  constexpr int PN = TN * 2 + 64, PK = TK * 2 + 64;          // row pitch in bytes
+  constexpr int DB = TM * PN, AB = TM * PK;                   // bytes per tile
+  constexpr int FN = TN / 64, FK = TK / 64;                   // 32x32 fragments per wave
+  constexpr int LN = TN / 64, LK = TK / 64;                   // 16-byte chunks per thread per tile
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * (DB + AB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+  const int mbeg = blockIdx.z * mslice, mend = min(M, mbeg + mslice);
+  const int nt = (mend - mbeg + TM - 1) / TM;
+  const bool do_sum = colsum != nullptr && blockIdx.y == 0;
+
+  f32x16 acc[FN][FK];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csum = 0.f;
+
+  u32x4 rd[LN], ra[LK];
+  auto fetch = [&](int t) {
+    const int m0 = mbeg + t * TM;
+#pragma unroll
+    for (int s = 0; s < LN; ++s) {
+      const int q = tid + 256 * s, r = q / (TN / 8), cc = q % (TN / 8);
+      const int m = m0 + r, n = n0 + 8 * cc;
+      const bool ok = m < mend && n < N;
+      const u32x4* src = reinterpret_cast<const u32x4*>(D + (size_t)(ok ? m : mbeg) * N + (ok ? n : 0));
+      const u32x4 v = *src;
+      rd[s] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int s = 0; s < LK; ++s) {
+      const int q = tid + 256 * s, r = q / (TK / 8), cc = q % (TK / 8);
+      const int m = m0 + r, k = k0 + 8 * cc;
+      const bool ok = m < mend && k < K;
+      const u32x4* src = reinterpret_cast<const u32x4*>(A + (size_t)(ok ? m : mbeg) * K + (ok ? k : 0));
+      const u32x4 v = *src;
+      ra[s] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&](int buf) {
+    unsigned char* ds = sm + buf * (DB + AB);
+    unsigned char* as = ds + DB;
+#pragma unroll
+    for (int s = 0; s < LN; ++s) {
+      const int q = tid + 256 * s, r = q / (TN / 8), cc = q % (TN / 8);
+      *reinterpret_cast<u32x4*>(ds + r * PN + cc * 16) = rd[s];
+    }
+#pragma unroll
+    for (int s = 0; s < LK; ++s) {
+      const int q = tid + 256 * s, r = q / (TK / 8), cc = q % (TK / 8);
+      *reinterpret_cast<u32x4*>(as + r * PK + cc * 16) = ra[s];
+    }
+  };
+
+  if (nt > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const bool more = t + 1 < nt;   // workgroup-uniform
+    if (more) fetch(t + 1);
+    const unsigned char* ds = sm + (t & 1) * (DB + AB);
+    const unsigned char* as = ds + DB;
+#pragma unroll
+    for (int ms = 0; ms < TM; ms += 16) {
+      s16x8 af[FN], bf[FK];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) af[i] = tr_frag(ds, PN, ms, wn * (TN / 2) + 32 * i, lane);
+#pragma unroll
+      for (int j = 0; j < FK; ++j) bf[j] = tr_frag(as, PK, ms, wk * (TK / 2) + 32 * j, lane);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FK; ++j) acc[i][j] = W2M<T>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (do_sum) {   // thread = (column, row group); rows rg, rg + G, ...
+      constexpr int G = 256 / TN;
+      const int col = tid % TN, rg = tid / TN;
+#pragma unroll
+      for (int r = 0; r < TM / G; ++r)
+        csum += W2M<T>::tofloat(
+            *reinterpret_cast<const unsigned short*>(ds + (rg + G * r) * PN + col * 2));
+    }
+    if (more) stash((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // C/D layout of 32x32: column = lane & 31 -> k, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n
+  const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * (TN / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = k0 + wk * (TK / 2) + 32 * j + lc;
+        if (n < N && k < K) atomicAdd(out + (size_t)n * ldo + k, acc[i][j][r]);
+      }
+  if (do_sum) {
+    constexpr int G = 256 / TN;
+    float* red = reinterpret_cast<float*>(sm);   // all tile reads are behind the loop's last barrier
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < TN && n0 + tid < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) s += red[tid + TN * g];
+      atomicAdd(colsum + n0 + tid, s);
+    }
+  }
+}
+
+template <typename T, int TN, int TK>
+int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M, int N, int K,
+                  int ldo, hipStream_t st) {
+  const int gx = (N + TN - 1) / TN, gy = (K + TK - 1) / TK;
+  // slices of the reduction: ~768 workgroups in flight, at least 256 rows each
+  int nsl = (768 + gx * gy - 1) / (gx * gy);
+  if (nsl > (M + 255) / 256) nsl = (M + 255) / 256;
+  if (nsl < 1) nsl = 1;
+  const int mslice = ((M + nsl - 1) / nsl + TM - 1) / TM * TM;
+  nsl = (M + mslice - 1) / mslice;
+  hipLaunchKernelGGL((wgrad2_kernel<T, TN, TK>), dim3(gx, gy, nsl), dim3(256), 0, st,
+                     reinterpret_cast<const T*>(D), reinterpret_cast<const T*>(A), out, colsum, M,
+                     N, K, ldo, mslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+template <typename T>
+int wgrad2_t(const void* D, const void* A, float* out, float* colsum, int M, int N, int K, int ldo,
+             hipStream_t st) {
+  if (N > 64 && K > 64) return wgrad2_launch<T, 128, 128>(D, A, out, colsum, M, N, K, ldo, st);
+  if (N > 64) return wgrad2_launch<T, 128, 64>(D, A, out, colsum, M, N, K, ldo, st);
+  if (K > 64) return wgrad2_launch<T, 64, 128>(D, A, out, colsum, M, N, K, ldo, st);
+  return wgrad2_launch<T, 64, 64>(D, A, out, colsum, M, N, K, ldo, st);
+}
+
+}  // namespace
+
+// 16-bit modes only; N and K must be multiples of 8 and the operands 16-byte aligned.
+int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
+                   int K, int ldo, hipStream_t st) {
+  if (M <= 0) return BTSBOT_OK;
+  if ((N & 7) || (K & 7) || ((uintptr_t)D & 15) || ((uintptr_t)A & 15)) {
+    btsbot_set_error("wgrad16: N=%d K=%d / operand alignment not supported", N, K);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  switch (prec) {
+    case BTSBOT_BF16: return wgrad2_t<bf16_t>(D, A, out, colsum, M, N, K, ldo, st);
+    case BTSBOT_F16: return wgrad2_t<f16_t>(D, A, out, colsum, M, N, K, ldo, st);
+    default:
+      btsbot_set_error("wgrad16: precision %d is not a 16-bit mode", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+}

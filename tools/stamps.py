@@ -14,7 +14,7 @@ img, meta, _ = synthetic_batch(B, seed=2)
 img, meta = img.to(dev), meta.to(dev)
 for _ in range(3):
     run_model(kind, m, img, meta)
-buf = torch.zeros(32, dtype=torch.int64, device=dev)
+buf = torch.zeros(32 + 16384, dtype=torch.int64, device=dev)
 _lib.check(_lib.lib().btsbot_debug_stamps(m._handle.ptr, C.c_void_p(buf.data_ptr())), "stamps")
 run_model(kind, m, img, meta)
 torch.cuda.synchronize()
@@ -25,3 +25,15 @@ for base, tag in ((0, "stage0"), (16, "stage1")):
     print(tag, "total cycles", t[base + 13] - t[base])
     for i in range(1, 14):
         print(f"   {names[i]:22s} +{t[base + i] - t[base + i - 1]:8d}")
+
+import numpy as np
+for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
+    w = np.array(t[off:off + 2 * n]).reshape(n, 2)
+    t0 = w[:, 0].min()
+    dur = (w[:, 1] - w[:, 0]) / 100.0
+    st = (w[:, 0] - t0) / 100.0
+    print(tag, f"workgroups {n}: kernel span {(w[:,1].max()-t0)/100.0:.1f} us; WG duration us min/median/max "
+          f"{dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f}; starts: {np.sum(st < 5)} within 5 us, "
+          f"last start {st.max():.1f} us")
+    print("   duration deciles", np.percentile(dur, [10, 30, 50, 70, 90]).round(1))
+    print("   start deciles   ", np.percentile(st, [10, 30, 50, 70, 90]).round(1))
