@@ -253,12 +253,16 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
   const size_t base = (size_t)blockIdx.x * P * C;
   for (int i = threadIdx.x; i < P * C; i += 256) xs[i] = x[base + i];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  // thread = (channel, row group): narrow maps (C < 256) spread their rows over the idle waves
+  const int G = C < 256 ? 256 / C : 1;
+  const int rg = C < 256 ? threadIdx.x / C : 0;
+  const bool idle = C < 256 && (int)threadIdx.x >= G * C;   // C does not divide 256 (nano)
+  for (int c = idle ? C : (C < 256 ? threadIdx.x % C : threadIdx.x); c < C; c += 256) {
     float wv[49];
 #pragma unroll
     for (int t = 0; t < 49; ++t) wv[t] = w[(flip ? 48 - t : t) * C + c];
     const float b = bias != nullptr ? bias[c] : 0.f;
-    for (int y = 0; y < HW; ++y) {
+    for (int y = rg; y < HW; y += G) {
       float acc[HW];
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) acc[xx] = b;
@@ -287,8 +291,8 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
 }
 
 // Depthwise filter gradient: sum_{alerts,pixels} dd[p][c] * x[p + delta_t][c] per tap, and sum dd
-// for the bias.  Workgroup = GA alerts (sequentially), thread = channel; every workgroup writes ONE
-// partial row [C*49 | C] which launch_dw_wgrad then column-sums into the gradient arena (the filter
+// for the bias.  Workgroup = GA alerts (sequentially), thread = (channel, row group); every row
+// group writes ONE partial row [C*49 | C] which launch_dw_wgrad then column-sums into the gradient arena (the filter
 // and its bias are adjacent there) -- no same-address atomic storm.
 template <int HW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x,
@@ -299,8 +303,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   float* xs = sm;
   float* ds = sm + P * C;
   const int a0 = blockIdx.x * ga, a1 = min(B, a0 + ga);
+  // thread = (channel, row group), as in dw_plain_kernel; every row group owns a partial row
+  const int G = C < 256 ? 256 / C : 1;
+  const int rg = C < 256 ? threadIdx.x / C : 0;
   for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + threadIdx.x;
+    const bool idle = C < 256 && (int)threadIdx.x >= G * C;   // C does not divide 256 (nano)
+    const int c = idle ? C : (C < 256 ? threadIdx.x % C : c0 + threadIdx.x);
     float acc[49], ab = 0.f;
 #pragma unroll
     for (int t = 0; t < 49; ++t) acc[t] = 0.f;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       }
       __syncthreads();
       if (c < C) {
-        for (int y = 0; y < HW; ++y) {
+        for (int y = rg; y < HW; y += G) {
           float g[HW];
 #pragma unroll
           for (int xx = 0; xx < HW; ++xx) {
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       }
     }
     if (c < C) {   // this workgroup's partial row: [C][49] filter taps, then [C] biases
-      float* row = dw + (size_t)blockIdx.x * 50 * C;
+      float* row = dw + ((size_t)blockIdx.x * G + rg) * 50 * C;
 #pragma unroll
       for (int t = 0; t < 49; ++t) row[(size_t)c * 49 + t] = acc[t];
       row[(size_t)49 * C + c] = ab;
@@ -479,11 +487,108 @@ int launch_fc2_grads(const float* G, const float* S, const float* w2, const floa
   return BTSBOT_OK;
 }
 
+// Narrow maps (C = 4 * LPR, LPR = 16 or 32 lanes per pixel row): every lane owns 4 consecutive
+// channels (float4 loads), a wave normalises 64 / LPR rows at once and runs two such groups per
+// iteration, so that 4 x 16-byte loads per lane are in flight instead of one dword.
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restrict__ d,
+                                                            const float* __restrict__ dxn,
+                                                            const float* __restrict__ g, float* dd,
+                                                            float* dg, float* dbeta, long rows) {
+  constexpr int C = 4 * LPR, R = 64 / LPR;       // rows per wave pass
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const float4 gl = *reinterpret_cast<const float4*>(g + 4 * l);
+  float adg[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
+  auto gsum = [](float v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  };
+  const long stride = (long)gridDim.x * 4 * R * 2;
+  for (long r0 = ((long)blockIdx.x * 4 + wv) * R * 2; r0 < rows; r0 += stride) {
+    float4 v[2], dx[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long r = r0 + u * R + sub;
+      ok[u] = r < rows;
+      const long rr = ok[u] ? r : 0;
+      v[u] = *reinterpret_cast<const float4*>(d + rr * C + 4 * l);
+      dx[u] = *reinterpret_cast<const float4*>(dxn + rr * C + 4 * l);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long r = r0 + u * R + sub;
+      float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      const float dxa[4] = {dx[u].x, dx[u].y, dx[u].z, dx[u].w};
+      const float ga[4] = {gl.x, gl.y, gl.z, gl.w};
+      const float mean = gsum((x[0] + x[1]) + (x[2] + x[3])) * (1.f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] -= mean;
+        q += x[i] * x[i];
+      }
+      const float rstd = rsqrtf(gsum(q) * (1.f / C) + LN_EPS);
+      float t[4], st = 0.f, stx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] *= rstd;
+        t[i] = dxa[i] * ga[i];
+        st += t[i];
+        stx += t[i] * x[i];
+        if (ok[u]) {
+          adg[i] += dxa[i] * x[i];
+          adb[i] += dxa[i];
+        }
+      }
+      st = gsum(st) * (1.f / C);
+      stx = gsum(stx) * (1.f / C);
+      if (ok[u])
+        *reinterpret_cast<float4*>(dd + r * C + 4 * l) =
+            make_float4(rstd * (t[0] - st - x[0] * stx), rstd * (t[1] - st - x[1] * stx),
+                        rstd * (t[2] - st - x[2] * stx), rstd * (t[3] - st - x[3] * stx));
+    }
+  }
+  // row groups of the wave and the 4 waves meet in LDS: one atomic per channel per block
+  __shared__ float sh[2][4 * R][C];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sh[0][wv * R + sub][4 * l + i] = adg[i];
+    sh[1][wv * R + sub][4 * l + i] = adb[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4 * R; ++j) {
+      a += sh[0][j][c];
+      b += sh[1][j][c];
+    }
+    atomicAdd(dg + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
                   float* dbeta, long rows, int C, hipStream_t st) {
   if (rows <= 0) return BTSBOT_OK;
   long blocks = (rows + 3) / 4;
   if (blocks > 512) blocks = 512;     // <= 512 same-address atomics per channel
+  if (C == 64 || C == 128) {
+    const int rpb = 4 * (C == 64 ? 4 : 2) * 2;   // rows per block pass
+    long nb = (rows + rpb - 1) / rpb;
+    if (nb > 512) nb = 512;
+    if (C == 64)
+      hipLaunchKernelGGL((ln_bwd_narrow_kernel<16>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
+                         dd, dg, dbeta, rows);
+    else
+      hipLaunchKernelGGL((ln_bwd_narrow_kernel<32>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
+                         dd, dg, dbeta, rows);
+    LAUNCH_CHECK();
+    return BTSBOT_OK;
+  }
   const int cpt = (C + 63) / 64;
 #define LNB(CPT)                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
@@ -563,7 +668,7 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, fl
   }
 #undef DWW
   LAUNCH_CHECK();
-  return colsum_t<float>(partials, dw, grid, 50 * C, st);
+  return colsum_t<float>(partials, dw, grid * (C < 256 ? 256 / C : 1), 50 * C, st);
 }
 
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st) {
