@@ -98,15 +98,21 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
         bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
                   for (d, p, c), f in zip(st, fused) if f))
     unf = [not f and not mega[i] for i, f in enumerate(fused)]
+    # stage 2 at C = 256: depthwise + LN + fc1 + GELU in one launch (stage2.hip), fc2 stays a GEMM
+    s2 = precision != "f32" and dims[2] == 256
+    w["s2_fc1_kernel"] = dict(
+        flop=pw(*st[2]) if s2 else 0,
+        bytes=st[2][0] * (batch * 9 * dims[2] * 4 + batch * 9 * 4 * dims[2] * esz + 4 * dims[2] ** 2 * esz))
+    unf1 = [u and not (s2 and i == 2) for i, u in enumerate(unf)]
     w["gemm_kernel<fc1,GELU>"] = dict(
-        flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
+        flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf1) if u),
         bytes=sum(d * (batch * p * c * esz + batch * p * 4 * c * esz + 4 * c * c * esz)
-                  for (d, p, c), u in zip(st, unf) if u))
+                  for (d, p, c), u in zip(st, unf1) if u))
     w["gemm_kernel<fc2,RESID>"] = dict(
         flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf) if u),
         bytes=sum(d * (batch * p * 4 * c * esz + 2 * batch * p * c * 4 + 4 * c * c * esz)
                   for (d, p, c), u in zip(st, unf) if u))
-    dwst = [(d, p, c) for i, (d, p, c) in enumerate(st) if not mega[i]]
+    dwst = [(d, p, c) for i, (d, p, c) in enumerate(st) if not mega[i] and not (s2 and i == 2)]
     w["dwconv_ln_kernel"] = dict(
         flop=sum(d * 2 * 49 * batch * p * c for d, p, c in dwst),
         bytes=sum(d * batch * p * c * (4 + esz) for d, p, c in dwst))
@@ -123,7 +129,8 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     return w
 
 
-POINTWISE = ("stage0_kernel", "stage1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>", "gemm_kernel<fc2,RESID>")
+POINTWISE = ("stage0_kernel", "stage1_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
+             "gemm_kernel<fc2,RESID>")
 
 
 def cpu_baseline(sample_batch=256, budget_s=20.0):

@@ -70,18 +70,34 @@ __device__ __forceinline__ float gelu_grad(float x) {
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
-// 64-lane butterfly sum; every lane ends with the total.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Sum within aligned groups of 16 lanes (a DPP "row"); every lane ends with its row's total.
+// quad_perm xor 1, xor 2, then row_half_mirror / row_mirror (the quads / halves are uniform by then):
+// four v_add_f32_dpp, no LDS crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ float group16_sum(float v) {
+#define BTS_DPP_ADD(ctrl)                                                                      \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, \
+                                                             0xF, 0xF, true))
+  BTS_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  BTS_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  BTS_DPP_ADD(0x141);   // row_half_mirror
+  BTS_DPP_ADD(0x140);   // row_mirror
+#undef BTS_DPP_ADD
   return v;
 }
 
-// sum within aligned groups of 16 lanes
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+// 64-lane sum; every lane ends with the total.  Rows meet through v_permlane16_swap /
+// v_permlane32_swap (gfx950): swap(v, v) hands every lane its own and its partner row's value.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group16_sum(v);
+  // (inline asm: given the same value for both operands of __builtin_amdgcn_permlane16_swap,
+  //  hipcc 7.2 folds its two results into one and adds a register to itself; s_nop covers the
+  //  VALU-write -> permlane-read hazard the compiler would otherwise pad)
+  float w = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  v += w;
+  w = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  return v + w;
 }
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
@@ -145,6 +161,9 @@ int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
 // backward kernels (backward.hip)
 int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
+int launch_s2_fc1(int prec, const float* x, const float* dw_w, const float* dw_b, const float* ln_w,
+                  const float* ln_b, const void* w1, const float* b1, void* h, int B,
+                  unsigned long long* stamps, hipStream_t st);   // stage2.hip: dw7x7+LN+fc1+GELU on 3x3x256 maps, 16-bit modes
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
                    int K, int ldo, hipStream_t st);   // wgrad.hip: 16-bit modes, colsum optional
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...

@@ -14,7 +14,7 @@ img, meta, _ = synthetic_batch(B, seed=2)
 img, meta = img.to(dev), meta.to(dev)
 for _ in range(3):
     run_model(kind, m, img, meta)
-buf = torch.zeros(32 + 16384, dtype=torch.int64, device=dev)
+buf = torch.zeros(32 + 16384 + 16, dtype=torch.int64, device=dev)
 _lib.check(_lib.lib().btsbot_debug_stamps(m._handle.ptr, C.c_void_p(buf.data_ptr())), "stamps")
 run_model(kind, m, img, meta)
 torch.cuda.synchronize()
@@ -37,3 +37,9 @@ for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
           f"last start {st.max():.1f} us")
     print("   duration deciles", np.percentile(dur, [10, 30, 50, 70, 90]).round(1))
     print("   start deciles   ", np.percentile(st, [10, 30, 50, 70, 90]).round(1))
+
+s2 = t[32 + 16384:32 + 16384 + 10]
+print("s2_fc1 (last block of stage 2) total cycles", s2[9] - s2[0])
+for i, nm in enumerate(["x + tap loads issued", "filter DMA issued", "alert 0 done", "alert 1 done", "alert 2 done",
+                        "alert 3 done", "main loop done", "GELU + staging done", "rows stored"]):
+    print(f"   {nm:32s} +{s2[i + 1] - s2[i]:8d}")

@@ -1,0 +1,49 @@
+// VALU issue-rate probe (gfx950): cycles per wave-instruction for v_fma_f32, v_pk_fma_f32,
+// v_pk_mul_f32, v_exp_f32, v_rcp_f32, v_add_f32_dpp; 1, 2 or 4 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define REP 64
+template <int MODE> __global__ void k(float* out, long long* cyc, int iters) {
+  float a[8]; f32x2 p[8];
+  for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 0.001f + i; p[i] = f32x2{a[i], a[i] + 0.5f}; }
+  const float m = 0.999f; const f32x2 pm = {0.999f, 0.998f};
+  long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (MODE == 0) a[i] = fmaf(a[i], m, 0.001f);
+        if (MODE == 1) p[i] = __builtin_elementwise_fma(p[i], pm, (f32x2)(0.001f));
+        if (MODE == 2) p[i] = p[i] * pm;
+        if (MODE == 3) a[i] = __builtin_amdgcn_exp2f(a[i]);
+        if (MODE == 4) a[i] = __builtin_amdgcn_rcpf(a[i]);
+        if (MODE == 5) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xF, 0xF, true));
+        if (MODE == 6) a[i] = __builtin_amdgcn_fmed3f(a[i], -5.f, 5.f);
+      }
+  }
+  long long t1 = clock64();
+  float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + p[i][0] + p[i][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+int main() {
+  float* out; long long* cyc; hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 4096);
+  const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp", "v_med3_f32"};
+  const int iters = 200;
+  for (int wps = 1; wps <= 4; wps *= 2)
+    for (int mode = 0; mode < 7; ++mode) {
+      dim3 g(256), b(256 * wps);
+      switch (mode) {
+        case 0: k<0><<<g, b>>>(out, cyc, iters); break; case 1: k<1><<<g, b>>>(out, cyc, iters); break;
+        case 2: k<2><<<g, b>>>(out, cyc, iters); break; case 3: k<3><<<g, b>>>(out, cyc, iters); break;
+        case 4: k<4><<<g, b>>>(out, cyc, iters); break; case 5: k<5><<<g, b>>>(out, cyc, iters); break;
+        case 6: k<6><<<g, b>>>(out, cyc, iters); break;
+      }
+      long long h[1]; hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost);
+      printf("%d waves/SIMD  %-14s %.2f cycles per wave-instruction (SIMD-level: %.2f)\n", wps, names[mode],
+             (double)h[0] / (iters * REP), (double)h[0] / (iters * REP) / wps);
+    }
+  return 0;
+}
