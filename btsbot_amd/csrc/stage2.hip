@@ -6,18 +6,22 @@
 // /root/reference/btsbot/architectures.py:108,132).  Replaces dw3_ln_kernel + the fc1 GEMM launch:
 // the LayerNorm output never goes to HBM, and the GEMM gets a tile shape that fits the problem.
 //
-// Workgroup = 16 alerts (144 pixel rows) x 256 hidden units, 4 waves, one workgroup per CU:
-// at B = 1024 that is exactly 64 x 4 = 256 workgroups.  The four workgroups that share a row tile
-// are given the same blockIdx % 8, i.e. the same XCD / L2 (speed only).
-//   prologue  W1 slabs 0..3 start by LDS-DMA; each wave takes 4 of the alerts: lane = 4 channels
-//             (16-byte loads), the 3x3 map of a channel lives in registers, LayerNorm sums are
-//             wave-local; the 16-bit result is the MFMA operand image in LDS
-//             ([144][256], 16-byte chunk c of row r at position c ^ (r & 15));
+// Workgroup = 16 alerts (144 pixel rows) x 256 hidden units, one workgroup per CU: at B = 1024
+// that is exactly 64 x 4 = 256 workgroups.  The four workgroups that share a row tile are given
+// the same blockIdx % 8, i.e. the same XCD / L2 (speed only).
+// 16 waves (1024 threads): two thirds of this kernel is VALU work (depthwise taps, LayerNorm,
+// GELU), and one wave can issue a VALU instruction only every ~4.7 cycles while the SIMD accepts
+// one from ANOTHER wave every ~1.2 (tools/unit/valu_rate.hip) -- so 4 waves per SIMD, 128 VGPRs.
+//   prologue  wave = one alert, lane = 4 channels (16-byte loads); the central 5x5 taps (all a 3x3
+//             map can touch) sit in LDS; LayerNorm sums are wave-local (DPP + permlane swaps); the
+//             16-bit result is the MFMA operand image ([144][256], 16-byte chunk c of row r at
+//             position c ^ (r & 15));
 //   main      K = 256 in 8 slabs of 32 through a 4-slot LDS-DMA ring (64-byte rows, chunk c of row r
-//             at position c ^ F[(r >> 2) & 3], F = {0,3,2,1}: conflict-free ds_read_b128);
-//             v_mfma_f32_16x16x32, wave = 144 rows x 64 columns = 36 accumulator tiles, filters
-//             as the A operand so a lane ends up with 4 consecutive hidden units of one pixel;
-//   epilogue  + bias, GELU, 16-bit, staged through LDS, whole 512-byte rows to HBM.
+//             at position c ^ F[(r >> 2) & 3], F = {0,3,2,1}: conflict-free ds_read_b128); a wave
+//             multiplies 144 pixels x ITS 16 filter rows -- the rows it fetched itself, so it only
+//             waits for its own DMA and there is no barrier in the loop; v_mfma_f32_16x16x32 with
+//             the filters as the A operand: a lane ends up with 4 consecutive hidden units of a pixel;
+//   epilogue  + bias, GELU (packed f32 math), 16-bit, staged through LDS, whole 512-byte rows out.
 #include "common.h"
 
 struct S2Fc1Args {
@@ -54,12 +58,13 @@ template <> struct M2<f16_t> {
 
 constexpr int C = 256, HID = 1024, GA = 16, ROWS = GA * 9;       // 144
 constexpr int TN = 256;                                            // hidden units per workgroup
+constexpr int NT = 1024;                                           // threads: 16 waves
 constexpr int AROW = C * 2;                                        // 512 B per operand-image row
 constexpr int ATILE = ROWS * AROW;                                 // 73728
 constexpr int KS = 32, NSLAB = C / KS, NSLOT = 4;
 constexpr int SLABB = TN * KS * 2;                                 // 16384
 constexpr int OPITCH = TN * 2 + 16;                                // epilogue staging pitch
-constexpr int MI = ROWS / 16, NI = 4;
+constexpr int MI = ROWS / 16;
 constexpr float LN_EPS = 1e-6f;
 #define S2STAMP(i)                                                                         \
   do {                                                                                     \
@@ -67,6 +72,9 @@ constexpr float LN_EPS = 1e-6f;
   } while (0)
 constexpr size_t LDS_BYTES = (size_t)ATILE + NSLOT * SLABB;       // 139264
 static_assert((size_t)ROWS * OPITCH <= LDS_BYTES, "epilogue staging must fit");
+static_assert(25 * C * 4 <= 2 * SLABB, "the tap table borrows ring slots 2..3");
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int swz4(int row) {   // F[(row >> 2) & 3], F = {0,3,2,1}
   const int g = (row >> 2) & 3;
@@ -77,18 +85,33 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
-  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z),
-                     fmaf(a.w, b.w, c.w));
+// gelu_fast (common.h) on two values: v_pk_mul / v_pk_fma where the math allows
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f);
+  const f32x2 x2 = xc * xc;
+  f32x2 t = __builtin_elementwise_fma(x2, (f32x2)(1.01426374e-3f), (f32x2)(-1.06775727e-1f));
+  t = __builtin_elementwise_fma(x2, t, (f32x2)(-2.30112134f));
+  const f32x2 z = xc * t;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(z[0]);
+  e[1] = __builtin_amdgcn_exp2f(z[1]);
+  const f32x2 d = e + (f32x2)(1.0f);
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]);
+  r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return x * r;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void s2_fc1_kernel(S2Fc1Args a) {
+__global__ __launch_bounds__(NT) void s2_fc1_kernel(S2Fc1Args a) {
   using frag = typename M2<T>::frag;
   typedef T T4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* atile = smem;
   unsigned char* ring = smem + ATILE;
+  float* taps = reinterpret_cast<float*>(ring + 2 * SLABB);   // [25][256], dead before slab 2 lands
 
   // ---- which tile: blocks with equal (blockIdx % 8) share an XCD; keep a row tile's 4 column
   //      tiles there so the stage input is fetched into one L2 only
@@ -100,168 +123,165 @@ __global__ __launch_bounds__(256) void s2_fc1_kernel(S2Fc1Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, lq = lane >> 4;
+  S2STAMP(0);
+  if (a.stamps != nullptr && tid == 0) a.stamps[64 + 2 * blockIdx.x] = wall_clock64();
 
-  // ---- W1 slabs: per-lane source pointers (slab s adds 64 bytes), wave-uniform LDS offsets
-  const unsigned char* wsrc[4];
+  // ---- this wave's alert (x) and the shared tap table are requested first
+  const int c4 = 4 * lane;
+  f32x2 in[9][2];
+  {
+    const int ag = min(mt * GA + wave, a.B - 1);
+    const float* src = a.x + (size_t)ag * 9 * C + c4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 16 + (lane >> 2);
-    wsrc[i] = reinterpret_cast<const unsigned char*>(a.w1) + (size_t)(n0 + row) * AROW +
-              (((lane & 3) ^ swz4(row)) << 4);
+    for (int p = 0; p < 9; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(src + p * C);
+      in[p][0] = f32x2{v.x, v.y};
+      in[p][1] = f32x2{v.z, v.w};
+    }
+  }
+  for (int i = tid; i < 25 * C / 4; i += NT) {   // tap t of the 5x5 = (dy+2)*5 + dx+2
+    const int t = i >> 6, cc = (i & 63) * 4;
+    const int dy = t / 5, dx = t - dy * 5;
+    *reinterpret_cast<float4*>(taps + t * C + cc) =
+        *reinterpret_cast<const float4*>(a.dw_w + ((dy + 1) * 7 + dx + 1) * C + cc);
+  }
+  // ---- W1 slabs: this wave fetches (and later multiplies) filter rows n0 + 16*wave .. +15
+  const unsigned char* wsrc;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    wsrc = reinterpret_cast<const unsigned char*>(a.w1) + (size_t)(n0 + row) * AROW +
+           (((lane & 3) ^ swz4(row)) << 4);
   }
   auto issue = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + s * (KS * 2)),
-                                       (lptr_t)(ring + (s % NSLOT) * SLABB + (wave * 4 + i) * 1024),
-                                       16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + s * (KS * 2)),
+                                     (lptr_t)(ring + (s % NSLOT) * SLABB + wave * 1024), 16, 0, 0);
   };
-  S2STAMP(0);
+  issue(0);
+  issue(1);
+  S2STAMP(1);
+  __syncthreads();   // tap table complete
+  S2STAMP(2);
 
-  // ---- prologue: depthwise 7x7 (only the central 5x5 taps can touch a 3x3 map) + LN
+  // ---- prologue: depthwise 7x7 (only the central 5x5 taps can touch a 3x3 map) + LN, one alert
   {
-    const int c4 = 4 * lane;
-    float4 in[4][9];   // all four alerts of this wave in flight at once (36 x 16-byte loads per lane)
+    const float4 b4 = *reinterpret_cast<const float4*>(a.dw_b + c4);
+    f32x2 acc[9][2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ag = min(mt * GA + wave + 4 * it, a.B - 1);
-      const float* src = a.x + (size_t)ag * 9 * C + c4;
-#pragma unroll
-      for (int p = 0; p < 9; ++p) in[it][p] = *reinterpret_cast<const float4*>(src + p * C);
+    for (int p = 0; p < 9; ++p) {
+      acc[p][0] = f32x2{b4.x, b4.y};
+      acc[p][1] = f32x2{b4.z, b4.w};
     }
-    float4 wq[25];
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy)
 #pragma unroll
-      for (int dx = -2; dx <= 2; ++dx)
-        wq[(dy + 2) * 5 + dx + 2] =
-            *reinterpret_cast<const float4*>(a.dw_w + ((dy + 3) * 7 + dx + 3) * C + c4);
-    const float4 bias = *reinterpret_cast<const float4*>(a.dw_b + c4);
-    const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c4);
-    const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + c4);
-    S2STAMP(1);
-    // the filter slabs queue up behind the prologue's own loads (vmcnt retires in order)
-    issue(0);
-    issue(1);
-    issue(2);
-    S2STAMP(2);
+      for (int dx = -2; dx <= 2; ++dx) {
+        const float4 w4 = *reinterpret_cast<const float4*>(taps + ((dy + 2) * 5 + dx + 2) * C + c4);
+        const f32x2 w0 = {w4.x, w4.y}, w1 = {w4.z, w4.w};
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int al = wave + 4 * it;
-      const float4* v = in[it];
-      float4 acc[9];
+        for (int oy = 0; oy < 3; ++oy)
 #pragma unroll
-      for (int p = 0; p < 9; ++p) acc[p] = bias;
-#pragma unroll
-      for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx)
-#pragma unroll
-          for (int oy = 0; oy < 3; ++oy)
-#pragma unroll
-            for (int ox = 0; ox < 3; ++ox) {
-              const int iy = oy + dy, ix = ox + dx;
-              if (iy >= 0 && iy < 3 && ix >= 0 && ix < 3)
-                acc[oy * 3 + ox] = f4fma(v[iy * 3 + ix], wq[(dy + 2) * 5 + dx + 2], acc[oy * 3 + ox]);
+          for (int ox = 0; ox < 3; ++ox) {
+            const int iy = oy + dy, ix = ox + dx;
+            if (iy >= 0 && iy < 3 && ix >= 0 && ix < 3) {
+              acc[oy * 3 + ox][0] = __builtin_elementwise_fma(in[iy * 3 + ix][0], w0, acc[oy * 3 + ox][0]);
+              acc[oy * 3 + ox][1] = __builtin_elementwise_fma(in[iy * 3 + ix][1], w1, acc[oy * 3 + ox][1]);
             }
-      float mean[9], var[9];
-#pragma unroll
-      for (int p = 0; p < 9; ++p)
-        mean[p] = wave_sum((acc[p].x + acc[p].y) + (acc[p].z + acc[p].w)) * (1.0f / C);
-#pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        acc[p] = make_float4(acc[p].x - mean[p], acc[p].y - mean[p], acc[p].z - mean[p],
-                             acc[p].w - mean[p]);
-        var[p] = wave_sum((acc[p].x * acc[p].x + acc[p].y * acc[p].y) +
-                          (acc[p].z * acc[p].z + acc[p].w * acc[p].w)) * (1.0f / C);
+          }
       }
+    float mean[9], var[9];
 #pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        const float4 d = acc[p];
-        const float rstd = rsqrtf(var[p] + LN_EPS);
-        T4 o;
-        o[0] = (T)(d.x * rstd * g.x + bb.x);
-        o[1] = (T)(d.y * rstd * g.y + bb.y);
-        o[2] = (T)(d.z * rstd * g.z + bb.z);
-        o[3] = (T)(d.w * rstd * g.w + bb.w);
-        const int r = al * 9 + p;
-        *reinterpret_cast<T4*>(atile + r * AROW + (((lane >> 1) ^ (r & 15)) << 4) + (lane & 1) * 8) = o;
-      }
-      S2STAMP(3 + it);
+    for (int p = 0; p < 9; ++p) {
+      const f32x2 t = acc[p][0] + acc[p][1];
+      mean[p] = wave_sum(t[0] + t[1]) * (1.0f / C);
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      acc[p][0] -= (f32x2)(mean[p]);
+      acc[p][1] -= (f32x2)(mean[p]);
+      const f32x2 q = __builtin_elementwise_fma(acc[p][0], acc[p][0], acc[p][1] * acc[p][1]);
+      var[p] = wave_sum(q[0] + q[1]) * (1.0f / C);
+    }
+    const float4 g4 = *reinterpret_cast<const float4*>(a.ln_w + c4);
+    const float4 bb4 = *reinterpret_cast<const float4*>(a.ln_b + c4);
+    const f32x2 g0 = {g4.x, g4.y}, g1 = {g4.z, g4.w}, bb0 = {bb4.x, bb4.y}, bb1 = {bb4.z, bb4.w};
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      const float rstd = rsqrtf(var[p] + LN_EPS);
+      const f32x2 o0 = __builtin_elementwise_fma(acc[p][0] * (f32x2)(rstd), g0, bb0);
+      const f32x2 o1 = __builtin_elementwise_fma(acc[p][1] * (f32x2)(rstd), g1, bb1);
+      T4 o;
+      o[0] = (T)o0[0];
+      o[1] = (T)o0[1];
+      o[2] = (T)o1[0];
+      o[3] = (T)o1[1];
+      const int r = wave * 9 + p;
+      *reinterpret_cast<T4*>(atile + r * AROW + (((lane >> 1) ^ (r & 15)) << 4) + (lane & 1) * 8) = o;
     }
   }
+  S2STAMP(3);
+  if (a.stamps != nullptr && blockIdx.x == 0 && lane == 0) a.stamps[16 + wave] = clock64();
+  __syncthreads();   // operand image complete; the tap table is dead
+  issue(2);
+  S2STAMP(4);
 
-  // ---- main loop: one 16x16x32 k-step per slab
-  f32x4 acc[NI][MI];
+  // ---- main loop: one 16x16x32 k-step per slab, no barriers (see the header)
+  f32x4 acc[MI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // the operand image is complete
-  // A wave multiplies only the 64 filter rows it fetched itself, so inside the loop it waits for
-  // its own LDS-DMA only: no barriers, the waves drift apart.  The pixel operand of slab s+1 is
-  // read from the (static) image while the MFMAs of slab s run.
-  frag bfr[2][MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-    bfr[0][mi] = *reinterpret_cast<const frag*>(atile + (mi * 16 + lrow) * AROW + ((lq ^ lrow) << 4));
+  for (int mi = 0; mi < MI; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NSLAB; ++s) {
     // slab s has landed once only the younger slabs' pieces are outstanding
-    if (s + 2 < NSLAB) wait_vm<8>();
-    else if (s + 1 < NSLAB) wait_vm<4>();
+    if (s + 2 < NSLAB) wait_vm<2>();
+    else if (s + 1 < NSLAB) wait_vm<1>();
     else wait_vm<0>();
-    const unsigned char* ws = ring + (s % NSLOT) * SLABB;
-    frag afr[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int row = wave * 64 + ni * 16 + lrow;
-      afr[ni] = *reinterpret_cast<const frag*>(ws + row * (KS * 2) + ((lq ^ swz4(row)) << 4));
-    }
+    const int row = wave * 16 + lrow;
+    const frag afr = *reinterpret_cast<const frag*>(ring + (s % NSLOT) * SLABB + row * (KS * 2) +
+                                                    ((lq ^ swz4(row)) << 4));
     if (s + 3 < NSLAB) issue(s + 3);   // into the slot of slab s-1, which this wave has consumed
-    if (s + 1 < NSLAB) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        bfr[(s + 1) & 1][mi] = *reinterpret_cast<const frag*>(
-            atile + (mi * 16 + lrow) * AROW + ((((s + 1) * 4 + lq) ^ lrow) << 4));
-    }
+    frag bfr[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
+      bfr[mi] = *reinterpret_cast<const frag*>(atile + (mi * 16 + lrow) * AROW +
+                                               (((s * 4 + lq) ^ lrow) << 4));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = M2<T>::run(afr[ni], bfr[s & 1][mi], acc[ni][mi]);
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = M2<T>::run(afr, bfr[mi], acc[mi]);
   }
-  S2STAMP(7);
+  S2STAMP(5);
+  if (a.stamps != nullptr && blockIdx.x == 0 && lane == 0) a.stamps[32 + wave] = clock64();
   __syncthreads();   // operand image and ring are idle (no LDS-DMA in flight: last wait was vmcnt(0))
 
   // ---- epilogue 1: bias + GELU -> staging tile [144][256] (lane owns 4 consecutive hidden units)
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int nl = wave * 64 + ni * 16 + lq * 4;
+  {
+    const int nl = wave * 16 + lq * 4;
     const float4 bv = *reinterpret_cast<const float4*>(a.b1 + n0 + nl);
+    const f32x2 b0 = {bv.x, bv.y}, b1 = {bv.z, bv.w};
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const f32x4 v = acc[ni][mi];
+      const f32x2 y0 = gelu_fast2(f32x2{acc[mi][0], acc[mi][1]} + b0);
+      const f32x2 y1 = gelu_fast2(f32x2{acc[mi][2], acc[mi][3]} + b1);
       T4 o;
-      o[0] = (T)gelu_fast(v[0] + bv.x);
-      o[1] = (T)gelu_fast(v[1] + bv.y);
-      o[2] = (T)gelu_fast(v[2] + bv.z);
-      o[3] = (T)gelu_fast(v[3] + bv.w);
+      o[0] = (T)y0[0];
+      o[1] = (T)y0[1];
+      o[2] = (T)y1[0];
+      o[3] = (T)y1[1];
       *reinterpret_cast<T4*>(smem + (mi * 16 + lrow) * OPITCH + nl * 2) = o;
     }
   }
-  S2STAMP(8);
+  S2STAMP(6);
+  if (a.stamps != nullptr && blockIdx.x == 0 && lane == 0) a.stamps[48 + wave] = clock64();
   __syncthreads();
   // ---- epilogue 2: whole 512-byte rows to HBM
   const long M = (long)a.B * 9;
   unsigned char* hb = reinterpret_cast<unsigned char*>(a.h);
-  for (int i = tid; i < ROWS * (TN * 2 / 16); i += 256) {
+  for (int i = tid; i < ROWS * (TN * 2 / 16); i += NT) {
     const int ml = i >> 5, ch = i & 31;
     const long m = (long)mt * ROWS + ml;
     if (m < M)
       *reinterpret_cast<uint4*>(hb + ((size_t)m * HID + n0) * 2 + ch * 16) =
           *reinterpret_cast<const uint4*>(smem + ml * OPITCH + ch * 16);
   }
-  S2STAMP(9);
+  S2STAMP(7);
+  if (a.stamps != nullptr && tid == 0) a.stamps[64 + 2 * blockIdx.x + 1] = wall_clock64();
 }
 
 template <typename T> int launch_s2_fc1_t(const S2Fc1Args& a, hipStream_t st) {
@@ -274,7 +294,7 @@ template <typename T> int launch_s2_fc1_t(const S2Fc1Args& a, hipStream_t st) {
   }
   const int MT = (a.B + GA - 1) / GA;
   const int grid = ((MT + 7) / 8) * 8 * 4;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

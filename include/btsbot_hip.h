@@ -162,7 +162,8 @@ int btsbot_set_debug(btsbot_handle h, int on);
 /* Developer aid: when non-NULL, workgroup 0 of the stage megakernels stores the shader clock at its
  * phase boundaries into device_buffer32[0..31] (uint64), and every workgroup its start / end on the
  * 100 MHz wall clock into [32 + 2*wg] (stage 0) and [32 + 8192 + 2*wg] (stage 1), and the stage-2
- * front kernel its phase clocks into [32 + 16384 ..+15]: the buffer holds 32 + 16384 + 16 entries and the batch must not exceed 4096 alerts while it is installed. */
+ * front kernel its phase clocks into [32 + 16384 ..+63] and per-workgroup wall clocks behind them: the
+ * buffer holds 32 + 16384 + 64 + 2048 entries and the batch must not exceed 4096 alerts while it is installed. */
 int btsbot_debug_stamps(btsbot_handle h, unsigned long long* device_buffer32);
 
 /* Debug/validation tap: copy an intermediate of the LAST forward chunk to `dst` (fp32).

@@ -14,7 +14,7 @@ img, meta, _ = synthetic_batch(B, seed=2)
 img, meta = img.to(dev), meta.to(dev)
 for _ in range(3):
     run_model(kind, m, img, meta)
-buf = torch.zeros(32 + 16384 + 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(32 + 16384 + 64 + 2048, dtype=torch.int64, device=dev)
 _lib.check(_lib.lib().btsbot_debug_stamps(m._handle.ptr, C.c_void_p(buf.data_ptr())), "stamps")
 run_model(kind, m, img, meta)
 torch.cuda.synchronize()
@@ -38,8 +38,21 @@ for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
     print("   duration deciles", np.percentile(dur, [10, 30, 50, 70, 90]).round(1))
     print("   start deciles   ", np.percentile(st, [10, 30, 50, 70, 90]).round(1))
 
-s2 = t[32 + 16384:32 + 16384 + 10]
-print("s2_fc1 (last block of stage 2) total cycles", s2[9] - s2[0])
-for i, nm in enumerate(["x + tap loads issued", "filter DMA issued", "alert 0 done", "alert 1 done", "alert 2 done",
-                        "alert 3 done", "main loop done", "GELU + staging done", "rows stored"]):
+s2 = t[32 + 16384:32 + 16384 + 8]
+print("s2_fc1 (last block of stage 2) total cycles", s2[7] - s2[0])
+for i, nm in enumerate(["loads + filter DMA issued", "tap table barrier", "depthwise + LN (1 alert / wave)", "image barrier",
+                        "main loop", "GELU + staging", "rows stored"]):
     print(f"   {nm:32s} +{s2[i + 1] - s2[i]:8d}")
+
+base = 32 + 16384
+for off, nm in ((16, "prologue end"), (32, "main loop end"), (48, "GELU end")):
+    print(f"   per wave {nm:14s}", [t[base + off + w] - s2[0] for w in range(16)])
+
+n = ((B + 15) // 16 + 7) // 8 * 8 * 4
+w = np.array(t[base + 64:base + 64 + 2 * n]).reshape(n, 2)
+w = w[w[:, 0] > 0]
+t0 = w[:, 0].min()
+dur = (w[:, 1] - w[:, 0]) / 100.0
+st = (w[:, 0] - t0) / 100.0
+print(f"s2_fc1 workgroups {len(w)}: kernel span {(w[:,1].max()-t0)/100.0:.1f} us; WG duration us min/median/max "
+      f"{dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f}; start deciles", np.percentile(st, [10, 50, 90, 100]).round(1))

@@ -26,7 +26,7 @@ template <int MODE> __global__ void k(float* out, long long* cyc, int iters) {
   long long t1 = clock64();
   float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + p[i][0] + p[i][1];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { cyc[2 * (threadIdx.x >> 6)] = t0; cyc[2 * (threadIdx.x >> 6) + 1] = t1; }
 }
 int main() {
   float* out; long long* cyc; hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 4096);
@@ -41,9 +41,11 @@ int main() {
         case 4: k<4><<<g, b>>>(out, cyc, iters); break; case 5: k<5><<<g, b>>>(out, cyc, iters); break;
         case 6: k<6><<<g, b>>>(out, cyc, iters); break;
       }
-      long long h[1]; hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost);
-      printf("%d waves/SIMD  %-14s %.2f cycles per wave-instruction (SIMD-level: %.2f)\n", wps, names[mode],
-             (double)h[0] / (iters * REP), (double)h[0] / (iters * REP) / wps);
+      long long h[64]; hipMemcpy(h, cyc, 64 * 8, hipMemcpyDeviceToHost);
+      long long tmin = h[0], tmax = h[1], own = h[1] - h[0];
+      for (int w = 0; w < 4 * wps; ++w) { if (h[2 * w] < tmin) tmin = h[2 * w]; if (h[2 * w + 1] > tmax) tmax = h[2 * w + 1]; }
+      printf("%d waves/SIMD  %-14s wave 0: %.2f cycles per own instruction; all waves of the CU: %.2f cycles per instruction per SIMD\n",
+             wps, names[mode], (double)own / (iters * REP), (double)(tmax - tmin) / (iters * REP) / wps);
     }
   return 0;
 }
