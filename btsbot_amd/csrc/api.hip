@@ -98,6 +98,7 @@ int build_tables(btsbot_ctx* h) {
         b.p_dw = bump(cur, (size_t)49 * ch * 4);
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
+        b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
         b.fused = fused_mlp_supported(c.precision, ch);
@@ -238,6 +239,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_stage0 = !(ns != nullptr && ns[0] == '1');
   const char* n1 = getenv("BTSBOT_AMD_NO_STAGE1");
   h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
+  const char* n0b = getenv("BTSBOT_AMD_NO_S0B");
+  h->use_s0b = !(n0b != nullptr && n0b[0] == '1');
   const char* n2 = getenv("BTSBOT_AMD_NO_STAGE2");
   h->use_s2 = !(n2 != nullptr && n2[0] == '1');
   *out = h;
@@ -315,6 +318,8 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                                  st));
         TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
+        TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
+                                 4 * ch, st));
         if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
           TRY(launch_transpose_cast(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch,
                                     ch, st));
@@ -476,6 +481,8 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.blk[j].b1 = m + b.fc1_b;
         a.blk[j].b2 = m + b.fc2_b;
         a.blk[j].gamma = m + b.gamma;
+        a.blk[j].w1 = h->extra + b.p_fc1;
+        a.blk[j].w2g = h->extra + b.p_fc2g;
       }
       a.ds_lnw = m + h->down[1].ln_w;
       a.ds_lnb = m + h->down[1].ln_b;
@@ -491,7 +498,9 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       }
       a.stamps = h->stamps;
       a.wgt = h->stamps ? h->stamps + 32 : nullptr;
-      TRY(timed(h, CAT_STAGE0, st, [&] { return launch_stage0(c.precision, a, st); }));
+      TRY(timed(h, CAT_STAGE0, st, [&] {
+        return h->use_s0b ? launch_stage0b(c.precision, a, st) : launch_stage0(c.precision, a, st);
+      }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
         return launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x,

@@ -143,6 +143,15 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
     out[i] = (T)(in[i] * (scale != nullptr ? scale[i % C] : 1.f));
 }
 
+// out[r][c] = (T)(in[r][c] * rowscale[r])
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_cast_kernel(const float* __restrict__ in,
+                                                            const float* __restrict__ rowscale,
+                                                            T* __restrict__ out, long n, int cols) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (T)(in[i] * rowscale[i / cols]);
+}
+
 // fc2 weight/scale gradients from G = dy^T h:  dW2[c][k] = gamma[c] G[c][k];
 // dgamma[c] = sum_k W2[c][k] G[c][k] + b2[c] S[c];  db2[c] = gamma[c] S[c]    (S = colsum(dy))
 __global__ __launch_bounds__(256) void fc2_grads_kernel(const float* __restrict__ G,
@@ -472,6 +481,31 @@ int launch_scale_cast(int prec, const float* in, const float* scale, void* out, 
       break;
     default:
       btsbot_set_error("scale_cast: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
+                         int cols, hipStream_t st) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return BTSBOT_OK;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(rowscale_cast_kernel<float>, dim3(gridn(n)), dim3(256), 0, st, in, rowscale,
+                         reinterpret_cast<float*>(out), n, cols);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(rowscale_cast_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, st, in, rowscale,
+                         reinterpret_cast<bf16_t*>(out), n, cols);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(rowscale_cast_kernel<f16_t>, dim3(gridn(n)), dim3(256), 0, st, in, rowscale,
+                         reinterpret_cast<f16_t*>(out), n, cols);
+      break;
+    default:
+      btsbot_set_error("rowscale_cast: bad precision %d", prec);
       return BTSBOT_ERR_INVALID_ARG;
   }
   LAUNCH_CHECK();

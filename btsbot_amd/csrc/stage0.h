@@ -10,6 +10,8 @@ struct Stage0Blk {
   const float* b1;
   const float* b2;
   const float* gamma;
+  const unsigned char* w1;    // plain 16-bit fc1 filter [4C][C]              (stage0b.hip / stage1b.hip)
+  const unsigned char* w2g;   // gamma-scaled 16-bit fc2 filter [C][4C]       (stage0b.hip / stage1b.hip)
 };
 struct Stage0Args {
   const float* img;       // [B][3][63][63]
