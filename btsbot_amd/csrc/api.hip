@@ -99,6 +99,7 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
+        b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes()) : 0;
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
         b.fused = fused_mlp_supported(c.precision, ch);
@@ -320,6 +321,10 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
         TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                  4 * ch, st));
+        if (i == 0 && ch == 64)   // (after the tap-major transpose above: same stream)
+          TRY(launch_pack_s0par(reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
+                                m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
+                                h->extra + b.p_s0par, st));
         if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
           TRY(launch_transpose_cast(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch,
                                     ch, st));
@@ -483,6 +488,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.blk[j].gamma = m + b.gamma;
         a.blk[j].w1 = h->extra + b.p_fc1;
         a.blk[j].w2g = h->extra + b.p_fc2g;
+        a.blk[j].par = h->extra + b.p_s0par;
       }
       a.ds_lnw = m + h->down[1].ln_w;
       a.ds_lnb = m + h->down[1].ln_b;

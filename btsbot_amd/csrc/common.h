@@ -163,6 +163,10 @@ int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int 
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
 struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
+size_t s0par_bytes();
+int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
+                      const float* b1, const float* b2, const float* gamma, void* out,
+                      hipStream_t st);
 int launch_s2_fc1(int prec, const float* x, const float* dw_w, const float* dw_b, const float* ln_w,
                   const float* ln_b, const void* w1, const float* b1, void* h, int B,
                   unsigned long long* stamps, hipStream_t st);   // stage2.hip: dw7x7+LN+fc1+GELU on 3x3x256 maps, 16-bit modes

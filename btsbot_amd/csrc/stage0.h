@@ -11,6 +11,7 @@ struct Stage0Blk {
   const float* b2;
   const float* gamma;
   const unsigned char* w1;    // plain 16-bit fc1 filter [4C][C]              (stage0b.hip / stage1b.hip)
+  const unsigned char* par;   // fp32 parameter image of the block (stage0b.hip: launch_pack_s0par)
   const unsigned char* w2g;   // gamma-scaled 16-bit fc2 filter [C][4C]       (stage0b.hip / stage1b.hip)
 };
 struct Stage0Args {

@@ -48,13 +48,19 @@ template <> struct SBM<f16_t> {
 constexpr int C = 64, HW = 15, P = 225, CT = 2, HID = 256;
 constexpr int PITCH = 2 * C + 16;                 // 144 bytes per map row
 constexpr int MAPB = 256 * PITCH;                 // 36864
-constexpr int CHUNKB = 8192, NCH = HID / 32, NSLOT = 4;
-constexpr int RINGB = NSLOT * CHUNKB;             // 32768
+constexpr int CHUNKB = 8192, NCH = HID / 32, NSLOT = 3;
+constexpr int RINGB = NSLOT * CHUNKB;             // 24576
+// per-block fp32 parameter image (packed once by launch_pack_s0par, fetched by LDS-DMA):
+// [49][64] depthwise taps | dw bias | LN weight | LN bias | fc1 bias [256] | gamma*b2 [64] | pad
+constexpr int PAR_DWB = 49 * C, PAR_LNW = PAR_DWB + C, PAR_LNB = PAR_LNW + C, PAR_B1 = PAR_LNB + C,
+              PAR_B2 = PAR_B1 + HID, PAR_FLOATS = 4096;
+static_assert(PAR_B2 + C <= PAR_FLOATS, "parameter image layout");
+constexpr int PARB = PAR_FLOATS * 4;              // 16384 = 16 LDS-DMA pieces, 4 per wave
 constexpr int OFF_RING = MAPB;
-constexpr int OFF_B1 = OFF_RING + RINGB;          // 256 floats
-constexpr int OFF_B2 = OFF_B1 + 256 * 4;          // 64 floats (gamma * b2)
-constexpr int OFF_RED = OFF_B2 + 64 * 4;          // 4 waves x 32 floats
-constexpr int LDS_BYTES = OFF_RED + 4 * 32 * 4;   // 71424
+constexpr int OFF_PAR = OFF_RING + RINGB;
+constexpr int OFF_B1 = OFF_PAR + PARB;            // 256 + 64 floats: this block's fc1 bias, gamma*b2
+constexpr int OFF_RED = OFF_B1 + (HID + C) * 4;   // 4 waves x 32 floats
+constexpr int LDS_BYTES = OFF_RED + 4 * 32 * 4;   // 79616: two workgroups per CU
 constexpr float LN_EPS = 1e-6f;
 
 #define SB_STAMP(i)                                                                \
@@ -156,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* map = smem;
   unsigned char* ring = smem + OFF_RING;
+  const float* par = reinterpret_cast<const float*>(smem + OFF_PAR);
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
-  float* b2s = reinterpret_cast<float*>(smem + OFF_B2);
+  float* b2s = b1s + HID;
   float* red = reinterpret_cast<float*>(smem + OFF_RED);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,6 +179,14 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   }
 
   SB_STAMP(0);
+  // per-block parameter image: 16 pieces, wave w takes w, w+4, w+8, w+12
+  auto issue_params = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.blk[j].par + (wave + 4 * i) * 1024 + lane * 16),
+                                       (lptr_t)(smem + OFF_PAR + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+  issue_params(0);   // lands under the stem
   // rows 225..255 of the image are padding: keep them finite
   for (int i = tid; i < (256 - P) * PITCH / 4; i += 256)
     reinterpret_cast<unsigned*>(map + P * PITCH)[i] = 0u;
@@ -227,18 +242,11 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 #pragma unroll 1
   for (int j = 0; j < 2; ++j) {
     const Stage0Blk& bk = a.blk[j];
-    // ---- this block's small parameters: ordinary loads, all issued BEFORE the first LDS-DMA of
-    //      the block (vmcnt retires in order: a load younger than a DMA would have to wait for it)
-    float w[49];
-#pragma unroll
-    for (int t = 0; t < 49; ++t) w[t] = bk.dw_w[t * C + lane];
-    const float dwbias = bk.dw_b[lane], lng = bk.ln_w[lane], lnb2 = bk.ln_b[lane];
-    const float b1v = bk.b1[tid];
-    const float b2v = tid < C ? bk.gamma[tid] * bk.b2[tid] : 0.f;
     SB_STAMP(2 + 5 * j);
-    __syncthreads();   // map complete (stem / previous MLP); ring, b1s, b2s free
-    b1s[tid] = b1v;
-    if (tid < C) b2s[tid] = b2v;
+    wait_vm<0>();      // this wave's quarter of the block's parameter image has landed
+    __syncthreads();   // ... everyone's; map complete (stem / previous MLP); ring free
+    b1s[tid] = par[PAR_B1 + tid];                  // the MLP reads these while the NEXT block's
+    if (tid < C) b2s[tid] = par[PAR_B2 + tid];     // image is already arriving
 
     // ---- pointwise filters: chunk = 32 hidden units = 8 pieces of 1 KiB, 2 per wave.
     //      pieces 0..3: W1 rows (LDS row m <- hidden unit 32*ch + swap23(m)), 128-byte rows,
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
     };
     issue(0);
     issue(1);
-    issue(2);
     SB_STAMP(3 + 5 * j);
+    const float dwbias = par[PAR_DWB + lane], lng = par[PAR_LNW + lane], lnb2 = par[PAR_LNB + lane];
 
     // ---- depthwise 7x7 + bias + LN: lane = channel, wave = map rows wave, wave+4, ...; the LN
     //      outputs wait in registers (xnv) until every wave is done reading the image
@@ -291,7 +299,9 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
             const int iy = y + ky - 3;
             if (iy < 0 || iy >= HW) continue;
             const T* row = mi + (iy * HW) * (PITCH / 2) + lane;
-            float in[HW];
+            float in[HW], w[7];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) w[kx] = par[(ky * 7 + kx) * C + lane];
 #pragma unroll
             for (int xx = 0; xx < HW; ++xx) in[xx] = (float)row[xx * (PITCH / 2)];
 #pragma unroll
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
               for (int xx = 0; xx < HW; ++xx) {
                 const int ix = xx + kx - 3;
-                if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[ky * 7 + kx], acc[xx]);
+                if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[kx], acc[xx]);
               }
           }
         }
@@ -332,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         }
       }
     }
-    __syncthreads();   // nobody reads the image any more
+    __syncthreads();   // nobody reads the image (or the taps) any more
+    if (j == 0) issue_params(1);   // lands under this block's MLP
     {
       T* mo = reinterpret_cast<T*>(map);
 #pragma unroll
@@ -370,14 +381,15 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
             x[t][ct][4 * qd + 3] += bv.w;
           }
         }
-#pragma unroll
+#pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
         // this wave's pieces of chunk ch have landed once only the younger chunks are outstanding
-        if (ch + 2 < NCH) wait_vm<4>();
+        // (VM order of a wave: chunk 0, chunk 1, [block 0: next parameter image, 4], chunk 2, ...)
+        if (ch < 2 && j == 0) wait_vm<6>();
         else if (ch + 1 < NCH) wait_vm<2>();
         else wait_vm<0>();
         __syncthreads();   // ... everyone's; chunk ch-1 is read out (and xf is loaded, ch == 0)
-        if (ch + 3 < NCH) issue(ch + 3);
+        if (ch + 2 < NCH) issue(ch + 2);
         const unsigned char* w1s = ring + (ch % NSLOT) * CHUNKB;
         const unsigned char* w2s = w1s + 4096;
         frag a1[4], a2[CT][2];
@@ -408,7 +420,10 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
           for (int ks = 0; ks < 4; ++ks) hacc = SBM<T>::run(a1[ks], xf[t][ks], hacc);
           frag hf[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
+          for (int r = 0; r < 16; ++r) {
+            hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 chains at a time: registers
+          }
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -478,6 +493,23 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   }
 }
 
+// one block's fp32 parameter image (see PAR_* above)
+__global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
+                                  const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                  const float* __restrict__ b1, const float* __restrict__ b2,
+                                  const float* __restrict__ gamma, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PAR_FLOATS) return;
+  float v = 0.f;
+  if (i < PAR_DWB) v = taps[i];
+  else if (i < PAR_LNW) v = dw_b[i - PAR_DWB];
+  else if (i < PAR_LNB) v = ln_w[i - PAR_LNW];
+  else if (i < PAR_B1) v = ln_b[i - PAR_LNB];
+  else if (i < PAR_B2) v = b1[i - PAR_B1];
+  else if (i < PAR_B2 + C) v = gamma[i - PAR_B2] * b2[i - PAR_B2];
+  out[i] = v;
+}
+
 template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
   auto kern = stage0b_kernel<T>;
   static bool attr_set = false;
@@ -493,7 +525,19 @@ template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) 
 
 }  // namespace
 
-// Needs Stage0Blk::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.
+size_t s0par_bytes() { return PARB; }
+
+// taps: the block's depthwise filter tap-major [49][64] fp32; the others the master parameters
+int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
+                      const float* b1, const float* b2, const float* gamma, void* out,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(pack_s0par_kernel, dim3(PAR_FLOATS / 256), dim3(256), 0, st, taps, dw_b, ln_w,
+                     ln_b, b1, b2, gamma, reinterpret_cast<float*>(out));
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// Needs Stage0Blk::par, ::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage0b_t<bf16_t>(a, st);
