@@ -240,6 +240,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_stage0 = !(ns != nullptr && ns[0] == '1');
   const char* n1 = getenv("BTSBOT_AMD_NO_STAGE1");
   h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
+  const char* n1b = getenv("BTSBOT_AMD_NO_S1B");
+  h->use_s1b = !(n1b != nullptr && n1b[0] == '1');
   const char* n0b = getenv("BTSBOT_AMD_NO_S0B");
   h->use_s0b = !(n0b != nullptr && n0b[0] == '1');
   const char* n2 = getenv("BTSBOT_AMD_NO_STAGE2");
@@ -549,6 +551,8 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].b1 = m + b.fc1_b;
           a.blk[j].b2 = m + b.fc2_b;
           a.blk[j].gamma = m + b.gamma;
+          a.blk[j].w1 = h->extra + b.p_fc1;
+          a.blk[j].w2g = h->extra + b.p_fc2g;
         }
         a.ds_lnw = m + h->down[2].ln_w;
         a.ds_lnb = m + h->down[2].ln_b;
@@ -563,7 +567,9 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         }
         a.stamps = h->stamps ? h->stamps + 16 : nullptr;
         a.wgt = h->stamps ? h->stamps + 32 + 2 * 4096 : nullptr;
-        TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1(c.precision, a, st); }));
+        TRY(timed(h, CAT_STAGE1, st, [&] {
+          return h->use_s1b ? launch_stage1b(c.precision, a, st) : launch_stage1(c.precision, a, st);
+        }));
         float* t = x;
         x = x2;
         x2 = t;

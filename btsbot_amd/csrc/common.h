@@ -163,6 +163,8 @@ int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int 
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
 struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
+struct Stage1Args;
+int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.hip
 size_t s0par_bytes();
 int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
                       const float* b1, const float* b2, const float* gamma, void* out,

@@ -70,6 +70,7 @@ struct btsbot_ctx {
   std::vector<int> prof_cat;
   size_t prof_used = 0;
 
+  bool use_s1b = true;     // BTSBOT_AMD_NO_S1B=1: stage1.hip's layout instead of stage1b.hip
   bool use_s0b = true;     // BTSBOT_AMD_NO_S0B=1: stage0.hip's one-workgroup-per-CU layout instead of stage0b.hip
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
