@@ -99,7 +99,8 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
-        b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes()) : 0;
+        b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
+                    : (i == 1 && ch == 128 && c.precision != BTSBOT_F32) ? bump(cur, s1par_bytes()) : 0;
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
         b.fused = fused_mlp_supported(c.precision, ch);
@@ -323,6 +324,9 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
         TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                  4 * ch, st));
+        if (i == 1 && ch == 128 && c.precision != BTSBOT_F32)
+          TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
+                                m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
         if (i == 0 && ch == 64)   // (after the tap-major transpose above: same stream)
           TRY(launch_pack_s0par(reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
@@ -553,6 +557,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].gamma = m + b.gamma;
           a.blk[j].w1 = h->extra + b.p_fc1;
           a.blk[j].w2g = h->extra + b.p_fc2g;
+          a.blk[j].par = h->extra + b.p_s0par;
         }
         a.ds_lnw = m + h->down[2].ln_w;
         a.ds_lnb = m + h->down[2].ln_b;

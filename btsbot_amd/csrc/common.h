@@ -165,6 +165,9 @@ struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
 struct Stage1Args;
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.hip
+size_t s1par_bytes();
+int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
+                      const float* ln_b, void* out, hipStream_t st);
 size_t s0par_bytes();
 int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
                       const float* b1, const float* b2, const float* gamma, void* out,

@@ -16,7 +16,7 @@ struct ParamRec {
 struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes into `extra`)
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
-  size_t p_s0par;          // stage-0 blocks: fp32 parameter image for stage0b.hip
+  size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;

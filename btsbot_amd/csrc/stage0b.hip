@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
           const float rstd = rsqrtf(myred[16 + xx] * (1.0f / C) + LN_EPS);
           xnv[rd][xx >> 3][xx & 7] = (T)(acc[xx] * rstd * lng + lnb2);
         }
+        __builtin_amdgcn_sched_barrier(0);   // one round at a time: registers (see stage1b.hip)
       }
     }
     __syncthreads();   // nobody reads the image (or the taps) any more

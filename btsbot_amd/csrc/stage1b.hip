@@ -9,10 +9,14 @@
 // apart, so one's depthwise phase (VALU + LDS) runs under the other's MLP (MFMA + GELU).
 //   * residual stream fp32 in registers, 32x32 MFMA accumulator layout: wave = 32 pixel slots of
 //     the 98, lane half h and 64 registers = the 128 channels;
-//   * ONE 16-bit map image in LDS ([98 px][128 ch], 272-byte rows); the depthwise phase (lane =
-//     channel, wave = (alert, channel half), 7 rounds = rows) keeps its LN outputs in registers until
-//     the last round's barrier, then overwrites the image in place; LayerNorm sums meet the other
-//     channel half's through LDS, one barrier per round (single-pass variance);
+//   * a 16-bit map image in LDS ([98 px][128 ch], 272-byte rows) holds x for the depthwise phase
+//     (lane = channel, wave = (alert, channel half), 7 rounds = rows); its LN outputs go to a
+//     second image that borrows ring slots 0..1 until the MLP has loaded its B operand from it;
+//     LayerNorm sums meet the other channel half's through LDS, one barrier per round
+//     (single-pass variance);
+//   * the depthwise taps (in the operand type) arrive by LDS-DMA in ring slot 2, which the filter
+//     ring only needs from the MLP's third chunk on: 7 tap registers instead of 49, which is what
+//     keeps the residual tile out of scratch;
 //   * pointwise filters: 16 KB chunks of 32 hidden units (W1 rows + gamma*W2 columns) through a
 //     3-slot LDS-DMA ring straight from the plain row-major filters; the per-lane source address
 //     applies the bank swizzles and the bit-2/bit-3 row swap that makes the fc1 accumulator the
@@ -51,6 +55,12 @@ constexpr int OFF_RED = OFF_B1 + (HID + C) * 4;   // [2 parities][4 waves][16]
 constexpr int LDS_BYTES = OFF_RED + 2 * 4 * 16 * 4;   // 78880: two workgroups per CU
 static_assert(MAPB % 16 == 0 && LDS_BYTES <= 80 * 1024, "LDS layout");
 constexpr float LN_EPS = 1e-6f;
+// per-block depthwise parameter image (launch_pack_s1par), fetched by LDS-DMA into ring slot 2,
+// which the filter ring does not need before the MLP's first chunk is consumed:
+// [49][128] taps in the operand type | dw bias | LN weight | LN bias (fp32) | zero pad to 16 KiB
+constexpr int TAPB = 49 * C * 2;                  // 12544
+constexpr int PARB = CHUNKB;                      // 16384 = 16 pieces, 4 per wave
+static_assert(TAPB + 3 * C * 4 <= PARB, "parameter image layout");
 
 #define SC_STAMP(i)                                                                \
   do {                                                                             \
@@ -154,6 +164,14 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   const int pm = inmap ? p : 0;                      // row to read for slots beyond the image
 
   SC_STAMP(0);
+  unsigned char* pimg = ring + 2 * CHUNKB;          // parameter image = ring slot 2 (see PARB)
+  auto issue_params = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.blk[j].par + (wave * 4 + i) * 1024 + lane * 16),
+                                       (lptr_t)(pimg + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  issue_params(0);   // lands under the input load
   // ---- stage input -> registers (accumulator layout) and the 16-bit map image
   f32x16 x[CT];
   {
@@ -177,19 +195,19 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 #pragma unroll 1
   for (int j = 0; j < 2; ++j) {
     const Stage0Blk& bk = a.blk[j];
-    // ---- this block's small parameters: ordinary loads, all issued BEFORE the block's first
-    //      LDS-DMA (vmcnt retires in order: a load younger than a DMA would have to wait for it)
-    float w[49];
-#pragma unroll
-    for (int t = 0; t < 49; ++t) w[t] = bk.dw_w[t * C + cdw];
-    const float dwbias = bk.dw_b[cdw], lng = bk.ln_w[cdw], lnb2 = bk.ln_b[cdw];
+    // ---- fc1 bias and gamma*b2: ordinary loads, issued BEFORE the block's first filter DMA
+    //      (vmcnt retires in order: a load younger than a DMA would have to wait for it)
     const float b1v0 = bk.b1[tid], b1v1 = bk.b1[256 + tid];
     const float b2v = bk.gamma[tid & (C - 1)] * bk.b2[tid & (C - 1)];
     SC_STAMP(2 + 5 * j);
-    __syncthreads();   // map complete (input / previous MLP); ring, b1s, b2s free
+    wait_vm<0>();      // this wave's quarter of the parameter image (and the loads above) landed
+    __syncthreads();   // ... everyone's; map complete (input / previous MLP); ring slots 0, 1 free
     b1s[tid] = b1v0;
     b1s[256 + tid] = b1v1;
     if (tid < C) b2s[tid] = b2v;
+    const T* taps = reinterpret_cast<const T*>(pimg) + cdw;
+    const float* pf = reinterpret_cast<const float*>(pimg + TAPB);
+    const float dwbias = pf[cdw], lng = pf[C + cdw], lnb2 = pf[2 * C + cdw];
 
     // ---- pointwise filters: chunk = 32 hidden units = 16 pieces of 1 KiB, 4 per wave.
     //      pieces 0..7 : W1 rows (LDS row m <- hidden unit 32*ch + swap23(m)), 256-byte rows,
@@ -215,30 +233,32 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)ch * wstep0),
-                                         (lptr_t)(ring + (ch % NSLOT) * CHUNKB + (wave * 4 + i) * 1024),
+                                         (lptr_t)(ring + ((ch + 2) % NSLOT) * CHUNKB + (wave * 4 + i) * 1024),
                                          16, 0, 0);
     };
-    issue(0);
-    issue(1);
     SC_STAMP(3 + 5 * j);
 
-    // ---- depthwise 7x7 + bias + LN: wave = (alert, channel half), round = map row;
-    //      the LN outputs wait in registers (xnv) until the last round's barrier
-    T8 xnv[7];
+    // ---- depthwise 7x7 + bias + LN: wave = (alert, channel half), round = map row (a real loop:
+    //      unrolled, the seven rounds cost ~36 live registers each and the residual tile went to
+    //      scratch).  The LN outputs go straight to a second image in ring slots 0..1, which the
+    //      filter ring only claims after the MLP has taken its B operand from it.
+    unsigned char* stg = ring;                       // [98][PITCH] = 26656 B <= 2 slots
     {
       const T* mi = reinterpret_cast<const T*>(map);
-#pragma unroll
-      for (int rd = 0; rd < 7; ++rd) {
-        const int g = wave >> 1, y = rd;             // (alert, row): the row is a compile-time constant
+      const int g = wave >> 1;                       // alert
+#pragma unroll 1
+      for (int y = 0; y < HW; ++y) {
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = (i < HW) ? dwbias : 0.f;
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
           const int iy = y + ky - 3;
-          if (iy < 0 || iy >= HW) continue;
+          if (iy < 0 || iy >= HW) continue;          // wave-uniform
           const T* row = mi + ((g * HW + iy) * HW) * (PITCH / 2) + cdw;
-          float in[HW];
+          float in[HW], w[7];
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) w[kx] = (float)taps[(ky * 7 + kx) * C];
 #pragma unroll
           for (int xx = 0; xx < HW; ++xx) in[xx] = (float)row[xx * (PITCH / 2)];
 #pragma unroll
@@ -246,11 +266,8 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
             for (int xx = 0; xx < HW; ++xx) {
               const int ix = xx + kx - 3;
-              if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[ky * 7 + kx], acc[xx]);
+              if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[kx], acc[xx]);
             }
-          // keep the scheduler from hoisting every filter row's 7 loads to the top of the round
-          // (49 more live registers, which pushed the residual tile into scratch)
-          if (ky & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // LN over 128 channels = this wave's 64 lanes + the partner wave's: sums and sums of
         // squares of the 7 pixels in one transposing reduction, exchanged through LDS
@@ -261,32 +278,25 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
           s[8 + i] = acc[i] * acc[i];
         }
         treduce16(s);
-        float* myred = red + ((rd & 1) * 4 + wave) * 16;
+        float* myred = red + ((y & 1) * 4 + wave) * 16;
         if ((lane & 15) == 0) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) myred[(lane >> 4) * 4 + jj] = s[jj];
         }
         __syncthreads();
-        const float* pred = red + ((rd & 1) * 4 + (wave ^ 1)) * 16;
+        const float* pred = red + ((y & 1) * 4 + (wave ^ 1)) * 16;
+        T* dst = reinterpret_cast<T*>(stg) + ((g * HW + y) * HW) * (PITCH / 2) + cdw;
 #pragma unroll
-        for (int xx = 0; xx < 8; ++xx) {
+        for (int xx = 0; xx < HW; ++xx) {
           const float mean = (myred[xx] + pred[xx]) * (1.0f / C);
           const float var = (myred[8 + xx] + pred[8 + xx]) * (1.0f / C) - mean * mean;
-          xnv[rd][xx] = (T)((acc[xx] - mean) * rsqrtf(var + LN_EPS) * lng + lnb2);
+          dst[xx * (PITCH / 2)] = (T)((acc[xx] - mean) * rsqrtf(var + LN_EPS) * lng + lnb2);
         }
-      }
-      // every wave has passed the last round's barrier => nobody reads the image any more
-      T* mo = reinterpret_cast<T*>(map);
-#pragma unroll
-      for (int rd = 0; rd < 7; ++rd) {
-        const int idx = (wave >> 1) * HW + rd;
-        T* dst = mo + (idx * HW) * (PITCH / 2) + cdw;
-#pragma unroll
-        for (int xx = 0; xx < HW; ++xx) dst[xx * (PITCH / 2)] = xnv[rd][xx];
       }
     }
     SC_STAMP(4 + 5 * j);   // depthwise done
-    __syncthreads();   // LN image complete
+    __syncthreads();   // LN image complete; the taps (ring slot 2) are dead
+    issue(0);          // chunk ch lives in slot (ch + 2) % 3: chunk 0 can start right away
     SC_STAMP(5 + 5 * j);
 
     // ---- fc1 -> GELU -> fc2 over 16 chunks; fc2 accumulates into x (gamma is in the filter)
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
       frag xf[KS1];
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks)
-        xf[ks] = *reinterpret_cast<const frag*>(map + pm * PITCH + ks * 32 + h * 16);
+        xf[ks] = *reinterpret_cast<const frag*>(stg + pm * PITCH + ks * 32 + h * 16);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -305,14 +315,19 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
           x[ct][4 * qd + 2] += bv.z;
           x[ct][4 * qd + 3] += bv.w;
         }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // xf is in registers
+      __syncthreads();   // ... everyone's: slots 0..1 may be overwritten
+      issue(1);
+      issue(2);
 #pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
-        // this wave's pieces of chunk ch have landed once only the younger chunk's are outstanding
-        if (ch + 1 < NCH) wait_vm<4>();
+        // VM order of a wave: chunk 0, chunk 1, chunk 2, then chunk ch+2 at iteration ch >= 1
+        if (ch == 0) wait_vm<8>();
+        else if (ch + 1 < NCH) wait_vm<4>();
         else wait_vm<0>();
-        __syncthreads();   // ... everyone's; chunk ch-1 is read out (and xf is loaded, ch == 0)
-        if (ch + 2 < NCH) issue(ch + 2);
-        const unsigned char* w1s = ring + (ch % NSLOT) * CHUNKB;
+        __syncthreads();   // chunk ch has landed for everyone; chunk ch-1 is read out
+        if (ch >= 1 && ch + 2 < NCH) issue(ch + 2);
+        const unsigned char* w1s = ring + ((ch + 2) % NSLOT) * CHUNKB;
         const unsigned char* w2s = w1s + 8192;
         frag a1[KS1], a2[CT][2];
 #pragma unroll
@@ -346,7 +361,11 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) x[ct] = SCM<T>::run(a2[ct][s2], hf[s2], x[ct]);
       }
-      // the LN image was last read (xf) before the first chunk barrier: free to overwrite
+      if (j == 0) {      // next block's parameter image -> ring slot 2 (chunk 15 must be read out)
+        __syncthreads();
+        issue_params(1);
+      }
+      // the map still holds the block's INPUT; the next block's depthwise phase wants the new x
       if (j == 0 && inmap) regs_to_map<T>(x, map, p, h);
     }
     SC_STAMP(6 + 5 * j);   // MLP done
@@ -414,6 +433,22 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   }
 }
 
+// one block's depthwise parameter image (see TAPB / PARB above); taps: tap-major [49][128] fp32
+template <typename T>
+__global__ void pack_s1par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
+                                  const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                  unsigned char* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 49 * C) reinterpret_cast<T*>(out)[i] = (T)taps[i];
+  if (i < (PARB - TAPB) / 4) {
+    float v = 0.f;
+    if (i < C) v = dw_b[i];
+    else if (i < 2 * C) v = ln_w[i - C];
+    else if (i < 3 * C) v = ln_b[i - 2 * C];
+    reinterpret_cast<float*>(out + TAPB)[i] = v;
+  }
+}
+
 template <typename T> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
   auto kern = stage1b_kernel<T>;
   static bool attr_set = false;
@@ -429,7 +464,25 @@ template <typename T> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) 
 
 }  // namespace
 
-// Needs Stage0Blk::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit.
+size_t s1par_bytes() { return PARB; }
+
+int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
+                      const float* ln_b, void* out, hipStream_t st) {
+  unsigned char* o = reinterpret_cast<unsigned char*>(out);
+  const dim3 grid((49 * C + 255) / 256), blk(256);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(pack_s1par_kernel<bf16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(pack_s1par_kernel<f16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
+  else {
+    btsbot_set_error("pack_s1par: precision %d is not a 16-bit mode", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// Needs Stage0Blk::par (launch_pack_s1par), ::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit.
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage1b_t<bf16_t>(a, st);

@@ -1,0 +1,49 @@
+"""Copy the judged summaries of tools/round_end.sh (gpurun_out/final/) into profiles/ under a round tag:
+kernel stats, the two PMC passes, the bench line, and the corrected per-kernel HBM-side traffic
+(bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024; calibration: tools/pmc_calib)."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def newest(pattern):   # gpurun merges every call's files into gpurun_out/: take the latest run's
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+F = newest("gpurun_out/final/pmc_fetch/*/*_counter_collection.csv")
+W = newest("gpurun_out/final/pmc_write/*/*_counter_collection.csv")
+
+
+def agg(path, name):
+    a = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            a[r["Kernel_Name"]][0] += 1
+            a[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in a.items()}
+
+
+def family(k):
+    m = re.search(r"\d+([a-z_0-9]+_kernel)", k)
+    return m.group(1) if m else k.split("(")[0][:40]
+
+
+fa, wa = agg(F, "FETCH_SIZE"), agg(W, "WRITE_SIZE")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 "
+                 "--warmup 2 --no-cpu-baseline --train-steps 0",
+       "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE reads 1/2: tools/pmc_calib, "
+                     "0.500 on dword, dwordx4 and the stem gather; WRITE_SIZE exact)",
+       "kernels": {}}
+for k in fa:
+    if "_GLOBAL__N_1" in k or "anonymous namespace" in k:
+        n, f = fa[k]
+        w = wa.get(k, (0, 0.0))[1]
+        out["kernels"][k] = {"family": family(k), "launches": n, "fetch_bytes": round(2 * f * 1024),
+                             "write_bytes": round(w * 1024), "traffic_bytes": round(2 * f * 1024 + w * 1024)}
+json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+shutil.copy(newest("gpurun_out/final/trace/*/*_kernel_stats.csv"), f"profiles/{tag}_kernel_stats_bench_bf16_b1024.csv")
+shutil.copy(F, f"profiles/{tag}_pmc_fetch_size.csv")
+shutil.copy(W, f"profiles/{tag}_pmc_write_size.csv")
+open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])
+for k, v in sorted(out["kernels"].items(), key=lambda x: -x[1]["traffic_bytes"] * x[1]["launches"])[:10]:
+    print(f'{v["family"]:24s} launches {v["launches"]:4d}  fetch {v["fetch_bytes"]/1e6:8.2f} MB  write {v["write_bytes"]/1e6:8.2f} MB')
