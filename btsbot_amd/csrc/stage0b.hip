@@ -404,27 +404,28 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
             const int r = ct * 32 + lr;
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
+        // both column blocks' fc1 first: the second one's MFMAs run under the first one's GELU
+        f32x16 hacc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          f32x16 hacc;
           // accumulator row (r&3) + 8(r>>2) + 4h holds hidden unit 32ch + (r&3) + 4((r>>2)&1) + 8h + 16(r>>3)
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             const float4 bv = *reinterpret_cast<const float4*>(b1s + ch * 32 + 4 * (qd & 1) + 8 * h +
                                                                16 * (qd >> 1));
-            hacc[4 * qd + 0] = bv.x;
-            hacc[4 * qd + 1] = bv.y;
-            hacc[4 * qd + 2] = bv.z;
-            hacc[4 * qd + 3] = bv.w;
+            hacc[t][4 * qd + 0] = bv.x;
+            hacc[t][4 * qd + 1] = bv.y;
+            hacc[t][4 * qd + 2] = bv.z;
+            hacc[t][4 * qd + 3] = bv.w;
           }
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) hacc = SBM<T>::run(a1[ks], xf[t][ks], hacc);
+          for (int ks = 0; ks < 4; ++ks) hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
           frag hf[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 chains at a time: registers
-          }
+          for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[t][r]);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
