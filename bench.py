@@ -98,11 +98,16 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
         bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
                   for (d, p, c), f in zip(st, fused) if f))
     unf = [not f and not mega[i] for i, f in enumerate(fused)]
-    # stage 2 at C = 256: depthwise + LN + fc1 + GELU in one launch (stage2.hip), fc2 stays a GEMM
+    # stage 2 at C = 256: depthwise + LN + fc1 + GELU per block (stage2.hip) and fc2 as a GEMM; with
+    # BTSBOT_AMD_S2M=1 every block of the stage in one launch (stage2m.hip)
     s2 = precision != "f32" and dims[2] == 256
+    s2m = s2 and depths[2] <= 8 and os.environ.get("BTSBOT_AMD_S2M", "0") == "1"
+    w["stage2_kernel"] = dict(flop=2 * pw(*st[2]) if s2m else 0, bytes=batch * 9 * dims[2] * 4 * 2)
+    mega[2] = s2m
     w["s2_fc1_kernel"] = dict(
-        flop=pw(*st[2]) if s2 else 0,
+        flop=pw(*st[2]) if s2 and not s2m else 0,
         bytes=st[2][0] * (batch * 9 * dims[2] * 4 + batch * 9 * 4 * dims[2] * esz + 4 * dims[2] ** 2 * esz))
+    unf = [u and not mega[i] for i, u in enumerate(unf)]
     unf1 = [u and not (s2 and i == 2) for i, u in enumerate(unf)]
     w["gemm_kernel<fc1,GELU>"] = dict(
         flop=sum(pw(d, p, c) for (d, p, c), u in zip(st, unf1) if u),
@@ -129,7 +134,7 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     return w
 
 
-POINTWISE = ("stage0_kernel", "stage1_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
+POINTWISE = ("stage0_kernel", "stage1_kernel", "stage2_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
              "gemm_kernel<fc2,RESID>")
 
 
@@ -344,7 +349,9 @@ def pmc_traffic(kernel, args):
         return None
     with open(files[-1]) as f:
         ks = json.load(f)["kernels"]
-    hits = [v for v in ks.values() if v["family"] == kernel]
+    # (the stage megakernels are profiled under their category names; their symbols carry a 'b')
+    names = {kernel, kernel.replace("_kernel", "b_kernel")}
+    hits = [v for v in ks.values() if v["family"] in names]
     return hits[0]["traffic_bytes"] if len(hits) == 1 else None
 
 

@@ -163,6 +163,11 @@ int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int 
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
 struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
+struct Stage2Args;
+int launch_stage2m(int prec, const Stage2Args& a, hipStream_t st);   // stage2m.hip: all 3x3 blocks, one launch
+int stage2m_max_depth();
+int launch_pack_w2_chunks(int prec, const float* w2, const float* gamma, void* dst, int Cc, int H,
+                          hipStream_t st);   // gamma-scaled fc2 filter, chunk-major [H/32][Cc][32]
 struct Stage1Args;
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.hip
 size_t s1par_bytes();

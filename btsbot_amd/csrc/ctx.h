@@ -17,6 +17,7 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
+  size_t p_fc2gc;          // diag(gamma) W2, chunk-major [4C/32][C][32] (megakernel LDS-DMA source)
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
@@ -28,11 +29,11 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_S2FC1, NCAT };
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_S2FC1, CAT_STAGE2, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
                                      "head_kernel", "fused_mlp_kernel", "stage0_kernel", "stage1_kernel",
-                                     "s2_fc1_kernel"};
+                                     "s2_fc1_kernel", "stage2_kernel"};
 constexpr size_t PROF_MAX_LAUNCHES = 8192;
 
 struct btsbot_ctx {
@@ -70,6 +71,7 @@ struct btsbot_ctx {
   std::vector<int> prof_cat;
   size_t prof_used = 0;
 
+  bool use_s2m = false;    // BTSBOT_AMD_S2M=1: all stage-2 blocks in one launch (stage2m.hip) instead of per-block launches
   bool use_s1b = true;     // BTSBOT_AMD_NO_S1B=1: stage1.hip's layout instead of stage1b.hip
   bool use_s0b = true;     // BTSBOT_AMD_NO_S0B=1: stage0.hip's one-workgroup-per-CU layout instead of stage0b.hip
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2

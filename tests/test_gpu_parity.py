@@ -186,3 +186,19 @@ def test_adamw_kernel(cuda):
             C.c_void_p(v.data_ptr()), p.numel(), 1e-4, 0.99, 0.99, 1e-8, 1e-2, s + 1,
             C.c_void_p(st)), "adamw")
         assert np.allclose(p.cpu().numpy(), g["traj"][s], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("env", ["BTSBOT_AMD_S2M", "BTSBOT_AMD_NO_S0B", "BTSBOT_AMD_NO_S1B", "BTSBOT_AMD_NO_STAGE2",
+                                 "BTSBOT_AMD_NO_STAGE0", "BTSBOT_AMD_NO_STAGE1"])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_alternative_schedules_match_oracle(cuda, monkeypatch, env, prec):
+    """The library's A/B schedule switches (read at model creation) select other kernels for the same
+    stages -- stage2m.hip's one-launch stage 2, stage0.hip / stage1.hip's one-workgroup-per-CU
+    layouts, the per-op launches -- every one of them must hold the same parity bound."""
+    monkeypatch.setenv(env, "1")
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(21, seed=5)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
