@@ -109,9 +109,13 @@ __global__ __launch_bounds__(512) void stage2m_kernel(Stage2Args a) {
     }
   }
   const bool w1wave = lw < 2;                        // loaders 0,1 fetch W1 pieces, loaders 2,3 W2 pieces
+  // Every workgroup walks the 32 chunks of a block in its own rotation (fc2 sums over the hidden
+  // units, so the order is free): at any moment the 256 CUs pull different lines out of L2
+  // instead of all hammering the same 32 KB.
+  const int rot = (blockIdx.x * 5 + (blockIdx.x >> 3)) & 31;
   auto issue = [&](int g) {
     const Stage2Blk& bk = a.blk[g >> 5];
-    const int ch = g & 31;
+    const int ch = (g + rot) & 31;
     const unsigned char* base = w1wave ? bk.w1 + (size_t)ch * W1CB : bk.w2g + (size_t)ch * W2CB;
     unsigned char* slot = ring + (g % NSLOT) * CHUNKB;
 #pragma unroll
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(512) void stage2m_kernel(Stage2Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // accumulator row 4q + r of tile t = LDS row 16t + 4q + r = hidden 32 ch + 8q + 4t + r
-          const float4 bv = *reinterpret_cast<const float4*>(b1s + ch * 32 + 8 * q + 4 * t);
+          const float4 bv = *reinterpret_cast<const float4*>(b1s + ((ch + rot) & 31) * 32 + 8 * q + 4 * t);
           hacc[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
           for (int ks = 0; ks < 8; ++ks) {
