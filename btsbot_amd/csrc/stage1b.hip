@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   }
   SC_STAMP(1);
 
+  const int rot = (blockIdx.x * 5 + (blockIdx.x >> 4)) & (NCH - 1);   // chunk rotation, see issue()
   const int half = wave & 1;                         // channel half owned in the depthwise phase
   const int cdw = half * 64 + lane;
 #pragma unroll 1
@@ -229,10 +230,12 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     }
     // chunk ch adds 32 W1 rows (8192 B) resp. 32 W2 columns (64 B)
     const int wstep0 = wave < 2 ? 32 * C * 2 : 64;
+    // (every workgroup walks the 16 chunks in its own rotation -- fc2 sums over the hidden units,
+    //  so the order is free -- which keeps the 512 workgroups off the same L2 lines)
     auto issue = [&](int ch) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)ch * wstep0),
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((ch + rot) & (NCH - 1)) * wstep0),
                                          (lptr_t)(ring + ((ch + 2) % NSLOT) * CHUNKB + (wave * 4 + i) * 1024),
                                          16, 0, 0);
     };
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         // accumulator row (r&3) + 8(r>>2) + 4h holds hidden unit 32ch + (r&3) + 4((r>>2)&1) + 8h + 16(r>>3)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          const float4 bv = *reinterpret_cast<const float4*>(b1s + ch * 32 + 4 * (qd & 1) + 8 * h +
-                                                             16 * (qd >> 1));
+          const float4 bv = *reinterpret_cast<const float4*>(b1s + ((ch + rot) & (NCH - 1)) * 32 +
+                                                             4 * (qd & 1) + 8 * h + 16 * (qd >> 1));
           hacc[4 * qd + 0] = bv.x;
           hacc[4 * qd + 1] = bv.y;
           hacc[4 * qd + 2] = bv.z;
