@@ -390,7 +390,6 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         else if (ch + 1 < NCH) wait_vm<2>();
         else wait_vm<0>();
         __syncthreads();   // ... everyone's; chunk ch-1 is read out (and xf is loaded, ch == 0)
-        if (ch + 2 < NCH) issue(ch + 2);
         const unsigned char* w1s = ring + (ch % NSLOT) * CHUNKB;
         const unsigned char* w2s = w1s + 4096;
         frag a1[4], a2[CT][2];
@@ -421,6 +420,9 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
         }
+        // (issued here, not at the barrier: an LDS-DMA holds the issuing wave ~90 cycles per
+        //  instruction, which now passes while the fc1 MFMAs drain)
+        if (ch + 2 < NCH) issue(ch + 2);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           frag hf[2];

@@ -329,7 +329,6 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         else if (ch + 1 < NCH) wait_vm<4>();
         else wait_vm<0>();
         __syncthreads();   // chunk ch has landed for everyone; chunk ch-1 is read out
-        if (ch >= 1 && ch + 2 < NCH) issue(ch + 2);
         const unsigned char* w1s = ring + ((ch + 2) % NSLOT) * CHUNKB;
         const unsigned char* w2s = w1s + 8192;
         frag a1[KS1], a2[CT][2];
@@ -356,6 +355,9 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         }
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) hacc = SCM<T>::run(a1[ks], xf[ks], hacc);
+        // the next chunk's LDS-DMA is issued HERE: an LDS-DMA holds the issuing wave for ~90 cycles
+        // per instruction, which now passes while the fc1 MFMA chain drains
+        if (ch >= 1 && ch + 2 < NCH) issue(ch + 2);
         frag hf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
