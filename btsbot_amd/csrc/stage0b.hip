@@ -425,13 +425,15 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         if (ch + 2 < NCH) issue(ch + 2);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          frag hf[2];
+          // GELU in two halves, each followed by the fc2 MFMAs that consume it
 #pragma unroll
-          for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[t][r]);
+          for (int s2 = 0; s2 < 2; ++s2) {
+            frag hf;
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
+            for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_fast(hacc[t][8 * s2 + r]);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) x[t][ct] = SBM<T>::run(a2[ct][s2], hf[s2], x[t][ct]);
+            for (int ct = 0; ct < CT; ++ct) x[t][ct] = SBM<T>::run(a2[ct][s2], hf, x[t][ct]);
+          }
         }
       }
       // the LN image was last read (xf) before the first chunk barrier: free to overwrite

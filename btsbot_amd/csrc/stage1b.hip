@@ -358,13 +358,16 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         // the next chunk's LDS-DMA is issued HERE: an LDS-DMA holds the issuing wave for ~90 cycles
         // per instruction, which now passes while the fc1 MFMA chain drains
         if (ch >= 1 && ch + 2 < NCH) issue(ch + 2);
-        frag hf[2];
+        // GELU in two halves, each followed by the fc2 MFMAs that consume it: the first half's
+        // MFMAs run while the second half's GELU issues
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hf[r >> 3][r & 7] = (T)gelu_fast(hacc[r]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          frag hf;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+          for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_fast(hacc[8 * s2 + r]);
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) x[ct] = SCM<T>::run(a2[ct][s2], hf[s2], x[ct]);
+          for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][s2], hf, x[ct]);
+        }
       }
       if (j == 0) {      // next block's parameter image -> ring slot 2 (chunk 15 must be read out)
         __syncthreads();
