@@ -101,8 +101,12 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   const btsbot_config& c = h->cfg;
   const float* m = h->mirror;
   BBCache k = carve_bb(h, h->bbcache, B);
-  TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, k.xs[0], B,
-                   c.dims[0], st));
+  // A block's input is kept for its backward.  Instead of copying it aside, every producer writes
+  // straight into the buffer its consumer keeps: the stem / downsample into block 0's xin, block j's
+  // fc2 (+ residual) into block j+1's xin, the stage's last block into xs[i].
+  auto stage_in = [&](int i) { return h->blocks[i].empty() ? k.xs[i] : k.blk[i][0].xin; };
+  TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
+                   B, c.dims[0], st));
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
     if (i > 0) {
@@ -110,18 +114,19 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
       TRYB(launch_gemm(c.precision, EPI_BIAS, k.patches[i], h->extra + h->down[i].p_w,
-                       m + h->down[i].b, nullptr, nullptr, k.xs[i], rows, ch, 4 * cin, st));
+                       m + h->down[i].b, nullptr, nullptr, stage_in(i), rows, ch, 4 * cin, st));
     }
-    for (size_t j = 0; j < h->blocks[i].size(); ++j) {
+    const size_t nblk = h->blocks[i].size();
+    for (size_t j = 0; j < nblk; ++j) {
       const BlockPk& b = h->blocks[i][j];
       const BlkBuf& s = k.blk[i][j];
-      HIP_TRY(hipMemcpyAsync(s.xin, k.xs[i], (size_t)rows * ch * 4, hipMemcpyDeviceToDevice, st));
-      TRYB(launch_dwconv_ln(c.precision, k.xs[i], reinterpret_cast<const float*>(h->extra + b.p_dw),
+      float* xout = j + 1 < nblk ? k.blk[i][j + 1].xin : k.xs[i];
+      TRYB(launch_dwconv_ln(c.precision, s.xin, reinterpret_cast<const float*>(h->extra + b.p_dw),
                             m + b.dw_b, m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, st));
       TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
                        reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, st));
       TRYB(launch_gemm(c.precision, EPI_RESID, s.h, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,
-                       k.xs[i], k.xs[i], rows, ch, 4 * ch, st));
+                       s.xin, xout, rows, ch, 4 * ch, st));
     }
   }
   *feat_out = k.xs[3];

@@ -43,9 +43,18 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ 
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * N) return;
   const int m = idx / N, n = idx - m * N;
-  float acc = bias[n];
   const float* ip = in + (size_t)m * ldi;
-  for (int k = 0; k < K; ++k) acc = fmaf(ip[k], wt[(size_t)k * N + n], acc);
+  const float* wp = wt + n;
+  float a0 = bias[n], a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains: the loads of a group overlap
+  int k = 0;
+  for (; k + 3 < K; k += 4) {
+    a0 = fmaf(ip[k], wp[(size_t)k * N], a0);
+    a1 = fmaf(ip[k + 1], wp[(size_t)(k + 1) * N], a1);
+    a2 = fmaf(ip[k + 2], wp[(size_t)(k + 2) * N], a2);
+    a3 = fmaf(ip[k + 3], wp[(size_t)(k + 3) * N], a3);
+  }
+  for (; k < K; ++k) a0 = fmaf(ip[k], wp[(size_t)k * N], a0);
+  float acc = (a0 + a1) + (a2 + a3);
   if (pre != nullptr) pre[idx] = acc;
   float v = act_fwd(acc, act);
   if (mask != nullptr) v = mask[idx] ? v * keep_scale : 0.f;
