@@ -12,8 +12,9 @@ There is NO CPU fallback: calling a model whose tensors are not on a HIP device 
 
 Covered: ``mm_ConvNeXt`` (:125-171), ``ConvNeXt`` (:104-122), ``um_nn`` (:277-293),
 ``frozen_fusion`` (:296-372) with ConvNeXt + um_nn branches; convnext_pico / convnext_nano
-backbones at 63x63.  ``MaxViT`` / ``mm_MaxViT`` / ``mm_cnn`` / ``um_cnn`` raise
-NotImplementedError (MaxViT is a later row, the VGG-like CNNs are out of scope).
+backbones at 63x63; ``MaxViT`` (:25-55) and ``mm_MaxViT`` (:58-101) with the maxvit_tiny_rw_224
+backbone, inference only (eval mode).  ``mm_cnn`` / ``um_cnn`` raise NotImplementedError (legacy
+VGG-like CNNs, out of scope per SURVEY.md section 2).
 """
 from __future__ import annotations
 
@@ -38,6 +39,9 @@ _CONVNEXT_TABLE = {
 }
 _DEFAULT_KIND = "convnext_nano.d1h_in1k"   # architectures.py:107,128
 MAX_CHUNK = 2048                            # alerts per internal workspace chunk
+_MAXVIT_TABLE = {"maxvit_tiny_rw_224": ((2, 2, 5, 2), (64, 128, 256, 512))}
+_MAXVIT_DEFAULT_KIND = "maxvit_tiny_rw_224.sw_in1k"   # architectures.py:28,61
+MAXVIT_MAX_CHUNK = 256                      # MaxViT keeps ~22 MB of bf16 activations per alert
 
 
 def get_model_image_size(model_kind: str) -> int:
@@ -239,7 +243,7 @@ class _HipModel(nn.Module):
             _lib.check(L.btsbot_pack_params(self._handle.ptr, C.c_void_p(self._arena.data_ptr()),
                                             C.c_void_p(stream)), "btsbot_pack_params")
             self._packed_version = ver
-        chunk = min(max(batch, 1), MAX_CHUNK)
+        chunk = min(max(batch, 1), getattr(self, "_max_chunk", MAX_CHUNK))
         if chunk > self._reserved:
             _lib.check(L.btsbot_reserve(self._handle.ptr, chunk), "btsbot_reserve")
             self._reserved = chunk
@@ -270,6 +274,11 @@ class _HipModel(nn.Module):
              want_scores: bool = False):
         image, meta, batch, dev = self._check_inputs(image, meta)
         if self.training:
+            if getattr(self, "_inference_only", False):
+                raise NotImplementedError(
+                    f"btsbot_amd.{type(self).__name__}: only eval-mode inference is built for the MaxViT "
+                    "image branch (its BatchNorm2d batch statistics and backward are not); call "
+                    ".eval() first")
             return self._run_train(image, meta)
         if batch == 0:
             empty = torch.empty(0, 1, dtype=torch.float32, device=dev)
@@ -583,7 +592,85 @@ def _not_built(name, why):
     return _Missing
 
 
-MaxViT = _not_built("MaxViT", "the MaxViT image branch is a later row of SURVEY.md section 8")
-mm_MaxViT = _not_built("mm_MaxViT", "the MaxViT image branch is a later row of SURVEY.md section 8")
+def _maxvit_table(model_kind: str):
+    mk = model_kind.lower()
+    for name, tab in _MAXVIT_TABLE.items():
+        if name in mk:
+            return tab
+    raise ValueError(f"btsbot_amd: model_kind {model_kind!r} is not a supported MaxViT "
+                     f"(have {sorted(_MAXVIT_TABLE)})")
+
+
+class _MaxVitModel(_HipModel):
+    _inference_only = True
+    _max_chunk = MAXVIT_MAX_CHUNK
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        super().reset_parameters()
+        for (canon, *_), t in zip(self._table_rows, self._tensor_list()):
+            if canon.endswith("relative_position_bias_table"):
+                nn.init.trunc_normal_(t, std=0.02)
+
+    def read_tap(self, name: str) -> torch.Tensor:
+        """fp32 NHWC copy of 'stem' (112x112x64) / 'stage0'..'stage3' (56, 28, 14, 7) of the last chunk."""
+        hw = {"stem": 112, "stage0": 56, "stage1": 28, "stage2": 14, "stage3": 7}[name]
+        c = self._cfg_args["dims"][0 if name == "stem" else int(name[-1])]
+        dev = self._arena.device
+        buf = torch.empty(self._reserved * hw * hw * c, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            n = _lib.check(_lib.lib().btsbot_read_tap(
+                self._handle.ptr, name.encode(), C.c_void_p(buf.data_ptr()), buf.numel(),
+                C.c_void_p(stream)), "btsbot_read_tap")
+        return buf[:n].view(-1, hw * hw, c)
+
+
+class MaxViT(_MaxVitModel):
+    """architectures.py:25-55 -- image-only MaxViT: bilinear resize to 224, maxvit_tiny_rw_224, global
+    average pool, Linear-GELU-Linear-GELU-Dropout-Linear (keys maxvit.head.{1,3,6})."""
+    _wiring = "MaxViT"
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        _warn_pretrained(config)
+        model_kind = config.get("model_kind", _MAXVIT_DEFAULT_KIND)
+        self.image_size = get_model_image_size(model_kind)
+        self._setup(
+            table=_maxvit_table(model_kind), head_norm=False, n_meta=0, meta_fc=(0, 0),
+            comb_fc=(config["fc1_neurons"], config["fc2_neurons"]),
+            dropouts=(0.0, config["dropout"]),
+            key_map=_backbone_key_map("maxvit.", "", "",
+                                      ["maxvit.head.1", "maxvit.head.3", "maxvit.head.6"]),
+            precision=precision or config.get("precision"))
+
+    def forward(self, input_data: torch.Tensor) -> torch.Tensor:
+        return self._run(input_data, None)
+
+
+class mm_MaxViT(_MaxVitModel):
+    """architectures.py:58-101 -- MaxViT image branch + GELU metadata branch + GELU fusion head."""
+    _wiring = "mm_MaxViT"
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        _warn_pretrained(config)
+        model_kind = config.get("model_kind", _MAXVIT_DEFAULT_KIND)
+        self.image_size = get_model_image_size(model_kind)
+        table = _maxvit_table(model_kind)
+        self.maxvit_feature_dim = table[1][-1]
+        self._setup(
+            table=table, head_norm=False, n_meta=len(config.get("metadata_cols", [])),
+            meta_fc=(config["meta_fc1_neurons"], config["meta_fc2_neurons"]),
+            comb_fc=(config["comb_fc1_neurons"], config["comb_fc2_neurons"]),
+            dropouts=(config["meta_dropout"], config["comb_dropout"]),
+            key_map=_backbone_key_map("maxvit_backbone.", "", "metadata_branch.",
+                                      ["combined_head.0", "combined_head.2", "combined_head.5"]),
+            precision=precision or config.get("precision"))
+
+    def forward(self, image_input: torch.Tensor, metadata_input: torch.Tensor) -> torch.Tensor:
+        return self._run(image_input, metadata_input)
+
+
 mm_cnn = _not_built("mm_cnn", "legacy VGG-like CNN, out of scope (SURVEY.md section 2)")
 um_cnn = _not_built("um_cnn", "legacy VGG-like CNN, out of scope (SURVEY.md section 2)")

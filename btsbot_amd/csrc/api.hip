@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "ctx.h"
+#include "maxvit.h"
 #include "stage0.h"
 #include "stage2m.h"
 
@@ -60,7 +61,9 @@ int build_tables(btsbot_ctx* h) {
   size_t cur = 0;
   const int esz = h->esz();
   char buf[96];
-  if (h->has_image) {
+  if (h->has_image && h->is_maxvit) {
+    maxvit_build_tables(h, &cur);
+  } else if (h->has_image) {
     const int c0 = c.dims[0];
     h->stem_w = add_param(h, "stem.0.weight", {c0, 3, 4, 4});
     h->stem_b = add_param(h, "stem.0.bias", {c0});
@@ -146,7 +149,9 @@ void ws_layout(const btsbot_ctx* h, int chunk, size_t* ox, size_t* ox2, size_t* 
   const btsbot_config& c = h->cfg;
   size_t cur = 0;
   *ox = *ox2 = *oxn = *oh = 0;
-  if (h->has_image) {
+  if (h->has_image && h->is_maxvit) {
+    cur = maxvit_ws_bytes(h, chunk);
+  } else if (h->has_image) {
     size_t x_el = 0, xn_el = 0, h_el = 0;
     for (int i = 0; i < 4; ++i) {
       const size_t pc = (size_t)STAGE_HW[i] * STAGE_HW[i] * c.dims[i];
@@ -179,7 +184,7 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     return BTSBOT_ERR_INVALID_ARG;
   }
   if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_F16 ||
-      cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_UM_NN) {
+      cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_MAXVIT) {
     btsbot_set_error("create: bad precision %d or wiring %d", cfg->precision, cfg->wiring);
     return BTSBOT_ERR_INVALID_ARG;
   }
@@ -187,10 +192,21 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->cfg = *cfg;
   const int w = cfg->wiring;
   h->has_image = (w != BTSBOT_UM_NN);
-  h->has_meta = (w != BTSBOT_CONVNEXT);
-  h->act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_CONVNEXT) ? ACT_GELU : ACT_RELU;
-  h->meta_trailing_act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_UM_NN) ? 1 : 0;
-  if (h->has_image) {
+  h->has_meta = (w != BTSBOT_CONVNEXT && w != BTSBOT_MAXVIT);
+  h->is_maxvit = (w == BTSBOT_MM_MAXVIT || w == BTSBOT_MAXVIT);
+  h->act = (w == BTSBOT_FROZEN_FUSION || w == BTSBOT_UM_NN) ? ACT_RELU : ACT_GELU;
+  h->meta_trailing_act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_UM_NN || w == BTSBOT_MM_MAXVIT) ? 1 : 0;
+  if (h->is_maxvit) {
+    const bool tiny = cfg->dims[0] == 64 && cfg->dims[1] == 128 && cfg->dims[2] == 256 &&
+                      cfg->dims[3] == 512 && cfg->depths[0] == 2 && cfg->depths[1] == 2 &&
+                      cfg->depths[2] == 5 && cfg->depths[3] == 2;
+    if (cfg->image_size != 63 || !tiny || cfg->head_norm != 0) {
+      btsbot_set_error("create: the MaxViT image branch is maxvit_tiny_rw_224 (dims 64,128,256,512, depths "
+                       "2,2,5,2) on 63x63 cutouts resized to 224, without a head LayerNorm");
+      delete h;
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+  } else if (h->has_image) {
     if (cfg->image_size != 63) {
       btsbot_set_error("create: kernels are specialised for 63x63 cutouts, got %d",
                        cfg->image_size);
@@ -262,6 +278,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->tcache) (void)hipFree(h->tcache);
   if (h->bbcache) (void)hipFree(h->bbcache);
+  if (h->mv) maxvit_free(h);
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -308,7 +325,9 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
   HIP_TRY(hipMemcpyAsync(h->mirror, master, (size_t)h->total_floats * 4, hipMemcpyDeviceToDevice,
                          st));
   const float* m = h->mirror;
-  if (h->has_image) {
+  if (h->has_image && h->is_maxvit) {
+    TRY(maxvit_pack(h, st));
+  } else if (h->has_image) {
     if (h->stage0 || h->train_packs)
       TRY(launch_cast(c.precision, m + h->stem_w, h->extra + h->p_stem16, (int64_t)c.dims[0] * 48,
                       st));
@@ -448,7 +467,11 @@ extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
     if (t) (void)hipFree(t);
     t = nullptr;
   }
-  if (h->debug && h->has_image) {
+  if (h->debug && h->is_maxvit) {   // stem 112x112x64, stages 56 / 28 / 14 / 7
+    HIP_TRY(hipMalloc(&h->taps[0], (size_t)max_chunk * 12544 * 64 * 4));
+    for (int i = 0; i < 4; ++i)
+      HIP_TRY(hipMalloc(&h->taps[i + 1], (size_t)max_chunk * (56 >> i) * (56 >> i) * h->cfg.dims[i] * 4));
+  } else if (h->debug && h->has_image) {
     HIP_TRY(hipMalloc(&h->taps[0], (size_t)max_chunk * 225 * h->cfg.dims[0] * 4));
     for (int i = 0; i < 4; ++i)
       HIP_TRY(hipMalloc(&h->taps[i + 1],
@@ -479,6 +502,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
   float* x2 = reinterpret_cast<float*>(h->ws + h->o_x2);
   void* xn = h->ws + h->o_xn;
   void* hb = h->ws + h->o_h;
+  if (h->is_maxvit) return maxvit_chunk(h, img, nb, st, feat_out);
   if (h->has_image) {
     const bool s0 = h->stage0 && h->use_stage0;
     if (s0) {
@@ -767,6 +791,11 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
     btsbot_set_error("reserve_train: bad argument");
     return BTSBOT_ERR_INVALID_ARG;
   }
+  if (h->is_maxvit) {
+    btsbot_set_error("reserve_train: the MaxViT wirings are inference-only (BatchNorm2d batch statistics "
+                     "and the backward of the MaxViT image branch are not built)");
+    return BTSBOT_ERR_STATE;
+  }
   const bool want_bb = with_image_grads && h->has_image;
   if (h->tcache != nullptr && max_batch <= h->tcache_batch &&
       (!want_bb || (h->bbcache != nullptr && max_batch <= h->bbcache_batch)))
@@ -901,8 +930,8 @@ extern "C" int64_t btsbot_read_tap(btsbot_handle h, const char* name, float* dst
     return BTSBOT_ERR_INVALID_ARG;
   }
   const int st_i = idx == 0 ? 0 : idx - 1;
-  const int64_t n =
-      (int64_t)h->last_chunk * STAGE_HW[st_i] * STAGE_HW[st_i] * h->cfg.dims[st_i];
+  const int thw = h->is_maxvit ? (idx == 0 ? 112 : 56 >> st_i) : STAGE_HW[st_i];
+  const int64_t n = (int64_t)h->last_chunk * thw * thw * h->cfg.dims[st_i];
   if (n > capacity) {
     btsbot_set_error("read_tap: need %lld floats, capacity %lld", (long long)n,
                      (long long)capacity);

@@ -67,6 +67,8 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return cdf + x * pdf;
 }
 
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
@@ -110,12 +112,15 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 // ---------------------------------------------------------------------------------------
 // launchers (one per kernel family); all return btsbot_status
 // ---------------------------------------------------------------------------------------
-enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2, EPI_GELU_SAVE = 3, EPI_DGELU = 4, EPI_PLAIN = 5 };
+enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2, EPI_GELU_SAVE = 3, EPI_DGELU = 4, EPI_PLAIN = 5,
+       EPI_SILU = 6, EPI_BIAS_T = 7 };
 
 // out = epi(X[M,K] . W[N,K]^T + bias[N]);  X, W are `prec`-typed, bias/gamma/resid fp32.
 //   EPI_GELU : out (prec-typed) [M,N] = gelu(acc + bias)
 //   EPI_RESID: out (fp32)       [M,N] = resid + gamma[n] * (acc + bias)   (in place allowed)
 //   EPI_BIAS : out (fp32)       [M,N] = acc + bias
+//   EPI_SILU : out (prec-typed) [M,N] = silu(acc + bias)     (MaxViT MBConv: BatchNorm folded into W / bias)
+//   EPI_BIAS_T: out (prec-typed) [M,N] = acc + bias           (MaxViT qkv projection)
 // training-only epilogues (register-staged kernel; `resid` carries a prec-typed aux pointer):
 //   EPI_GELU_SAVE: aux [M,N] = acc + bias (pre-activation, written), out = gelu(aux)
 //   EPI_DGELU    : out (prec-typed) = acc * gelu'(aux[m][n])            (aux read, no bias)
@@ -123,6 +128,11 @@ enum { EPI_GELU = 0, EPI_RESID = 1, EPI_BIAS = 2, EPI_GELU_SAVE = 3, EPI_DGELU =
 int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
                 const float* gamma, const float* resid, void* out, int M, int N, int K,
                 hipStream_t st);
+
+// out (fp32) [M,N] = resid + (X[m][k] * gate[m / rows_per_alert][k]) . W[n][k]^T: the squeeze-excite gate of a
+// MaxViT MBConv block applied to the A operand on its way to LDS (register-staged kernel); in place allowed
+int launch_gemm_gated(int prec, const void* X, const float* gate, int rows_per_alert, const void* W,
+                      const float* resid, float* out, int M, int N, int K, hipStream_t st);
 
 // pipelined LDS-DMA variant for the 16-bit modes (gemm2.hip); launch_gemm dispatches to it
 bool gemm2_supported(int prec, int M, int N, int K);

@@ -47,13 +47,14 @@ template <> struct Mma<f16_t> {
   }
 };
 
-template <typename T, int TM, int TN, int WM, int WN, int EPI>
+template <typename T, int TM, int TN, int WM, int WN, int EPI, bool GATED = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
                                                    const T* __restrict__ W,
                                                    const float* __restrict__ bias,
                                                    const float* __restrict__ gamma,
                                                    const float* resid, void* out, int M, int N,
-                                                   int K) {
+                                                   int K, const float* __restrict__ gate = nullptr,
+                                                   int rows_per_alert = 1) {
   using MM = Mma<T>;
   using frag = typename MM::frag;
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -73,6 +74,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
   const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
 
   uint4 xr[XCH], wr[WCH];
+  const float* grow[XCH];   // GATED: this thread's rows' gate vectors
+  if (GATED) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int gm = min(m0 + ((tid + i * 256) >> 3), M - 1);
+      grow[i] = gate + (size_t)(gm / rows_per_alert) * K;
+    }
+  }
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
 #pragma unroll
@@ -81,6 +90,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
       const int gm = m0 + row, gk = k0 + kc * EPC;
       xr[i] = (gm < M && gk < K) ? *reinterpret_cast<const uint4*>(X + (size_t)gm * K + gk)
                                  : make_uint4(0, 0, 0, 0);
+      if (GATED && gk < K) {   // A operand times the per-alert squeeze-excite gate
+        T* e = reinterpret_cast<T*>(&xr[i]);
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) e[q] = (T)((float)e[q] * grow[i][gk + q]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
@@ -141,9 +155,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
     const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
     if (n >= N) continue;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI != EPI_DGELU && EPI != EPI_PLAIN) bv = *reinterpret_cast<const float4*>(bias + n);
+    if (EPI != EPI_DGELU && EPI != EPI_PLAIN && !GATED) bv = *reinterpret_cast<const float4*>(bias + n);
     float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (EPI == EPI_RESID) gv = *reinterpret_cast<const float4*>(gamma + n);
+    if (EPI == EPI_RESID && !GATED) gv = *reinterpret_cast<const float4*>(gamma + n);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = m0 + wm * WTM + mi * 16 + lrow;
@@ -176,6 +190,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
         v[1] = (T)gelu_for<T>(a[1] + bv.y);
         v[2] = (T)gelu_for<T>(a[2] + bv.z);
         v[3] = (T)gelu_for<T>(a[3] + bv.w);
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
+      } else if (EPI == EPI_SILU || EPI == EPI_BIAS_T) {
+        typedef T __attribute__((ext_vector_type(4))) T4;
+        T4 v;
+        const float p[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_f(p[e]) : p[e]);
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
       } else if (EPI == EPI_RESID) {
         const float4 r = *reinterpret_cast<const float4*>(resid + o);
@@ -231,12 +252,50 @@ int launch_epi(int epi, const void* X, const void* W, const float* bias, const f
       return launch_typed<T, EPI_GELU_SAVE>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_DGELU: return launch_typed<T, EPI_DGELU>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_PLAIN: return launch_typed<T, EPI_PLAIN>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_SILU: return launch_typed<T, EPI_SILU>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_BIAS_T: return launch_typed<T, EPI_BIAS_T>(X, W, bias, gamma, resid, out, M, N, K, st);
   }
   btsbot_set_error("launch_gemm: bad epilogue %d", epi);
   return BTSBOT_ERR_INVALID_ARG;
 }
 
+template <typename T>
+int launch_gated_typed(const void* X, const float* gate, int rpa, const void* W, const float* resid,
+                       float* out, int M, int N, int K, hipStream_t st) {
+  const T* x = reinterpret_cast<const T*>(X);
+  const T* w = reinterpret_cast<const T*>(W);
+  const long wg12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+  if (wg12864 >= 512) {
+    dim3 grid((M + 127) / 128, (N + 63) / 64);
+    hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 4, 1, EPI_RESID, true>), grid, dim3(256), 0, st, x, w,
+                       nullptr, nullptr, resid, out, M, N, K, gate, rpa);
+  } else {
+    dim3 grid((M + 63) / 64, (N + 63) / 64);
+    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, EPI_RESID, true>), grid, dim3(256), 0, st, x, w,
+                       nullptr, nullptr, resid, out, M, N, K, gate, rpa);
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 }  // namespace
+
+int launch_gemm_gated(int prec, const void* X, const float* gate, int rows_per_alert, const void* W,
+                      const float* resid, float* out, int M, int N, int K, hipStream_t st) {
+  if (M <= 0) return BTSBOT_OK;
+  const int epc = prec == BTSBOT_F32 ? 4 : 8;
+  if (K % epc != 0 || N % 4 != 0 || rows_per_alert < 1) {
+    btsbot_set_error("launch_gemm_gated: K=%d must be a multiple of %d and N=%d of 4", K, epc, N);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  switch (prec) {
+    case BTSBOT_F32: return launch_gated_typed<float>(X, gate, rows_per_alert, W, resid, out, M, N, K, st);
+    case BTSBOT_BF16: return launch_gated_typed<bf16_t>(X, gate, rows_per_alert, W, resid, out, M, N, K, st);
+    case BTSBOT_F16: return launch_gated_typed<f16_t>(X, gate, rows_per_alert, W, resid, out, M, N, K, st);
+  }
+  btsbot_set_error("launch_gemm_gated: bad precision %d", prec);
+  return BTSBOT_ERR_INVALID_ARG;
+}
 
 int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bias,
                 const float* gamma, const float* resid, void* out, int M, int N, int K,
@@ -255,7 +314,7 @@ int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bi
     const char* e = getenv("BTSBOT_AMD_GEMM_V1");   // A/B switch for timing
     return e != nullptr && e[0] == '1';
   }();
-  if (!v1_only && epi <= EPI_BIAS && gemm2_supported(prec, M, N, K))
+  if (!v1_only && (epi <= EPI_BIAS || epi >= EPI_SILU) && gemm2_supported(prec, M, N, K))
     return launch_gemm2(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   switch (prec) {
     case BTSBOT_F32: return launch_epi<float>(epi, X, W, bias, gamma, resid, out, M, N, K, st);

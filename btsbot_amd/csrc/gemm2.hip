@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int XB = TM / 8 / 4, WB = TN / 8 / 4; // 8-row blocks per wave per tile
   constexpr int LPT = XB + WB;                    // LDS-DMA instructions per thread per k-tile
-  using OT = typename std::conditional<EPI == EPI_GELU, T, float>::type;
+  constexpr bool TOUT = EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T;   // operand-typed output
+  using OT = typename std::conditional<TOUT, T, float>::type;
   constexpr int OPITCH = TN * (int)sizeof(OT) + 16;  // epilogue staging row pitch
     static_assert(NSLOT == 2 || NSLOT == 3, "ring depth");
   static_assert(WM * WN == 4 && XB >= 1 && WB >= 1, "tile/wave layout");
@@ -154,6 +155,13 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
         v[2] = (T)gelu_fast(a[2] + bv.z);
         v[3] = (T)gelu_fast(a[3] + bv.w);
         *reinterpret_cast<T4*>(dst) = v;
+      } else if (EPI == EPI_SILU || EPI == EPI_BIAS_T) {
+        typedef T __attribute__((ext_vector_type(4))) T4;
+        T4 v;
+        const float p[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_f(p[e]) : p[e]);
+        *reinterpret_cast<T4*>(dst) = v;
       } else {
         *reinterpret_cast<float4*>(dst) =
             make_float4(gv.x * (a[0] + bv.x), gv.y * (a[1] + bv.y), gv.z * (a[2] + bv.z),
@@ -186,7 +194,7 @@ template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
 int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                  const float* resid, void* out, int M, int N, int K, hipStream_t st) {
   constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
-  constexpr size_t otile = (size_t)TM * (TN * (EPI == EPI_GELU ? sizeof(T) : sizeof(float)) + 16);
+  constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
   auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT>;
   static bool attr_set = false;
@@ -219,6 +227,8 @@ int launch_epi2(int epi, const void* X, const void* W, const float* bias, const 
     case EPI_GELU: return launch_typed2<T, EPI_GELU>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_RESID: return launch_typed2<T, EPI_RESID>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_BIAS: return launch_typed2<T, EPI_BIAS>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_SILU: return launch_typed2<T, EPI_SILU>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_BIAS_T: return launch_typed2<T, EPI_BIAS_T>(X, W, bias, gamma, resid, out, M, N, K, st);
   }
   btsbot_set_error("launch_gemm2: bad epilogue %d", epi);
   return BTSBOT_ERR_INVALID_ARG;

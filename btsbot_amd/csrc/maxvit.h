@@ -1,0 +1,60 @@
+// Internal: MaxViT image branch (timm maxvit_tiny_rw_224 reached from
+// /root/reference/btsbot/architectures.py:31,62) -- launchers of maxvit_ops.hip and the schedule
+// entry points of maxvit.hip.
+#pragma once
+#include "common.h"
+
+struct btsbot_ctx;
+
+// ---- schedule (maxvit.hip), called from api.hip
+int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor);            // parameter table + operand images
+int maxvit_pack(btsbot_ctx* h, hipStream_t st);                          // mirror -> operand images
+size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk);
+int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float** feat_out);
+void maxvit_free(btsbot_ctx* h);
+constexpr int MV_MAX_CHUNK = 256;   // alerts per workspace chunk (about 22 MB of activations each in bf16)
+
+// ---- kernels (maxvit_ops.hip).  `prec` selects the staged activation type T (float / bf16 / f16).
+// bilinear 63 -> 224 (align_corners=False, architectures.py:44-50) fused with the im2col of the stem's
+// 3x3 s2 p1 convolution: img [B,3,63,63] f32 -> out [B*112*112, 32] T, k = (ky*3+kx)*3 + c, 27..31 zero
+int launch_mv_resize_im2col(int prec, const float* img, void* out, int B, hipStream_t st);
+// im2col of a 3x3 s1 p1 convolution on an NHWC map: in [B,HW,HW,C] T -> out [B*HW*HW, 9*C] T
+int launch_mv_im2col3(int prec, const void* in, void* out, int B, int HW, int C, hipStream_t st);
+// eval-mode BatchNorm2d as scale/shift + cast: x [M,C] f32 -> out [M,C] T
+int launch_mv_bn_cast(int prec, const float* x, const float* scale, const float* shift, void* out,
+                      long M, int C, hipStream_t st);
+// depthwise 3x3 p1 (stride 1 or 2) + folded BatchNorm + SiLU: in [B,H,H,C] T -> out [B,H/s,H/s,C] T;
+// w9 is tap-major [9][C] f32 (BatchNorm scale folded in), bias [C] f32 (conv bias and BN shift folded)
+int launch_mv_dw3(int prec, const void* in, const float* w9, const float* bias, void* out, int B,
+                  int H, int C, int stride, hipStream_t st);
+// squeeze-excite gate: y [B,HW,C] T -> gate [B,C] f32 = sigmoid(fc2(silu(fc1(mean_hw y))))
+int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2,
+                 const float* b2, float* gate, int B, int HW, int C, int RD, hipStream_t st);
+// 2x2 average pool of the fp32 residual map: x [B,H,H,C] -> out [B,H/2,H/2,C] (T when to_t, else f32)
+int launch_mv_avgpool2(int prec, const float* x, void* out, int to_t, int B, int H, int C,
+                       hipStream_t st);
+// LayerNorm over C (eps 1e-6): x [M,C] f32 -> out [M,C] T;  C in {64,128,256,512}
+int launch_mv_ln(int prec, const float* x, const float* w, const float* b, void* out, long M, int C,
+                 hipStream_t st);
+// multi-head self-attention inside 7x7 windows (grid_mode 0) or on the 7x7 dilated grid (grid_mode 1):
+// qkv [B*H*H, 3C] T with channel order [head][q|k|v][32], bias_t [heads][49 (key)][49 (query)] f32 ->
+// out [B*H*H, C] T (channel = head*32 + d); rows stay in image order, the partition is an index map
+int launch_mv_attn(int prec, const void* qkv, const float* bias_t, void* out, int B, int H, int C,
+                   int grid_mode, hipStream_t st);
+// final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
+int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
+                    hipStream_t st);
+
+// ---- packing kernels
+// stem conv1 [32][3][3][3] * BN scale -> [32][32] T (k = (ky*3+kx)*3 + c, zero padded)
+int launch_mv_pack_stem1(int prec, const float* w, const float* scale, void* out, hipStream_t st);
+// conv [O][C][3][3] f32 -> [O][(ky*3+kx)*C + c] T
+int launch_mv_pack_conv3(int prec, const float* w, void* out, int O, int C, hipStream_t st);
+// out[i] = b[i] * s[i] + t[i]  (b may be NULL = 0)
+int launch_mv_fold_bias(const float* b, const float* s, const float* t, float* out, int n,
+                        hipStream_t st);
+// depthwise [C][1][3][3] -> tap-major [9][C] * scale[c]
+int launch_mv_pack_dw(const float* w, const float* scale, float* out, int C, hipStream_t st);
+// relative position table [169][heads] -> bias_t [heads][49][49] (key-major, see launch_mv_attn)
+int launch_mv_pack_relbias(const float* table, float* out, int heads, hipStream_t st);
+int launch_mv_fill(float* out, float v, int n, hipStream_t st);

@@ -50,7 +50,10 @@ enum btsbot_wiring {
   BTSBOT_MM_CONVNEXT = 0,   /* mm_ConvNeXt     architectures.py:125-171 (GELU heads)            */
   BTSBOT_CONVNEXT = 1,      /* ConvNeXt        architectures.py:104-122 (image only)            */
   BTSBOT_FROZEN_FUSION = 2, /* frozen_fusion   architectures.py:296-372 (ConvNeXt + um_nn, ReLU)*/
-  BTSBOT_UM_NN = 3          /* um_nn           architectures.py:277-293 (metadata only)         */
+  BTSBOT_UM_NN = 3,         /* um_nn           architectures.py:277-293 (metadata only)         */
+  BTSBOT_MM_MAXVIT = 4,     /* mm_MaxViT       architectures.py:58-101 (maxvit_tiny_rw_224 + GELU heads);
+                               inference only: reserve_train / forward_train return BTSBOT_ERR_STATE */
+  BTSBOT_MAXVIT = 5         /* MaxViT          architectures.py:25-55  (image only)             */
 };
 
 /* arithmetic type of the MFMA operands / staged activations (accumulation is always fp32;
@@ -65,7 +68,9 @@ typedef struct btsbot_config {
   int32_t abi_version;   /* = BTSBOT_ABI_VERSION                                                 */
   int32_t wiring;        /* enum btsbot_wiring                                                   */
   int32_t precision;     /* enum btsbot_precision                                                */
-  /* timm ConvNeXt table (pico: depths 2,2,6,2 dims 64,128,256,512; nano: 2,2,8,2 / 80..640)     */
+  /* timm ConvNeXt table (pico: depths 2,2,6,2 dims 64,128,256,512; nano: 2,2,8,2 / 80..640);
+   * MaxViT wirings: maxvit_tiny_rw_224 = depths 2,2,5,2 dims 64,128,256,512 (the 63x63 cutouts are
+   * resized to 224x224 inside the library, architectures.py:44-50)                                */
   int32_t depths[4];
   int32_t dims[4];
   int32_t image_size;    /* 63 (the only size the kernels are specialised for)                   */

@@ -19,6 +19,11 @@ FUSION = dict(model_name="frozen_fusion", image_model_dir="unused", meta_model_d
               image_model_config=IMG_PICO, meta_model_config=META, skip_load_state=True,
               comb_fc1_neurons=64, comb_fc2_neurons=16, comb_dropout=0.1)
 
+MM_MAXVIT = dict(MM_PICO, model_name="mm_MaxViT", model_kind="maxvit_tiny_rw_224.sw_in1k")
+IMG_MAXVIT = dict(model_name="MaxViT", model_kind="maxvit_tiny_rw_224.sw_in1k", pretrained=False,
+                  fc1_neurons=64, fc2_neurons=16, dropout=0.1)
+MV_CONFIGS = {"mm_maxvit": ("mm_MaxViT", MM_MAXVIT), "maxvit": ("MaxViT", IMG_MAXVIT)}
+
 CONFIGS = {"mm_pico": ("mm_ConvNeXt", MM_PICO), "mm_nano_ls": ("mm_ConvNeXt", MM_NANO_LS),
            "convnext": ("ConvNeXt", IMG_PICO), "um_nn": ("um_nn", META),
            "frozen_fusion": ("frozen_fusion", FUSION)}
@@ -26,6 +31,11 @@ CONFIGS = {"mm_pico": ("mm_ConvNeXt", MM_PICO), "mm_nano_ls": ("mm_ConvNeXt", MM
 
 def seeded_state(kind: str, config: dict, seed: int, gamma: float = 1.0):
     return O.random_state_dict(O.model_param_shapes(kind, config), seed, gamma)
+
+
+def seeded_state_mv(kind: str, config: dict, seed: int):
+    from oracle import maxvit_oracle as MO
+    return O.random_state_dict(MO.model_param_shapes(kind, config), seed)
 
 
 def build_model(kind: str, config: dict, sd: dict, device, precision="f32"):
@@ -39,8 +49,8 @@ def build_model(kind: str, config: dict, sd: dict, device, precision="f32"):
 
 def run_model(kind, m, img, meta):
     with torch.no_grad():
-        if kind in ("mm_ConvNeXt", "frozen_fusion"):
+        if kind in ("mm_ConvNeXt", "frozen_fusion", "mm_MaxViT"):
             return m(image_input=img, metadata_input=meta)
-        if kind == "ConvNeXt":
+        if kind in ("ConvNeXt", "MaxViT"):
             return m(input_data=img)
         return m(input_data=meta)
