@@ -138,6 +138,106 @@ POINTWISE = ("stage0_kernel", "stage1_kernel", "stage2_kernel", "s2_fc1_kernel",
              "gemm_kernel<fc2,RESID>")
 
 
+MAXVIT_CONFIG = dict(CONFIG, model_name="mm_MaxViT", model_kind="maxvit_tiny_rw_224.sw_in1k")
+
+
+def maxvit_blocks():
+    """[(cin, c, mid, stride, hin, hout)] of maxvit_tiny_rw_224 (oracle/maxvit_oracle.block_table)."""
+    rows, cin, hw = [], 64, 112
+    for d, c in zip((2, 2, 5, 2), (64, 128, 256, 512)):
+        for j in range(d):
+            s = 2 if j == 0 else 1
+            rows.append((cin, c, 4 * cin, s, hw, hw // s))
+            cin, hw = c, hw // s
+    return rows
+
+
+def maxvit_family_work(batch, precision):
+    """Algorithmic FLOP / compulsory HBM bytes per forward of `batch` alerts, per MaxViT kernel family."""
+    esz = 4 if precision == "f32" else 2
+    w = {k: dict(flop=0, bytes=0) for k in (
+        "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
+        "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
+        "mv_gemm<fc2,RESID>", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
+        "mv_attn_kernel", "head_kernel")}
+
+    def add(k, macs, nbytes):
+        w[k]["flop"] += 2 * macs * batch
+        w[k]["bytes"] += nbytes * batch
+
+    add("mv_gemm<stem>", 12544 * (27 * 32 + 288 * 64), 12544 * (32 * esz * 2 + 288 * esz + 64 * 4))
+    add("mv_stem_im2col", 0, 3 * 63 * 63 * 4 + 12544 * 32 * esz + 12544 * 32 * esz + 12544 * 288 * esz)
+    for cin, c, mid, s, hi, ho in maxvit_blocks():
+        pi, po = hi * hi, ho * ho
+        add("mv_elementwise", 0, pi * cin * (4 + esz) + (po * cin * (4 + esz) if s == 2 else 0))
+        add("mv_gemm<conv1,SILU>", pi * cin * mid, pi * (cin + mid) * esz)
+        add("mv_dw3_kernel", po * 9 * mid, (pi + po) * mid * esz)
+        add("mv_se_kernel", 2 * mid * (mid // 16), po * mid * esz)
+        add("mv_gemm<conv3,gated>", po * mid * c, po * (mid * esz + 8 * c))
+        if s == 2 and cin != c:
+            add("mv_gemm<shortcut>", po * cin * c, po * (cin * esz + 4 * c))
+        for _ in range(2):
+            add("mv_ln_kernel", 0, 2 * po * c * (4 + esz))
+            add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
+            add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)
+            add("mv_gemm<proj,RESID>", po * c * c, po * c * (esz + 8))
+            add("mv_gemm<fc1,GELU>", po * 4 * c * c, po * 5 * c * esz)
+            add("mv_gemm<fc2,RESID>", po * 4 * c * c, po * c * (4 * esz + 8))
+    add("mv_ln_kernel", 0, 49 * 512 * 4)
+    add("head_kernel", 25 * 128 + 128 * 128 + 640 * 128 + 128 * 32 + 32, 512 * 4 + 108)
+    return w
+
+
+def maxvit_leg(dev, rank, world, dist, fence, args):
+    """BASELINE.json configs[3]: mm_MaxViT (maxvit_tiny_rw_224 on cutouts resized to 224) inference."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mv = btsbot_amd.mm_MaxViT(MAXVIT_CONFIG, precision=args.precision)
+    seeded_weights(mv)
+    mv = mv.to(dev).eval()
+    img, meta, _ = synthetic_batch(args.maxvit_batch, seed=50 + rank)
+    img, meta = img.to(dev), meta.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return mv(image_input=img, metadata_input=meta)
+
+    out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.maxvit_steps):
+        out = step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    mv.set_profile(True)
+    step()
+    prof = mv.collect_profile()
+    mv.set_profile(False)
+    work = maxvit_family_work(args.maxvit_batch, args.precision)
+    kernels = {}
+    for name, (ms, n) in prof.items():
+        if n == 0 or name not in work:
+            continue
+        kernels[name] = dict(launches_per_step=n, ms_per_step=round(ms, 4),
+                             tflops=round(work[name]["flop"] / (ms * 1e-3) / 1e12, 2),
+                             gbs=round(work[name]["bytes"] / (ms * 1e-3) / 1e9, 1))
+    flop_alert = sum(v["flop"] for v in work.values()) / args.maxvit_batch
+    total = args.maxvit_batch * world * args.maxvit_steps
+    return {
+        "workload": "BASELINE.json configs[3]: mm_MaxViT (maxvit_tiny_rw_224, 63x63 cutouts resized to "
+                    f"224x224 on device) {args.precision} inference, batch={args.maxvit_batch} per GPU",
+        "value": round(total / el, 1), "unit": "alerts/s", "per_gpu_batch": args.maxvit_batch,
+        "steps": args.maxvit_steps, "ms_per_step": round(1e3 * el / args.maxvit_steps, 3),
+        "flop_per_alert": int(flop_alert),
+        "whole_net_tflops": round(flop_alert * total / el / 1e12, 2),
+        "finite": bool(torch.isfinite(out).all().item()), "kernels": kernels,
+    }
+
+
 def cpu_baseline(sample_batch=256, budget_s=20.0):
     """CPU oracle (kind 'port'): fp32, eval, no_grad, all host cores."""
     from oracle import convnext_oracle as O   # CPU baseline leg only
@@ -178,6 +278,9 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5,
                     help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
+    ap.add_argument("--maxvit-steps", type=int, default=3,
+                    help="steps of the MaxViT inference leg (BASELINE.json configs[3]); 0 = skip")
+    ap.add_argument("--maxvit-batch", type=int, default=256, help="alerts per GPU per MaxViT step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,11 +376,15 @@ def main():
         }
         del tm, tr
 
+    maxvit = None
+    if args.maxvit_steps > 0:
+        maxvit = maxvit_leg(dev, rank, world, dist, fence, args)
+
     if rank == 0:
         work = family_work(args.batch, args.precision)
         kernels = {}
         for name, (ms, n) in prof.items():
-            if n == 0:
+            if n == 0 or name not in work:
                 continue
             per_fwd_ms = ms / args.steps
             wk = work[name]
@@ -327,6 +434,8 @@ def main():
         }
         if train is not None:
             line["train"] = train
+        if maxvit is not None:
+            line["maxvit"] = maxvit
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -299,12 +299,12 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
   // ---- stem: resize + conv3x3 s2 (+BN, SiLU) + conv3x3 s1, both as im2col GEMMs
   const int M0 = nb * 12544;
   MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_resize_im2col(prec, img, Bb, nb, st); }));
-  MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+  MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
     return launch_gemm(prec, EPI_SILU, Bb, ex + mv->p_stem1, F(mv->stem_bn.p_shift), nullptr, nullptr,
                        Cc, M0, 32, 32, st);
   }));
   MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_im2col3(prec, Cc, A, nb, 112, 32, st); }));
-  MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+  MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
     return launch_gemm(prec, EPI_BIAS, A, ex + mv->p_stem2, zero, nullptr, nullptr, x, M0, 64, 288,
                        st);
   }));
@@ -323,7 +323,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
           return launch_mv_avgpool2(prec, x, E, 1, nb, b.hin, b.cin, st);
         }));
-        MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+        MTRY(mv_timed(h, CAT_MV_G_SC, st, [&] {
           return launch_gemm(prec, EPI_BIAS, E, ex + b.p_sc, zero, nullptr, nullptr, x2, Mo, b.c,
                              b.cin, st);
         }));
@@ -338,7 +338,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
       return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
     }));
-    MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+    MTRY(mv_timed(h, CAT_MV_G_CONV1, st, [&] {
       return launch_gemm(prec, EPI_SILU, Cc, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
                          b.cin, st);
     }));
@@ -349,7 +349,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       return launch_mv_se(prec, Bb, m + b.se1_w, m + b.se1_b, m + b.se2_w, m + b.se2_b, gate, nb,
                           b.hout * b.hout, b.mid, b.rd, st);
     }));
-    MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+    MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
       return launch_gemm_gated(prec, Bb, gate, b.hout * b.hout, ex + b.p_c3, resid, dst, Mo, b.c,
                                b.mid, st);
     }));
@@ -365,24 +365,24 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
         return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
       }));
-      MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+      MTRY(mv_timed(h, CAT_MV_G_QKV, st, [&] {
         return launch_gemm(prec, EPI_BIAS_T, Cc, ex + a.p_qkv, m + a.qkv_b, nullptr, nullptr, D, Mo,
                            3 * c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_ATTN, st, [&] {
         return launch_mv_attn(prec, D, F(a.p_bias), E, nb, b.hout, c, g, st);
       }));
-      MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+      MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
         return launch_gemm(prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
         return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
       }));
-      MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+      MTRY(mv_timed(h, CAT_MV_G_FC1, st, [&] {
         return launch_gemm(prec, EPI_GELU, Cc, ex + a.p_fc1, m + a.fc1_b, nullptr, nullptr, Bb, Mo,
                            4 * c, c, st);
       }));
-      MTRY(mv_timed(h, CAT_MV_GEMM, st, [&] {
+      MTRY(mv_timed(h, CAT_MV_G_FC2, st, [&] {
         return launch_gemm(prec, EPI_RESID, Bb, ex + a.p_fc2, m + a.fc2_b, one, x, x, Mo, c, 4 * c,
                            st);
       }));

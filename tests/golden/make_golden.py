@@ -11,6 +11,8 @@ fixed inputs with seeded weights and stores inputs + logits:
                     (a) example8 and (b) synthetic_batch(6, seed=2); seeded weights
                     (oracle.random_state_dict(seed=3)) are regenerated at test time, a float64
                     checksum of every state dict is stored to detect RNG drift
+  ref_logits_maxvit.npz  the same for the reference's MaxViT / mm_MaxViT wrappers around the
+                    maxvit_tiny_rw_224 stand-in (first 4 example alerts + synthetic_batch(3, seed=2))
   lr_sequences.json torch's own SequentialLR sequences for (warmup, epochs) in {(0,6),(2,8)}
   adamw_bce.npz     3 AdamW steps (torch.optim.AdamW) and BCEWithLogitsLoss(pos_weight) values
 
@@ -30,9 +32,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import CONFIGS, seeded_state  # noqa: E402
+from helpers import CONFIGS, MV_CONFIGS, seeded_state, seeded_state_mv  # noqa: E402
 from btsbot_amd.synthetic import METADATA_COLS, synthetic_batch  # noqa: E402
-from oracle import convnext_oracle as O, timm_standin  # noqa: E402
+from oracle import convnext_oracle as O, maxvit_oracle as MO, timm_standin  # noqa: E402
 
 REF = "/root/reference/btsbot"
 
@@ -64,18 +66,46 @@ def checksum(sd):
 
 def call(kind, model, img, meta):
     with torch.no_grad():
-        if kind in ("mm_ConvNeXt", "frozen_fusion"):
+        if kind in ("mm_ConvNeXt", "frozen_fusion", "mm_MaxViT"):
             return model(image_input=img, metadata_input=meta)
-        if kind == "ConvNeXt":
+        if kind in ("ConvNeXt", "MaxViT"):
             return model(input_data=img)
         return model(input_data=meta)
+
+
+def maxvit_goldens(ref, ex):
+    """MaxViT / mm_MaxViT: the reference's wrapper classes (resize, head surgery, metadata and
+    fusion heads) around the stand-in backbone; the functional oracle must agree."""
+    eimg = torch.from_numpy(ex["triplets"][[0, 1, 4, 5]])
+    emeta = torch.from_numpy(ex["metadata"][[0, 1, 4, 5]])
+    simg, smeta, _ = synthetic_batch(3, seed=2)
+    out = {}
+    for name, (kind, cfg) in MV_CONFIGS.items():
+        sd = seeded_state_mv(kind, cfg, seed=3)
+        model = getattr(ref, kind)(cfg).eval()
+        model.load_state_dict(sd, strict=True)
+        out[f"{name}/example4"] = call(kind, model, eimg, emeta).numpy()
+        out[f"{name}/synthetic3"] = call(kind, model, simg, smeta).numpy()
+        out[f"{name}/checksum"] = np.array(checksum(sd))
+        with torch.no_grad():
+            o = MO.forward(kind, sd, cfg, eimg, emeta)
+        r = torch.from_numpy(out[f"{name}/example4"])
+        err = (o - r).abs().max().item()
+        scale = max(1.0, r.abs().max().item())
+        print(f"{name}: reference-wrapper vs oracle max|dlogit| = {err:.2e} (max|logit| {scale:.1f})")
+        assert err < 2e-5 * scale, name
+    np.savez_compressed(os.path.join(HERE, "ref_logits_maxvit.npz"), **out)
 
 
 def main():
     torch.manual_seed(0)
     ref = load_reference_architectures()
+    if len(sys.argv) > 1 and sys.argv[1] == "maxvit":      # only (re)generate the MaxViT file
+        maxvit_goldens(ref, dict(np.load(os.path.join(HERE, "example8.npz"))))
+        return
     ex = example8()
     np.savez_compressed(os.path.join(HERE, "example8.npz"), **ex)
+    maxvit_goldens(ref, ex)
     eimg, emeta = torch.from_numpy(ex["triplets"]), torch.from_numpy(ex["metadata"])
     simg, smeta, _ = synthetic_batch(6, seed=2)
 

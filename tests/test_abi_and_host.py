@@ -76,8 +76,14 @@ def test_bad_configs_raise():
         _build("mm_ConvNeXt", dict(CONFIGS["mm_pico"][1], model_kind="resnet50"))
     with pytest.raises(KeyError):
         _build("mm_ConvNeXt", {k: v for k, v in CONFIGS["mm_pico"][1].items() if k != "comb_fc1_neurons"})
-    with pytest.raises(NotImplementedError):
-        btsbot_amd.mm_MaxViT({})
+    with pytest.raises(KeyError):                   # like the reference: missing config keys
+        btsbot_amd.mm_MaxViT({"pretrained": False})
+    with pytest.raises(NotImplementedError):        # legacy VGG-like CNNs are out of scope
+        btsbot_amd.mm_cnn({})
+    cfg = _lib.make_config("mm_MaxViT", "f32", (2, 2, 6, 2), (64, 128, 256, 512), False, 25, 128,
+                           128, 128, 32, 0.1, 0.1)
+    with pytest.raises(_lib.BtsbotHipError, match="maxvit_tiny_rw_224"):
+        _lib.Handle(cfg)
     with pytest.raises(ValueError):
         _build("um_nn", CONFIGS["um_nn"][1], precision="int8")
     # C side rejects an impossible table directly
@@ -147,3 +153,25 @@ def test_weight_version_tracking():
     with torch.no_grad():
         next(m.parameters()).add_(1.0)
     assert m._version() != v0
+
+
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+def test_maxvit_state_dict_layout_matches_reference(name):
+    """timm MaxxVit key names / shapes / order (verified == the reference wrappers around the stand-in
+    in make_golden.py), BatchNorm buffers included; strict load round-trips."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    from oracle import maxvit_oracle as MO
+    kind, cfg = MV_CONFIGS[name]
+    m = _build(kind, cfg)
+    shapes = MO.model_param_shapes(kind, cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    ref_sd = seeded_state_mv(kind, cfg, seed=3)
+    m.load_state_dict(ref_sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
+    assert m.image_size == 224 and m.training
+    with pytest.raises(ValueError):
+        _build(kind, dict(cfg, model_kind="maxvit_base_tf_384.in1k"))

@@ -202,3 +202,73 @@ def test_alternative_schedules_match_oracle(cuda, monkeypatch, env, prec):
     ref = _oracle(kind, cfg, sd, img, meta)
     m = build_model(kind, cfg, sd, cuda, prec)
     _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
+
+
+# ---- MaxViT wirings: maxvit_tiny_rw_224 on cutouts resized to 224 ------------
+def _mv(name):
+    from helpers import MV_CONFIGS, seeded_state_mv
+    kind, cfg = MV_CONFIGS[name]
+    return kind, cfg, seeded_state_mv(kind, cfg, seed=3)
+
+
+def _mv_oracle(kind, cfg, sd, img, meta):
+    from oracle import maxvit_oracle as MO
+    with torch.no_grad():
+        return MO.forward(kind, sd, cfg, img, meta)
+
+
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+def test_maxvit_forward_matches_oracle(cuda, name, prec):
+    kind, cfg, sd = _mv(name)
+    img, meta, _ = synthetic_batch(5, seed=2)
+    ref = _mv_oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
+
+
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+def test_maxvit_matches_reference_wrapper_goldens(cuda, name):
+    kind, cfg, sd = _mv(name)
+    gold = np.load(os.path.join(GOLD, "ref_logits_maxvit.npz"))
+    ex = np.load(os.path.join(GOLD, "example8.npz"))
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    img = torch.from_numpy(ex["triplets"][[0, 1, 4, 5]]).to(cuda)
+    meta = torch.from_numpy(ex["metadata"][[0, 1, 4, 5]]).to(cuda)
+    _check(run_model(kind, m, img, meta), torch.from_numpy(gold[f"{name}/example4"]), "f32")
+
+
+def test_maxvit_stage_activations_match_oracle(cuda):
+    from oracle import maxvit_oracle as MO
+    kind, cfg, sd = _mv("mm_maxvit")
+    img, meta, _ = synthetic_batch(2, seed=7)
+    taps = {}
+    with torch.no_grad():
+        MO.mm_maxvit_forward(sd, cfg, img, meta, taps=taps)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    m.set_debug_taps(True)
+    run_model(kind, m, img.to(cuda), meta.to(cuda))
+    for t, key in (("stem", "stem"), ("stage0", "s0b1"), ("stage1", "s1b1"), ("stage2", "s2b4"),
+                   ("stage3", "s3b1")):
+        got = m.read_tap(t).cpu()
+        ref = taps[key].permute(0, 2, 3, 1).reshape(got.shape)
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), t
+
+
+def test_maxvit_chunking_independence_and_modes(cuda):
+    """Internal workspace chunks (forced to 4 alerts here) and batch permutation do not change a
+    logit; train mode is refused loudly (inference-only row)."""
+    kind, cfg, sd = _mv("mm_maxvit")
+    img, meta, _ = synthetic_batch(10, seed=4)
+    img, meta = img.to(cuda), meta.to(cuda)
+    m = build_model(kind, cfg, sd, cuda, "bf16")
+    full = run_model(kind, m, img, meta)
+    m2 = build_model(kind, cfg, sd, cuda, "bf16")
+    m2._max_chunk = 4
+    assert torch.equal(run_model(kind, m2, img, meta), full)
+    perm = torch.randperm(10, generator=torch.Generator().manual_seed(0)).to(cuda)
+    assert torch.equal(run_model(kind, m, img[perm].contiguous(), meta[perm].contiguous()), full[perm])
+    assert run_model(kind, m, img[:0], meta[:0]).shape == (0, 1)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(image_input=img, metadata_input=meta)

@@ -123,3 +123,66 @@ def test_grads_match_autograd_through_functional_oracle():
     gn = {k: v.grad.norm().item() for k, v in sd.items() if getattr(v, "grad", None) is not None}
     assert len(gn) == 136 and all(np.isfinite(x) for x in gn.values())
     assert gn["convnext_backbone.stem.0.weight"] > 0
+
+
+# ---- MaxViT row -----------------------------------------------------
+def test_maxvit_definition_matches_published_model_table():
+    """No timm here: the restated maxvit_tiny_rw_224 must at least reproduce the two numbers timm's
+    model table publishes for it -- 29.1 M parameters, 5.1 GMACs at 224x224."""
+    from oracle import maxvit_oracle as MO
+    n = MO.count_params("maxvit_tiny_rw_224") + 512 * 1000 + 1000      # + the 1000-class fc
+    assert n == 29_075_232 and round(n / 1e6, 1) == 29.1
+    assert round(MO.count_macs("maxvit_tiny_rw_224") / 1e9, 1) == 5.1
+
+
+def test_maxvit_module_form_matches_functional_oracle():
+    """oracle/timm_standin.MaxxVitStandIn (nn.Module form, einsum attention, explicit index loops) vs
+    oracle/maxvit_oracle (functional form): same timm key set, same features."""
+    from oracle import maxvit_oracle as MO, timm_standin as TS
+    net = TS.create_model("maxvit_tiny_rw_224.sw_in1k").eval()
+    shapes = MO.backbone_param_shapes("maxvit_tiny_rw_224", "")
+    keys = [k for k in net.state_dict() if not k.startswith("head.fc")]
+    assert keys == list(shapes)
+    sd = O.random_state_dict(shapes, seed=5)
+    net.load_state_dict(dict(sd, **{"head.fc.weight": torch.zeros(1000, 512),
+                                    "head.fc.bias": torch.zeros(1000)}), strict=True)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        a = net.forward_features(x)
+        b = MO.forward_features(x, sd, "", "maxvit_tiny_rw_224")
+    assert a.shape == (1, 512, 7, 7)
+    assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+
+
+def test_maxvit_partitions_are_inverse_pairs_and_rel_index():
+    from oracle import maxvit_oracle as MO
+    x = torch.arange(2 * 14 * 14 * 3, dtype=torch.float32).view(2, 14, 14, 3)
+    assert torch.equal(MO.window_reverse(MO.window_partition(x, 7), 7, 14, 14), x)
+    assert torch.equal(MO.grid_reverse(MO.grid_partition(x, 7), 7, 14, 14), x)
+    # grid partition: token (gy, gx) of window (iy, ix) is pixel (gy*2 + iy, gx*2 + ix)
+    g = MO.grid_partition(x, 7).view(2, 2, 2, 7, 7, 3)
+    assert torch.equal(g[1, 1, 0, 3, 5], x[1, 3 * 2 + 1, 5 * 2 + 0])
+    idx = MO.rel_pos_index(7)
+    assert idx.shape == (49, 49) and idx.min() == 0 and idx.max() == 168
+    assert idx[0, 0] == 84 and idx[0, 48] == 0 and idx[48, 0] == 168
+
+
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+def test_maxvit_oracle_matches_reference_wrapper_goldens(name):
+    """Committed logits of the reference's own MaxViT / mm_MaxViT classes (architectures.py:25-101:
+    resize, head surgery, metadata + fusion heads) run around the stand-in backbone."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    from oracle import maxvit_oracle as MO
+    kind, cfg = MV_CONFIGS[name]
+    gold = np.load(os.path.join(GOLD, "ref_logits_maxvit.npz"))
+    ex = np.load(os.path.join(GOLD, "example8.npz"))
+    sd = seeded_state_mv(kind, cfg, seed=3)
+    chk = float(sum(v.double().abs().sum().item() for v in sd.values()))
+    assert abs(chk - float(gold[f"{name}/checksum"])) < 1e-6 * chk, "seeded weight stream drifted"
+    img = torch.from_numpy(ex["triplets"][[0, 1, 4, 5]])
+    meta = torch.from_numpy(ex["metadata"][[0, 1, 4, 5]])
+    with torch.no_grad():
+        o = MO.forward(kind, sd, cfg, img, meta)
+    ref = torch.from_numpy(gold[f"{name}/example4"])
+    assert o.shape == ref.shape == (4, 1)
+    assert (o - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
