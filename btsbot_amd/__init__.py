@@ -9,6 +9,9 @@ __version__ = "0.1.0"
 
 from . import architectures
 from . import from_HF
+from . import to_HF
+from . import data
+from . import val
 from .architectures import (
     MaxViT,
     ConvNeXt,
@@ -23,7 +26,7 @@ from .from_HF import download_HF_model, load_HF_model
 from .synthetic import METADATA_COLS, synthetic_batch
 
 __all__ = [
-    "__version__", "architectures", "from_HF",
+    "__version__", "architectures", "from_HF", "to_HF", "data", "val",
     "MaxViT", "ConvNeXt", "mm_MaxViT", "mm_ConvNeXt", "mm_cnn", "um_cnn", "um_nn", "frozen_fusion",
     "download_HF_model", "load_HF_model", "METADATA_COLS", "synthetic_batch",
 ]

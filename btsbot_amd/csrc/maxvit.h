@@ -27,9 +27,16 @@ int launch_mv_bn_cast(int prec, const float* x, const float* scale, const float*
 // w9 is tap-major [9][C] f32 (BatchNorm scale folded in), bias [C] f32 (conv bias and BN shift folded)
 int launch_mv_dw3(int prec, const void* in, const float* w9, const float* bias, void* out, int B,
                   int H, int C, int stride, hipStream_t st);
-// squeeze-excite gate: y [B,HW,C] T -> gate [B,C] f32 = sigmoid(fc2(silu(fc1(mean_hw y))))
-int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2,
-                 const float* b2, float* gate, int B, int HW, int C, int RD, hipStream_t st);
+// 16-bit modes: the same in strips of 7 outputs x 8 channels per thread, plus the squeeze-excite pool as
+// per-workgroup partial sums: part [B][mv_dw3s_groups(H,C,stride)][C] f32 (feed to launch_mv_se as f32 rows)
+int mv_dw3s_groups(int H, int C, int stride);
+int launch_mv_dw3s(int prec, const void* in, const float* w9, const float* bias, void* out, float* part,
+                   int B, int H, int C, int stride, hipStream_t st);
+// squeeze-excite gate: y [B,HW,C] T -> gate [B,C] f32 = sigmoid(fc2(silu(fc1(inv_count * sum_hw y))))
+// (w2t = fc2 weight transposed to [RD][C]; scratch = B * (C + RD) floats)
+int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2t,
+                 const float* b2, float* gate, float* scratch, int B, int HW, int C, int RD,
+                 float inv_count, hipStream_t st);
 // 2x2 average pool of the fp32 residual map: x [B,H,H,C] -> out [B,H/2,H/2,C] (T when to_t, else f32)
 int launch_mv_avgpool2(int prec, const float* x, void* out, int to_t, int B, int H, int C,
                        hipStream_t st);
@@ -41,6 +48,11 @@ int launch_mv_ln(int prec, const float* x, const float* w, const float* b, void*
 // out [B*H*H, C] T (channel = head*32 + d); rows stay in image order, the partition is an index map
 int launch_mv_attn(int prec, const void* qkv, const float* bias_t, void* out, int B, int H, int C,
                    int grid_mode, hipStream_t st);
+// the same on MFMA for the 16-bit modes (maxvit_attn.hip); bias64 is the padded [heads][64 key][64 query]
+// image of launch_mv_pack_relbias64 (key padding mask folded in)
+int launch_mv_attn_mfma(int prec, const void* qkv, const float* bias64, void* out, int B, int H, int C,
+                        int grid_mode, hipStream_t st);
+int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

@@ -16,6 +16,7 @@
 //   2 x partition attention (windows, then grid):
 //            x += proj(attn(qkv(LN1(x))))                         mv_ln, GEMM EPI_BIAS_T, mv_attn, GEMM EPI_RESID
 //            x += fc2(gelu(fc1(LN2(x))))                          mv_ln, GEMM EPI_GELU, GEMM EPI_RESID
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -32,14 +33,15 @@ struct BnPk {
 };
 struct AttnPk {
   int64_t n1w, n1b, qkv_w, qkv_b, rel, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b;
-  size_t p_qkv, p_proj, p_fc1, p_fc2, p_bias;
+  size_t p_qkv, p_proj, p_fc1, p_fc2, p_bias, p_bias64, p_fused;
+  bool fused;
 };
 struct MvBlock {
   int cin, c, mid, rd, stride, hin, hout;
   int64_t sc_w = -1;
   BnPk pre, n1, n2;
   int64_t c1_w, c1_b, c2_w, c2_b, se1_w, se1_b, se2_w, se2_b, c3_w;
-  size_t p_sc, p_c1, p_c1b, p_dw, p_dwb, p_c3;
+  size_t p_sc, p_c1, p_c1b, p_dw, p_dwb, p_c3, p_se2t;
   AttnPk attn[2];   // [0] windows ("attn_block"), [1] grid ("attn_grid")
 };
 
@@ -51,7 +53,10 @@ struct MaxVit {
   size_t p_stem1, p_stem2, p_zero, p_one;
   std::vector<MvBlock> blocks;
   // workspace offsets (bytes) for the current reservation
-  size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat;
+  size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr;
+  bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
+  bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
+  bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
 
 namespace {
@@ -116,6 +121,9 @@ AttnPk add_attn(btsbot_ctx* h, const std::string& p, int c, size_t& cur, int esz
   a.p_fc1 = mv_bump(cur, (size_t)4 * c * c * esz);
   a.p_fc2 = mv_bump(cur, (size_t)4 * c * c * esz);
   a.p_bias = mv_bump(cur, (size_t)heads * 2401 * 4);
+  a.p_bias64 = mv_bump(cur, (size_t)heads * 4096 * 4);
+  a.fused = fused_mlp_supported(h->cfg.precision, c);
+  a.p_fused = a.fused ? mv_bump(cur, fused_mlp_packed_bytes(c)) : 0;
   return a;
 }
 
@@ -126,6 +134,14 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
   const int esz = h->esz();
   MaxVit* mv = new MaxVit();
   h->mv = mv;
+  {
+    const char* e = getenv("BTSBOT_AMD_MV_ATTN_VALU");
+    mv->attn_valu = e != nullptr && e[0] == '1';
+    const char* d = getenv("BTSBOT_AMD_MV_DW_PLAIN");
+    mv->dw_plain = d != nullptr && d[0] == '1';
+    const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
+    mv->mlp_unfused = u != nullptr && u[0] == '1';
+  }
   char buf[96];
   mv->stem1_w = mv_add(h, "stem.conv1.weight", {32, 3, 3, 3});
   mv->stem_bn = add_bn(h, "stem.norm1.", 32, cur);
@@ -170,6 +186,7 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
       b.p_dw = mv_bump(cur, (size_t)9 * b.mid * 4);
       b.p_dwb = mv_bump(cur, (size_t)b.mid * 4);
       b.p_c3 = mv_bump(cur, (size_t)b.c * b.mid * esz);
+      b.p_se2t = mv_bump(cur, (size_t)b.mid * b.rd * 4);
       b.attn[0] = add_attn(h, bp + "attn_block.", b.c, cur, esz);
       b.attn[1] = add_attn(h, bp + "attn_grid.", b.c, cur, esz);
       mv->blocks.push_back(b);
@@ -223,6 +240,7 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st) {
     MTRY(launch_mv_pack_dw(m + b.c2_w, F(b.n2.p_scale), F(b.p_dw), b.mid, st));
     MTRY(launch_mv_fold_bias(m + b.c2_b, F(b.n2.p_scale), F(b.n2.p_shift), F(b.p_dwb), b.mid, st));
     MTRY(launch_cast(prec, m + b.c3_w, ex + b.p_c3, (int64_t)b.c * b.mid, st));
+    MTRY(launch_transpose_f32(m + b.se2_w, F(b.p_se2t), b.mid, b.rd, st));
     for (const AttnPk& a : b.attn) {
       const int c = b.c;
       MTRY(launch_cast(prec, m + a.qkv_w, ex + a.p_qkv, (int64_t)3 * c * c, st));
@@ -230,6 +248,8 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st) {
       MTRY(launch_cast(prec, m + a.fc1_w, ex + a.p_fc1, (int64_t)4 * c * c, st));
       MTRY(launch_cast(prec, m + a.fc2_w, ex + a.p_fc2, (int64_t)4 * c * c, st));
       MTRY(launch_mv_pack_relbias(m + a.rel, F(a.p_bias), c / 32, st));
+      MTRY(launch_mv_pack_relbias64(m + a.rel, F(a.p_bias64), c / 32, st));
+      if (a.fused) MTRY(launch_pack_fused_mlp(prec, c, m + a.fc1_w, m + a.fc2_w, ex + a.p_fused, st));
     }
   }
   return BTSBOT_OK;
@@ -255,6 +275,8 @@ static void mv_layout(const btsbot_ctx* h, int chunk, MaxVit* out, size_t* total
   o->o_e = bump(n * 3136 * 64 * esz);      // attention output; pooled shortcut input
   o->o_gate = bump(n * 2048 * 4);
   o->o_feat = bump(n * 512 * 4);
+  o->o_sescr = bump(n * (2048 + 128) * 4);   // squeeze-excite mean + hidden
+  o->o_part = bump(n * 14336 * 4);         // squeeze-excite partial sums [<=56 groups][mid], 14336 floats max
   *total = cur;
 }
 
@@ -293,6 +315,8 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
   void* E = h->ws + mv->o_e;
   float* gate = reinterpret_cast<float*>(h->ws + mv->o_gate);
   float* feat = reinterpret_cast<float*>(h->ws + mv->o_feat);
+  float* part = reinterpret_cast<float*>(h->ws + mv->o_part);
+  float* sescr = reinterpret_cast<float*>(h->ws + mv->o_sescr);
   const float* zero = F(mv->p_zero);
   const float* one = F(mv->p_one);
 
@@ -342,13 +366,25 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       return launch_gemm(prec, EPI_SILU, Cc, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
                          b.cin, st);
     }));
-    MTRY(mv_timed(h, CAT_MV_DW, st, [&] {
-      return launch_mv_dw3(prec, A, F(b.p_dw), F(b.p_dwb), Bb, nb, b.hin, b.mid, b.stride, st);
-    }));
-    MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
-      return launch_mv_se(prec, Bb, m + b.se1_w, m + b.se1_b, m + b.se2_w, m + b.se2_b, gate, nb,
-                          b.hout * b.hout, b.mid, b.rd, st);
-    }));
+    const float inv_hw = 1.0f / (float)(b.hout * b.hout);
+    if (prec != BTSBOT_F32 && !mv->dw_plain) {
+      // depthwise conv with the squeeze-excite pool fused (partial sums per workgroup, no second pass)
+      MTRY(mv_timed(h, CAT_MV_DW, st, [&] {
+        return launch_mv_dw3s(prec, A, F(b.p_dw), F(b.p_dwb), Bb, part, nb, b.hin, b.mid, b.stride, st);
+      }));
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
+        return launch_mv_se(BTSBOT_F32, part, m + b.se1_w, m + b.se1_b, F(b.p_se2t), m + b.se2_b, gate,
+                            sescr, nb, mv_dw3s_groups(b.hin, b.mid, b.stride), b.mid, b.rd, inv_hw, st);
+      }));
+    } else {
+      MTRY(mv_timed(h, CAT_MV_DW, st, [&] {
+        return launch_mv_dw3(prec, A, F(b.p_dw), F(b.p_dwb), Bb, nb, b.hin, b.mid, b.stride, st);
+      }));
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
+        return launch_mv_se(prec, Bb, m + b.se1_w, m + b.se1_b, F(b.p_se2t), m + b.se2_b, gate, sescr, nb,
+                            b.hout * b.hout, b.mid, b.rd, inv_hw, st);
+      }));
+    }
     MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
       return launch_gemm_gated(prec, Bb, gate, b.hout * b.hout, ex + b.p_c3, resid, dst, Mo, b.c,
                                b.mid, st);
@@ -370,6 +406,8 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
                            3 * c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_ATTN, st, [&] {
+        if (prec != BTSBOT_F32 && !mv->attn_valu)
+          return launch_mv_attn_mfma(prec, D, F(a.p_bias64), E, nb, b.hout, c, g, st);
         return launch_mv_attn(prec, D, F(a.p_bias), E, nb, b.hout, c, g, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
@@ -378,6 +416,12 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
         return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
       }));
+      if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
+        MTRY(mv_timed(h, CAT_MV_FUSED, st, [&] {
+          return launch_fused_mlp(prec, c, Cc, ex + a.p_fused, m + a.fc1_b, m + a.fc2_b, one, x, Mo, st);
+        }));
+        continue;
+      }
       MTRY(mv_timed(h, CAT_MV_G_FC1, st, [&] {
         return launch_gemm(prec, EPI_GELU, Cc, ex + a.p_fc1, m + a.fc1_b, nullptr, nullptr, Bb, Mo,
                            4 * c, c, st);

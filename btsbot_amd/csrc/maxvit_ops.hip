@@ -137,57 +137,183 @@ __global__ __launch_bounds__(256) void mv_dw3_kernel(const T* __restrict__ in,
   *reinterpret_cast<T4*>(out + pix * C + c) = o;
 }
 
-// one workgroup per alert: mean over the map, two tiny dense layers, sigmoid
-template <typename T>
-__global__ __launch_bounds__(256) void mv_se_kernel(const T* __restrict__ y,
-                                                    const float* __restrict__ w1,
-                                                    const float* __restrict__ b1,
-                                                    const float* __restrict__ w2,
-                                                    const float* __restrict__ b2,
-                                                    float* __restrict__ gate, int HW, int C, int RD) {
-  extern __shared__ float sm[];           // part[RG][C] | s[RD]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c4n = C / 4;
-  const int CT = c4n < 256 ? c4n : 256;   // channel-group lanes
-  const int RG = 256 / CT;                // row groups
-  const int cl = tid % CT, rg = tid / CT;
-  float* part = sm;
-  float* sv = sm + (size_t)RG * C;
-  const T* yb = y + (size_t)b * HW * C;
-  typedef typename V4<T>::type T4;
-  if (rg < RG) {
-    for (int cg = cl; cg < c4n; cg += CT) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = rg; r < HW; r += RG) {
-        const T4 v = *reinterpret_cast<const T4*>(yb + (size_t)r * C + cg * 4);
-        a.x += (float)v[0];
-        a.y += (float)v[1];
-        a.z += (float)v[2];
-        a.w += (float)v[3];
+// 16-bit modes: one thread = a strip of 7 output pixels of one row x 8 channels (16-byte accesses, every
+// input column loaded once per row and used for up to three outputs), and the squeeze-excite pool comes for
+// free: the thread sums its 7 outputs, the workgroup (PL strips x all channel groups of ONE alert) reduces
+// them in LDS and writes one partial row -> part [B][gridDim.x][C] f32, summed by mv_se_kernel in a fixed
+// order (no atomics: bit-reproducible).
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(256) void mv_dw3s_kernel(const T* __restrict__ in,
+                                                      const float* __restrict__ w9,
+                                                      const float* __restrict__ bias,
+                                                      T* __restrict__ out, float* __restrict__ part,
+                                                      int H, int C) {
+  typedef T __attribute__((ext_vector_type(8))) T8;
+  constexpr int NIN = 7 * STRIDE + (STRIDE == 1 ? 2 : 1);   // input columns a strip touches
+  extern __shared__ float red[];                              // [PL][C]
+  const int Ho = H / STRIDE, SPR = Ho / 7, S = Ho * SPR;      // strips per row / per alert
+  const int c8n = C / 8;
+  const int CT = c8n < 256 ? c8n : 256, PL = 256 / CT;
+  const int cl = threadIdx.x % CT, pl = threadIdx.x / CT;
+  const long b = blockIdx.y;
+  const int strip = blockIdx.x * PL + pl;
+  const int c = cl * 8;
+  float psum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+  if (strip < S) {
+    const int oy = strip / SPR, ox0 = (strip % SPR) * 7;
+    float acc[7][8];
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c);
+      const float4 b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+#pragma unroll
+      for (int p = 0; p < 7; ++p) {
+        acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+        acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
       }
-      *reinterpret_cast<float4*>(part + (size_t)rg * C + cg * 4) = a;
+    }
+    const int ix0 = ox0 * STRIDE - 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * STRIDE - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      float w[3][8];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w9 + (ky * 3 + kx) * C + c);
+        const float4 w1 = *reinterpret_cast<const float4*>(w9 + (ky * 3 + kx) * C + c + 4);
+        w[kx][0] = w0.x; w[kx][1] = w0.y; w[kx][2] = w0.z; w[kx][3] = w0.w;
+        w[kx][4] = w1.x; w[kx][5] = w1.y; w[kx][6] = w1.z; w[kx][7] = w1.w;
+      }
+      const T* rowp = in + ((b * H + iy) * H) * C + c;
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) {
+        const int ix = ix0 + j;
+        if (ix < 0 || ix >= H) continue;
+        const T8 v = *reinterpret_cast<const T8*>(rowp + (long)ix * C);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          // input column j feeds output p when j == p*STRIDE + kx
+          if ((j - kx) >= 0 && (j - kx) % STRIDE == 0 && (j - kx) / STRIDE < 7) {
+            const int p = (j - kx) / STRIDE;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[e], w[kx][e], acc[p][e]);
+          }
+        }
+      }
+    }
+    T* orow = out + ((b * Ho + oy) * Ho + ox0) * C + c;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+      T8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (T)silu_f(acc[p][e]);
+        psum[e] += (float)o[e];          // the pool sees the rounded activations, like the separate pass
+      }
+      *reinterpret_cast<T8*>(orow + (long)p * C) = o;
     }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[pl * C + c + e] = psum[e];
   __syncthreads();
-  const float inv = 1.0f / (float)HW;
-  for (int c = tid; c < C; c += 256) {
+  for (int i = threadIdx.x; i < C; i += 256) {
     float a = 0.f;
-    for (int g = 0; g < RG; ++g) a += part[(size_t)g * C + c];
-    part[c] = a * inv;                    // row group 0's slot now holds the mean
+    for (int q = 0; q < PL; ++q) a += red[q * C + i];
+    part[(b * gridDim.x + blockIdx.x) * C + i] = a;
   }
+}
+
+// squeeze-excite gate as three small, fully parallel launches (the one-workgroup-per-alert version spent
+// 100+ us per block in serial loops on 64..256 workgroups):
+//   mv_se_pool_kernel  mean[b][c] = inv * sum_r y[b][r][c]        one thread per (alert, 4 channels); y = the
+//                                                                 map itself or mv_dw3s_kernel's partial rows
+//   mv_se_fc1_kernel   s[b][r]   = silu(W1[r] . mean[b] + b1[r])  workgroup = 8 alerts x 16 outputs, one wave
+//                                                                 per 4 outputs: weight rows coalesced, read
+//                                                                 once per 8 alerts
+//   mv_se_fc2_kernel   gate[b][c] = sigmoid(W2t[:,c] . s[b] + b2[c])  workgroup = 8 alerts x 256 channels over
+//                                                                 the TRANSPOSED fc2 matrix [RD][C]
+constexpr int SE_AG = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void mv_se_pool_kernel(const T* __restrict__ y,
+                                                         float* __restrict__ mean, long total, int HW,
+                                                         int C, float inv) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= total) return;
+  const int c4n = C / 4;
+  const int cg = (int)(idx % c4n);
+  const long b = idx / c4n;
+  typedef typename V4<T>::type T4;
+  const T* p = y + (size_t)b * HW * C + cg * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < HW; ++r) {
+    const T4 v = *reinterpret_cast<const T4*>(p + (size_t)r * C);
+    acc.x += (float)v[0];
+    acc.y += (float)v[1];
+    acc.z += (float)v[2];
+    acc.w += (float)v[3];
+  }
+  *reinterpret_cast<float4*>(mean + b * C + cg * 4) =
+      make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+__global__ __launch_bounds__(256) void mv_se_fc1_kernel(const float* __restrict__ mean,
+                                                        const float* __restrict__ w1,
+                                                        const float* __restrict__ b1,
+                                                        float* __restrict__ s, int B, int C, int RD) {
+  const int b0 = blockIdx.x * SE_AG, r0 = blockIdx.y * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[4][SE_AG];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int a = 0; a < SE_AG; ++a) acc[i][a] = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float mv[SE_AG];
+#pragma unroll
+    for (int a = 0; a < SE_AG; ++a) mv[a] = mean[(size_t)min(b0 + a, B - 1) * C + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(r0 + wave * 4 + i, RD - 1);
+      const float w = w1[(size_t)r * C + c];
+#pragma unroll
+      for (int a = 0; a < SE_AG; ++a) acc[i][a] = fmaf(w, mv[a], acc[i][a]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + wave * 4 + i;
+#pragma unroll
+    for (int a = 0; a < SE_AG; ++a) {
+      const float t = wave_sum(acc[i][a]);
+      if (lane == 0 && r < RD && b0 + a < B) s[(size_t)(b0 + a) * RD + r] = silu_f(t + b1[r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mv_se_fc2_kernel(const float* __restrict__ s,
+                                                        const float* __restrict__ w2t,
+                                                        const float* __restrict__ b2,
+                                                        float* __restrict__ gate, int B, int C, int RD) {
+  extern __shared__ float sv[];   // [SE_AG][RD]
+  const int b0 = blockIdx.x * SE_AG, c = blockIdx.y * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < SE_AG * RD; i += 256)
+    sv[i] = s[(size_t)min(b0 + i / RD, B - 1) * RD + i % RD];
   __syncthreads();
-  for (int r = wave; r < RD; r += 4) {    // fc1 + SiLU: one wave per output
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(w1[(size_t)r * C + c], part[c], a);
-    a = wave_sum(a);
-    if (lane == 0) sv[r] = silu_f(a + b1[r]);
+  if (c >= C) return;
+  float acc[SE_AG];
+#pragma unroll
+  for (int a = 0; a < SE_AG; ++a) acc[a] = b2[c];
+  for (int r = 0; r < RD; ++r) {
+    const float w = w2t[(size_t)r * C + c];
+#pragma unroll
+    for (int a = 0; a < SE_AG; ++a) acc[a] = fmaf(w, sv[a * RD + r], acc[a]);
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {    // fc2 + sigmoid
-    float a = b2[c];
-    for (int r = 0; r < RD; ++r) a = fmaf(w2[(size_t)c * RD + r], sv[r], a);
-    gate[(size_t)b * C + c] = 1.0f / (1.0f + __expf(-a));
-  }
+#pragma unroll
+  for (int a = 0; a < SE_AG; ++a)
+    if (b0 + a < B) gate[(size_t)(b0 + a) * C + c] = 1.0f / (1.0f + __expf(-acc[a]));
 }
 
 template <typename OT>
@@ -215,35 +341,50 @@ __global__ __launch_bounds__(256) void mv_avgpool2_kernel(const float* __restric
   *reinterpret_cast<O4*>(out + pix * C + c) = o;
 }
 
-// one wave per row, EPL = C/64 contiguous channels per lane
-template <typename T, int EPL>
+// 16 lanes per row (a DPP row: the two reductions are four v_add_dpp each), 16 rows per workgroup; lane l
+// holds the float4 chunks l, l+16, ... of its row, so every load / store instruction of a row is one
+// contiguous 256-byte (f32) piece
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void mv_ln_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ w,
                                                     const float* __restrict__ bsh,
                                                     T* __restrict__ out, long M) {
-  constexpr int C = EPL * 64;
-  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int lane = threadIdx.x & 63;
-  float v[EPL];
-  const float* p = x + row * C + lane * EPL;
+  constexpr int C = NCH * 64;
+  const long row_raw = blockIdx.x * 16L + (threadIdx.x >> 4);
+  const long row = row_raw < M ? row_raw : M - 1;     // keep every lane of the DPP row alive
+  const int l = threadIdx.x & 15;
+  float4 v[NCH];
+  const float* p = x + row * C;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) v[i] = p[i];
+  for (int k = 0; k < NCH; ++k) v[k] = *reinterpret_cast<const float4*>(p + (k * 16 + l) * 4);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) s += v[i];
-  const float mean = wave_sum(s) * (1.0f / C);
+  for (int k = 0; k < NCH; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  const float mean = group16_sum(s) * (1.0f / C);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    v[i] -= mean;
-    q = fmaf(v[i], v[i], q);
+  for (int k = 0; k < NCH; ++k) {
+    v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+    q = fmaf(v[k].x, v[k].x, q);
+    q = fmaf(v[k].y, v[k].y, q);
+    q = fmaf(v[k].z, v[k].z, q);
+    q = fmaf(v[k].w, v[k].w, q);
   }
-  const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-6f);
-  T* o = out + row * C + lane * EPL;
+  const float rstd = rsqrtf(group16_sum(q) * (1.0f / C) + 1e-6f);
+  if (row_raw >= M) return;
+  typedef typename V4<T>::type T4;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i)
-    o[i] = (T)(v[i] * rstd * w[lane * EPL + i] + bsh[lane * EPL + i]);
+  for (int k = 0; k < NCH; ++k) {
+    const int c = (k * 16 + l) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(w + c);
+    const float4 bb = *reinterpret_cast<const float4*>(bsh + c);
+    T4 o4;
+    o4[0] = (T)(v[k].x * rstd * g.x + bb.x);
+    o4[1] = (T)(v[k].y * rstd * g.y + bb.y);
+    o4[2] = (T)(v[k].z * rstd * g.z + bb.z);
+    o4[3] = (T)(v[k].w * rstd * g.w + bb.w);
+    *reinterpret_cast<T4*>(out + row * C + c) = o4;
+  }
 }
 
 // one wave per (alert, partition, head); lane = query token (49 active)
@@ -492,18 +633,54 @@ int launch_mv_dw3(int prec, const void* in, const float* w9, const float* bias, 
   return BTSBOT_OK;
 }
 
-int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2,
-                 const float* b2, float* gate, int B, int HW, int C, int RD, hipStream_t st) {
+int mv_dw3s_groups(int H, int C, int stride) {
+  const int Ho = H / stride, S = Ho * (Ho / 7), c8n = C / 8;
+  const int PL = 256 / (c8n < 256 ? c8n : 256);
+  return (S + PL - 1) / PL;
+}
+
+int launch_mv_dw3s(int prec, const void* in, const float* w9, const float* bias, void* out, float* part,
+                   int B, int H, int C, int stride, hipStream_t st) {
+  const int c8n = C / 8;
+  if (prec == BTSBOT_F32 || C % 8 != 0 || (c8n < 256 && 256 % c8n != 0) || c8n > 256 ||
+      (stride != 1 && stride != 2) || (H / stride) % 7 != 0) {
+    btsbot_set_error("mv_dw3s: bad shape H=%d C=%d stride=%d prec=%d", H, C, stride, prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (B <= 0) return BTSBOT_OK;
-  const int c4n = C / 4;
-  if (C % 4 != 0 || (c4n < 256 && 256 % c4n != 0) || RD < 1 || RD > 512) {
+  const int PL = 256 / (c8n < 256 ? c8n : 256);
+  const dim3 grid(mv_dw3s_groups(H, C, stride), B);
+  const size_t lds = (size_t)PL * C * sizeof(float);
+#define MV_DWS(TT, SS)                                                                              \
+  hipLaunchKernelGGL((mv_dw3s_kernel<TT, SS>), grid, dim3(256), lds, st,                            \
+                     reinterpret_cast<const TT*>(in), w9, bias, reinterpret_cast<TT*>(out), part, H, C)
+  if (prec == BTSBOT_BF16) {
+    if (stride == 1) MV_DWS(bf16_t, 1); else MV_DWS(bf16_t, 2);
+  } else {
+    if (stride == 1) MV_DWS(f16_t, 1); else MV_DWS(f16_t, 2);
+  }
+#undef MV_DWS
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2t,
+                 const float* b2, float* gate, float* scratch, int B, int HW, int C, int RD,
+                 float inv_count, hipStream_t st) {
+  if (B <= 0) return BTSBOT_OK;
+  if (C % 4 != 0 || RD < 1 || RD > 512) {
     btsbot_set_error("mv_se: bad shape C=%d RD=%d", C, RD);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  const int RG = c4n < 256 ? 256 / c4n : 1;
-  const size_t lds = ((size_t)RG * C + RD) * sizeof(float);
-  MV_DISPATCH(prec, hipLaunchKernelGGL(mv_se_kernel<T>, dim3(B), dim3(256), lds, st,
-                                       reinterpret_cast<const T*>(y), w1, b1, w2, b2, gate, HW, C, RD));
+  float* mean = scratch;                  // [B][C]
+  float* s = scratch + (size_t)B * C;     // [B][RD]
+  const long total = (long)B * (C / 4);
+  MV_DISPATCH(prec, hipLaunchKernelGGL(mv_se_pool_kernel<T>, dim3(nblk(total)), dim3(256), 0, st,
+                                       reinterpret_cast<const T*>(y), mean, total, HW, C, inv_count));
+  hipLaunchKernelGGL(mv_se_fc1_kernel, dim3((B + SE_AG - 1) / SE_AG, (RD + 15) / 16), dim3(256), 0, st,
+                     mean, w1, b1, s, B, C, RD);
+  hipLaunchKernelGGL(mv_se_fc2_kernel, dim3((B + SE_AG - 1) / SE_AG, (C + 255) / 256), dim3(256),
+                     (size_t)SE_AG * RD * sizeof(float), st, s, w2t, b2, gate, B, C, RD);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -530,7 +707,7 @@ int launch_mv_avgpool2(int prec, const float* x, void* out, int to_t, int B, int
 int launch_mv_ln(int prec, const float* x, const float* w, const float* b, void* out, long M, int C,
                  hipStream_t st) {
   if (M <= 0) return BTSBOT_OK;
-  const dim3 grid(nblk(M, 4));
+  const dim3 grid(nblk(M, 16));
 #define MV_LN_CASE(EPL)                                                                              \
   MV_DISPATCH(prec, hipLaunchKernelGGL((mv_ln_kernel<T, EPL>), grid, dim3(256), 0, st, x, w, b,      \
                                        reinterpret_cast<T*>(out), M))

@@ -128,3 +128,28 @@ class Trainer:
             m.mark_weights_dirty()
             self.last_logits = logits
         return loss[0] / n_global
+
+
+def train_epoch(trainer: Trainer, dataset, epoch_metrics: bool = True):
+    """train.py:481-566 for a DeviceDataset: one pass over the shuffled, augmented batches with
+    ``Trainer.step`` and -- like the reference, which recomputes them on the concatenated logits
+    (train.py:550-558) -- the epoch's BCE loss and accuracy, evaluated once on the device at the end
+    instead of a ``.item()`` per batch.  Returns (epoch_loss, epoch_accuracy) as Python floats."""
+    from .val import device_metrics
+    logits, labels = [], []
+    for batch in dataset:
+        if len(batch) == 3:
+            images, meta, y = batch
+        elif dataset.images is not None:
+            (images, y), meta = batch, None
+        else:
+            (meta, y), images = batch, None
+        trainer.step(images, meta, y)
+        if epoch_metrics:
+            logits.append(trainer.last_logits)
+            labels.append(y)
+    trainer.scheduler_step()                              # train.py:332
+    if not epoch_metrics or not logits:
+        return float("nan"), float("nan")
+    loss, acc = device_metrics(torch.cat(logits), torch.cat(labels), trainer.pos_weight)
+    return loss.item(), acc.item()

@@ -225,6 +225,22 @@ int btsbot_adamw_step(float* params, const float* grads, float* exp_avg, float* 
                       int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int step, void* stream);
 
+/* ---- the callers either side of the path ---- */
+
+/* Replaces: FlexibleDataset.__getitem__ + DataLoader collation + the torchvision transforms of
+ * train.py:178-199 / utils.py:12-48 for a training set resident in HBM.  dst[b] = T_b(src[index[b]]),
+ * T_b = rot90^k(vflip?(hflip?(.))) with ops[b] = hflip | vflip<<1 | k<<2 (k quarter turns counter-clockwise,
+ * utils.py:44-48); src [N,3,63,63] f32, dst [batch,3,63,63] f32, index int64 [batch] (NULL = identity),
+ * ops uint8 [batch] (NULL = no transform).  Pure index permutation: bit-exact. */
+int btsbot_augment(const float* src, const int64_t* index, const uint8_t* ops, float* dst, int batch,
+                   void* stream);
+
+/* Replaces: the epoch / validation metrics of val.py:159-168 and train.py:550-558 -- out2[0] += sum_i of
+ * BCEWithLogitsLoss(pos_weight) terms over n logits, out2[1] += number of alerts whose sigmoid(z) > 0.5
+ * agrees with the label (caller zeroes out2 and divides by n). */
+int btsbot_eval_metrics(const float* logits, const float* labels, float pos_weight, int64_t n,
+                        float* out2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,34 @@
+"""CPU restatement of the data-side callers of the path.  TEST INFRASTRUCTURE.
+
+  * augment():  FlexibleDataset.__getitem__ + transforms of /root/reference/btsbot/train.py:178-199 and
+    utils.py:44-48 for GIVEN random draws -- RandomHorizontalFlip = flip of the last (width) axis,
+    RandomVerticalFlip = flip of the height axis, RandomRightAngleRotation = rotate(img, 0/90/180/270)
+    counter-clockwise, which on a square cutout is torch.rot90(img, k, (-2, -1)).  torchvision is not
+    installed here, so rot90's direction is pinned on a hand-written 3x3 case in the tests.
+  * metrics():  val.py:159-168 / train.py:550-558 with torch's own BCEWithLogitsLoss.
+"""
+import torch
+
+
+def augment(images: torch.Tensor, index, ops) -> torch.Tensor:
+    """ops[b] = hflip | vflip << 1 | k << 2;  out[b] = rot90^k(vflip?(hflip?(images[index[b]])))."""
+    n = len(ops) if ops is not None else (len(index) if index is not None else images.shape[0])
+    out = []
+    for b in range(n):
+        img = images[int(index[b])] if index is not None else images[b]
+        op = int(ops[b]) if ops is not None else 0
+        if op & 1:
+            img = torch.flip(img, dims=(-1,))
+        if op & 2:
+            img = torch.flip(img, dims=(-2,))
+        img = torch.rot90(img, (op >> 2) & 3, dims=(-2, -1))
+        out.append(img)
+    return torch.stack(out) if out else images[:0]
+
+
+def metrics(logits: torch.Tensor, labels: torch.Tensor, pos_weight: float):
+    z = logits.reshape(-1, 1).float()
+    y = labels.reshape(-1, 1).float()
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([pos_weight]))(z, y).item()
+    acc = ((torch.sigmoid(z) > 0.5).float() == y).float().mean().item()
+    return loss, acc

@@ -1,0 +1,155 @@
+"""Callers either side of the classifier path: on-device dataset + augmentation,
+validation metrics, checkpoint hand-over.  CPU tests pin the oracle and the host logic; GPU tests
+compare the HIP kernels (through the C ABI) with the oracle -- bit-exact for the index permutations."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import btsbot_amd
+from btsbot_amd import data, to_HF, val
+from btsbot_amd.synthetic import synthetic_batch
+from helpers import CONFIGS, seeded_state, build_model, run_model
+from oracle import data_oracle as DO
+
+
+# ---- CPU ------------------------------------------------------------------------------------------
+def test_oracle_rotation_direction_and_group_structure():
+    img = torch.arange(9.0).view(1, 1, 3, 3)
+    # 90 degrees counter-clockwise (transforms.functional.rotate's positive direction): the right
+    # column becomes the top row
+    r1 = DO.augment(img, None, [1 << 2])[0, 0]
+    assert r1.tolist() == [[2.0, 5.0, 8.0], [1.0, 4.0, 7.0], [0.0, 3.0, 6.0]]
+    x = torch.randn(5, 3, 63, 63, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(DO.augment(x, None, [2 << 2] * 5), DO.augment(x, None, [3] * 5))  # rot180 = h.v flips
+    twice = DO.augment(DO.augment(x, None, [1 << 2] * 5), None, [3 << 2] * 5)
+    assert torch.equal(twice, x)
+    idx = torch.tensor([4, 0, 0])
+    assert torch.equal(DO.augment(x, idx, [0, 0, 1])[2], torch.flip(x[0], dims=(-1,)))
+
+
+def test_checkpoint_round_trip(tmp_path, monkeypatch):
+    """best_model.pth + report.json -> train_config.json + pytorch_model.bin -> load_HF_model, with a
+    DataParallel-style ``module.`` prefix on the way in (to_HF.py:10-43, from_HF.py:59-81)."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.mm_ConvNeXt(cfg)
+    m.load_state_dict(sd)
+    mdir = tmp_path / "models" / "BTSbot-convnext-pico-randinit-metadata"
+    to_HF.save_checkpoint(m, cfg, str(mdir), {"val_acc": 0.5})
+    # a stock-BTSbot DataParallel checkpoint has the prefix: make sure it is accepted
+    state = torch.load(mdir / "best_model.pth")
+    assert list(state) == list(sd) and all(v.device.type == "cpu" for v in state.values())
+    torch.save({"module." + k: v for k, v in state.items()}, mdir / "best_model.pth")
+    config = to_HF.prep_config(str(mdir))
+    assert config == json.load(open(mdir / "train_config.json")) and config["model_name"] == "mm_ConvNeXt"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        to_HF.prep_model(str(mdir), config)
+        monkeypatch.chdir(tmp_path)
+        monkeypatch.setattr(btsbot_amd.from_HF, "device", "cpu")
+        m2 = btsbot_amd.load_HF_model("convnext", True, "randinit")
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    with pytest.raises(FileNotFoundError):
+        to_HF.prep_config(str(tmp_path))
+
+
+def test_device_dataset_refuses_cpu_and_nans():
+    img, meta, lab = synthetic_batch(8, seed=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        data.augment(img, None, None)
+    bad = meta.clone()
+    bad[0, 0] = float("nan")
+    with pytest.raises(ValueError, match="NaNs"):
+        data.DeviceDataset(img, bad, lab, 4, device="cpu")
+    ds = data.DeviceDataset(None, meta, lab, 3, device="cpu")
+    assert len(ds) == 2 and abs(ds.pos_weight - ds.num_notbts / max(ds.num_bts, 1)) < 1e-12
+    batches = list(ds)                       # metadata-only sets need no kernel
+    assert len(batches) == 2 and batches[0][0].shape == (3, 25)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_augment_kernel_is_the_exact_permutation(cuda):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 3, 63, 63, generator=g)
+    idx = torch.randint(0, 37, (64,), generator=g)
+    ops = torch.arange(64, dtype=torch.uint8) % 16          # every (hflip, vflip, k) combination
+    want = DO.augment(x, idx, ops)
+    got = data.augment(x.to(cuda), idx.to(cuda), ops.to(cuda)).cpu()
+    assert torch.equal(got, want)
+    assert torch.equal(data.augment(x.to(cuda), None, None).cpu(), x)
+    assert data.augment(x.to(cuda), idx[:0].to(cuda), ops[:0].to(cuda)).shape == (0, 3, 63, 63)
+
+
+@pytest.mark.gpu
+def test_device_dataset_epoch_is_a_permutation_with_reference_augment_rates(cuda):
+    img, meta, lab = synthetic_batch(1000, seed=3)
+    meta[:, 0] = torch.arange(1000.0)                      # tag every alert
+    gen = torch.Generator(device=cuda).manual_seed(0)
+    ds = data.DeviceDataset(img, meta, lab, 64, config={}, device=cuda, generator=gen)
+    seen, nflip = [], 0
+    for im, me, la in ds:
+        assert im.shape == (64, 3, 63, 63) and me.shape == (64, 25) and la.shape == (64,)
+        tags = me[:, 0].long().cpu()
+        seen.append(tags)
+        assert torch.equal(la.cpu(), lab[tags])
+        # every augmented cutout is one of the 8 dihedral images of its source
+        src = img[tags[0]]
+        cands = [torch.rot90(torch.flip(src, dims=(-1,)) if f else src, k, dims=(-2, -1))
+                 for f in (0, 1) for k in range(4)]
+        assert any(torch.equal(im[0].cpu(), c) for c in cands)
+        nflip += int(sum(not torch.equal(im[j].cpu(), img[tags[j]]) for j in range(8)))
+    seen = torch.cat(seen)
+    assert len(ds) == 15 and seen.numel() == 960 and seen.unique().numel() == 960    # drop_last
+    assert nflip > 60                                      # 7/8 of the draws change the image
+    ops = ds.draw_ops(20000).cpu()
+    assert abs((ops & 1).float().mean().item() - 0.5) < 0.02
+    assert abs(((ops >> 1) & 1).float().mean().item() - 0.5) < 0.02
+    assert torch.bincount((ops >> 2).long(), minlength=4).min().item() > 4600
+    off = data.DeviceDataset(img, meta, lab, 64, device=cuda,
+                             config=dict(data_aug_h_flip=False, data_aug_v_flip=False, data_aug_rot=False))
+    assert off.draw_ops(4) is None
+
+
+@pytest.mark.gpu
+def test_validation_pass_matches_oracle_metrics(cuda):
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "f32")
+    img, meta, lab = synthetic_batch(150, seed=8)
+    loss, acc, raw, labels = val.run_val_tensors(m, img, meta, lab, batch_size=64, pos_weight=2.5)
+    logits = run_model(kind, m, img.to(cuda), meta.to(cuda)).cpu()
+    want_loss, want_acc = DO.metrics(logits, lab, 2.5)
+    assert abs(loss - want_loss) < 1e-5 * max(1.0, want_loss) and abs(acc - want_acc) < 1e-6
+    assert raw.shape == (150,) and np.allclose(raw, torch.sigmoid(logits).squeeze(1).numpy(), atol=1e-6)
+    assert np.array_equal(labels, lab.float().numpy()) and not m.training
+    # default pos_weight = N_neg / N_pos of the split (val.py:60-62)
+    loss2, _, _, _ = val.run_val_tensors(m, img, meta, lab, batch_size=150)
+    pw = float((lab == 0).sum()) / float((lab == 1).sum())
+    assert abs(loss2 - DO.metrics(logits, lab, pw)[0]) < 1e-5 * max(1.0, loss2)
+
+
+@pytest.mark.gpu
+def test_train_epoch_over_device_dataset(cuda):
+    """train.py:481-566 end to end on the device: augmented batches -> Trainer.step -> epoch metrics."""
+    from btsbot_amd.train import Trainer, train_epoch
+    kind, cfg = CONFIGS["mm_pico"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.mm_ConvNeXt(dict(cfg, meta_dropout=0.0, comb_dropout=0.0), precision="bf16")
+    m.load_state_dict(seeded_state(kind, cfg, seed=3))
+    m = m.to(cuda).train()
+    img, meta, lab = synthetic_batch(192, seed=11)
+    ds = data.DeviceDataset(img, meta, lab, 64, config={}, device=cuda,
+                            generator=torch.Generator(device=cuda).manual_seed(1))
+    tr = Trainer(m, lr=1e-3, betas=(0.9, 0.999), pos_weight=ds.pos_weight, epochs=4, warmup_epochs=1)
+    hist = [train_epoch(tr, ds) for _ in range(3)]
+    assert all(np.isfinite(l) and 0.0 <= a <= 1.0 for l, a in hist)
+    assert tr.epoch == 3 and tr.t == 9

@@ -272,3 +272,18 @@ def test_maxvit_chunking_independence_and_modes(cuda):
     m.train()
     with pytest.raises(NotImplementedError):
         m(image_input=img, metadata_input=meta)
+
+
+@pytest.mark.parametrize("env", ["BTSBOT_AMD_MV_ATTN_VALU", "BTSBOT_AMD_MV_DW_PLAIN",
+                                 "BTSBOT_AMD_MV_MLP_UNFUSED"])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_maxvit_alternative_kernels_match_oracle(cuda, monkeypatch, env, prec):
+    """16-bit modes default to the MFMA attention kernel and the strip depthwise kernel with the fused
+    squeeze-excite pool; the switches select the one-query-per-lane / per-pixel kernels the f32 mode
+    uses.  Both must hold the same bound."""
+    monkeypatch.setenv(env, "1")
+    kind, cfg, sd = _mv("mm_maxvit")
+    img, meta, _ = synthetic_batch(3, seed=2)
+    ref = _mv_oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
