@@ -12,6 +12,8 @@
 //         16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7);
 //   * the epilogue is staged through the (then idle) ring so that HBM sees whole rows: 16-byte
 //     vectors, 256..512 contiguous bytes per output row instead of 8-byte pieces.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   constexpr bool TOUT = EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T;   // operand-typed output
   using OT = typename std::conditional<TOUT, T, float>::type;
   constexpr int OPITCH = TN * (int)sizeof(OT) + 16;  // epilogue staging row pitch
-    static_assert(NSLOT == 2 || NSLOT == 3, "ring depth");
+  static_assert(NSLOT >= 1 && NSLOT <= 3, "ring depth");   // NSLOT == 1: K == 64 only (one k-tile)
   static_assert(WM * WN == 4 && XB >= 1 && WB >= 1, "tile/wave layout");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
     // tile kt has landed for this wave once only the younger tiles are outstanding
     if (NSLOT == 3 && kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // ... for every wave; and everyone is done reading tile kt-1
-    if (kt + NSLOT - 1 < nk) issue(kt + NSLOT - 1, (kt + NSLOT - 1) % NSLOT);
+    if (NSLOT > 1 && kt + NSLOT - 1 < nk) issue(kt + NSLOT - 1, (kt + NSLOT - 1) % NSLOT);
     const unsigned char* xs = smem + (kt % NSLOT) * SLOT;
     const unsigned char* ws = xs + TM * ROWB;
 #pragma unroll
@@ -215,8 +217,19 @@ int launch_typed2(const void* X, const void* W, const float* bias, const float* 
   const T* x = reinterpret_cast<const T*>(X);
   const T* w = reinterpret_cast<const T*>(W);
   const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (N >= 128 && wg128 >= 256)
+  // K == 64 is a single k-tile: a one-slot ring halves (thirds) the LDS per workgroup, so twice (three
+  // times) as many workgroups share a CU and cover each other's load -> MFMA -> store chain
+  static const bool one_slot = [] {
+    const char* e = getenv("BTSBOT_AMD_GEMM2_NO_1SLOT");
+    return !(e != nullptr && e[0] == '1');
+  }();
+  if (N >= 128 && wg128 >= 256) {
+    if (K == 64 && one_slot)
+      return launch_tile2<T, 128, 128, 2, 2, EPI, 1>(x, w, bias, gamma, resid, out, M, N, K, st);
     return launch_tile2<T, 128, 128, 2, 2, EPI, 2>(x, w, bias, gamma, resid, out, M, N, K, st);
+  }
+  if (K == 64 && one_slot)
+    return launch_tile2<T, 64, 64, 2, 2, EPI, 1>(x, w, bias, gamma, resid, out, M, N, K, st);
   return launch_tile2<T, 64, 64, 2, 2, EPI, 3>(x, w, bias, gamma, resid, out, M, N, K, st);
 }
 

@@ -48,6 +48,8 @@ def augment(images: torch.Tensor, index: Optional[torch.Tensor], ops: Optional[t
         if ops.numel() != n:
             raise ValueError("ops length != batch")
     out = torch.empty(n, 3, 63, 63, dtype=torch.float32, device=images.device)
+    if n == 0:
+        return out
     with torch.cuda.device(images.device):
         st = torch.cuda.current_stream(images.device).cuda_stream
         _lib.check(_lib.lib().btsbot_augment(

@@ -15,6 +15,10 @@ published ConvNeXt-v1 block; it is written independently of oracle/convnext_orac
 (module form vs functional form) so the two cross-check each other, and both are checked
 against ``transformers.ConvNextModel``.
 
+``MaxxVitStandIn`` does the same for ``maxvit_tiny_rw_224`` (architectures.py:31,62: ``.head.in_features``,
+``.head.global_pool``, ``backbone(x)``), with timm's MaxxVit parameter names; see
+oracle/maxvit_oracle.py for what is and is not pinned about that definition.
+
 Use:  ``install()`` puts this module in ``sys.modules['timm']``.
 """
 from __future__ import annotations
