@@ -140,6 +140,13 @@ int launch_gemm2(int prec, int epi, const void* X, const void* W, const float* b
                  const float* gamma, const float* resid, void* out, int M, int N, int K,
                  hipStream_t st);
 
+// LDS-free streaming variant for K in {64,128} (gemm3.hip): filter slice in registers, activation rows
+// fetched as MFMA fragments; 16-bit modes, N % 32 == 0, epilogues SILU / BIAS_T / GELU / RESID / BIAS
+bool gemm3_supported(int prec, int epi, int M, int N, int K);
+int launch_gemm3(int prec, int epi, const void* X, const void* W, const float* bias,
+                 const float* gamma, const float* resid, void* out, int M, int N, int K,
+                 hipStream_t st);
+
 // stem: conv 4x4 s4 (+bias) + LayerNorm over C0.  img [B,3,63,63] fp32 -> out [B,225,C0] fp32.
 int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
                 const float* lnb, float* out, int B, int C0, hipStream_t st);

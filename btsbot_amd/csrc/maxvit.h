@@ -53,6 +53,9 @@ int launch_mv_attn(int prec, const void* qkv, const float* bias_t, void* out, in
 int launch_mv_attn_mfma(int prec, const void* qkv, const float* bias64, void* out, int B, int H, int C,
                         int grid_mode, hipStream_t st);
 int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStream_t st);
+// stem conv 3x3 s1 p1 32 -> 64 as an LDS-free implicit GEMM (16-bit modes): in [B,112,112,32] T,
+// w = the [64][288] image of launch_mv_pack_conv3, out [B,112,112,64] f32
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int B, hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

@@ -55,6 +55,8 @@ struct MaxVit {
   // workspace offsets (bytes) for the current reservation
   size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr;
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
+  bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
+  bool no_gemm3 = false;    // BTSBOT_AMD_MV_NO_GEMM3=1: LDS-tiled GEMMs for the K = 64 / 128 shapes too
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -139,6 +141,10 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->attn_valu = e != nullptr && e[0] == '1';
     const char* d = getenv("BTSBOT_AMD_MV_DW_PLAIN");
     mv->dw_plain = d != nullptr && d[0] == '1';
+    const char* s2 = getenv("BTSBOT_AMD_MV_STEM_IM2COL");
+    mv->stem_im2col = s2 != nullptr && s2[0] == '1';
+    const char* g3 = getenv("BTSBOT_AMD_MV_NO_GEMM3");
+    mv->no_gemm3 = g3 != nullptr && g3[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -286,6 +292,14 @@ size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk) {
   return total;
 }
 
+// GEMM dispatch of the MaxViT schedule: the LDS-free streaming kernel where it applies (K = 64 / 128)
+static int mv_gemm(const MaxVit* mv, int prec, int epi, const void* X, const void* W, const float* bias,
+                   const float* gamma, const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+  if (!mv->no_gemm3 && gemm3_supported(prec, epi, M, N, K))
+    return launch_gemm3(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
+  return launch_gemm(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
+}
+
 template <typename F> static int mv_timed(btsbot_ctx* h, int cat, hipStream_t st, F&& fn) {
   const bool rec = h->prof_on && h->prof_used < PROF_MAX_LAUNCHES;
   if (rec) HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_used], st));
@@ -327,11 +341,15 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     return launch_gemm(prec, EPI_SILU, Bb, ex + mv->p_stem1, F(mv->stem_bn.p_shift), nullptr, nullptr,
                        Cc, M0, 32, 32, st);
   }));
-  MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_im2col3(prec, Cc, A, nb, 112, 32, st); }));
-  MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
-    return launch_gemm(prec, EPI_BIAS, A, ex + mv->p_stem2, zero, nullptr, nullptr, x, M0, 64, 288,
-                       st);
-  }));
+  if (prec != BTSBOT_F32 && !mv->stem_im2col) {
+    MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] { return launch_mv_stem2(prec, Cc, ex + mv->p_stem2, x, nb, st); }));
+  } else {
+    MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_im2col3(prec, Cc, A, nb, 112, 32, st); }));
+    MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
+      return launch_gemm(prec, EPI_BIAS, A, ex + mv->p_stem2, zero, nullptr, nullptr, x, M0, 64, 288,
+                         st);
+    }));
+  }
   if (h->debug && h->taps[0])
     HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)M0 * 64 * 4, hipMemcpyDeviceToDevice, st));
 
@@ -348,7 +366,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           return launch_mv_avgpool2(prec, x, E, 1, nb, b.hin, b.cin, st);
         }));
         MTRY(mv_timed(h, CAT_MV_G_SC, st, [&] {
-          return launch_gemm(prec, EPI_BIAS, E, ex + b.p_sc, zero, nullptr, nullptr, x2, Mo, b.c,
+          return mv_gemm(mv, prec, EPI_BIAS, E, ex + b.p_sc, zero, nullptr, nullptr, x2, Mo, b.c,
                              b.cin, st);
         }));
       } else {
@@ -363,7 +381,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
     }));
     MTRY(mv_timed(h, CAT_MV_G_CONV1, st, [&] {
-      return launch_gemm(prec, EPI_SILU, Cc, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
+      return mv_gemm(mv, prec, EPI_SILU, Cc, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
                          b.cin, st);
     }));
     const float inv_hw = 1.0f / (float)(b.hout * b.hout);
@@ -402,7 +420,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_QKV, st, [&] {
-        return launch_gemm(prec, EPI_BIAS_T, Cc, ex + a.p_qkv, m + a.qkv_b, nullptr, nullptr, D, Mo,
+        return mv_gemm(mv, prec, EPI_BIAS_T, Cc, ex + a.p_qkv, m + a.qkv_b, nullptr, nullptr, D, Mo,
                            3 * c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_ATTN, st, [&] {
@@ -411,7 +429,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         return launch_mv_attn(prec, D, F(a.p_bias), E, nb, b.hout, c, g, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
-        return launch_gemm(prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
+        return mv_gemm(mv, prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
         return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);

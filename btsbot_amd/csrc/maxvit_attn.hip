@@ -226,3 +226,85 @@ int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStrea
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stem conv 3x3 s1 p1 (32 -> 64) as an implicit GEMM without LDS (16-bit modes): every tap is one
+// K = 32 step of v_mfma_f32_16x16x32.  The 64 x 288 filter lives in registers as 36 A fragments per wave
+// (loaded once, reused over the wave's image rows); the B fragment of a tap is a 16-byte piece of each of
+// 16 neighbouring input pixels, fetched straight from the NHWC map (L1/L2 serve the 9x re-reads), zero
+// for taps that fall off the image.  Replaces mv_im2col3_kernel + GEMM, which moved a 7.2 MB/alert patch
+// matrix through HBM twice.  in [B,112,112,32] T -> out [B,112,112,64] f32.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
+                                                       const T* __restrict__ w, float* __restrict__ out,
+                                                       int rows_total, int rows_per_wave) {
+  using frag = typename AM<T>::frag;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  frag wf[4][9];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      wf[mt][tap] = *reinterpret_cast<const frag*>(w + (mt * 16 + l15) * 288 + tap * 32 + g * 8);
+  frag zero;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = wid * rows_per_wave + rr;
+    if (row >= rows_total) break;                      // wave-uniform
+    const long b = row / 112;
+    const int y = row - (int)b * 112;
+    for (int xt = 0; xt < 7; ++xt) {
+      const int x = xt * 16 + l15;
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if (iy < 0 || iy >= 112) continue;             // wave-uniform
+        const T* rowp = in + ((b * 112 + iy) * 112) * 32 + g * 8;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = x + kx - 1;
+          const bool ok = ix >= 0 && ix < 112;
+          frag xf = *reinterpret_cast<const frag*>(rowp + (long)(ok ? ix : x) * 32);
+          if (!ok) xf = zero;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf, acc[mt]);
+        }
+      }
+      float* o = out + ((b * 112 + y) * 112 + x) * 64 + 4 * g;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        *reinterpret_cast<float4*>(o + mt * 16) =
+            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int B, hipStream_t st) {
+  if (B <= 0) return BTSBOT_OK;
+  if (prec != BTSBOT_BF16 && prec != BTSBOT_F16) {
+    btsbot_set_error("mv_stem2: 16-bit modes only (precision %d)", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const int rows = B * 112, rpw = 4;
+  const int waves = (rows + rpw - 1) / rpw;
+  const dim3 grid((waves + 3) / 4);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(mv_stem2_kernel<bf16_t>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(in), reinterpret_cast<const bf16_t*>(w), out, rows,
+                       rpw);
+  else
+    hipLaunchKernelGGL(mv_stem2_kernel<f16_t>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const f16_t*>(in), reinterpret_cast<const f16_t*>(w), out, rows,
+                       rpw);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
