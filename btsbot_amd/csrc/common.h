@@ -68,6 +68,13 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU for the 16-bit modes: v_exp + v_rcp instead of the IEEE division sequence (relative error ~1e-6,
+// far below half an ulp of f16 / bf16); the fp32 parity mode keeps silu_f
+__device__ __forceinline__ float silu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+template <typename T> __device__ __forceinline__ float silu_for(float x) { return silu_fast(x); }
+template <> __device__ __forceinline__ float silu_for<float>(float x) { return silu_f(x); }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
@@ -139,6 +146,10 @@ bool gemm2_supported(int prec, int M, int N, int K);
 int launch_gemm2(int prec, int epi, const void* X, const void* W, const float* bias,
                  const float* gamma, const float* resid, void* out, int M, int N, int K,
                  hipStream_t st);
+
+int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const float* zero_bias,
+                               const float* one_gamma, const float* resid, float* out, int batch, int M,
+                               int N, int K, hipStream_t st);
 
 // LDS-free streaming variant for K in {64,128} (gemm3.hip): filter slice in registers, activation rows
 // fetched as MFMA fragments; 16-bit modes, N % 32 == 0, epilogues SILU / BIAS_T / GELU / RESID / BIAS

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
         T4 v;
         const float p[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_f(p[e]) : p[e]);
+        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_for<T>(p[e]) : p[e]);
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
       } else if (EPI == EPI_RESID) {
         const float4 r = *reinterpret_cast<const float4*>(resid + o);

@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
                                                     const float* __restrict__ bias,
                                                     const float* __restrict__ gamma,
                                                     const float* resid, void* out, int M, int N,
-                                                    int K) {
+                                                    int K, long bsX = 0, long bsW = 0, long bsO = 0) {
   using MM = Mma2<T>;
+  // batched form (gridDim.z > 1): problem z reads X + z*bsX, W + z*bsW and writes out/resid + z*bsO
+  X += blockIdx.z * bsX;
+  W += blockIdx.z * bsW;
   using frag = typename MM::frag;
   constexpr int ROWB = 128;                       // bytes per staged row (64 elements)
   constexpr int SLOT = (TM + TN) * ROWB;          // one ring slot
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
         T4 v;
         const float p[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_f(p[e]) : p[e]);
+        for (int e = 0; e < 4; ++e) v[e] = (T)(EPI == EPI_SILU ? silu_for<T>(p[e]) : p[e]);
         *reinterpret_cast<T4*>(dst) = v;
       } else {
         *reinterpret_cast<float4*>(dst) =
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
     const int m = m0 + ml, n = n0 + ch * EPC;
     if (m >= M || n >= N) continue;
     uint4 v = *reinterpret_cast<const uint4*>(smem + ml * OPITCH + ch * 16);
-    const size_t o = (size_t)m * N + n;
+    const size_t o = (size_t)blockIdx.z * bsO + (size_t)m * N + n;
     if (EPI == EPI_RESID) {
       const float4 r = *reinterpret_cast<const float4*>(resid + o);
       float4 f = *reinterpret_cast<float4*>(&v);
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
 
 template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
 int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
-                 const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+                 const float* resid, void* out, int M, int N, int K, hipStream_t st, int batch = 1,
+                 long bsX = 0, long bsW = 0, long bsO = 0) {
   constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
   constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
@@ -205,8 +209,9 @@ int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, bias, gamma, resid, out, M, N, K);
+  dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, bias, gamma, resid, out, M, N, K, bsX, bsW,
+                     bsO);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -248,6 +253,29 @@ int launch_epi2(int epi, const void* X, const void* W, const float* bias, const 
 }
 
 }  // namespace
+
+// out_b (f32) = resid_b + X_b . W_b^T for `batch` independent problems of M rows each (per-alert filters)
+int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const float* zero_bias,
+                               const float* one_gamma, const float* resid, float* out, int batch, int M,
+                               int N, int K, hipStream_t st) {
+  if (!gemm2_supported(prec, M, N, K) || batch < 1) {
+    btsbot_set_error("gemm2_batched: unsupported (prec %d, M %d, N %d, K %d)", prec, M, N, K);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const long bsX = (long)M * K, bsW = (long)N * K, bsO = (long)M * N;
+  const bool big = N >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 256;
+#define G2B(TT)                                                                                         \
+  (big ? launch_tile2<TT, 128, 128, 2, 2, EPI_RESID, 2>(reinterpret_cast<const TT*>(X),                \
+                                                        reinterpret_cast<const TT*>(W), zero_bias,      \
+                                                        one_gamma, resid, out, M, N, K, st, batch, bsX,  \
+                                                        bsW, bsO)                                        \
+       : launch_tile2<TT, 64, 64, 2, 2, EPI_RESID, 3>(reinterpret_cast<const TT*>(X),                  \
+                                                      reinterpret_cast<const TT*>(W), zero_bias,        \
+                                                      one_gamma, resid, out, M, N, K, st, batch, bsX,    \
+                                                      bsW, bsO))
+  return prec == BTSBOT_BF16 ? G2B(bf16_t) : G2B(f16_t);
+#undef G2B
+}
 
 bool gemm2_supported(int prec, int M, int N, int K) {
   return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && K % 64 == 0 && N % 64 == 0 && N >= 64 &&

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const T* __restrict__ X, con
         T8 r;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          r[e] = (T)(EPI == EPI_SILU ? silu_f(v[e]) : EPI == EPI_GELU ? gelu_fast(v[e]) : v[e]);
+          r[e] = (T)(EPI == EPI_SILU ? silu_fast(v[e]) : EPI == EPI_GELU ? gelu_fast(v[e]) : v[e]);
         *reinterpret_cast<T8*>(reinterpret_cast<T*>(out) + o) = r;
       } else {
         if (EPI == EPI_RESID) {

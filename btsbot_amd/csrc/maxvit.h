@@ -37,6 +37,11 @@ int launch_mv_dw3s(int prec, const void* in, const float* w9, const float* bias,
 int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2t,
                  const float* b2, float* gate, float* scratch, int B, int HW, int C, int RD,
                  float inv_count, hipStream_t st);
+// y [B,HW,C] T *= gate [B,C] in place (16-bit modes)
+int launch_mv_gate(int prec, void* y, const float* gate, int B, int HW, int C, hipStream_t st);
+// wg [B][N][K] T = w [N][K] f32 * gate [B][K]
+int launch_mv_scale_w(int prec, const float* w, const float* gate, void* wg, int B, int N, int K,
+                      hipStream_t st);
 // 2x2 average pool of the fp32 residual map: x [B,H,H,C] -> out [B,H/2,H/2,C] (T when to_t, else f32)
 int launch_mv_avgpool2(int prec, const float* x, void* out, int to_t, int B, int H, int C,
                        hipStream_t st);
@@ -55,7 +60,9 @@ int launch_mv_attn_mfma(int prec, const void* qkv, const float* bias64, void* ou
 int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStream_t st);
 // stem conv 3x3 s1 p1 32 -> 64 as an LDS-free implicit GEMM (16-bit modes): in [B,112,112,32] T,
 // w = the [64][288] image of launch_mv_pack_conv3, out [B,112,112,64] f32
-int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int B, hipStream_t st);
+// (xn != NULL: also xn [B,112,112,64] T = out * scale[c] + shift[c], the next block's pre-norm)
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, void* xn, const float* scale,
+                    const float* shift, int B, hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

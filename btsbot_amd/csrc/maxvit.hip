@@ -53,10 +53,12 @@ struct MaxVit {
   size_t p_stem1, p_stem2, p_zero, p_one;
   std::vector<MvBlock> blocks;
   // workspace offsets (bytes) for the current reservation
-  size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr;
+  size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr, o_wg;
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
   bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
-  bool no_gemm3 = false;    // BTSBOT_AMD_MV_NO_GEMM3=1: LDS-tiled GEMMs for the K = 64 / 128 shapes too
+  bool no_gemm3 = true;     // BTSBOT_AMD_MV_GEMM3=1: LDS-free streaming GEMM (gemm3.hip) for the K = 64 / 128 shapes
+                            // (measured slower than gemm2 on these shapes: opt-in, kept as the record)
+  bool gated_gemm = false;  // BTSBOT_AMD_MV_GATED_GEMM=1: register-staged gated GEMM for every conv3 (f32 mode's path)
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -143,8 +145,10 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->dw_plain = d != nullptr && d[0] == '1';
     const char* s2 = getenv("BTSBOT_AMD_MV_STEM_IM2COL");
     mv->stem_im2col = s2 != nullptr && s2[0] == '1';
-    const char* g3 = getenv("BTSBOT_AMD_MV_NO_GEMM3");
-    mv->no_gemm3 = g3 != nullptr && g3[0] == '1';
+    const char* g3 = getenv("BTSBOT_AMD_MV_GEMM3");
+    mv->no_gemm3 = !(g3 != nullptr && g3[0] == '1');
+    const char* gg = getenv("BTSBOT_AMD_MV_GATED_GEMM");
+    mv->gated_gemm = gg != nullptr && gg[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -281,6 +285,7 @@ static void mv_layout(const btsbot_ctx* h, int chunk, MaxVit* out, size_t* total
   o->o_e = bump(n * 3136 * 64 * esz);      // attention output; pooled shortcut input
   o->o_gate = bump(n * 2048 * 4);
   o->o_feat = bump(n * 512 * 4);
+  o->o_wg = bump(n * 65536 * esz);          // per-alert gated conv3 filters (<= 128 x 512)
   o->o_sescr = bump(n * (2048 + 128) * 4);   // squeeze-excite mean + hidden
   o->o_part = bump(n * 14336 * 4);         // squeeze-excite partial sums [<=56 groups][mid], 14336 floats max
   *total = cur;
@@ -331,9 +336,11 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
   float* feat = reinterpret_cast<float*>(h->ws + mv->o_feat);
   float* part = reinterpret_cast<float*>(h->ws + mv->o_part);
   float* sescr = reinterpret_cast<float*>(h->ws + mv->o_sescr);
+  void* wg = h->ws + mv->o_wg;
   const float* zero = F(mv->p_zero);
   const float* one = F(mv->p_one);
 
+  bool xn_ready = false;
   // ---- stem: resize + conv3x3 s2 (+BN, SiLU) + conv3x3 s1, both as im2col GEMMs
   const int M0 = nb * 12544;
   MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_resize_im2col(prec, img, Bb, nb, st); }));
@@ -342,7 +349,12 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
                        Cc, M0, 32, 32, st);
   }));
   if (prec != BTSBOT_F32 && !mv->stem_im2col) {
-    MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] { return launch_mv_stem2(prec, Cc, ex + mv->p_stem2, x, nb, st); }));
+    // (writes block 0's pre-norm + cast into the conv1 im2col buffer, which is free by now)
+    const MvBlock& b0 = mv->blocks[0];
+    MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
+      return launch_mv_stem2(prec, Cc, ex + mv->p_stem2, x, Bb, F(b0.pre.p_scale), F(b0.pre.p_shift), nb, st);
+    }));
+    xn_ready = true;
   } else {
     MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_im2col3(prec, Cc, A, nb, 112, 32, st); }));
     MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
@@ -354,6 +366,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     HIP_TRY(hipMemcpyAsync(h->taps[0], x, (size_t)M0 * 64 * 4, hipMemcpyDeviceToDevice, st));
 
   int stage = 0, jblk = 0;
+  // (bool xn_ready: block 0's BN-cast input already sits in Bb)
   for (size_t bi = 0; bi < mv->blocks.size(); ++bi) {
     const MvBlock& b = mv->blocks[bi];
     const int Min = nb * b.hin * b.hin, Mo = nb * b.hout * b.hout;
@@ -377,11 +390,16 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
       resid = x2;
       dst = x2;
     }
-    MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
-      return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
-    }));
+    const void* c1_in = Cc;
+    if (bi == 0 && xn_ready) {
+      c1_in = Bb;
+    } else {
+      MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
+        return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
+      }));
+    }
     MTRY(mv_timed(h, CAT_MV_G_CONV1, st, [&] {
-      return mv_gemm(mv, prec, EPI_SILU, Cc, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
+      return mv_gemm(mv, prec, EPI_SILU, c1_in, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
                          b.cin, st);
     }));
     const float inv_hw = 1.0f / (float)(b.hout * b.hout);
@@ -403,10 +421,26 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
                             b.hout * b.hout, b.mid, b.rd, inv_hw, st);
       }));
     }
-    MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
-      return launch_gemm_gated(prec, Bb, gate, b.hout * b.hout, ex + b.p_c3, resid, dst, Mo, b.c,
-                               b.mid, st);
-    }));
+    const int hw2 = b.hout * b.hout;
+    if (prec != BTSBOT_F32 && !mv->gated_gemm && (size_t)b.c * b.mid * 4 <= (size_t)hw2 * b.mid) {
+      // wide stages: per-alert filters W3 diag(g_b) (a fraction of the map's size) + batched LDS-DMA GEMM
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
+        return launch_mv_scale_w(prec, m + b.c3_w, gate, wg, nb, b.c, b.mid, st);
+      }));
+      MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
+        return launch_gemm2_batched_resid(prec, Bb, wg, zero, one, resid, dst, nb, hw2, b.c, b.mid, st);
+      }));
+    } else if (prec != BTSBOT_F32 && !mv->gated_gemm) {
+      // narrow stages: the map is small -- gate it in place, then the plain LDS-DMA GEMM
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] { return launch_mv_gate(prec, Bb, gate, nb, hw2, b.mid, st); }));
+      MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
+        return launch_gemm(prec, EPI_RESID, Bb, ex + b.p_c3, zero, one, resid, dst, Mo, b.c, b.mid, st);
+      }));
+    } else {
+      MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
+        return launch_gemm_gated(prec, Bb, gate, hw2, ex + b.p_c3, resid, dst, Mo, b.c, b.mid, st);
+      }));
+    }
     if (b.stride == 2) {   // the block's output lives in x2: swap the roles of the two maps
       float* t = x;
       x = x2;

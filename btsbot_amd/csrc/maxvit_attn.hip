@@ -239,7 +239,9 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
                                                        const T* __restrict__ w, float* __restrict__ out,
-                                                       int rows_total, int rows_per_wave) {
+                                                       T* __restrict__ xn, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int rows_total,
+                                                       int rows_per_wave) {
   using frag = typename AM<T>::frag;
   const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -277,18 +279,31 @@ __global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
           for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf, acc[mt]);
         }
       }
-      float* o = out + ((b * 112 + y) * 112 + x) * 64 + 4 * g;
+      const long po = ((b * 112 + y) * 112 + x) * 64 + 4 * g;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        *reinterpret_cast<float4*>(o + mt * 16) =
+      for (int mt = 0; mt < 4; ++mt) {
+        *reinterpret_cast<float4*>(out + po + mt * 16) =
             make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+        if (xn != nullptr) {   // the first MBConv block's pre-norm BatchNorm + cast, while the values are here
+          const float4 sc = *reinterpret_cast<const float4*>(scale + mt * 16 + 4 * g);
+          const float4 sh = *reinterpret_cast<const float4*>(shift + mt * 16 + 4 * g);
+          typedef T __attribute__((ext_vector_type(4))) T4;
+          T4 v;
+          v[0] = (T)(acc[mt][0] * sc.x + sh.x);
+          v[1] = (T)(acc[mt][1] * sc.y + sh.y);
+          v[2] = (T)(acc[mt][2] * sc.z + sh.z);
+          v[3] = (T)(acc[mt][3] * sc.w + sh.w);
+          *reinterpret_cast<T4*>(xn + po + mt * 16) = v;
+        }
+      }
     }
   }
 }
 
 }  // namespace
 
-int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int B, hipStream_t st) {
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, void* xn, const float* scale,
+                    const float* shift, int B, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
   if (prec != BTSBOT_BF16 && prec != BTSBOT_F16) {
     btsbot_set_error("mv_stem2: 16-bit modes only (precision %d)", prec);
@@ -299,12 +314,12 @@ int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int B, 
   const dim3 grid((waves + 3) / 4);
   if (prec == BTSBOT_BF16)
     hipLaunchKernelGGL(mv_stem2_kernel<bf16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(in), reinterpret_cast<const bf16_t*>(w), out, rows,
-                       rpw);
+                       reinterpret_cast<const bf16_t*>(in), reinterpret_cast<const bf16_t*>(w), out,
+                       reinterpret_cast<bf16_t*>(xn), scale, shift, rows, rpw);
   else
     hipLaunchKernelGGL(mv_stem2_kernel<f16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const f16_t*>(in), reinterpret_cast<const f16_t*>(w), out, rows,
-                       rpw);
+                       reinterpret_cast<const f16_t*>(in), reinterpret_cast<const f16_t*>(w), out,
+                       reinterpret_cast<f16_t*>(xn), scale, shift, rows, rpw);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

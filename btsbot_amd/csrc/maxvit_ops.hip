@@ -130,10 +130,10 @@ __global__ __launch_bounds__(256) void mv_dw3_kernel(const T* __restrict__ in,
     }
   }
   T4 o;
-  o[0] = (T)silu_f(acc.x);
-  o[1] = (T)silu_f(acc.y);
-  o[2] = (T)silu_f(acc.z);
-  o[3] = (T)silu_f(acc.w);
+  o[0] = (T)silu_for<T>(acc.x);
+  o[1] = (T)silu_for<T>(acc.y);
+  o[2] = (T)silu_for<T>(acc.z);
+  o[3] = (T)silu_for<T>(acc.w);
   *reinterpret_cast<T4*>(out + pix * C + c) = o;
 }
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void mv_dw3s_kernel(const T* __restrict__ in,
       T8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o[e] = (T)silu_f(acc[p][e]);
+        o[e] = (T)silu_fast(acc[p][e]);
         psum[e] += (float)o[e];          // the pool sees the rounded activations, like the separate pass
       }
       *reinterpret_cast<T8*>(orow + (long)p * C) = o;
@@ -514,6 +514,47 @@ __global__ __launch_bounds__(256) void mv_final_kernel(const float* __restrict__
     feat[(size_t)b * C + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) * (1.0f / (float)P);
 }
 
+// y[b][p][c] *= gate[b][c] in place (the narrow MBConv stages: the map is small, and the projection can then
+// run on the LDS-DMA GEMM instead of the register-staged gated one)
+template <typename T>
+__global__ __launch_bounds__(256) void mv_gate_kernel(T* __restrict__ y, const float* __restrict__ gate,
+                                                      long n8, int HW, int C) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n8) return;
+  const int c8n = C / 8;
+  const int c = (int)(i % c8n) * 8;
+  const long b = i / ((long)c8n * HW);
+  typedef T __attribute__((ext_vector_type(8))) T8;
+  T8 v = *reinterpret_cast<T8*>(y + i * 8);
+  const float4 g0 = *reinterpret_cast<const float4*>(gate + b * C + c);
+  const float4 g1 = *reinterpret_cast<const float4*>(gate + b * C + c + 4);
+  v[0] = (T)((float)v[0] * g0.x); v[1] = (T)((float)v[1] * g0.y);
+  v[2] = (T)((float)v[2] * g0.z); v[3] = (T)((float)v[3] * g0.w);
+  v[4] = (T)((float)v[4] * g1.x); v[5] = (T)((float)v[5] * g1.y);
+  v[6] = (T)((float)v[6] * g1.z); v[7] = (T)((float)v[7] * g1.w);
+  *reinterpret_cast<T8*>(y + i * 8) = v;
+}
+
+// wg[b][n][k] = w[n][k] * gate[b][k]: per-alert projection filters of the wide MBConv stages, where the
+// filter (32..128 KB) is far smaller than the map it multiplies
+template <typename T>
+__global__ __launch_bounds__(256) void mv_scale_w_kernel(const float* __restrict__ w,
+                                                         const float* __restrict__ gate,
+                                                         T* __restrict__ wg, long total, int N, int K) {
+  const long i = blockIdx.x * 256L + threadIdx.x;    // 4 k per thread
+  if (i >= total) return;
+  const int k4n = K / 4;
+  const int k = (int)(i % k4n) * 4;
+  const int n = (int)((i / k4n) % N);
+  const long b = i / ((long)k4n * N);
+  const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)n * K + k);
+  const float4 gv = *reinterpret_cast<const float4*>(gate + b * K + k);
+  typedef typename V4<T>::type T4;
+  T4 o;
+  o[0] = (T)(wv.x * gv.x); o[1] = (T)(wv.y * gv.y); o[2] = (T)(wv.z * gv.z); o[3] = (T)(wv.w * gv.w);
+  *reinterpret_cast<T4*>(wg + (b * N + n) * K + k) = o;
+}
+
 // ---- packing ------------------------------------------------------------------------------------
 template <typename T>
 __global__ void mv_pack_stem1_kernel(const float* w, const float* scale, T* out) {
@@ -681,6 +722,33 @@ int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, cons
                      mean, w1, b1, s, B, C, RD);
   hipLaunchKernelGGL(mv_se_fc2_kernel, dim3((B + SE_AG - 1) / SE_AG, (C + 255) / 256), dim3(256),
                      (size_t)SE_AG * RD * sizeof(float), st, s, w2t, b2, gate, B, C, RD);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_mv_gate(int prec, void* y, const float* gate, int B, int HW, int C, hipStream_t st) {
+  if (prec == BTSBOT_F32 || C % 8 != 0) {
+    btsbot_set_error("mv_gate: 16-bit modes, C %% 8 == 0 (prec %d, C %d)", prec, C);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const long n8 = (long)B * HW * C / 8;
+  if (n8 <= 0) return BTSBOT_OK;
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(mv_gate_kernel<bf16_t>, dim3(nblk(n8)), dim3(256), 0, st,
+                       reinterpret_cast<bf16_t*>(y), gate, n8, HW, C);
+  else
+    hipLaunchKernelGGL(mv_gate_kernel<f16_t>, dim3(nblk(n8)), dim3(256), 0, st,
+                       reinterpret_cast<f16_t*>(y), gate, n8, HW, C);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_mv_scale_w(int prec, const float* w, const float* gate, void* wg, int B, int N, int K,
+                      hipStream_t st) {
+  const long total = (long)B * N * (K / 4);
+  if (total <= 0) return BTSBOT_OK;
+  MV_DISPATCH(prec, hipLaunchKernelGGL(mv_scale_w_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, w, gate,
+                                       reinterpret_cast<T*>(wg), total, N, K));
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
