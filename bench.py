@@ -158,7 +158,7 @@ def maxvit_family_work(batch, precision):
     w = {k: dict(flop=0, bytes=0) for k in (
         "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
         "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
-        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
+        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
         "mv_attn_kernel", "head_kernel")}
 
     def add(k, macs, nbytes):
@@ -170,8 +170,12 @@ def maxvit_family_work(batch, precision):
     for cin, c, mid, s, hi, ho in maxvit_blocks():
         pi, po = hi * hi, ho * ho
         add("mv_elementwise", 0, pi * cin * (4 + esz) + (po * cin * (4 + esz) if s == 2 else 0))
-        add("mv_gemm<conv1,SILU>", pi * cin * mid, pi * (cin + mid) * esz)
-        add("mv_dw3_kernel", po * 9 * mid, (pi + po) * mid * esz)
+        if precision != "f32" and cin in (64, 128) and ho >= 28 and \
+                os.environ.get("BTSBOT_AMD_MV_NO_FRONT", "0") != "1":
+            add("mv_mbconv_front", pi * cin * mid + po * 9 * mid, (pi * cin + po * mid) * esz)
+        else:
+            add("mv_gemm<conv1,SILU>", pi * cin * mid, pi * (cin + mid) * esz)
+            add("mv_dw3_kernel", po * 9 * mid, (pi + po) * mid * esz)
         add("mv_se_kernel", 2 * mid * (mid // 16), po * mid * esz)
         add("mv_gemm<conv3,gated>", po * mid * c, po * (mid * esz + 8 * c))
         if s == 2 and cin != c:

@@ -27,7 +27,7 @@ SYMBOLS = [
     "btsbot_profile_collect",
     "btsbot_op_gemm", "btsbot_op_dwconv_ln", "btsbot_op_stem", "btsbot_op_ln_patch",
     "btsbot_reserve_train", "btsbot_forward_train", "btsbot_backward", "btsbot_debug_stamps",
-    "btsbot_augment", "btsbot_eval_metrics",
+    "btsbot_augment", "btsbot_eval_metrics", "btsbot_prep_triplets",
 ]
 
 
@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
     L.btsbot_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.btsbot_augment.restype = i32
     L.btsbot_augment.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.btsbot_prep_triplets.restype = i32
+    L.btsbot_prep_triplets.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.btsbot_eval_metrics.restype = i32
     L.btsbot_eval_metrics.argtypes = [vp, vp, f32, i64, vp, vp]
     if L.btsbot_abi_version() != ABI_VERSION:

@@ -88,3 +88,92 @@ extern "C" int btsbot_eval_metrics(const float* logits, const float* labels, flo
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// btsbot_prep_triplets: the arithmetic of make_triplet (/root/reference/btsbot/alert_utils.py:110-196) after
+// the host has gunzipped and FITS-decoded the three stamps of every alert -- per cutout, in the order
+// science, template, difference:
+//   median test   drop the alert if nanmedian(data) is +-inf                         (:152-161)
+//   nan_to_num    NaN -> 0, +-inf -> +-FLT_MAX                                        (:164)
+//   L2 normalise  data /= ||data||_2, skipped once the alert is flagged              (:167-168)
+//   zero test     drop if every value is 0                                            (:171-177)
+//   pad           to 63x63 at the bottom / right with 1e-9                            (:180-192)
+// and the float32 NCHW layout inference_example.py:62-64 hands to the model.  One workgroup per alert
+// (the drop flag carries from one cutout to the next, exactly as in the reference's loop).
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void prep_triplets_kernel(const float* __restrict__ raw,
+                                                            const int* __restrict__ shapes,
+                                                            float* __restrict__ out,
+                                                            uint8_t* __restrict__ drop, int normalize) {
+  __shared__ float sh[4];
+  const long b = blockIdx.x;
+  bool dropped = false;
+  for (int c = 0; c < 3; ++c) {
+    const int h = shapes ? shapes[(b * 3 + c) * 2] : S, w = shapes ? shapes[(b * 3 + c) * 2 + 1] : S;
+    const float* src = raw + (b * 3 + c) * PLANE;
+    float n = 0.f, pinf = 0.f, ninf = 0.f, ssq = 0.f;
+    for (int i = threadIdx.x; i < PLANE; i += 256) {
+      const int y = i / S, x = i - y * S;
+      if (y >= h || x >= w) continue;
+      float v = src[i];
+      if (v != v) continue;                        // NaN: ignored by nanmedian, 0 after nan_to_num
+      n += 1.f;
+      if (v == INFINITY) { pinf += 1.f; v = 3.4028234663852886e38f; }
+      else if (v == -INFINITY) { ninf += 1.f; v = -3.4028234663852886e38f; }
+      ssq += v * v;
+    }
+    n = block_sum(n, sh);
+    pinf = block_sum(pinf, sh);
+    ninf = block_sum(ninf, sh);
+    ssq = block_sum(ssq, sh);
+    // nanmedian == +-inf  <=>  the (upper) middle order statistic is infinite and the pair does not cancel
+    const int ni = (int)n, lo_cnt = ni - ni / 2;     // elements from the upper-middle one to the top
+    const bool med_pinf = ni > 0 && (int)pinf >= lo_cnt && !((ni % 2 == 0) && (int)ninf >= ni / 2);
+    const bool med_ninf = ni > 0 && (int)ninf >= lo_cnt && !((ni % 2 == 0) && (int)pinf >= ni / 2);
+    if (med_pinf || med_ninf) dropped = true;
+    const bool do_norm = normalize && !dropped;
+    const float norm = sqrtf(ssq);
+    float nz = 0.f;
+    float* dst = out + (b * 3 + c) * PLANE;
+    for (int i = threadIdx.x; i < PLANE; i += 256) {
+      const int y = i / S, x = i - y * S;
+      float v = 1e-9f;                               // padding value
+      if (y < h && x < w) {
+        v = src[i];
+        if (v != v) v = 0.f;
+        else if (v == INFINITY) v = 3.4028234663852886e38f;
+        else if (v == -INFINITY) v = -3.4028234663852886e38f;
+        if (do_norm) v = v / norm;                   // 0/0 -> NaN for an all-zero stamp, as numpy does
+        if (v != 0.f) nz += 1.f;
+      }
+      dst[i] = v;
+    }
+    nz = block_sum(nz, sh);
+    if (nz == 0.f) dropped = true;
+  }
+  if (threadIdx.x == 0 && drop != nullptr) drop[b] = dropped ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int btsbot_prep_triplets(const float* raw, const int* shapes, float* triplets, uint8_t* drop,
+                                    int batch, int normalize, void* stream) {
+  if (raw == nullptr || triplets == nullptr || batch < 0) {
+    btsbot_set_error("prep_triplets: NULL raw/triplets or negative batch");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (batch == 0) return BTSBOT_OK;
+  hipLaunchKernelGGL(prep_triplets_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, raw, shapes,
+                     triplets, drop, normalize);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}

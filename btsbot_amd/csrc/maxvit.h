@@ -32,6 +32,14 @@ int launch_mv_dw3(int prec, const void* in, const float* w9, const float* bias, 
 int mv_dw3s_groups(int H, int C, int stride);
 int launch_mv_dw3s(int prec, const void* in, const float* w9, const float* bias, void* out, float* part,
                    int B, int H, int C, int stride, hipStream_t st);
+// conv1 1x1 + BN + SiLU + depthwise 3x3 + BN + SiLU + SE-pool partials in one kernel (maxvit_mbconv.hip;
+// 16-bit modes, C_in 64 / 128, output maps >= 28x28): xn [B,H,H,CIN] T -> m2 [B,H/s,H/s,MID] T,
+// part [B][mv_mbconv_front_tiles(H,stride)][MID] f32
+bool mv_mbconv_front_supported(int prec, int H, int CIN, int MID, int stride);
+int mv_mbconv_front_tiles(int H, int stride);
+int launch_mv_mbconv_front(int prec, const void* xn, const void* w1, const float* b1, const float* w9,
+                           const float* b2, void* m2, float* part, int B, int H, int CIN, int MID,
+                           int stride, hipStream_t st);
 // squeeze-excite gate: y [B,HW,C] T -> gate [B,C] f32 = sigmoid(fc2(silu(fc1(inv_count * sum_hw y))))
 // (w2t = fc2 weight transposed to [RD][C]; scratch = B * (C + RD) floats)
 int launch_mv_se(int prec, const void* y, const float* w1, const float* b1, const float* w2t,

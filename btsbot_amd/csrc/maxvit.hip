@@ -59,6 +59,7 @@ struct MaxVit {
   bool no_gemm3 = true;     // BTSBOT_AMD_MV_GEMM3=1: LDS-free streaming GEMM (gemm3.hip) for the K = 64 / 128 shapes
                             // (measured slower than gemm2 on these shapes: opt-in, kept as the record)
   bool gated_gemm = false;  // BTSBOT_AMD_MV_GATED_GEMM=1: register-staged gated GEMM for every conv3 (f32 mode's path)
+  bool no_front = false;    // BTSBOT_AMD_MV_NO_FRONT=1: conv1 GEMM + depthwise kernel instead of the fused MBConv front
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -149,6 +150,8 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_gemm3 = !(g3 != nullptr && g3[0] == '1');
     const char* gg = getenv("BTSBOT_AMD_MV_GATED_GEMM");
     mv->gated_gemm = gg != nullptr && gg[0] == '1';
+    const char* nf = getenv("BTSBOT_AMD_MV_NO_FRONT");
+    mv->no_front = nf != nullptr && nf[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -287,7 +290,7 @@ static void mv_layout(const btsbot_ctx* h, int chunk, MaxVit* out, size_t* total
   o->o_feat = bump(n * 512 * 4);
   o->o_wg = bump(n * 65536 * esz);          // per-alert gated conv3 filters (<= 128 x 512)
   o->o_sescr = bump(n * (2048 + 128) * 4);   // squeeze-excite mean + hidden
-  o->o_part = bump(n * 14336 * 4);         // squeeze-excite partial sums [<=56 groups][mid], 14336 floats max
+  o->o_part = bump(n * 16384 * 4);         // squeeze-excite partial sums [<=56 groups][mid], 14336 floats max
   *total = cur;
 }
 
@@ -398,11 +401,25 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
       }));
     }
+    const float inv_hw = 1.0f / (float)(b.hout * b.hout);
+    void* m2b = Bb;      // where the gated-conv input (depthwise output) lives
+    const bool front = !mv->no_front && mv_mbconv_front_supported(prec, b.hin, b.cin, b.mid, b.stride);
+    if (front) {
+      // wide stages: conv1 + depthwise + pool partials in one kernel, the expanded map stays on-chip
+      m2b = A;
+      MTRY(mv_timed(h, CAT_MV_FRONT, st, [&] {
+        return launch_mv_mbconv_front(prec, c1_in, ex + b.p_c1, F(b.p_c1b), F(b.p_dw), F(b.p_dwb), m2b, part,
+                                      nb, b.hin, b.cin, b.mid, b.stride, st);
+      }));
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
+        return launch_mv_se(BTSBOT_F32, part, m + b.se1_w, m + b.se1_b, F(b.p_se2t), m + b.se2_b, gate,
+                            sescr, nb, mv_mbconv_front_tiles(b.hin, b.stride), b.mid, b.rd, inv_hw, st);
+      }));
+    } else {
     MTRY(mv_timed(h, CAT_MV_G_CONV1, st, [&] {
       return mv_gemm(mv, prec, EPI_SILU, c1_in, ex + b.p_c1, F(b.p_c1b), nullptr, nullptr, A, Min, b.mid,
                          b.cin, st);
     }));
-    const float inv_hw = 1.0f / (float)(b.hout * b.hout);
     if (prec != BTSBOT_F32 && !mv->dw_plain) {
       // depthwise conv with the squeeze-excite pool fused (partial sums per workgroup, no second pass)
       MTRY(mv_timed(h, CAT_MV_DW, st, [&] {
@@ -421,6 +438,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
                             b.hout * b.hout, b.mid, b.rd, inv_hw, st);
       }));
     }
+    }
     const int hw2 = b.hout * b.hout;
     if (prec != BTSBOT_F32 && !mv->gated_gemm && (size_t)b.c * b.mid * 4 <= (size_t)hw2 * b.mid) {
       // wide stages: per-alert filters W3 diag(g_b) (a fraction of the map's size) + batched LDS-DMA GEMM
@@ -428,17 +446,17 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         return launch_mv_scale_w(prec, m + b.c3_w, gate, wg, nb, b.c, b.mid, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
-        return launch_gemm2_batched_resid(prec, Bb, wg, zero, one, resid, dst, nb, hw2, b.c, b.mid, st);
+        return launch_gemm2_batched_resid(prec, m2b, wg, zero, one, resid, dst, nb, hw2, b.c, b.mid, st);
       }));
     } else if (prec != BTSBOT_F32 && !mv->gated_gemm) {
       // narrow stages: the map is small -- gate it in place, then the plain LDS-DMA GEMM
-      MTRY(mv_timed(h, CAT_MV_SE, st, [&] { return launch_mv_gate(prec, Bb, gate, nb, hw2, b.mid, st); }));
+      MTRY(mv_timed(h, CAT_MV_SE, st, [&] { return launch_mv_gate(prec, m2b, gate, nb, hw2, b.mid, st); }));
       MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
-        return launch_gemm(prec, EPI_RESID, Bb, ex + b.p_c3, zero, one, resid, dst, Mo, b.c, b.mid, st);
+        return launch_gemm(prec, EPI_RESID, m2b, ex + b.p_c3, zero, one, resid, dst, Mo, b.c, b.mid, st);
       }));
     } else {
       MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
-        return launch_gemm_gated(prec, Bb, gate, hw2, ex + b.p_c3, resid, dst, Mo, b.c, b.mid, st);
+        return launch_gemm_gated(prec, m2b, gate, hw2, ex + b.p_c3, resid, dst, Mo, b.c, b.mid, st);
       }));
     }
     if (b.stride == 2) {   // the block's output lives in x2: swap the roles of the two maps

@@ -235,6 +235,15 @@ int btsbot_adamw_step(float* params, const float* grads, float* exp_avg, float* 
 int btsbot_augment(const float* src, const int64_t* index, const uint8_t* ops, float* dst, int batch,
                    void* stream);
 
+/* Replaces: the arithmetic of make_triplet (alert_utils.py:110-196) once the host has gunzipped and
+ * FITS-decoded the stamps: per cutout (science, template, difference) nanmedian +-inf test, nan_to_num,
+ * L2 normalisation (skipped once the alert is flagged), all-zero test, padding to 63x63 with 1e-9 at the
+ * bottom / right; output in the float32 NCHW layout of inference_example.py:62-64.
+ * raw [batch,3,63,63] f32 with each stamp in the top-left h x w corner; shapes int32 [batch,3,2] = (h, w)
+ * per stamp (NULL = all 63x63); triplets [batch,3,63,63] f32; drop uint8 [batch] (NULL = not wanted). */
+int btsbot_prep_triplets(const float* raw, const int* shapes, float* triplets, uint8_t* drop, int batch,
+                         int normalize, void* stream);
+
 /* Replaces: the epoch / validation metrics of val.py:159-168 and train.py:550-558 -- out2[0] += sum_i of
  * BCEWithLogitsLoss(pos_weight) terms over n logits, out2[1] += number of alerts whose sigmoid(z) > 0.5
  * agrees with the label (caller zeroes out2 and divides by n). */

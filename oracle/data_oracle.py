@@ -32,3 +32,33 @@ def metrics(logits: torch.Tensor, labels: torch.Tensor, pos_weight: float):
     loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([pos_weight]))(z, y).item()
     acc = ((torch.sigmoid(z) > 0.5).float() == y).float().mean().item()
     return loss, acc
+
+
+def make_triplet_arith(stamps, normalize: bool = True):
+    """alert_utils.py:149-196 from the decoded stamps on (numpy, the reference's own calls): returns
+    (triplet [63,63,3] float64, drop)."""
+    import numpy as np
+    import warnings
+    cut = {}
+    drop = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, data in zip(("science", "template", "difference"), stamps):
+            data = np.array(data, dtype=np.float32)
+            median = np.nanmedian(data.flatten())
+            if median == np.nan or median == -np.inf or median == np.inf:
+                drop = True
+            cut[name] = np.nan_to_num(data)
+            if normalize and not drop:
+                cut[name] /= np.linalg.norm(cut[name])
+            if np.all(cut[name].flatten() == 0):
+                drop = True
+            shape = cut[name].shape
+            if shape != (63, 63):
+                cut[name] = np.pad(cut[name], [(0, 63 - shape[0]), (0, 63 - shape[1])], mode="constant",
+                                   constant_values=1e-9)
+    triplet = np.zeros((63, 63, 3))
+    triplet[:, :, 0] = cut["science"]
+    triplet[:, :, 1] = cut["template"]
+    triplet[:, :, 2] = cut["difference"]
+    return triplet, drop

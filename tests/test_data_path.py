@@ -153,3 +153,49 @@ def test_train_epoch_over_device_dataset(cuda):
     hist = [train_epoch(tr, ds) for _ in range(3)]
     assert all(np.isfinite(l) and 0.0 <= a <= 1.0 for l, a in hist)
     assert tr.epoch == 3 and tr.t == 9
+
+
+# ---- alert -> triplet arithmetic (alert_utils.py:110-196) -------------------------------------------
+def _stamp_cases():
+    g = np.random.default_rng(7)
+    base = lambda h=63, w=63: np.abs(g.normal(size=(h, w))).astype(np.float32) * 50 + 100
+    cases = []
+    cases.append([base(), base(), base()])                                  # plain
+    a = base(); a[3:9, 10:20] = np.nan; cases.append([a, base(), base()])   # NaN patch
+    cases.append([base(63, 40), base(), base(51, 63)])                      # edge stamps: padding
+    z = np.zeros((63, 63), np.float32); cases.append([base(), z, base()])   # zero image -> drop
+    i = base(); i[:40] = np.inf; cases.append([i, base(), base()])          # inf median -> drop, later stamps raw
+    n = np.full((63, 63), np.nan, np.float32); cases.append([base(), base(), n])   # all NaN -> zero -> drop
+    m = base(); m[0, 0] = -np.inf; cases.append([m, base(), base()])        # one -inf: norm overflows
+    return cases
+
+
+def test_oracle_prep_matches_example_data_normalisation():
+    """The bundled example triplets are what make_triplet produced: every cutout has unit L2 norm."""
+    ex = np.load(os.path.join(os.path.dirname(__file__), "golden", "example8.npz"))
+    for trip in ex["triplets"][:3]:
+        stamps = [trip[c] * 37.0 for c in range(3)]               # undo the scale, redo the arithmetic
+        out, drop = DO.make_triplet_arith(stamps)
+        assert not drop
+        assert np.allclose(np.transpose(out, (2, 0, 1)), trip, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_prep_triplets_kernel_matches_reference_arithmetic(cuda):
+    from btsbot_amd import alert_utils
+    cases = _stamp_cases()
+    raw, shapes = alert_utils.stack_stamps(cases)
+    got, drop = alert_utils.prep_triplets(raw.to(cuda), shapes.to(cuda))
+    got, drop = got.cpu().numpy(), drop.cpu().numpy()
+    for k, stamps in enumerate(cases):
+        want, wdrop = DO.make_triplet_arith(stamps)
+        want = np.transpose(want, (2, 0, 1)).astype(np.float32)
+        assert bool(drop[k]) == bool(wdrop), k
+        both_nan = np.isnan(got[k]) & np.isnan(want)
+        assert np.allclose(np.where(both_nan, 0, got[k]), np.where(both_nan, 0, want),
+                           rtol=3e-6, atol=1e-12), k
+    # all-63x63 fast path (shapes = NULL) and normalize=False
+    got2, _ = alert_utils.prep_triplets(raw[:2].to(cuda))
+    assert np.array_equal(got2.cpu().numpy(), got[:2])
+    raw_only, d = alert_utils.prep_triplets(raw[:1].to(cuda), shapes[:1].to(cuda), normalize=False)
+    assert torch.equal(raw_only.cpu(), raw[:1]) and not d.any()
