@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
     ap.add_argument("--maxvit-steps", type=int, default=3,
                     help="steps of the MaxViT inference leg (BASELINE.json configs[3]); 0 = skip")
-    ap.add_argument("--maxvit-batch", type=int, default=256, help="alerts per GPU per MaxViT step")
+    ap.add_argument("--maxvit-batch", type=int, default=1024, help="alerts per GPU per MaxViT step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

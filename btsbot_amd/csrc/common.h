@@ -149,7 +149,8 @@ int launch_gemm2(int prec, int epi, const void* X, const void* W, const float* b
 
 int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const float* zero_bias,
                                const float* one_gamma, const float* resid, float* out, int batch, int M,
-                               int N, int K, hipStream_t st);
+                               int N, int K, hipStream_t st, const float* ln_w = nullptr,
+                               const float* ln_b = nullptr, void* ln_out = nullptr);
 
 // LDS-free streaming variant for K in {64,128} (gemm3.hip): filter slice in registers, activation rows
 // fetched as MFMA fragments; 16-bit modes, N % 32 == 0, epilogues SILU / BIAS_T / GELU / RESID / BIAS

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
                                                     const float* __restrict__ bias,
                                                     const float* __restrict__ gamma,
                                                     const float* resid, void* out, int M, int N,
-                                                    int K, long bsX = 0, long bsW = 0, long bsO = 0) {
+                                                    int K, long bsX = 0, long bsW = 0, long bsO = 0,
+                                                    const float* __restrict__ ln_w = nullptr,
+                                                    const float* __restrict__ ln_b = nullptr,
+                                                    T* __restrict__ ln_out = nullptr) {
   using MM = Mma2<T>;
   // batched form (gridDim.z > 1): problem z reads X + z*bsX, W + z*bsW and writes out/resid + z*bsO
   X += blockIdx.z * bsX;
@@ -178,6 +181,37 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   // ---- epilogue stage 2: whole rows LDS -> HBM, 16 bytes per lane
   constexpr int CPR = TN * (int)sizeof(OT) / 16;   // 16-byte chunks per row
   constexpr int EPC = 16 / (int)sizeof(OT);        // elements per chunk
+  if (EPI == EPI_RESID && ln_out != nullptr) {
+    // RESID with the NEXT LayerNorm fused (host guarantees N == TN, so a row of the staged tile is a whole
+    // row of the map): the row sits on CPR = TN/4 consecutive lanes -- one or two DPP rows
+    for (int i = tid; i < TM * CPR; i += 256) {
+      const int ml = i / CPR, ch = i - ml * CPR;
+      const int m = min(m0 + ml, M - 1), n = ch * 4;
+      const size_t o = (size_t)blockIdx.z * bsO + (size_t)m * N + n;
+      float4 f = *reinterpret_cast<const float4*>(smem + ml * OPITCH + ch * 16);
+      const float4 r = *reinterpret_cast<const float4*>(resid + o);
+      f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
+      float s = group16_sum((f.x + f.y) + (f.z + f.w));
+      if (CPR == 32) s += __shfl_xor(s, 16);
+      const float mean = s * (1.0f / TN);
+      const float dx = f.x - mean, dy = f.y - mean, dz = f.z - mean, dw = f.w - mean;
+      float q = group16_sum(fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw))));
+      if (CPR == 32) q += __shfl_xor(q, 16);
+      const float rstd = rsqrtf(q * (1.0f / TN) + 1e-6f);
+      if (m0 + ml >= M) continue;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = f;
+      const float4 gw = *reinterpret_cast<const float4*>(ln_w + n);
+      const float4 gb = *reinterpret_cast<const float4*>(ln_b + n);
+      typedef T __attribute__((ext_vector_type(4))) T4;
+      T4 y;
+      y[0] = (T)(dx * rstd * gw.x + gb.x);
+      y[1] = (T)(dy * rstd * gw.y + gb.y);
+      y[2] = (T)(dz * rstd * gw.z + gb.z);
+      y[3] = (T)(dw * rstd * gw.w + gb.w);
+      *reinterpret_cast<T4*>(ln_out + o) = y;
+    }
+    return;
+  }
   for (int i = tid; i < TM * CPR; i += 256) {
     const int ml = i / CPR, ch = i - ml * CPR;
     const int m = m0 + ml, n = n0 + ch * EPC;
@@ -198,7 +232,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
 template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
 int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                  const float* resid, void* out, int M, int N, int K, hipStream_t st, int batch = 1,
-                 long bsX = 0, long bsW = 0, long bsO = 0) {
+                 long bsX = 0, long bsW = 0, long bsO = 0, const float* ln_w = nullptr,
+                 const float* ln_b = nullptr, void* ln_out = nullptr) {
   constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
   constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
@@ -211,7 +246,7 @@ int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
   }
   dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, bias, gamma, resid, out, M, N, K, bsX, bsW,
-                     bsO);
+                     bsO, ln_w, ln_b, reinterpret_cast<T*>(ln_out));
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -255,24 +290,32 @@ int launch_epi2(int epi, const void* X, const void* W, const float* bias, const 
 }  // namespace
 
 // out_b (f32) = resid_b + X_b . W_b^T for `batch` independent problems of M rows each (per-alert filters)
+// (ln_out != NULL: also ln_out [rows][N] T = LayerNorm_N(out row) * ln_w + ln_b, eps 1e-6; needs N in {64,128}.
+//  bsW == 0 with batch == 1 is the plain, un-batched case: `bias` / `gamma` are then real vectors)
 int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const float* zero_bias,
                                const float* one_gamma, const float* resid, float* out, int batch, int M,
-                               int N, int K, hipStream_t st) {
+                               int N, int K, hipStream_t st, const float* ln_w, const float* ln_b,
+                               void* ln_out) {
   if (!gemm2_supported(prec, M, N, K) || batch < 1) {
     btsbot_set_error("gemm2_batched: unsupported (prec %d, M %d, N %d, K %d)", prec, M, N, K);
     return BTSBOT_ERR_INVALID_ARG;
   }
   const long bsX = (long)M * K, bsW = (long)N * K, bsO = (long)M * N;
-  const bool big = N >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 256;
+  if (ln_out != nullptr && N != 64 && N != 128) {
+    btsbot_set_error("gemm2 resid+LN: N=%d must be 64 or 128 (one tile per row)", N);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const bool big = ln_out != nullptr ? N == 128
+                                     : N >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 256;
 #define G2B(TT)                                                                                         \
   (big ? launch_tile2<TT, 128, 128, 2, 2, EPI_RESID, 2>(reinterpret_cast<const TT*>(X),                \
                                                         reinterpret_cast<const TT*>(W), zero_bias,      \
                                                         one_gamma, resid, out, M, N, K, st, batch, bsX,  \
-                                                        bsW, bsO)                                        \
+                                                        bsW, bsO, ln_w, ln_b, ln_out)                    \
        : launch_tile2<TT, 64, 64, 2, 2, EPI_RESID, 3>(reinterpret_cast<const TT*>(X),                  \
                                                       reinterpret_cast<const TT*>(W), zero_bias,        \
                                                       one_gamma, resid, out, M, N, K, st, batch, bsX,    \
-                                                      bsW, bsO))
+                                                      bsW, bsO, ln_w, ln_b, ln_out))
   return prec == BTSBOT_BF16 ? G2B(bf16_t) : G2B(f16_t);
 #undef G2B
 }

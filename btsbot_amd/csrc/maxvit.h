@@ -12,7 +12,7 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st);                          // mirr
 size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk);
 int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float** feat_out);
 void maxvit_free(btsbot_ctx* h);
-constexpr int MV_MAX_CHUNK = 256;   // alerts per workspace chunk (about 22 MB of activations each in bf16)
+constexpr int MV_MAX_CHUNK = 1024;  // alerts per workspace chunk the host asks for (about 22 MB of activations each in bf16)
 
 // ---- kernels (maxvit_ops.hip).  `prec` selects the staged activation type T (float / bf16 / f16).
 // bilinear 63 -> 224 (align_corners=False, architectures.py:44-50) fused with the im2col of the stem's

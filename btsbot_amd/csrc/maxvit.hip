@@ -60,6 +60,7 @@ struct MaxVit {
                             // (measured slower than gemm2 on these shapes: opt-in, kept as the record)
   bool gated_gemm = false;  // BTSBOT_AMD_MV_GATED_GEMM=1: register-staged gated GEMM for every conv3 (f32 mode's path)
   bool no_front = false;    // BTSBOT_AMD_MV_NO_FRONT=1: conv1 GEMM + depthwise kernel instead of the fused MBConv front
+  bool no_ln_fuse = false;  // BTSBOT_AMD_MV_NO_LN_FUSE=1: separate LayerNorm launches everywhere
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -152,6 +153,8 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->gated_gemm = gg != nullptr && gg[0] == '1';
     const char* nf = getenv("BTSBOT_AMD_MV_NO_FRONT");
     mv->no_front = nf != nullptr && nf[0] == '1';
+    const char* lf = getenv("BTSBOT_AMD_MV_NO_LN_FUSE");
+    mv->no_ln_fuse = lf != nullptr && lf[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -440,14 +443,21 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     }
     }
     const int hw2 = b.hout * b.hout;
+    // wide stages (C = 64 / 128): the LayerNorm that follows a residual GEMM is computed in that GEMM's
+    // epilogue (the staged output tile holds whole rows)
+    const bool ln_fuse = prec != BTSBOT_F32 && !mv->no_ln_fuse && (b.c == 64 || b.c == 128);
+    bool ln1_done = false;
     if (prec != BTSBOT_F32 && !mv->gated_gemm && (size_t)b.c * b.mid * 4 <= (size_t)hw2 * b.mid) {
       // wide stages: per-alert filters W3 diag(g_b) (a fraction of the map's size) + batched LDS-DMA GEMM
       MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
         return launch_mv_scale_w(prec, m + b.c3_w, gate, wg, nb, b.c, b.mid, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_CONV3, st, [&] {
-        return launch_gemm2_batched_resid(prec, m2b, wg, zero, one, resid, dst, nb, hw2, b.c, b.mid, st);
+        return launch_gemm2_batched_resid(prec, m2b, wg, zero, one, resid, dst, nb, hw2, b.c, b.mid, st,
+                                          ln_fuse ? m + b.attn[0].n1w : nullptr,
+                                          ln_fuse ? m + b.attn[0].n1b : nullptr, ln_fuse ? Cc : nullptr);
       }));
+      ln1_done = ln_fuse;
     } else if (prec != BTSBOT_F32 && !mv->gated_gemm) {
       // narrow stages: the map is small -- gate it in place, then the plain LDS-DMA GEMM
       MTRY(mv_timed(h, CAT_MV_SE, st, [&] { return launch_mv_gate(prec, m2b, gate, nb, hw2, b.mid, st); }));
@@ -468,9 +478,11 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     for (int g = 0; g < 2; ++g) {
       const AttnPk& a = b.attn[g];
       const int c = b.c;
-      MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
-        return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
-      }));
+      if (!(g == 0 && ln1_done)) {
+        MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
+          return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
+        }));
+      }
       MTRY(mv_timed(h, CAT_MV_G_QKV, st, [&] {
         return mv_gemm(mv, prec, EPI_BIAS_T, Cc, ex + a.p_qkv, m + a.qkv_b, nullptr, nullptr, D, Mo,
                            3 * c, c, st);
@@ -480,12 +492,19 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           return launch_mv_attn_mfma(prec, D, F(a.p_bias64), E, nb, b.hout, c, g, st);
         return launch_mv_attn(prec, D, F(a.p_bias), E, nb, b.hout, c, g, st);
       }));
-      MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
-        return mv_gemm(mv, prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
-      }));
-      MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
-        return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
-      }));
+      if (ln_fuse && gemm2_supported(prec, Mo, c, c)) {   // proj + residual + LN2 in one launch
+        MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
+          return launch_gemm2_batched_resid(prec, E, ex + a.p_proj, m + a.proj_b, one, x, x, 1, Mo, c, c, st,
+                                            m + a.n2w, m + a.n2b, Cc);
+        }));
+      } else {
+        MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
+          return mv_gemm(mv, prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
+        }));
+        MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
+          return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
+        }));
+      }
       if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
         MTRY(mv_timed(h, CAT_MV_FUSED, st, [&] {
           return launch_fused_mlp(prec, c, Cc, ex + a.p_fused, m + a.fc1_b, m + a.fc2_b, one, x, Mo, st);
