@@ -165,8 +165,12 @@ def maxvit_family_work(batch, precision):
         w[k]["flop"] += 2 * macs * batch
         w[k]["bytes"] += nbytes * batch
 
-    add("mv_gemm<stem>", 12544 * (27 * 32 + 288 * 64), 12544 * (32 * esz * 2 + 288 * esz + 64 * 4))
-    add("mv_stem_im2col", 0, 3 * 63 * 63 * 4 + 12544 * 32 * esz + 12544 * 32 * esz + 12544 * 288 * esz)
+    if precision == "f32":      # im2col + GEMM for both stem convolutions
+        add("mv_gemm<stem>", 12544 * (27 * 32 + 288 * 64), 12544 * (32 * esz * 2 + 288 * esz + 64 * 4))
+        add("mv_stem_im2col", 0, 3 * 63 * 63 * 4 + 12544 * 32 * esz + 12544 * 32 * esz + 12544 * 288 * esz)
+    else:                       # direct conv1 (VALU) and implicit-GEMM conv2 (+ block 0's pre-norm output)
+        add("mv_stem_im2col", 12544 * 27 * 32, 3 * 63 * 63 * 4 + 12544 * 32 * esz)
+        add("mv_gemm<stem>", 12544 * 288 * 64, 12544 * (32 * esz + 64 * 4 + 64 * esz))
     for cin, c, mid, s, hi, ho in maxvit_blocks():
         pi, po = hi * hi, ho * ho
         add("mv_elementwise", 0, pi * cin * (4 + esz) + (po * cin * (4 + esz) if s == 2 else 0))
@@ -180,8 +184,11 @@ def maxvit_family_work(batch, precision):
         add("mv_gemm<conv3,gated>", po * mid * c, po * (mid * esz + 8 * c))
         if s == 2 and cin != c:
             add("mv_gemm<shortcut>", po * cin * c, po * (cin * esz + 4 * c))
-        for _ in range(2):
-            add("mv_ln_kernel", 0, 2 * po * c * (4 + esz))
+        ln_fused = precision != "f32" and c in (64, 128) and \
+            os.environ.get("BTSBOT_AMD_MV_NO_LN_FUSE", "0") != "1"
+        for g in range(2):
+            # C = 64 / 128: LN1 of the window attention rides on conv3's epilogue, both LN2 on proj's
+            add("mv_ln_kernel", 0, (g if ln_fused else 2) * po * c * (4 + esz))
             add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
             add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)
             add("mv_gemm<proj,RESID>", po * c * c, po * c * (esz + 8))

@@ -18,6 +18,10 @@ constexpr int MV_MAX_CHUNK = 1024;  // alerts per workspace chunk the host asks 
 // bilinear 63 -> 224 (align_corners=False, architectures.py:44-50) fused with the im2col of the stem's
 // 3x3 s2 p1 convolution: img [B,3,63,63] f32 -> out [B*112*112, 32] T, k = (ky*3+kx)*3 + c, 27..31 zero
 int launch_mv_resize_im2col(int prec, const float* img, void* out, int B, hipStream_t st);
+// 16-bit modes: resize + stem conv 3x3 s2 + BN + SiLU directly (no im2col): img -> out [B*112*112, 32] T;
+// w = the [32][32] image of launch_mv_pack_stem1, shift = folded BatchNorm shift
+int launch_mv_stem1(int prec, const float* img, const void* w, const float* shift, void* out, int B,
+                    hipStream_t st);
 // im2col of a 3x3 s1 p1 convolution on an NHWC map: in [B,HW,HW,C] T -> out [B*HW*HW, 9*C] T
 int launch_mv_im2col3(int prec, const void* in, void* out, int B, int HW, int C, hipStream_t st);
 // eval-mode BatchNorm2d as scale/shift + cast: x [M,C] f32 -> out [M,C] T
@@ -68,9 +72,10 @@ int launch_mv_attn_mfma(int prec, const void* qkv, const float* bias64, void* ou
 int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStream_t st);
 // stem conv 3x3 s1 p1 32 -> 64 as an LDS-free implicit GEMM (16-bit modes): in [B,112,112,32] T,
 // w = the [64][288] image of launch_mv_pack_conv3, out [B,112,112,64] f32
-// (xn != NULL: also xn [B,112,112,64] T = out * scale[c] + shift[c], the next block's pre-norm)
-int launch_mv_stem2(int prec, const void* in, const void* w, float* out, void* xn, const float* scale,
-                    const float* shift, int B, hipStream_t st);
+// (xn != NULL: also xn [B,112,112,64] T = result * scale[c] + shift[c], the next block's pre-norm;
+//  pooled != 0: out is the 2x2 average pool [B,56,56,64] f32 of the result instead of the full map)
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int pooled, void* xn,
+                    const float* scale, const float* shift, int B, hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

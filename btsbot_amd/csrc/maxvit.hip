@@ -346,19 +346,29 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
   const float* zero = F(mv->p_zero);
   const float* one = F(mv->p_one);
 
-  bool xn_ready = false;
+  bool xn_ready = false, pool_ready = false;
   // ---- stem: resize + conv3x3 s2 (+BN, SiLU) + conv3x3 s1, both as im2col GEMMs
   const int M0 = nb * 12544;
-  MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_resize_im2col(prec, img, Bb, nb, st); }));
-  MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
-    return launch_gemm(prec, EPI_SILU, Bb, ex + mv->p_stem1, F(mv->stem_bn.p_shift), nullptr, nullptr,
-                       Cc, M0, 32, 32, st);
-  }));
+  if (prec != BTSBOT_F32 && !mv->stem_im2col) {
+    MTRY(mv_timed(h, CAT_MV_STEM, st, [&] {
+      return launch_mv_stem1(prec, img, ex + mv->p_stem1, F(mv->stem_bn.p_shift), Cc, nb, st);
+    }));
+  } else {
+    MTRY(mv_timed(h, CAT_MV_STEM, st, [&] { return launch_mv_resize_im2col(prec, img, Bb, nb, st); }));
+    MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
+      return launch_gemm(prec, EPI_SILU, Bb, ex + mv->p_stem1, F(mv->stem_bn.p_shift), nullptr, nullptr,
+                         Cc, M0, 32, 32, st);
+    }));
+  }
   if (prec != BTSBOT_F32 && !mv->stem_im2col) {
     // (writes block 0's pre-norm + cast into the conv1 im2col buffer, which is free by now)
     const MvBlock& b0 = mv->blocks[0];
+    // (without debug taps nobody needs the fp32 stem map itself: block 0's shortcut only wants its 2x2
+    //  average pool, which the kernel then writes straight into the residual buffer x2)
+    pool_ready = !h->debug && b0.stride == 2 && b0.sc_w < 0;
     MTRY(mv_timed(h, CAT_MV_G_STEM, st, [&] {
-      return launch_mv_stem2(prec, Cc, ex + mv->p_stem2, x, Bb, F(b0.pre.p_scale), F(b0.pre.p_shift), nb, st);
+      return launch_mv_stem2(prec, Cc, ex + mv->p_stem2, pool_ready ? x2 : x, pool_ready ? 1 : 0, Bb,
+                             F(b0.pre.p_scale), F(b0.pre.p_shift), nb, st);
     }));
     xn_ready = true;
   } else {
@@ -388,7 +398,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           return mv_gemm(mv, prec, EPI_BIAS, E, ex + b.p_sc, zero, nullptr, nullptr, x2, Mo, b.c,
                              b.cin, st);
         }));
-      } else {
+      } else if (!(bi == 0 && pool_ready)) {
         MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
           return launch_mv_avgpool2(prec, x, x2, 0, nb, b.hin, b.cin, st);
         }));

@@ -236,12 +236,16 @@ int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStrea
 // matrix through HBM twice.  in [B,112,112,32] T -> out [B,112,112,64] f32.
 namespace {
 
-template <typename T>
-__global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256, 2) void mv_stem2_kernel(const T* __restrict__ in,
                                                        const T* __restrict__ w, float* __restrict__ out,
                                                        T* __restrict__ xn, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int rows_total,
-                                                       int rows_per_wave) {
+                                                       const float* __restrict__ shift, int pairs_total,
+                                                       int pairs_per_wave) {
+  // A wave walks image-row PAIRS (2y, 2y+1).  POOL: `out` receives the 2x2 average pool of the result
+  // ([B,56,56,64] f32 -- the first MBConv block's shortcut is the only consumer of the fp32 map) instead of
+  // the full map [B,112,112,64]: the horizontal neighbour comes from the adjacent lane (quad_perm [1,0,3,2]),
+  // the vertical one from the pair's first row, summed in avg_pool2d's order ((a+b)+c)+d.
   using frag = typename AM<T>::frag;
   const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -254,46 +258,69 @@ __global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
   frag zero;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
-  for (int rr = 0; rr < rows_per_wave; ++rr) {
-    const int row = wid * rows_per_wave + rr;
-    if (row >= rows_total) break;                      // wave-uniform
-    const long b = row / 112;
-    const int y = row - (int)b * 112;
+  typedef T __attribute__((ext_vector_type(4))) T4;
+  for (int pp = 0; pp < pairs_per_wave; ++pp) {
+    const int pair = wid * pairs_per_wave + pp;
+    if (pair >= pairs_total) break;                    // wave-uniform
+    const long b = pair / 56;
+    const int yp = pair - (int)b * 56;
     for (int xt = 0; xt < 7; ++xt) {
       const int x = xt * 16 + l15;
-      f32x4 acc[4];
+      float top[4][4];                                 // POOL: a + b of the pair's first row
+#pragma unroll 1
+      for (int sub = 0; sub < 2; ++sub) {
+        const int y = 2 * yp + sub;
+        f32x4 acc[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y + ky - 1;
-        if (iy < 0 || iy >= 112) continue;             // wave-uniform
-        const T* rowp = in + ((b * 112 + iy) * 112) * 32 + g * 8;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = y + ky - 1;
+          if (iy < 0 || iy >= 112) continue;           // wave-uniform
+          const T* rowp = in + ((b * 112 + iy) * 112) * 32 + g * 8;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = x + kx - 1;
-          const bool ok = ix >= 0 && ix < 112;
-          frag xf = *reinterpret_cast<const frag*>(rowp + (long)(ok ? ix : x) * 32);
-          if (!ok) xf = zero;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = x + kx - 1;
+            const bool ok = ix >= 0 && ix < 112;
+            frag xf = *reinterpret_cast<const frag*>(rowp + (long)(ok ? ix : x) * 32);
+            if (!ok) xf = zero;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf, acc[mt]);
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf, acc[mt]);
+          }
         }
-      }
-      const long po = ((b * 112 + y) * 112 + x) * 64 + 4 * g;
+        const long po = ((b * 112 + y) * 112 + x) * 64 + 4 * g;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        *reinterpret_cast<float4*>(out + po + mt * 16) =
-            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-        if (xn != nullptr) {   // the first MBConv block's pre-norm BatchNorm + cast, while the values are here
-          const float4 sc = *reinterpret_cast<const float4*>(scale + mt * 16 + 4 * g);
-          const float4 sh = *reinterpret_cast<const float4*>(shift + mt * 16 + 4 * g);
-          typedef T __attribute__((ext_vector_type(4))) T4;
-          T4 v;
-          v[0] = (T)(acc[mt][0] * sc.x + sh.x);
-          v[1] = (T)(acc[mt][1] * sc.y + sh.y);
-          v[2] = (T)(acc[mt][2] * sc.z + sh.z);
-          v[3] = (T)(acc[mt][3] * sc.w + sh.w);
-          *reinterpret_cast<T4*>(xn + po + mt * 16) = v;
+        for (int mt = 0; mt < 4; ++mt) {
+          if (!POOL)
+            *reinterpret_cast<float4*>(out + po + mt * 16) =
+                make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+          if (xn != nullptr) {   // the first MBConv block's pre-norm BatchNorm + cast, while the values are here
+            const float4 sc = *reinterpret_cast<const float4*>(scale + mt * 16 + 4 * g);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + mt * 16 + 4 * g);
+            T4 v;
+            v[0] = (T)(acc[mt][0] * sc.x + sh.x);
+            v[1] = (T)(acc[mt][1] * sc.y + sh.y);
+            v[2] = (T)(acc[mt][2] * sc.z + sh.z);
+            v[3] = (T)(acc[mt][3] * sc.w + sh.w);
+            *reinterpret_cast<T4*>(xn + po + mt * 16) = v;
+          }
+        }
+        if (POOL) {
+          const long pq = ((b * 56 + yp) * 56 + (x >> 1)) * 64 + 4 * g;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            float res[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float own = acc[mt][r];
+              const float nb = __builtin_bit_cast(
+                  float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0xB1, 0xF, 0xF, true));
+              if (sub == 0) top[mt][r] = own + nb;                           // a + b  (even lanes)
+              else res[r] = ((top[mt][r] + own) + nb) * 0.25f;               // ((a+b)+c)+d
+            }
+            if (sub == 1 && (l15 & 1) == 0)
+              *reinterpret_cast<float4*>(out + pq + mt * 16) = make_float4(res[0], res[1], res[2], res[3]);
+          }
         }
       }
     }
@@ -302,24 +329,26 @@ __global__ __launch_bounds__(256) void mv_stem2_kernel(const T* __restrict__ in,
 
 }  // namespace
 
-int launch_mv_stem2(int prec, const void* in, const void* w, float* out, void* xn, const float* scale,
-                    const float* shift, int B, hipStream_t st) {
+int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int pooled, void* xn,
+                    const float* scale, const float* shift, int B, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
   if (prec != BTSBOT_BF16 && prec != BTSBOT_F16) {
     btsbot_set_error("mv_stem2: 16-bit modes only (precision %d)", prec);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  const int rows = B * 112, rpw = 4;
-  const int waves = (rows + rpw - 1) / rpw;
+  const int pairs = B * 56, ppw = 2;
+  const int waves = (pairs + ppw - 1) / ppw;
   const dim3 grid((waves + 3) / 4);
-  if (prec == BTSBOT_BF16)
-    hipLaunchKernelGGL(mv_stem2_kernel<bf16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(in), reinterpret_cast<const bf16_t*>(w), out,
-                       reinterpret_cast<bf16_t*>(xn), scale, shift, rows, rpw);
-  else
-    hipLaunchKernelGGL(mv_stem2_kernel<f16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const f16_t*>(in), reinterpret_cast<const f16_t*>(w), out,
-                       reinterpret_cast<f16_t*>(xn), scale, shift, rows, rpw);
+#define STEM2(TT, PP)                                                                                  \
+  hipLaunchKernelGGL((mv_stem2_kernel<TT, PP>), grid, dim3(256), 0, st, reinterpret_cast<const TT*>(in), \
+                     reinterpret_cast<const TT*>(w), out, reinterpret_cast<TT*>(xn), scale, shift, pairs, \
+                     ppw)
+  if (prec == BTSBOT_BF16) {
+    if (pooled) STEM2(bf16_t, true); else STEM2(bf16_t, false);
+  } else {
+    if (pooled) STEM2(f16_t, true); else STEM2(f16_t, false);
+  }
+#undef STEM2
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

@@ -60,6 +60,66 @@ __global__ __launch_bounds__(256) void mv_resize_im2col_kernel(const float* __re
   for (int i = 0; i < 8; ++i) o[i] = v[i];
 }
 
+// 16-bit modes: bilinear resize + stem conv 3x3 s2 (3 -> 32) + folded BN + SiLU as ONE direct kernel: a
+// thread samples its output pixel's 27 inputs once and runs the 27 x 32 FMAs against the filter in LDS
+// (broadcast reads).  Replaces the im2col matrix (64 B per pixel written + read) and a K = 27 GEMM whose
+// MFMA tiles were 16 % full.  w is the packed [32][32] image of mv_pack_stem1 (k = (ky*3+kx)*3 + c).
+template <typename T>
+__global__ __launch_bounds__(256) void mv_stem1_kernel(const float* __restrict__ img,
+                                                       const T* __restrict__ w,
+                                                       const float* __restrict__ shift,
+                                                       T* __restrict__ out, long total) {
+  __shared__ float ws[27][32];
+  __shared__ float sh[32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i / 32][i % 32] = (float)w[(i % 32) * 32 + i / 32];
+  if (threadIdx.x < 32) sh[threadIdx.x] = shift[threadIdx.x];
+  __syncthreads();
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / 12544), p = (int)(idx % 12544), oy = p / 112, ox = p % 112;
+  const float* im = img + (size_t)b * 3 * 3969;
+  const float scale = 63.0f / 224.0f;
+  float acc[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) acc[o] = sh[o];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+    if (iy < 0 || iy >= 224) continue;
+    const float sy = fmaxf(scale * ((float)iy + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, 62), y1 = y0 + (y0 < 62 ? 1 : 0);
+    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      if (ix < 0 || ix >= 224) continue;
+      const float sx = fmaxf(scale * ((float)ix + 0.5f) - 0.5f, 0.f);
+      const int x0 = min((int)sx, 62), x1 = x0 + (x0 < 62 ? 1 : 0);
+      const float lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* pc = im + c * 3969;
+        const float top = (1.f - lx) * pc[y0 * 63 + x0] + lx * pc[y0 * 63 + x1];
+        const float bot = (1.f - lx) * pc[y1 * 63 + x0] + lx * pc[y1 * 63 + x1];
+        // the GEMM path rounds the sample to T before the product: keep that (same numbers either way)
+        const float v = (float)(T)((1.f - ly) * top + ly * bot);
+        const float* wr = ws[(ky * 3 + kx) * 3 + c];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+      }
+    }
+  }
+  typedef T __attribute__((ext_vector_type(8))) T8;
+  T8* op = reinterpret_cast<T8*>(out + (size_t)idx * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    T8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (T)silu_fast(acc[q * 8 + e]);
+    op[q] = r;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void mv_im2col3_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                          long total, int HW, int C) {
@@ -619,6 +679,24 @@ int launch_mv_resize_im2col(int prec, const float* img, void* out, int B, hipStr
   if (total <= 0) return BTSBOT_OK;
   MV_DISPATCH(prec, hipLaunchKernelGGL(mv_resize_im2col_kernel<T>, dim3(nblk(total)), dim3(256), 0, st,
                                        img, reinterpret_cast<T*>(out), total));
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_mv_stem1(int prec, const float* img, const void* w, const float* shift, void* out, int B,
+                    hipStream_t st) {
+  const long total = (long)B * 12544;
+  if (total <= 0) return BTSBOT_OK;
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(mv_stem1_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, st, img,
+                       reinterpret_cast<const bf16_t*>(w), shift, reinterpret_cast<bf16_t*>(out), total);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(mv_stem1_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, st, img,
+                       reinterpret_cast<const f16_t*>(w), shift, reinterpret_cast<f16_t*>(out), total);
+  else {
+    btsbot_set_error("mv_stem1: 16-bit modes only");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
