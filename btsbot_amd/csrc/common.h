@@ -179,8 +179,12 @@ bool fused_mlp_supported(int prec, int C);
 size_t fused_mlp_packed_bytes(int C);
 int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, void* dst,
                           hipStream_t st);
+// post_out != NULL: also post_out [M,C] (prec-typed) = LayerNorm_C(x_new) * pw + pb (post_mode 1, eps 1e-6) or
+// x_new * pw + pb (post_mode 2) -- the next consumer's normalised input (MaxViT schedule)
 int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
-                     const float* b2, const float* gamma, float* x, int M, hipStream_t st);
+                     const float* b2, const float* gamma, float* x, int M, hipStream_t st,
+                     void* post_out = nullptr, const float* pw = nullptr, const float* pb = nullptr,
+                     int post_mode = 0);
 
 // stage-0 megakernel (stage0.hip): stem + 2 blocks + downsample in one launch, 16-bit modes, C0 = 64
 struct Stage0Args;

@@ -55,7 +55,9 @@ template <int C> struct FusedGeom {
 template <typename T, int C>
 __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
     const T* __restrict__ xn, const unsigned char* __restrict__ wpk, const float* __restrict__ b1,
-    const float* __restrict__ b2, const float* __restrict__ gamma, float* x, int M, int ntiles) {
+    const float* __restrict__ b2, const float* __restrict__ gamma, float* x, int M, int ntiles,
+    T* __restrict__ post_out = nullptr, const float* __restrict__ pw = nullptr,
+    const float* __restrict__ pb = nullptr, int post_mode = 0) {
   using G = FusedGeom<C>;
   using frag = typename M32<T>::frag;
   constexpr int KS1 = C / 16;   // k-steps of GEMM1
@@ -184,6 +186,51 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
           r.z += gv.z * (yacc[ct][4 * q + 2] + bv.z);
           r.w += gv.w * (yacc[ct][4 * q + 3] + bv.w);
           *px = r;
+          yacc[ct][4 * q + 0] = r.x;   // keep the new row for the optional post-op below
+          yacc[ct][4 * q + 1] = r.y;
+          yacc[ct][4 * q + 2] = r.z;
+          yacc[ct][4 * q + 3] = r.w;
+        }
+      }
+      // ---- optional second output for the next consumer of x (MaxViT schedule): post_mode 1 =
+      // LayerNorm_C(x) * pw + pb (eps 1e-6), post_mode 2 = x * pw + pb (an eval-mode BatchNorm), in the operand
+      // type.  A pixel's channels live on lanes lr and lr + 32: one cross-lane step per reduction.
+      if (post_mode != 0) {
+        float mean = 0.f, rstd = 1.f;
+        if (post_mode == 1) {
+          float s = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += yacc[ct][r];
+          s += __shfl_xor(s, 32);
+          mean = s * (1.0f / C);
+          float qv = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = yacc[ct][r] - mean;
+              qv = fmaf(d, d, qv);
+            }
+          qv += __shfl_xor(qv, 32);
+          rstd = rsqrtf(qv * (1.0f / C) + 1e-6f);
+        }
+        typedef T __attribute__((ext_vector_type(4))) T4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = ct * 32 + 8 * q + 4 * h;
+            const float4 wv = *reinterpret_cast<const float4*>(pw + c);
+            const float4 sv = *reinterpret_cast<const float4*>(pb + c);
+            T4 o;
+            o[0] = (T)((yacc[ct][4 * q + 0] - mean) * rstd * wv.x + sv.x);
+            o[1] = (T)((yacc[ct][4 * q + 1] - mean) * rstd * wv.y + sv.y);
+            o[2] = (T)((yacc[ct][4 * q + 2] - mean) * rstd * wv.z + sv.z);
+            o[3] = (T)((yacc[ct][4 * q + 3] - mean) * rstd * wv.w + sv.w);
+            *reinterpret_cast<T4*>(post_out + (size_t)m * C + c) = o;
+          }
         }
       }
     }
@@ -222,7 +269,8 @@ __global__ void pack_fused_kernel(const float* __restrict__ w1, const float* __r
 
 template <typename T, int C>
 int launch_fused_cfg(const void* xn, const void* wpk, const float* b1, const float* b2,
-                     const float* gamma, float* x, int M, hipStream_t st) {
+                     const float* gamma, float* x, int M, hipStream_t st, void* post_out,
+                     const float* pw, const float* pb, int post_mode) {
   using G = FusedGeom<C>;
   const size_t lds = 2 * (size_t)G::CHUNKBYTES + 4 * C * sizeof(float);
   auto kern = fused_mlp_kernel<T, C>;
@@ -236,7 +284,8 @@ int launch_fused_cfg(const void* xn, const void* wpk, const float* b1, const flo
   const int maxwg = (C <= 64 ? 2 : 1) * 256;   // workgroups resident on the chip
   const int grid = ntiles < maxwg ? ntiles : maxwg;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, reinterpret_cast<const T*>(xn),
-                     reinterpret_cast<const unsigned char*>(wpk), b1, b2, gamma, x, M, ntiles);
+                     reinterpret_cast<const unsigned char*>(wpk), b1, b2, gamma, x, M, ntiles,
+                     reinterpret_cast<T*>(post_out), pw, pb, post_out ? post_mode : 0);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -274,16 +323,17 @@ int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, voi
 }
 
 int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
-                     const float* b2, const float* gamma, float* x, int M, hipStream_t st) {
+                     const float* b2, const float* gamma, float* x, int M, hipStream_t st,
+                     void* post_out, const float* pw, const float* pb, int post_mode) {
   if (M <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16 && C == 64)
-    return launch_fused_cfg<bf16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st);
+    return launch_fused_cfg<bf16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
   if (prec == BTSBOT_BF16 && C == 128)
-    return launch_fused_cfg<bf16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st);
+    return launch_fused_cfg<bf16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
   if (prec == BTSBOT_F16 && C == 64)
-    return launch_fused_cfg<f16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st);
+    return launch_fused_cfg<f16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
   if (prec == BTSBOT_F16 && C == 128)
-    return launch_fused_cfg<f16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st);
+    return launch_fused_cfg<f16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
   btsbot_set_error("fused_mlp: unsupported (prec %d, C %d)", prec, C);
   return BTSBOT_ERR_INVALID_ARG;
 }

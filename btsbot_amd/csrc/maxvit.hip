@@ -346,7 +346,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
   const float* zero = F(mv->p_zero);
   const float* one = F(mv->p_one);
 
-  bool xn_ready = false, pool_ready = false;
+  bool xn_ready = false, pool_ready = false, next_xn_ready = false;
   // ---- stem: resize + conv3x3 s2 (+BN, SiLU) + conv3x3 s1, both as im2col GEMMs
   const int M0 = nb * 12544;
   if (prec != BTSBOT_F32 && !mv->stem_im2col) {
@@ -409,6 +409,8 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     const void* c1_in = Cc;
     if (bi == 0 && xn_ready) {
       c1_in = Bb;
+    } else if (next_xn_ready) {   // the previous block's last MLP already wrote BN_pre(x) into Cc
+      next_xn_ready = false;
     } else {
       MTRY(mv_timed(h, CAT_MV_ELT, st, [&] {
         return launch_mv_bn_cast(prec, x, F(b.pre.p_scale), F(b.pre.p_shift), Cc, (long)Min, b.cin, st);
@@ -456,7 +458,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     // wide stages (C = 64 / 128): the LayerNorm that follows a residual GEMM is computed in that GEMM's
     // epilogue (the staged output tile holds whole rows)
     const bool ln_fuse = prec != BTSBOT_F32 && !mv->no_ln_fuse && (b.c == 64 || b.c == 128);
-    bool ln1_done = false;
+    bool ln1_done = false, ln1_grid_done = false;
     if (prec != BTSBOT_F32 && !mv->gated_gemm && (size_t)b.c * b.mid * 4 <= (size_t)hw2 * b.mid) {
       // wide stages: per-alert filters W3 diag(g_b) (a fraction of the map's size) + batched LDS-DMA GEMM
       MTRY(mv_timed(h, CAT_MV_SE, st, [&] {
@@ -488,7 +490,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     for (int g = 0; g < 2; ++g) {
       const AttnPk& a = b.attn[g];
       const int c = b.c;
-      if (!(g == 0 && ln1_done)) {
+      if (!(g == 0 && ln1_done) && !(g == 1 && ln1_grid_done)) {
         MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
           return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
         }));
@@ -516,9 +518,27 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         }));
       }
       if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
+        // ... and the next consumer's normalised copy of x from the same registers: the grid attention's
+        // LN1 after the window attention's MLP, the next block's pre-norm BatchNorm after the grid one's.
+        // (the kernel reads its input Cc completely before any row is written? no: rows are independent
+        //  and a lane reads its row's xn fragments before it writes that row -- in place is safe)
+        const float *pw = nullptr, *pb = nullptr;
+        int post = 0;
+        if (ln_fuse && g == 0) {
+          pw = m + b.attn[1].n1w;
+          pb = m + b.attn[1].n1b;
+          post = 1;
+        } else if (ln_fuse && g == 1 && bi + 1 < mv->blocks.size()) {
+          pw = F(mv->blocks[bi + 1].pre.p_scale);
+          pb = F(mv->blocks[bi + 1].pre.p_shift);
+          post = 2;
+        }
         MTRY(mv_timed(h, CAT_MV_FUSED, st, [&] {
-          return launch_fused_mlp(prec, c, Cc, ex + a.p_fused, m + a.fc1_b, m + a.fc2_b, one, x, Mo, st);
+          return launch_fused_mlp(prec, c, Cc, ex + a.p_fused, m + a.fc1_b, m + a.fc2_b, one, x, Mo, st,
+                                  post ? Cc : nullptr, pw, pb, post);
         }));
+        if (post == 1) ln1_grid_done = true;
+        if (post == 2) next_xn_ready = true;
         continue;
       }
       MTRY(mv_timed(h, CAT_MV_G_FC1, st, [&] {
