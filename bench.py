@@ -171,9 +171,16 @@ def maxvit_family_work(batch, precision):
     else:                       # direct conv1 (VALU) and implicit-GEMM conv2 (+ block 0's pre-norm output)
         add("mv_stem_im2col", 12544 * 27 * 32, 3 * 63 * 63 * 4 + 12544 * 32 * esz)
         add("mv_gemm<stem>", 12544 * 288 * 64, 12544 * (32 * esz + 64 * 4 + 64 * esz))
-    for cin, c, mid, s, hi, ho in maxvit_blocks():
+    prev_c = None
+    for bi, (cin, c, mid, s, hi, ho) in enumerate(maxvit_blocks()):
         pi, po = hi * hi, ho * ho
-        add("mv_elementwise", 0, pi * cin * (4 + esz) + (po * cin * (4 + esz) if s == 2 else 0))
+        # 16-bit modes: block 0's pre-norm and pooled shortcut come out of the stem kernel, and a block that
+        # follows a C = 64 / 128 block gets its pre-norm from that block's last fused MLP
+        pre_fused = precision != "f32" and (bi == 0 or prev_c in (64, 128))
+        pool_fused = precision != "f32" and bi == 0
+        add("mv_elementwise", 0, (0 if pre_fused else pi * cin * (4 + esz)) +
+            (po * cin * (4 + esz) if s == 2 and not pool_fused else 0))
+        prev_c = c
         if precision != "f32" and cin in (64, 128) and ho >= 28 and \
                 os.environ.get("BTSBOT_AMD_MV_NO_FRONT", "0") != "1":
             add("mv_mbconv_front", pi * cin * mid + po * 9 * mid, (pi * cin + po * mid) * esz)
@@ -187,8 +194,8 @@ def maxvit_family_work(batch, precision):
         ln_fused = precision != "f32" and c in (64, 128) and \
             os.environ.get("BTSBOT_AMD_MV_NO_LN_FUSE", "0") != "1"
         for g in range(2):
-            # C = 64 / 128: LN1 of the window attention rides on conv3's epilogue, both LN2 on proj's
-            add("mv_ln_kernel", 0, (g if ln_fused else 2) * po * c * (4 + esz))
+            # C = 64 / 128: every LayerNorm rides on the epilogue of the kernel that produces its input
+            add("mv_ln_kernel", 0, (0 if ln_fused else 2) * po * c * (4 + esz))
             add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
             add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)
             add("mv_gemm<proj,RESID>", po * c * c, po * c * (esz + 8))
