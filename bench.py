@@ -158,7 +158,7 @@ def maxvit_family_work(batch, precision):
     w = {k: dict(flop=0, bytes=0) for k in (
         "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
         "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
-        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
+        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
         "mv_attn_kernel", "head_kernel")}
 
     def add(k, macs, nbytes):
@@ -196,9 +196,12 @@ def maxvit_family_work(batch, precision):
         for g in range(2):
             # C = 64 / 128: every LayerNorm rides on the epilogue of the kernel that produces its input
             add("mv_ln_kernel", 0, (0 if ln_fused else 2) * po * c * (4 + esz))
-            add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
-            add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)
-            add("mv_gemm<proj,RESID>", po * c * c, po * c * (esz + 8))
+            if precision != "f32" and c == 64 and os.environ.get("BTSBOT_AMD_MV_NO_ATTN_BLOCK", "0") != "1":
+                add("mv_attn_block", po * (4 * c * c + 49 * c * 2), po * c * (2 * esz + 8))
+            else:
+                add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
+                add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)
+                add("mv_gemm<proj,RESID>", po * c * c, po * c * (esz + 8))
             if precision != "f32" and c in (64, 128) and \
                     os.environ.get("BTSBOT_AMD_MV_MLP_UNFUSED", "0") != "1":
                 add("mv_fused_mlp", po * 8 * c * c, po * c * (esz + 8))

@@ -76,6 +76,13 @@ int launch_mv_pack_relbias64(const float* table, float* out, int heads, hipStrea
 //  pooled != 0: out is the 2x2 average pool [B,56,56,64] f32 of the result instead of the full map)
 int launch_mv_stem2(int prec, const void* in, const void* w, float* out, int pooled, void* xn,
                     const float* scale, const float* shift, int B, hipStream_t st);
+// qkv + window/grid attention + proj + residual + LN2 in one kernel (maxvit_attnblock.hip; 16-bit modes,
+// C = 64): xn [B*H*H,64] T = LN1(x) in, x f32 updated in place, xn2 [B*H*H,64] T = LN2(x) out (may alias xn)
+bool mv_attn_block_supported(int prec, int C);
+int launch_mv_attn_block(int prec, const void* xn, float* x, void* xn2, const void* wqkv,
+                         const float* bqkv, const void* wproj, const float* bproj, const float* bias64,
+                         const float* ln_w, const float* ln_b, int B, int H, int C, int grid_mode,
+                         hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

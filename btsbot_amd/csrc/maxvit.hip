@@ -61,6 +61,7 @@ struct MaxVit {
   bool gated_gemm = false;  // BTSBOT_AMD_MV_GATED_GEMM=1: register-staged gated GEMM for every conv3 (f32 mode's path)
   bool no_front = false;    // BTSBOT_AMD_MV_NO_FRONT=1: conv1 GEMM + depthwise kernel instead of the fused MBConv front
   bool no_ln_fuse = false;  // BTSBOT_AMD_MV_NO_LN_FUSE=1: separate LayerNorm launches everywhere
+  bool no_attn_block = false;  // BTSBOT_AMD_MV_NO_ATTN_BLOCK=1: qkv GEMM + attention + proj GEMM at C = 64 too
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -155,6 +156,8 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_front = nf != nullptr && nf[0] == '1';
     const char* lf = getenv("BTSBOT_AMD_MV_NO_LN_FUSE");
     mv->no_ln_fuse = lf != nullptr && lf[0] == '1';
+    const char* ab = getenv("BTSBOT_AMD_MV_NO_ATTN_BLOCK");
+    mv->no_attn_block = ab != nullptr && ab[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -495,6 +498,13 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
         }));
       }
+      if (!mv->no_attn_block && mv_attn_block_supported(prec, c)) {
+        // C = 64: qkv, attention, proj, residual and LN2 in one kernel (qkv never reaches HBM)
+        MTRY(mv_timed(h, CAT_MV_ABLK, st, [&] {
+          return launch_mv_attn_block(prec, Cc, x, Cc, ex + a.p_qkv, m + a.qkv_b, ex + a.p_proj, m + a.proj_b,
+                                      F(a.p_bias64), m + a.n2w, m + a.n2b, nb, b.hout, c, g, st);
+        }));
+      } else {
       MTRY(mv_timed(h, CAT_MV_G_QKV, st, [&] {
         return mv_gemm(mv, prec, EPI_BIAS_T, Cc, ex + a.p_qkv, m + a.qkv_b, nullptr, nullptr, D, Mo,
                            3 * c, c, st);
@@ -516,6 +526,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
           return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
         }));
+      }
       }
       if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
         // ... and the next consumer's normalised copy of x from the same registers: the grid attention's
