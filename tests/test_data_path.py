@@ -199,3 +199,49 @@ def test_prep_triplets_kernel_matches_reference_arithmetic(cuda):
     assert np.array_equal(got2.cpu().numpy(), got[:2])
     raw_only, d = alert_utils.prep_triplets(raw[:1].to(cuda), shapes[:1].to(cuda), normalize=False)
     assert torch.equal(raw_only.cpu(), raw[:1]) and not d.any()
+
+
+# ---- examples/inference_example.py (the reference's harness, inference_example.py:47-95) ------------
+def _harness():
+    import importlib.util
+    p = os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "inference_example.py")
+    spec = importlib.util.spec_from_file_location("inference_example_amd", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_inference_example_input_preparation():
+    """Column list / order, float32 cast and NHWC -> NCHW of the reference harness, on the committed
+    example8 fixture (stored as the reference prepares it, so the round trip must be exact)."""
+    import pandas as pd
+    ex = _harness()
+    from btsbot_amd.synthetic import METADATA_COLS
+    assert ex.METADATA_COLS == METADATA_COLS and len(ex.METADATA_COLS) == 25
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "example8.npz"))
+    cand = pd.DataFrame(g["metadata"], columns=ex.METADATA_COLS)
+    cand = cand[ex.METADATA_COLS[::-1]].copy()              # csv column order must not matter
+    cand["label"] = g["labels"]
+    nhwc = np.transpose(g["triplets"], (0, 2, 3, 1)).astype(np.float64)   # as the .npy file stores them
+    img, meta, lab = ex.prepare_inputs(cand, nhwc, True)
+    assert img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (8, 3, 63, 63)
+    assert torch.equal(img, torch.from_numpy(g["triplets"]))
+    assert torch.equal(meta, torch.from_numpy(g["metadata"])) and lab.dtype == torch.long
+    assert ex.prepare_inputs(cand, nhwc, False)[1] is None
+
+
+@pytest.mark.gpu
+def test_inference_example_end_to_end(cuda, tmp_path):
+    import pandas as pd
+    ex = _harness()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "example8.npz"))
+    cand = pd.DataFrame(g["metadata"], columns=ex.METADATA_COLS)
+    cand["label"] = g["labels"]
+    cand.to_csv(tmp_path / "usage_candidates.csv", index=False)
+    np.save(tmp_path / "usage_triplets.npy", np.transpose(g["triplets"], (0, 2, 3, 1)).astype(np.float64))
+    kind, cfg = CONFIGS["mm_pico"]
+    m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "f32")
+    preds, labels = ex.run_inference(m, True, str(tmp_path), device=cuda)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_logits.npz"))["mm_pico/example8"]
+    want = torch.sigmoid(torch.from_numpy(gold)).round().squeeze().numpy().astype(int)
+    assert np.array_equal(preds, want) and np.array_equal(labels, g["labels"])
