@@ -547,21 +547,36 @@ class frozen_fusion(_HipModel):
         super().__init__()
         icfg = self._branch_config(config, "image")
         mcfg = self._branch_config(config, "meta")
-        if icfg["model_name"] != "ConvNeXt" or mcfg["model_name"] != "um_nn":
+        if icfg["model_name"] not in ("ConvNeXt", "MaxViT") or mcfg["model_name"] != "um_nn":
             raise NotImplementedError(
-                "btsbot_amd.frozen_fusion supports a ConvNeXt image branch and a um_nn metadata "
-                f"branch (got {icfg['model_name']} / {mcfg['model_name']})")
+                "btsbot_amd.frozen_fusion supports a ConvNeXt or MaxViT image branch and a um_nn "
+                f"metadata branch (got {icfg['model_name']} / {mcfg['model_name']})")
         _warn_pretrained(icfg)
-        table = _convnext_table(icfg.get("model_kind", _DEFAULT_KIND))
+        if icfg["model_name"] == "MaxViT":
+            # architectures.py:304-308: the MaxViT branch keeps head[0:1] = its global pool (no parameters)
+            model_kind = icfg.get("model_kind", _MAXVIT_DEFAULT_KIND)
+            self.image_size = get_model_image_size(model_kind)
+            self._wiring = "frozen_fusion_MaxViT"
+            self._inference_only = True
+            self._max_chunk = MAXVIT_MAX_CHUNK
+            table, head_norm = _maxvit_table(model_kind), False
+            bprefix, hn_key = "image_branch.maxvit.", ""
+        else:
+            table, head_norm = _convnext_table(icfg.get("model_kind", _DEFAULT_KIND)), True
+            bprefix, hn_key = "image_branch.convnext.", "image_branch.convnext.head.1."
         self._setup(
-            table=table, head_norm=True, n_meta=len(mcfg.get("metadata_cols", [])),
+            table=table, head_norm=head_norm, n_meta=len(mcfg.get("metadata_cols", [])),
             meta_fc=(mcfg["meta_fc1_neurons"], mcfg["meta_fc2_neurons"]),
             comb_fc=(config["comb_fc1_neurons"], config["comb_fc2_neurons"]),
             dropouts=(mcfg["meta_dropout"], config["comb_dropout"]),
-            key_map=_backbone_key_map("image_branch.convnext.", "image_branch.convnext.head.1.",
-                                      "meta_branch.network.",
+            key_map=_backbone_key_map(bprefix, hn_key, "meta_branch.network.",
                                       ["combined_head.0", "combined_head.2", "combined_head.5"]),
             precision=precision or config.get("precision"))
+        if icfg["model_name"] == "MaxViT":
+            with torch.no_grad():
+                for (canon, *_), t in zip(self._table_rows, self._tensor_list()):
+                    if canon.endswith("relative_position_bias_table"):
+                        nn.init.trunc_normal_(t, std=0.02)
         if not config.get("skip_load_state", False):      # architectures.py:334-335
             self._load_branch(path.join(config["image_model_dir"], "best_model.pth"),
                               "image_branch.")

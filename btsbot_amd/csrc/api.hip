@@ -184,7 +184,7 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     return BTSBOT_ERR_INVALID_ARG;
   }
   if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_F16 ||
-      cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_MAXVIT) {
+      cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_FROZEN_FUSION_MAXVIT) {
     btsbot_set_error("create: bad precision %d or wiring %d", cfg->precision, cfg->wiring);
     return BTSBOT_ERR_INVALID_ARG;
   }
@@ -193,8 +193,9 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   const int w = cfg->wiring;
   h->has_image = (w != BTSBOT_UM_NN);
   h->has_meta = (w != BTSBOT_CONVNEXT && w != BTSBOT_MAXVIT);
-  h->is_maxvit = (w == BTSBOT_MM_MAXVIT || w == BTSBOT_MAXVIT);
-  h->act = (w == BTSBOT_FROZEN_FUSION || w == BTSBOT_UM_NN) ? ACT_RELU : ACT_GELU;
+  h->is_maxvit = (w == BTSBOT_MM_MAXVIT || w == BTSBOT_MAXVIT || w == BTSBOT_FROZEN_FUSION_MAXVIT);
+  h->act = (w == BTSBOT_FROZEN_FUSION || w == BTSBOT_UM_NN || w == BTSBOT_FROZEN_FUSION_MAXVIT) ? ACT_RELU
+                                                                                               : ACT_GELU;
   h->meta_trailing_act = (w == BTSBOT_MM_CONVNEXT || w == BTSBOT_UM_NN || w == BTSBOT_MM_MAXVIT) ? 1 : 0;
   if (h->is_maxvit) {
     const bool tiny = cfg->dims[0] == 64 && cfg->dims[1] == 128 && cfg->dims[2] == 256 &&

@@ -53,7 +53,10 @@ enum btsbot_wiring {
   BTSBOT_UM_NN = 3,         /* um_nn           architectures.py:277-293 (metadata only)         */
   BTSBOT_MM_MAXVIT = 4,     /* mm_MaxViT       architectures.py:58-101 (maxvit_tiny_rw_224 + GELU heads);
                                inference only: reserve_train / forward_train return BTSBOT_ERR_STATE */
-  BTSBOT_MAXVIT = 5         /* MaxViT          architectures.py:25-55  (image only)             */
+  BTSBOT_MAXVIT = 5,        /* MaxViT          architectures.py:25-55  (image only)             */
+  BTSBOT_FROZEN_FUSION_MAXVIT = 6 /* frozen_fusion with a MaxViT image branch (head stripped to its global
+                               pool, architectures.py:304-308) + um_nn metadata branch, ReLU fusion head:
+                               what the published maxvit "-metadata" checkpoints instantiate      */
 };
 
 /* arithmetic type of the MFMA operands / staged activations (accumulation is always fp32;

@@ -245,6 +245,22 @@ def maxvit_forward(sd: SD, config: dict, image: Tensor, training: bool = False,
     return F.linear(x, sd[bp + "head.6.weight"], sd[bp + "head.6.bias"])
 
 
+def frozen_fusion_maxvit_forward(sd: SD, config: dict, image: Tensor, meta: Tensor,
+                                 training: bool = False, masks: Optional[dict] = None) -> Tensor:
+    """architectures.py:296-372 with a MaxViT image branch (head stripped to its global pool, :304-308)
+    and a um_nn metadata branch (:299-303): keys image_branch.maxvit.*, meta_branch.network.{0,1,4},
+    ReLU combined_head.{0,2,5}."""
+    icfg, mcfg = config["image_model_config"], config["meta_model_config"]
+    arch = arch_of(icfg.get("model_kind", "maxvit_tiny_rw_224.sw_in1k"))
+    masks = masks or {}
+    x = resize(image, ARCHS[arch]["img"])
+    f = pooled(forward_features(x, sd, "image_branch.maxvit.", arch))
+    m = CO.metadata_branch(meta, sd, "meta_branch.network.", "relu", False, training,
+                           mcfg["meta_dropout"], masks.get("meta"))
+    return CO.fusion_head(torch.cat((f, m), dim=1), sd, "combined_head.", "relu", training,
+                          config["comb_dropout"], masks.get("comb"))
+
+
 # --------------------------------------------------------------------------------------
 # parameter tables
 # --------------------------------------------------------------------------------------
@@ -305,6 +321,11 @@ def model_param_shapes(kind: str, config: dict) -> dict:
         s["maxvit.head.1.weight"], s["maxvit.head.1.bias"] = (f1, feat), (f1,)
         s["maxvit.head.3.weight"], s["maxvit.head.3.bias"] = (f2, f1), (f2,)
         s["maxvit.head.6.weight"], s["maxvit.head.6.bias"] = (1, f2), (1,)
+    elif kind == "frozen_fusion":
+        icfg = config["image_model_config"]
+        arch = arch_of(icfg.get("model_kind", "maxvit_tiny_rw_224.sw_in1k"))
+        s = backbone_param_shapes(arch, "image_branch.maxvit.")
+        s.update(CO.head_param_shapes("frozen_fusion", ARCHS[arch]["dims"][-1], config))
     else:
         raise ValueError(kind)
     return s
@@ -343,4 +364,6 @@ def forward(kind: str, sd: SD, config: dict, image: Optional[Tensor], meta: Opti
         return mm_maxvit_forward(sd, config, image, meta, training, masks)
     if kind == "MaxViT":
         return maxvit_forward(sd, config, image, training, masks)
+    if kind == "frozen_fusion":
+        return frozen_fusion_maxvit_forward(sd, config, image, meta, training, masks)
     raise ValueError(kind)

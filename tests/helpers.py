@@ -22,7 +22,11 @@ FUSION = dict(model_name="frozen_fusion", image_model_dir="unused", meta_model_d
 MM_MAXVIT = dict(MM_PICO, model_name="mm_MaxViT", model_kind="maxvit_tiny_rw_224.sw_in1k")
 IMG_MAXVIT = dict(model_name="MaxViT", model_kind="maxvit_tiny_rw_224.sw_in1k", pretrained=False,
                   fc1_neurons=64, fc2_neurons=16, dropout=0.1)
-MV_CONFIGS = {"mm_maxvit": ("mm_MaxViT", MM_MAXVIT), "maxvit": ("MaxViT", IMG_MAXVIT)}
+FUSION_MAXVIT = dict(model_name="frozen_fusion", image_model_dir="unused", meta_model_dir="unused",
+                     image_model_config=IMG_MAXVIT, meta_model_config=META, skip_load_state=True,
+                     comb_fc1_neurons=64, comb_fc2_neurons=16, comb_dropout=0.1)
+MV_CONFIGS = {"mm_maxvit": ("mm_MaxViT", MM_MAXVIT), "maxvit": ("MaxViT", IMG_MAXVIT),
+              "frozen_fusion_maxvit": ("frozen_fusion", FUSION_MAXVIT)}
 
 CONFIGS = {"mm_pico": ("mm_ConvNeXt", MM_PICO), "mm_nano_ls": ("mm_ConvNeXt", MM_NANO_LS),
            "convnext": ("ConvNeXt", IMG_PICO), "um_nn": ("um_nn", META),
@@ -49,7 +53,7 @@ def build_model(kind: str, config: dict, sd: dict, device, precision="f32"):
 
 def run_model(kind, m, img, meta):
     with torch.no_grad():
-        if kind in ("mm_ConvNeXt", "frozen_fusion", "mm_MaxViT"):
+        if kind in ("mm_ConvNeXt", "frozen_fusion", "mm_MaxViT"):   # (frozen_fusion: either image branch)
             return m(image_input=img, metadata_input=meta)
         if kind in ("ConvNeXt", "MaxViT"):
             return m(input_data=img)

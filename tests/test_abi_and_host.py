@@ -155,7 +155,7 @@ def test_weight_version_tracking():
     assert m._version() != v0
 
 
-@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit", "frozen_fusion_maxvit"])
 def test_maxvit_state_dict_layout_matches_reference(name):
     """timm MaxxVit key names / shapes / order (verified == the reference wrappers around the stand-in
     in make_golden.py), BatchNorm buffers included; strict load round-trips."""
@@ -173,5 +173,33 @@ def test_maxvit_state_dict_layout_matches_reference(name):
     for k, v in m.state_dict().items():
         assert torch.equal(v, ref_sd[k]), k
     assert m.image_size == 224 and m.training
+    bad = dict(cfg, model_kind="maxvit_base_tf_384.in1k") if kind != "frozen_fusion" else \
+        dict(cfg, image_model_config=dict(cfg["image_model_config"], model_kind="maxvit_base_tf_384.in1k"))
     with pytest.raises(ValueError):
-        _build(kind, dict(cfg, model_kind="maxvit_base_tf_384.in1k"))
+        _build(kind, bad)
+
+
+def test_load_hf_model_maxvit_metadata_from_local_dir(tmp_path, monkeypatch):
+    """``load_HF_model("maxvit", True, ...)`` is what the reference's README tells users to call: the
+    "-metadata" checkpoints are frozen_fusion models with a MaxViT image branch (from_HF.py:59-81,
+    architectures.py:304-308)."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    kind, cfg = MV_CONFIGS["frozen_fusion_maxvit"]
+    sd = seeded_state_mv(kind, cfg, seed=3)
+    mdir = tmp_path / "models" / "BTSbot-maxvit-tiny-randinit-metadata"
+    mdir.mkdir(parents=True)
+    torch.save({"module." + k: v for k, v in sd.items()}, mdir / "pytorch_model.bin")
+    with open(mdir / "train_config.json", "w") as f:
+        json.dump(cfg, f)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(from_HF, "device", "cpu")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.load_HF_model("maxvit", True, "randinit")
+    assert type(m).__name__ == "frozen_fusion" and m.image_size == 224
+    got = m.state_dict()
+    assert list(got) == list(sd)
+    for k in ("image_branch.maxvit.stem.conv1.weight", "image_branch.maxvit.norm.bias",
+              "meta_branch.network.4.weight", "combined_head.5.bias",
+              "image_branch.maxvit.stages.2.blocks.4.attn_grid.attn.rel_pos.relative_position_bias_table"):
+        assert torch.equal(got[k], sd[k]), k

@@ -217,7 +217,7 @@ def _mv_oracle(kind, cfg, sd, img, meta):
         return MO.forward(kind, sd, cfg, img, meta)
 
 
-@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit", "frozen_fusion_maxvit"])
 @pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_maxvit_forward_matches_oracle(cuda, name, prec):
     kind, cfg, sd = _mv(name)
@@ -227,7 +227,7 @@ def test_maxvit_forward_matches_oracle(cuda, name, prec):
     _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
 
 
-@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit", "frozen_fusion_maxvit"])
 def test_maxvit_matches_reference_wrapper_goldens(cuda, name):
     kind, cfg, sd = _mv(name)
     gold = np.load(os.path.join(GOLD, "ref_logits_maxvit.npz"))

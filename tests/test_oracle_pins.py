@@ -167,7 +167,7 @@ def test_maxvit_partitions_are_inverse_pairs_and_rel_index():
     assert idx[0, 0] == 84 and idx[0, 48] == 0 and idx[48, 0] == 168
 
 
-@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit", "frozen_fusion_maxvit"])
 def test_maxvit_oracle_matches_reference_wrapper_goldens(name):
     """Committed logits of the reference's own MaxViT / mm_MaxViT classes (architectures.py:25-101:
     resize, head surgery, metadata + fusion heads) run around the stand-in backbone."""
