@@ -21,6 +21,7 @@ PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16":
 SYMBOLS = [
     "btsbot_last_error", "btsbot_abi_version", "btsbot_create", "btsbot_destroy",
     "btsbot_param_count", "btsbot_param_floats", "btsbot_param_info_at", "btsbot_pack_params",
+    "btsbot_pack_params_train",
     "btsbot_workspace_bytes", "btsbot_reserve", "btsbot_forward", "btsbot_set_debug",
     "btsbot_read_tap", "btsbot_bce_fwd_bwd", "btsbot_adamw_step",
     "btsbot_set_profile", "btsbot_profile_categories", "btsbot_profile_category_name",
@@ -83,6 +84,8 @@ def lib() -> C.CDLL:
     L.btsbot_param_info_at.argtypes = [vp, i32, C.POINTER(ParamInfo)]
     L.btsbot_pack_params.restype = i32
     L.btsbot_pack_params.argtypes = [vp, vp, vp]
+    L.btsbot_pack_params_train.restype = i32
+    L.btsbot_pack_params_train.argtypes = [vp, vp, vp]
     L.btsbot_workspace_bytes.restype = i64
     L.btsbot_workspace_bytes.argtypes = [vp, i32]
     L.btsbot_reserve.restype = i32

@@ -223,7 +223,7 @@ class _HipModel(nn.Module):
     def _version(self):
         return tuple(t._version for t in self._tensor_list())
 
-    def _prepare(self, device: torch.device, batch: int):
+    def _prepare(self, device: torch.device, batch: int, train_only: bool = False):
         if device.type != "cuda":
             raise RuntimeError(
                 "btsbot_amd: this model runs only on an AMD GPU through libbtsbot_hip.so "
@@ -240,10 +240,13 @@ class _HipModel(nn.Module):
         self._handle_device = device
         stream = torch.cuda.current_stream(device).cuda_stream
         ver = self._version()
-        if ver != self._packed_version:
-            _lib.check(L.btsbot_pack_params(self._handle.ptr, C.c_void_p(self._arena.data_ptr()),
-                                            C.c_void_p(stream)), "btsbot_pack_params")
+        if ver != self._packed_version or (not train_only and not getattr(self, "_packed_full", True)):
+            # a training step that differentiates the image branch only needs the per-op operand images
+            pack = L.btsbot_pack_params_train if train_only else L.btsbot_pack_params
+            _lib.check(pack(self._handle.ptr, C.c_void_p(self._arena.data_ptr()), C.c_void_p(stream)),
+                       "btsbot_pack_params")
             self._packed_version = ver
+            self._packed_full = not train_only
         chunk = min(max(batch, 1), getattr(self, "_max_chunk", MAX_CHUNK))
         if chunk > self._reserved:
             _lib.check(L.btsbot_reserve(self._handle.ptr, chunk), "btsbot_reserve")
@@ -350,7 +353,7 @@ class _HipModel(nn.Module):
         ref = image if image is not None else meta
         batch, dev = ref.shape[0], ref.device
         with torch.cuda.device(dev):
-            L, stream = self._prepare(dev, batch)
+            L, stream = self._prepare(dev, batch, train_only=keep_image and self._reserved_image)
             if batch > self._reserved_train or (keep_image and not self._reserved_image):
                 _lib.check(L.btsbot_reserve_train(self._handle.ptr, max(batch, self._reserved_train),
                                                   int(keep_image or self._reserved_image)),

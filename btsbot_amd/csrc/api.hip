@@ -312,7 +312,21 @@ extern "C" int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_inf
     if (_s != BTSBOT_OK) return _s; \
   } while (0)
 
+static int pack_impl(btsbot_handle h, const float* master, void* stream, bool train_only);
+
 extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* stream) {
+  return pack_impl(h, master, stream, false);
+}
+
+extern "C" int btsbot_pack_params_train(btsbot_handle h, const float* master, void* stream) {
+  return pack_impl(h, master, stream, true);
+}
+
+// train_only: skip the operand images only the fused inference kernels read (gamma-scaled fc2 filters and
+// their chunk-major form, the megakernels' parameter images, the fused-MLP image): the per-op training
+// schedule (backbone_train.hip) and the backward never touch them, and they are re-packed after every
+// optimiser step
+static int pack_impl(btsbot_handle h, const float* master, void* stream, bool train_only) {
   if (h == nullptr || master == nullptr) {
     btsbot_set_error("pack_params: NULL argument");
     return BTSBOT_ERR_INVALID_ARG;
@@ -346,15 +360,16 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
                                  st));
         TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
         TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
-        TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
-                                 4 * ch, st));
-        if (c.precision != BTSBOT_F32)
+        if (!train_only)
+          TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
+                                   4 * ch, st));
+        if (c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_w2_chunks(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2gc, ch,
                                     4 * ch, st));
-        if (i == 1 && ch == 128 && c.precision != BTSBOT_F32)
+        if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
-        if (i == 0 && ch == 64)   // (after the tap-major transpose above: same stream)
+        if (i == 0 && ch == 64 && !train_only)   // (after the tap-major transpose above: same stream)
           TRY(launch_pack_s0par(reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
@@ -364,7 +379,7 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
           TRY(launch_transpose_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch,
                                     4 * ch, st));
         }
-        if (b.fused)
+        if (b.fused && !train_only)
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
                                     h->extra + b.p_fused, st));
       }
@@ -383,6 +398,7 @@ extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* st
     TRY(launch_transpose_f32(m + h->comb_w[i], reinterpret_cast<float*>(h->extra + h->p_comb[i]),
                              h->comb_dims[i + 1], h->comb_dims[i], st));
   h->packed = true;
+  h->packed_full = !train_only || !h->has_image || h->is_maxvit;
   return BTSBOT_OK;
 }
 
@@ -742,8 +758,10 @@ extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const floa
     btsbot_set_error("forward: NULL handle/logits or negative batch");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (!h->packed) {
-    btsbot_set_error("forward: btsbot_pack_params() has not been called");
+  if (!h->packed || !h->packed_full) {
+    btsbot_set_error(h->packed ? "forward: the last pack was btsbot_pack_params_train(); call "
+                                 "btsbot_pack_params() before an inference forward"
+                               : "forward: btsbot_pack_params() has not been called");
     return BTSBOT_ERR_STATE;
   }
   if ((h->has_image && triplets == nullptr) || (h->has_meta && meta == nullptr)) {

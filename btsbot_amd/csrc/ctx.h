@@ -70,6 +70,7 @@ struct btsbot_ctx {
   unsigned char* extra = nullptr;   // transformed operands
   size_t extra_bytes = 0;
   bool packed = false;
+  bool packed_full = false;   // false after btsbot_pack_params_train(): inference-only operand images are stale
 
   unsigned char* ws = nullptr;
   size_t ws_bytes = 0;

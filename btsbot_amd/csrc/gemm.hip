@@ -314,7 +314,12 @@ int launch_gemm(int prec, int epi, const void* X, const void* W, const float* bi
     const char* e = getenv("BTSBOT_AMD_GEMM_V1");   // A/B switch for timing
     return e != nullptr && e[0] == '1';
   }();
-  if (!v1_only && (epi <= EPI_BIAS || epi >= EPI_SILU) && gemm2_supported(prec, M, N, K))
+  static const bool train_v1 = [] {
+    const char* e = getenv("BTSBOT_AMD_TRAIN_GEMM_V1");   // A/B: training epilogues on the register-staged kernel
+    return e != nullptr && e[0] == '1';
+  }();
+  const bool train_epi = epi == EPI_GELU_SAVE || epi == EPI_DGELU || epi == EPI_PLAIN;
+  if (!v1_only && !(train_epi && train_v1) && gemm2_supported(prec, M, N, K))
     return launch_gemm2(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   switch (prec) {
     case BTSBOT_F32: return launch_epi<float>(epi, X, W, bias, gamma, resid, out, M, N, K, st);

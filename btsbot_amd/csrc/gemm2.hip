@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int XB = TM / 8 / 4, WB = TN / 8 / 4; // 8-row blocks per wave per tile
   constexpr int LPT = XB + WB;                    // LDS-DMA instructions per thread per k-tile
-  constexpr bool TOUT = EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T;   // operand-typed output
+  constexpr bool TOUT = EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T ||
+                        EPI == EPI_GELU_SAVE;   // operand-typed staging tile
   using OT = typename std::conditional<TOUT, T, float>::type;
   constexpr int OPITCH = TN * (int)sizeof(OT) + 16;  // epilogue staging row pitch
   static_assert(NSLOT >= 1 && NSLOT <= 3, "ring depth");   // NSLOT == 1: K == 64 only (one k-tile)
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   for (int ni = 0; ni < NI; ++ni) {
     const int nl = wn * WTN + ni * 16 + lq * 4;
     const int n = min(n0 + nl, N - 4);
-    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != EPI_DGELU && EPI != EPI_PLAIN) bv = *reinterpret_cast<const float4*>(bias + n);
     float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == EPI_RESID) gv = *reinterpret_cast<const float4*>(gamma + n);
 #pragma unroll
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
         v[2] = (T)gelu_fast(a[2] + bv.z);
         v[3] = (T)gelu_fast(a[3] + bv.w);
         *reinterpret_cast<T4*>(dst) = v;
-      } else if (EPI == EPI_SILU || EPI == EPI_BIAS_T) {
+      } else if (EPI == EPI_SILU || EPI == EPI_BIAS_T || EPI == EPI_GELU_SAVE) {
+        // (GELU_SAVE stages the rounded pre-activation; stage 2 writes it and its GELU)
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
         const float p[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
@@ -223,6 +226,25 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
       float4 f = *reinterpret_cast<float4*>(&v);
       f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = f;
+    } else if (EPI == EPI_GELU_SAVE) {
+      // training forward: aux (passed through `resid`) keeps the pre-activation the backward
+      // differentiates, out = GELU of that ROUNDED value
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(const_cast<float*>(resid)) + o) = v;
+      T* pe = reinterpret_cast<T*>(&v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pe[e] = (T)gelu_for<T>((float)pe[e]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(out) + o) = v;
+    } else if (EPI == EPI_DGELU) {
+      // backward: out = acc * gelu'(pre), pre read from aux (`resid`)
+      typedef T __attribute__((ext_vector_type(4))) T4;
+      const float4 f = *reinterpret_cast<float4*>(&v);
+      const T4 pre = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
+      T4 r;
+      r[0] = (T)(f.x * gelu_grad((float)pre[0]));
+      r[1] = (T)(f.y * gelu_grad((float)pre[1]));
+      r[2] = (T)(f.z * gelu_grad((float)pre[2]));
+      r[3] = (T)(f.w * gelu_grad((float)pre[3]));
+      *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = r;
     } else {
       *reinterpret_cast<uint4*>(reinterpret_cast<OT*>(out) + o) = v;
     }
@@ -235,7 +257,7 @@ int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                  long bsX = 0, long bsW = 0, long bsO = 0, const float* ln_w = nullptr,
                  const float* ln_b = nullptr, void* ln_out = nullptr) {
   constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
-  constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T) ? sizeof(T) : sizeof(float)) + 16);
+  constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T || EPI == EPI_GELU_SAVE) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
   auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT>;
   static bool attr_set = false;
@@ -282,6 +304,9 @@ int launch_epi2(int epi, const void* X, const void* W, const float* bias, const 
     case EPI_BIAS: return launch_typed2<T, EPI_BIAS>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_SILU: return launch_typed2<T, EPI_SILU>(X, W, bias, gamma, resid, out, M, N, K, st);
     case EPI_BIAS_T: return launch_typed2<T, EPI_BIAS_T>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_GELU_SAVE: return launch_typed2<T, EPI_GELU_SAVE>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_DGELU: return launch_typed2<T, EPI_DGELU>(X, W, bias, gamma, resid, out, M, N, K, st);
+    case EPI_PLAIN: return launch_typed2<T, EPI_PLAIN>(X, W, bias, gamma, resid, out, M, N, K, st);
   }
   btsbot_set_error("launch_gemm2: bad epilogue %d", epi);
   return BTSBOT_ERR_INVALID_ARG;

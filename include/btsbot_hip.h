@@ -121,6 +121,10 @@ int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_info* out);
  * Replaces: load_state_dict (from_HF.py:74) / the implicit "weights are where cuDNN wants them".
  * Must be called after every change of the master arena (load, optimiser step). */
 int btsbot_pack_params(btsbot_handle h, const float* master_arena, void* stream);
+/* The same for a training loop that differentiates the image branch (btsbot_forward_train with
+ * keep_image_activations != 0): skips the operand images only the fused inference kernels read; an inference
+ * btsbot_forward() afterwards needs a full btsbot_pack_params() first (it returns BTSBOT_ERR_STATE otherwise). */
+int btsbot_pack_params_train(btsbot_handle h, const float* master_arena, void* stream);
 
 /* Workspace: activations of one chunk of alerts.  reserve() (re)allocates for chunks of up to
  * `max_chunk` alerts; forward() splits larger batches into chunks internally. */

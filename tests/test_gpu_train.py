@@ -193,3 +193,33 @@ def test_lr_schedule_matches_golden():
     for key, seq in gold.items():
         w, e = map(int, key.split(","))
         assert np.allclose(lr_schedule(1e-4, e, w), seq, rtol=1e-9)
+
+
+def test_eval_after_training_step_repacks_inference_images(cuda):
+    """A training step that differentiates the image branch re-packs only the per-op operand images
+    (btsbot_pack_params_train); the next eval forward must see freshly packed megakernel images too:
+    its logits equal those of a new model loaded with the trained state dict."""
+    import warnings
+    import btsbot_amd
+    from btsbot_amd.train import Trainer
+    from helpers import CONFIGS, seeded_state, build_model, run_model
+    from btsbot_amd.synthetic import synthetic_batch
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.mm_ConvNeXt(dict(cfg, meta_dropout=0.0, comb_dropout=0.0), precision="bf16")
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    img, meta, lab = synthetic_batch(32, seed=5)
+    img, meta, lab = img.to(cuda), meta.to(cuda), lab.to(cuda)
+    tr = Trainer(m, lr=1e-2, betas=(0.9, 0.999))
+    for _ in range(2):
+        tr.step(img, meta, lab)
+    m.eval()
+    got = run_model(kind, m, img, meta)
+    trained = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    fresh = build_model(kind, cfg, trained, cuda, "bf16")
+    want = run_model(kind, fresh, img, meta)
+    assert torch.equal(got, want)
+    assert not torch.equal(want, run_model(kind, build_model(kind, cfg, sd, cuda, "bf16"), img, meta))
