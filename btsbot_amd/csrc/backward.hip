@@ -257,37 +257,67 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
                                                        const float* __restrict__ w, int flip,
                                                        const float* __restrict__ bias,
                                                        const float* addend, float* out, int C) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [HW*HW][C]
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [HW*HW][C] map | [49][C] taps
   constexpr int P = HW * HW;
+  float* ws = xs + P * C;
   const size_t base = (size_t)blockIdx.x * P * C;
-  for (int i = threadIdx.x; i < P * C; i += 256) xs[i] = x[base + i];
+  // taps in LDS (already flipped if asked) and a rolled ky loop: with the 49 taps in registers and the ky
+  // loop unrolled the 15x15 instance needed 256 VGPRs + scratch and ran one wave per SIMD (131 us per launch)
+  constexpr bool TAPS_LDS = HW >= 15;
+  constexpr int KY_UNROLL = TAPS_LDS ? 1 : 7;   // small maps: the taps stay in registers (staging them costs more
+                                        // than the whole convolution there)
+  if (TAPS_LDS)
+    for (int i = threadIdx.x; i < 49 * C; i += 256) {
+      const int t = i / C, cc = i - t * C;
+      ws[i] = w[(flip ? 48 - t : t) * C + cc];
+    }
+  {
+    // 16-byte pieces, four in flight per thread before the first LDS store (the scalar copy loop waited
+    // for every 4-byte load: 56 exposed HBM latencies per workgroup at 15x15x64)
+    const float4* src = reinterpret_cast<const float4*>(x + base);
+    float4* dst = reinterpret_cast<float4*>(xs);
+    const int n4 = P * C / 4;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 256 < n4) v[k] = src[i0 + k * 256];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 256 < n4) dst[i0 + k * 256] = v[k];
+    }
+  }
   __syncthreads();
   // thread = (channel, row group): narrow maps (C < 256) spread their rows over the idle waves
   const int G = C < 256 ? 256 / C : 1;
   const int rg = C < 256 ? threadIdx.x / C : 0;
   const bool idle = C < 256 && (int)threadIdx.x >= G * C;   // C does not divide 256 (nano)
   for (int c = idle ? C : (C < 256 ? threadIdx.x % C : threadIdx.x); c < C; c += 256) {
-    float wv[49];
-#pragma unroll
-    for (int t = 0; t < 49; ++t) wv[t] = w[(flip ? 48 - t : t) * C + c];
     const float b = bias != nullptr ? bias[c] : 0.f;
+    float wv[TAPS_LDS ? 1 : 49];
+    if (!TAPS_LDS) {
+#pragma unroll
+      for (int t = 0; t < 49; ++t) wv[t] = w[(flip ? 48 - t : t) * C + c];
+    }
     for (int y = rg; y < HW; y += G) {
       float acc[HW];
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) acc[xx] = b;
-#pragma unroll
+#pragma unroll KY_UNROLL
       for (int ky = 0; ky < 7; ++ky) {
         const int iy = y + ky - 3;
         if (iy < 0 || iy >= HW) continue;
-        float in[HW];
+        float in[HW], wk[7];
 #pragma unroll
         for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) wk[kx] = TAPS_LDS ? ws[(ky * 7 + kx) * C + c] : wv[TAPS_LDS ? 0 : ky * 7 + kx];
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
           for (int xx = 0; xx < HW; ++xx) {
             const int ix = xx + kx - 3;
-            if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], wv[ky * 7 + kx], acc[xx]);
+            if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], wk[kx], acc[xx]);
           }
       }
 #pragma unroll
@@ -324,9 +354,27 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     for (int a = a0; a < a1; ++a) {
       __syncthreads();
       const size_t base = (size_t)a * P * C;
-      for (int i = threadIdx.x; i < P * C; i += 256) {
-        xs[i] = x[base + i];
-        ds[i] = dd[base + i];
+      {
+        const float4* sx = reinterpret_cast<const float4*>(x + base);
+        const float4* sd = reinterpret_cast<const float4*>(dd + base);
+        float4* dx4 = reinterpret_cast<float4*>(xs);
+        float4* dd4 = reinterpret_cast<float4*>(ds);
+        const int n4 = P * C / 4;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 512) {
+          float4 a[2], b[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (i0 + k * 256 < n4) {
+              a[k] = sx[i0 + k * 256];
+              b[k] = sd[i0 + k * 256];
+            }
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (i0 + k * 256 < n4) {
+              dx4[i0 + k * 256] = a[k];
+              dd4[i0 + k * 256] = b[k];
+            }
+        }
       }
       __syncthreads();
       if (c < C) {
@@ -645,7 +693,7 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
                     const float* addend, float* out, int B, int HW, int C, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
-  const size_t lds = (size_t)HW * HW * C * sizeof(float);
+  const size_t lds = ((size_t)HW * HW + 49) * C * sizeof(float);
 #define DWP(H)                                                                                 \
   {                                                                                            \
     static size_t attr = 0;                                                                    \

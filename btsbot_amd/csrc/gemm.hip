@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ X,
         const T4 pre = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
         T4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (T)(a[e] * gelu_grad((float)pre[e]));
+        for (int e = 0; e < 4; ++e) v[e] = (T)(a[e] * gelu_grad_for<T>((float)pre[e]));
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = v;
       } else if (EPI == EPI_GELU) {
         typedef T __attribute__((ext_vector_type(4))) T4;

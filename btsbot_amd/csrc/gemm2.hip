@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
       const float4 f = *reinterpret_cast<float4*>(&v);
       const T4 pre = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
       T4 r;
-      r[0] = (T)(f.x * gelu_grad((float)pre[0]));
-      r[1] = (T)(f.y * gelu_grad((float)pre[1]));
-      r[2] = (T)(f.z * gelu_grad((float)pre[2]));
-      r[3] = (T)(f.w * gelu_grad((float)pre[3]));
+      r[0] = (T)(f.x * gelu_grad_for<T>((float)pre[0]));
+      r[1] = (T)(f.y * gelu_grad_for<T>((float)pre[1]));
+      r[2] = (T)(f.z * gelu_grad_for<T>((float)pre[2]));
+      r[3] = (T)(f.w * gelu_grad_for<T>((float)pre[3]));
       *reinterpret_cast<T4*>(reinterpret_cast<T*>(out) + o) = r;
     } else {
       *reinterpret_cast<uint4*>(reinterpret_cast<OT*>(out) + o) = v;
