@@ -170,6 +170,12 @@ int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const flo
                                int N, int K, hipStream_t st, const float* ln_w = nullptr,
                                const float* ln_b = nullptr, void* ln_out = nullptr);
 
+// persistent variant with the filter panel resident in LDS (gemm4.hip): 16-bit modes, K in {128,256},
+// N % 128 == 0, typed-output epilogues SILU / GELU / BIAS_T
+bool gemm4_supported(int prec, int epi, int M, int N, int K);
+int launch_gemm4(int prec, int epi, const void* X, const void* W, const float* bias, void* out, int M,
+                 int N, int K, hipStream_t st);
+
 // LDS-free streaming variant for K in {64,128} (gemm3.hip): filter slice in registers, activation rows
 // fetched as MFMA fragments; 16-bit modes, N % 32 == 0, epilogues SILU / BIAS_T / GELU / RESID / BIAS
 bool gemm3_supported(int prec, int epi, int M, int N, int K);

@@ -62,6 +62,8 @@ struct MaxVit {
   bool no_front = false;    // BTSBOT_AMD_MV_NO_FRONT=1: conv1 GEMM + depthwise kernel instead of the fused MBConv front
   bool no_ln_fuse = false;  // BTSBOT_AMD_MV_NO_LN_FUSE=1: separate LayerNorm launches everywhere
   bool no_attn_block = false;  // BTSBOT_AMD_MV_NO_ATTN_BLOCK=1: qkv GEMM + attention + proj GEMM at C = 64 too
+  bool no_gemm4 = true;     // BTSBOT_AMD_MV_GEMM4=1: persistent GEMM with the filter panel resident in LDS (gemm4.hip)
+                            // for the K = 128 / 256 wide-N shapes (measured 20-25 % slower than gemm2: opt-in)
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
 };
@@ -158,6 +160,8 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_ln_fuse = lf != nullptr && lf[0] == '1';
     const char* ab = getenv("BTSBOT_AMD_MV_NO_ATTN_BLOCK");
     mv->no_attn_block = ab != nullptr && ab[0] == '1';
+    const char* g4 = getenv("BTSBOT_AMD_MV_GEMM4");
+    mv->no_gemm4 = !(g4 != nullptr && g4[0] == '1');
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -309,6 +313,8 @@ size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk) {
 // GEMM dispatch of the MaxViT schedule: the LDS-free streaming kernel where it applies (K = 64 / 128)
 static int mv_gemm(const MaxVit* mv, int prec, int epi, const void* X, const void* W, const float* bias,
                    const float* gamma, const float* resid, void* out, int M, int N, int K, hipStream_t st) {
+  if (!mv->no_gemm4 && gemm4_supported(prec, epi, M, N, K))
+    return launch_gemm4(prec, epi, X, W, bias, out, M, N, K, st);
   if (!mv->no_gemm3 && gemm3_supported(prec, epi, M, N, K))
     return launch_gemm3(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   return launch_gemm(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
@@ -553,7 +559,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         continue;
       }
       MTRY(mv_timed(h, CAT_MV_G_FC1, st, [&] {
-        return launch_gemm(prec, EPI_GELU, Cc, ex + a.p_fc1, m + a.fc1_b, nullptr, nullptr, Bb, Mo,
+        return mv_gemm(mv, prec, EPI_GELU, Cc, ex + a.p_fc1, m + a.fc1_b, nullptr, nullptr, Bb, Mo,
                            4 * c, c, st);
       }));
       MTRY(mv_timed(h, CAT_MV_G_FC2, st, [&] {
