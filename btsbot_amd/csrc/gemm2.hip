@@ -285,6 +285,12 @@ int launch_typed2(const void* X, const void* W, const float* bias, const float* 
     const char* e = getenv("BTSBOT_AMD_GEMM2_NO_1SLOT");
     return !(e != nullptr && e[0] == '1');
   }();
+  static const bool tm64 = [] {
+    const char* e = getenv("BTSBOT_AMD_GEMM2_TM64");   // A/B: 64x128 tiles (48 KB ring: three workgroups per CU)
+    return e != nullptr && e[0] == '1';
+  }();
+  if (tm64 && N >= 128 && wg128 >= 512 && K >= 128)
+    return launch_tile2<T, 64, 128, 1, 4, EPI, 2>(x, w, bias, gamma, resid, out, M, N, K, st);
   if (N >= 128 && wg128 >= 256) {
     if (K == 64 && one_slot)
       return launch_tile2<T, 128, 128, 2, 2, EPI, 1>(x, w, bias, gamma, resid, out, M, N, K, st);
