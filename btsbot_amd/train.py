@@ -153,3 +153,48 @@ def train_epoch(trainer: Trainer, dataset, epoch_metrics: bool = True):
         return float("nan"), float("nan")
     loss, acc = device_metrics(torch.cat(logits), torch.cat(labels), trainer.pos_weight)
     return loss.item(), acc.item()
+
+
+def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model_dir: str,
+        epochs: int, patience: int = 10, val_batch_size: int = 1024, config: Optional[dict] = None):
+    """The epoch loop of train.py:303-352 on the device: per epoch ``train_epoch`` -> ``latest_model.pth`` ->
+    validation pass (val.py's loop, on the live model instead of re-instantiating it from the file) ->
+    scheduler step -> ``best_model.pth`` when the validation loss improved by at least 0.5 % ->
+    early stopping after ``patience`` epochs without improvement.  Checkpoints are state dicts only, like
+    the reference's (no optimiser state); ``report.json`` carries ``config`` for
+    to_HF.prep_config.  Returns the run history dict (train/val loss and accuracy per epoch)."""
+    import json
+    import os
+    import numpy as np
+    from .to_HF import cpu_state_dict
+    from .val import run_val_tensors
+    os.makedirs(model_dir, exist_ok=True)
+    hist = {k: np.zeros(epochs) for k in ("train_loss", "train_accuracy", "val_loss", "val_accuracy")}
+    best_raw_preds = best_val_labels = None
+    since = 0
+    done = 0
+    for epoch in range(epochs):
+        # (train_epoch also steps the LR schedule; the reference steps it after validation, with the same
+        #  effect on the next epoch's learning rate)
+        tl, ta = train_epoch(trainer, train_set)
+        hist["train_loss"][epoch], hist["train_accuracy"][epoch] = tl, ta
+        torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "latest_model.pth"))
+        vl, va, raw, lab = run_val_tensors(trainer.model, val_images, val_metadata, val_labels,
+                                           batch_size=val_batch_size, pos_weight=trainer.pos_weight)
+        trainer.model.train()
+        hist["val_loss"][epoch], hist["val_accuracy"][epoch] = vl, va
+        done = epoch + 1
+        prev_best = min([np.inf] + list(hist["val_loss"][:epoch]))
+        if 1.005 * vl < prev_best:                                   # train.py:334-336
+            torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "best_model.pth"))
+            best_raw_preds, best_val_labels = np.copy(raw), np.copy(lab)
+            since = 0
+        else:
+            since += 1
+            if since >= patience:                                    # train.py:350-352
+                break
+    out = {k: v[:done].tolist() for k, v in hist.items()}
+    with open(os.path.join(model_dir, "report.json"), "w") as f:
+        json.dump({"train_config": dict(config or {}), "Training history": out}, f, indent=2)
+    out["best_raw_preds"], out["best_val_labels"] = best_raw_preds, best_val_labels
+    return out

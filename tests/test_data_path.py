@@ -245,3 +245,32 @@ def test_inference_example_end_to_end(cuda, tmp_path):
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_logits.npz"))["mm_pico/example8"]
     want = torch.sigmoid(torch.from_numpy(gold)).round().squeeze().numpy().astype(int)
     assert np.array_equal(preds, want) and np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.gpu
+def test_fit_loop_checkpoints_and_early_stopping(cuda, tmp_path):
+    """train.py:303-352: latest_model.pth every epoch, best_model.pth on a >= 0.5 % better validation loss,
+    early stopping; the saved files load strictly into a fresh model."""
+    from btsbot_amd.train import Trainer, fit
+    kind, cfg = CONFIGS["um_nn"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.um_nn(cfg, precision="f32")
+    m.load_state_dict(seeded_state(kind, cfg, seed=3))
+    m = m.to(cuda).train()
+    _, meta, _ = synthetic_batch(512, seed=21)
+    lab = (meta[:, 5] > meta[:, 5].median()).long()                     # learnable from one column
+    ds = data.DeviceDataset(None, meta[:384], lab[:384], 64, device=cuda,
+                            generator=torch.Generator(device=cuda).manual_seed(2))
+    tr = Trainer(m, lr=3e-3, betas=(0.9, 0.999), pos_weight=ds.pos_weight, epochs=6, warmup_epochs=1)
+    hist = fit(tr, ds, None, meta[384:], lab[384:], str(tmp_path), epochs=6, patience=2, config=cfg)
+    n = len(hist["val_loss"])
+    assert 1 <= n <= 6 and os.path.isfile(tmp_path / "latest_model.pth") and os.path.isfile(tmp_path / "best_model.pth")
+    assert hist["val_loss"][-1] < 0.9 * hist["val_loss"][0] or n < 6      # it learns, or stopped early
+    best = torch.load(tmp_path / "best_model.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2 = btsbot_amd.um_nn(cfg)
+    m2.load_state_dict(best, strict=True)
+    assert json.load(open(tmp_path / "report.json"))["train_config"]["model_name"] == "um_nn"
+    assert hist["best_raw_preds"] is not None and hist["best_raw_preds"].shape == (128,)
