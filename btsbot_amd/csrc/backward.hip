@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
   // taps in LDS (already flipped if asked) and a rolled ky loop: with the 49 taps in registers and the ky
   // loop unrolled the 15x15 instance needed 256 VGPRs + scratch and ran one wave per SIMD (131 us per launch)
   constexpr bool TAPS_LDS = HW >= 15;
-  constexpr int KY_UNROLL = TAPS_LDS ? 1 : 7;   // small maps: the taps stay in registers (staging them costs more
+  constexpr bool TAPS_GLOBAL = HW == 7;   // 7x7 maps: rolled ky loop, the row's 7 taps re-read from L1 per ky
+  constexpr int KY_UNROLL = (TAPS_LDS || TAPS_GLOBAL) ? 1 : 7;   // small maps: the taps stay in registers (staging them costs more
                                         // than the whole convolution there)
   if (TAPS_LDS)
     for (int i = threadIdx.x; i < 49 * C; i += 256) {
@@ -280,8 +281,7 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
     for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
       float4 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k * 256 < n4) v[k] = src[i0 + k * 256];
+      for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + k * 256, n4 - 1)];   // (clamped: no conditional definition)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (i0 + k * 256 < n4) dst[i0 + k * 256] = v[k];
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
   const bool idle = C < 256 && (int)threadIdx.x >= G * C;   // C does not divide 256 (nano)
   for (int c = idle ? C : (C < 256 ? threadIdx.x % C : threadIdx.x); c < C; c += 256) {
     const float b = bias != nullptr ? bias[c] : 0.f;
-    float wv[TAPS_LDS ? 1 : 49];
-    if (!TAPS_LDS) {
+    float wv[(TAPS_LDS || TAPS_GLOBAL) ? 1 : 49];
+    if (!TAPS_LDS && !TAPS_GLOBAL) {
 #pragma unroll
       for (int t = 0; t < 49; ++t) wv[t] = w[(flip ? 48 - t : t) * C + c];
     }
@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
 #pragma unroll
         for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) wk[kx] = TAPS_LDS ? ws[(ky * 7 + kx) * C + c] : wv[TAPS_LDS ? 0 : ky * 7 + kx];
+        for (int kx = 0; kx < 7; ++kx)
+          wk[kx] = TAPS_LDS      ? ws[(ky * 7 + kx) * C + c]
+                   : TAPS_GLOBAL ? w[(flip ? 48 - (ky * 7 + kx) : ky * 7 + kx) * C + c]
+                                 : wv[(TAPS_LDS || TAPS_GLOBAL) ? 0 : ky * 7 + kx];
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
@@ -363,11 +366,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         for (int i0 = threadIdx.x; i0 < n4; i0 += 512) {
           float4 a[2], b[2];
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (i0 + k * 256 < n4) {
-              a[k] = sx[i0 + k * 256];
-              b[k] = sd[i0 + k * 256];
-            }
+          for (int k = 0; k < 2; ++k) {
+            const int ii = min(i0 + k * 256, n4 - 1);
+            a[k] = sx[ii];
+            b[k] = sd[ii];
+          }
 #pragma unroll
           for (int k = 0; k < 2; ++k)
             if (i0 + k * 256 < n4) {
