@@ -5,10 +5,10 @@
 // torch autograd does between model(...) (train.py:510) and loss.backward() (train.py:526).
 // The image branch has no BatchNorm and no dropout (drop-path 0): its training forward computes the
 // same function as inference, only unfused (per-op kernels) with per-block buffers:
-//     kept per block : x_in (fp32), xn = LN(dwconv(x_in)) (operand type), a = fc1 pre-activation,
-//                      h = gelu(a)
+//     kept per block : x_in (fp32), d = dwconv(x_in) (fp32), xn = LN(d) (operand type),
+//                      a = fc1 pre-activation, h = gelu(a)
 //     kept per stage : the stage output (input of the next downsample), the 2x2 patch matrix
-// Everything else (depthwise output, LN statistics, stem conv output) is recomputed in the backward.
+// Everything else (LN statistics, stem conv output) is recomputed in the backward.
 #include <string.h>
 
 #include "ctx.h"
@@ -17,6 +17,7 @@ namespace {
 
 struct BlkBuf {
   float* xin;
+  float* d;      // depthwise output before the LayerNorm (fp32)
   void* xn;
   void* a;
   void* h;
@@ -60,6 +61,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
     for (int j = 0; j < c.depths[i]; ++j) {
       BlkBuf b;
       b.xin = reinterpret_cast<float*>(take(rows * ch * 4));
+      b.d = reinterpret_cast<float*>(take(rows * ch * 4));
       b.xn = take(rows * ch * esz);
       b.a = take(rows * 4 * ch * esz);
       b.h = take(rows * 4 * ch * esz);
@@ -122,7 +124,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       const BlkBuf& s = k.blk[i][j];
       float* xout = j + 1 < nblk ? k.blk[i][j + 1].xin : k.xs[i];
       TRYB(launch_dwconv_ln(c.precision, s.xin, reinterpret_cast<const float*>(h->extra + b.p_dw),
-                            m + b.dw_b, m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, st));
+                            m + b.dw_b, m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, st, s.d));
       TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
                        reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, st));
       TRYB(launch_gemm(c.precision, EPI_RESID, s.h, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,
@@ -175,9 +177,8 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(wgrad_cs(prec, k.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, st));
       TRYB(launch_gemm(prec, EPI_PLAIN, k.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
-      // ---- LayerNorm backward on the recomputed depthwise output d = dwconv(x_in) + bias
-      TRYB(launch_dw_plain(s.xin, wdw, 0, m + b.dw_b, nullptr, k.dC, B, hw, ch, st));
-      TRYB(launch_ln_bwd(k.dC, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
+      // ---- LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
+      TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
       // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
       TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
       TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st));

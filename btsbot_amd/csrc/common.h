@@ -189,9 +189,10 @@ int launch_stem(const float* img, const float* w48xC, const float* bias, const f
 
 // depthwise 7x7 p3 (+bias) + LayerNorm over C.  x [B,HW*HW,C] fp32 -> xn [B,HW*HW,C] prec-typed.
 // wdw is tap-major [49][C] fp32.
+// dsave != NULL: also the pre-LayerNorm map d = dwconv(x) + bias, [B,HW*HW,C] fp32 (kept for the backward)
 int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bdw,
                      const float* lnw, const float* lnb, void* xn, int B, int HW, int C,
-                     hipStream_t st);
+                     hipStream_t st, float* dsave = nullptr);
 
 // downsample prologue: LayerNorm over Cin per pixel, then 2x2/s2 patch gather.
 // x [B,HW,HW,Cin] fp32 -> patches [B*(HW/2)^2, 4*Cin] prec-typed, k = (ky*2+kx)*Cin + c.

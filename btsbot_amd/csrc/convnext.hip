@@ -58,7 +58,8 @@ template <int C> struct Chunking {
 template <int C, int HW, int G, int NW, typename T>
 __global__ __launch_bounds__(NW * 64) void dwconv_ln_kernel(
     const float* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
-    const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ xn, int B) {
+    const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ xn, int B,
+    float* __restrict__ dsave) {
   constexpr int LPC = Chunking<C>::LPC, NCH = Chunking<C>::NCH;
   constexpr int P = HW * HW;
   constexpr int NV = HW <= 3 ? 4 : (HW <= 7 ? 8 : 16);
@@ -163,6 +164,11 @@ __global__ __launch_bounds__(NW * 64) void dwconv_ln_kernel(
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx)
         dst[xx * C] = (T)((acc[xx] - mean[xx]) * rstd[xx] * g + bb);
+      if (dsave != nullptr) {   // training: the pre-LayerNorm map, so the backward need not recompute it
+        float* dd = dsave + ((size_t)(a0 + ga) * P + y * HW) * C + c;
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) dd[xx * C] = acc[xx];
+      }
     }
   }
 }
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(C) void dw3_ln_kernel(const float* __restrict__ x,
                                                    const float* __restrict__ bdw,
                                                    const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb,
-                                                   T* __restrict__ xn, int B) {
+                                                   T* __restrict__ xn, int B,
+                                                   float* __restrict__ dsave) {
   constexpr int NW = C / 64;
   __shared__ float red[2][NW][9];
   const int c = threadIdx.x, wave = c >> 6;
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(C) void dw3_ln_kernel(const float* __restrict__ x,
     for (int w2 = 0; w2 < NW; ++w2) t += red[1][w2][p];
     rstd[p] = rsqrtf(t * (1.0f / C) + LN_EPS);
     dst[p * C] = (T)((acc[p] - mean[p]) * rstd[p] * g + bb);
+    if (dsave != nullptr) dsave[(size_t)a * 9 * C + c + p * C] = acc[p];
   }
 }
 
@@ -240,7 +248,8 @@ __global__ __launch_bounds__(256) void dw1_ln_kernel(const float* __restrict__ x
                                                      const float* __restrict__ bdw,
                                                      const float* __restrict__ lnw,
                                                      const float* __restrict__ lnb,
-                                                     T* __restrict__ xn, int B, int C) {
+                                                     T* __restrict__ xn, int B, int C,
+                                                     float* __restrict__ dsave) {
   const int lane = threadIdx.x & 63;
   const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (a >= B) return;
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(256) void dw1_ln_kernel(const float* __restrict__ x
   for (int i = 0; i < CPT; ++i) {
     const int c = lane + 64 * i;
     if (c < C) xn[(size_t)a * C + c] = (T)((v[i] - mean) * rstd * lnw[c] + lnb[c]);
+    if (c < C && dsave != nullptr) dsave[(size_t)a * C + c] = v[i];
   }
 }
 
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 
 template <int C, int HW, int G, int NW, typename T>
 int launch_dw_cfg(const float* x, const float* wdw, const float* bdw, const float* lnw,
-                  const float* lnb, void* xn, int B, hipStream_t st) {
+                  const float* lnb, void* xn, int B, hipStream_t st, float* dsave) {
   constexpr int NV = HW <= 3 ? 4 : (HW <= 7 ? 8 : 16);
   const size_t lds = ((size_t)G * HW * HW * C + 2 * NW * NV) * sizeof(float);
   auto kern = dwconv_ln_kernel<C, HW, G, NW, T>;
@@ -394,24 +404,26 @@ int launch_dw_cfg(const float* x, const float* wdw, const float* bdw, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((B + G - 1) / G), dim3(NW * 64), lds, st, x, wdw, bdw, lnw, lnb,
-                     reinterpret_cast<T*>(xn), B);
+                     reinterpret_cast<T*>(xn), B, dsave);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
 
 template <typename T>
 int launch_dw_typed(const float* x, const float* wdw, const float* bdw, const float* lnw,
-                    const float* lnb, void* xn, int B, int HW, int C, hipStream_t st) {
+                    const float* lnb, void* xn, int B, int HW, int C, hipStream_t st, float* dsave) {
 #define DW_CASE(CC, HH, GG, WW) \
-  if (C == CC && HW == HH) return launch_dw_cfg<CC, HH, GG, WW, T>(x, wdw, bdw, lnw, lnb, xn, B, st)
+  if (C == CC && HW == HH) return launch_dw_cfg<CC, HH, GG, WW, T>(x, wdw, bdw, lnw, lnb, xn, B, st, dsave)
   DW_CASE(64, 15, 1, 8);
   DW_CASE(128, 7, 2, 8);
   if (HW == 3 && (C == 256 || C == 320)) {
     T* o = reinterpret_cast<T*>(xn);
     if (C == 256)
-      hipLaunchKernelGGL((dw3_ln_kernel<256, T>), dim3(B), dim3(256), 0, st, x, wdw, bdw, lnw, lnb, o, B);
+      hipLaunchKernelGGL((dw3_ln_kernel<256, T>), dim3(B), dim3(256), 0, st, x, wdw, bdw, lnw, lnb, o, B,
+                         dsave);
     else
-      hipLaunchKernelGGL((dw3_ln_kernel<320, T>), dim3(B), dim3(320), 0, st, x, wdw, bdw, lnw, lnb, o, B);
+      hipLaunchKernelGGL((dw3_ln_kernel<320, T>), dim3(B), dim3(320), 0, st, x, wdw, bdw, lnw, lnb, o, B,
+                         dsave);
     LAUNCH_CHECK();
     return BTSBOT_OK;
   }
@@ -423,9 +435,9 @@ int launch_dw_typed(const float* x, const float* wdw, const float* bdw, const fl
     dim3 grid((B + 3) / 4), blk(256);
     T* o = reinterpret_cast<T*>(xn);
     if (cpt <= 8)
-      hipLaunchKernelGGL((dw1_ln_kernel<8, T>), grid, blk, 0, st, x, wdw, bdw, lnw, lnb, o, B, C);
+      hipLaunchKernelGGL((dw1_ln_kernel<8, T>), grid, blk, 0, st, x, wdw, bdw, lnw, lnb, o, B, C, dsave);
     else if (cpt <= 10)
-      hipLaunchKernelGGL((dw1_ln_kernel<10, T>), grid, blk, 0, st, x, wdw, bdw, lnw, lnb, o, B, C);
+      hipLaunchKernelGGL((dw1_ln_kernel<10, T>), grid, blk, 0, st, x, wdw, bdw, lnw, lnb, o, B, C, dsave);
     else {
       btsbot_set_error("dwconv_ln: C=%d too wide for the 1x1 kernel", C);
       return BTSBOT_ERR_INVALID_ARG;
@@ -460,12 +472,12 @@ int launch_lnp_typed(const float* x, const float* lnw, const float* lnb, void* p
 
 int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bdw,
                      const float* lnw, const float* lnb, void* xn, int B, int HW, int C,
-                     hipStream_t st) {
+                     hipStream_t st, float* dsave) {
   if (B <= 0) return BTSBOT_OK;
   switch (prec) {
-    case BTSBOT_F32: return launch_dw_typed<float>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st);
-    case BTSBOT_BF16: return launch_dw_typed<bf16_t>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st);
-    case BTSBOT_F16: return launch_dw_typed<f16_t>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st);
+    case BTSBOT_F32: return launch_dw_typed<float>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st, dsave);
+    case BTSBOT_BF16: return launch_dw_typed<bf16_t>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st, dsave);
+    case BTSBOT_F16: return launch_dw_typed<f16_t>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st, dsave);
   }
   btsbot_set_error("dwconv_ln: bad precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
