@@ -14,6 +14,8 @@
 // buffer, one barrier per 32-row tile).  Slices meet in the output through fp32 atomics.
 // Replaces (with backward.hip) what autograd does for nn.Linear / 1x1 Conv2d weight gradients at
 // /root/reference/btsbot/train.py:526.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -185,9 +187,20 @@ template <typename T, int TN, int TK>
 int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M, int N, int K,
                   int ldo, hipStream_t st) {
   const int gx = (N + TN - 1) / TN, gy = (K + TK - 1) / TK;
-  // slices of the reduction: ~768 workgroups in flight, at least 256 rows each
-  int nsl = (768 + gx * gy - 1) / (gx * gy);
-  if (nsl > (M + 255) / 256) nsl = (M + 255) / 256;
+  // slices of the reduction: ~384 workgroups in flight, at least 512 rows each (every slice ends in
+  // TN x TK fp32 atomics: fewer, longer slices beat more parallelism on the 9216-row stage-2 shapes)
+  static const int min_rows = [] {
+    const char* e = getenv("BTSBOT_AMD_WGRAD_MIN_ROWS");   // tuning knob (default 512; measured 256: +3 %, 1024: +4 %)
+    const int v = e ? atoi(e) : 512;
+    return v >= 32 ? v : 512;
+  }();
+  static const int target_wg = [] {
+    const char* e = getenv("BTSBOT_AMD_WGRAD_WGS");        // tuning knob (default 384)
+    const int v = e ? atoi(e) : 384;
+    return v >= 1 ? v : 384;
+  }();
+  int nsl = (target_wg + gx * gy - 1) / (gx * gy);
+  if (nsl > (M + min_rows - 1) / min_rows) nsl = (M + min_rows - 1) / min_rows;
   if (nsl < 1) nsl = 1;
   const int mslice = ((M + nsl - 1) / nsl + TM - 1) / TM * TM;
   nsl = (M + mslice - 1) / mslice;
