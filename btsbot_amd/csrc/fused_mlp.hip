@@ -106,14 +106,39 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
   __syncthreads();
 
   long seq = 0;  // chunks consumed so far by this workgroup (ring position)
+  // B operand of GEMM1: the pixel's C channels, k-step ks holds channels 16ks + 8h .. +7.  The fragments of
+  // the NEXT tile and the residual rows of THIS tile are requested before the tile's MFMA work, so their HBM
+  // latency hides under it (PMC: the waves of this kernel were parked on s_waitcnt / barriers 55 % of the time)
+  frag xf[KS1], xnext[KS1];
+  {
+    const int m0 = (int)blockIdx.x * 256 + wave * 32 + lr;
+    const int mc0 = m0 < M ? m0 : M - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      xf[ks] = *reinterpret_cast<const frag*>(xn + (size_t)mc0 * C + ks * 16 + h * 8);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m = tile * 256 + wave * 32 + lr;          // this lane's pixel row
     const int mc = m < M ? m : M - 1;
-    // B operand of GEMM1: the pixel's C channels, k-step ks holds channels 16ks + 8h .. +7
-    frag xf[KS1];
+    // (C = 64 runs four waves per SIMD on 128 VGPRs: no room to hold the residual rows across the tile)
+    constexpr bool PRE_R = C > 64;
+    float4 rres[PRE_R ? CT : 1][4];                      // x[m][c .. c+3] for the epilogue
+    if (PRE_R) {
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks)
-      xf[ks] = *reinterpret_cast<const frag*>(xn + (size_t)mc * C + ks * 16 + h * 8);
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rres[PRE_R ? ct : 0][q] =
+              *reinterpret_cast<const float4*>(x + (size_t)mc * C + ct * 32 + 8 * q + 4 * h);
+    }
+    {
+      const int tn = tile + (int)gridDim.x;
+      const int mn = (tn < ntiles ? tn : tile) * 256 + wave * 32 + lr;
+      const int mcn = mn < M ? mn : M - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+        xnext[ks] = *reinterpret_cast<const frag*>(xn + (size_t)mcn * C + ks * 16 + h * 8);
+    }
     f32x16 yacc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
           const float4 bv = *reinterpret_cast<const float4*>(b2 + c);
           const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
           float4* px = reinterpret_cast<float4*>(x + (size_t)m * C + c);
-          float4 r = *px;
+          float4 r = PRE_R ? rres[PRE_R ? ct : 0][q] : *px;
           r.x += gv.x * (yacc[ct][4 * q + 0] + bv.x);
           r.y += gv.y * (yacc[ct][4 * q + 1] + bv.y);
           r.z += gv.z * (yacc[ct][4 * q + 2] + bv.z);
@@ -234,6 +259,8 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
         }
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) xf[ks] = xnext[ks];
   }
 }
 
