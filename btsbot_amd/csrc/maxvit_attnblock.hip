@@ -81,25 +81,33 @@ __global__ __launch_bounds__(256, 2) void mv_attn_block64_kernel(
   __syncthreads();
 
   typedef T __attribute__((ext_vector_type(4))) T4;
-  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+  // row of this lane's phase-A / phase-C token (16*wave + l15, padded tokens repeat token 48) in unit u
+  const int tokA = wave * 16 + l15;
+  auto rowA_of = [&](int u) -> long {
     const int w = u % nW;
     const long b = u / nW;
     const int wy = w / G, wx = w % G;
-    // row of this lane's token in each role: phase A / C use token 16*wave + l15
-    auto row_of = [&](int t) -> long {
-      const int ty = t / 7, tx = t - ty * 7;
-      const int py = grid_mode ? ty * G + wy : wy * 7 + ty;
-      const int px = grid_mode ? tx * G + wx : wx * 7 + tx;
-      return (b * H + py) * H + px;
-    };
-    const int tokA = wave * 16 + l15;
-    const long rowA = row_of(min(tokA, 48));
+    const int t = min(tokA, 48);
+    const int ty = t / 7, tx = t - ty * 7;
+    const int py = grid_mode ? ty * G + wy : wy * 7 + ty;
+    const int px = grid_mode ? tx * G + wx : wx * 7 + tx;
+    return (b * H + py) * H + px;
+  };
+  // the NEXT partition's token rows are requested during the current one's attention phase, this
+  // partition's residual rows at its start (PMC: the waves were parked on s_waitcnt / barriers 62 % of the time)
+  frag xf[2];
+  if ((int)blockIdx.x < units) {
+    const long r0 = rowA_of(blockIdx.x);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xf[ks] = *reinterpret_cast<const frag*>(xn + r0 * C + ks * 32 + g * 8);
+  }
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const long rowA = rowA_of(u);
+    float4 rres[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) rres[ct] = *reinterpret_cast<const float4*>(x + rowA * C + ct * 16 + 4 * g);
     // ---- phase A: qkv^T tile of this wave's 16 tokens
     {
-      frag xf[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        xf[ks] = *reinterpret_cast<const frag*>(xn + rowA * C + ks * 32 + g * 8);
 #pragma unroll
       for (int ct = 0; ct < 12; ++ct) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -118,6 +126,12 @@ __global__ __launch_bounds__(256, 2) void mv_attn_block64_kernel(
       }
     }
     __syncthreads();
+    {
+      const int un = u + (int)gridDim.x < units ? u + (int)gridDim.x : u;
+      const long rn = rowA_of(un);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xf[ks] = *reinterpret_cast<const frag*>(xn + rn * C + ks * 32 + g * 8);
+    }
     // ---- phase B: attention of (head, two query tiles)
     {
       frag kf[4], qf[2];
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void mv_attn_block64_kernel(
         }
         const int c = ct * 16 + 4 * g;
         const float4 bv = *reinterpret_cast<const float4*>(bproj + c);
-        const float4 rv = *reinterpret_cast<const float4*>(x + rowA * C + c);
+        const float4 rv = rres[ct];
         v[ct][0] = rv.x + (acc[0] + bv.x);
         v[ct][1] = rv.y + (acc[1] + bv.y);
         v[ct][2] = rv.z + (acc[2] + bv.z);
