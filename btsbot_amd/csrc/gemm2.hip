@@ -286,11 +286,13 @@ int launch_typed2(const void* X, const void* W, const float* bias, const float* 
     return !(e != nullptr && e[0] == '1');
   }();
   static const bool tm64 = [] {
-    const char* e = getenv("BTSBOT_AMD_GEMM2_TM64");   // A/B: 64x128 tiles (48 KB ring: three workgroups per CU)
+    const char* e = getenv("BTSBOT_AMD_GEMM2_TM64");   // A/B: 64x128 tiles, 3-slot ring (72 KB: two workgroups per CU, two k-tiles in flight each)
     return e != nullptr && e[0] == '1';
   }();
-  if (tm64 && N >= 128 && wg128 >= 512 && K >= 128)
-    return launch_tile2<T, 64, 128, 1, 4, EPI, 2>(x, w, bias, gamma, resid, out, M, N, K, st);
+  // long reductions on big problems (MaxViT fc2 / conv3 at C >= 256: K >= 1024) run 7 % faster on 64x128 tiles
+  // with a 3-slot ring (two workgroups per CU, two k-tiles in flight each); the short-K shapes lose 15 % there
+  if (N >= 128 && wg128 >= 512 && (K >= 1024 || (tm64 && K >= 128)))
+    return launch_tile2<T, 64, 128, 1, 4, EPI, 3>(x, w, bias, gamma, resid, out, M, N, K, st);
   if (N >= 128 && wg128 >= 256) {
     if (K == 64 && one_slot)
       return launch_tile2<T, 128, 128, 2, 2, EPI, 1>(x, w, bias, gamma, resid, out, M, N, K, st);
