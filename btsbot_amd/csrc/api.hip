@@ -276,6 +276,8 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h == nullptr) return BTSBOT_OK;
   if (h->mirror) (void)hipFree(h->mirror);
   if (h->extra) (void)hipFree(h->extra);
+  for (void* t : h->pack_jobs)
+    if (t) (void)hipFree(t);
   if (h->ws) (void)hipFree(h->ws);
   if (h->tcache) (void)hipFree(h->tcache);
   if (h->bbcache) (void)hipFree(h->bbcache);
@@ -340,26 +342,82 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   HIP_TRY(hipMemcpyAsync(h->mirror, master, (size_t)h->total_floats * 4, hipMemcpyDeviceToDevice,
                          st));
   const float* m = h->mirror;
-  if (h->has_image && h->is_maxvit) {
-    TRY(maxvit_pack(h, st));
-  } else if (h->has_image) {
+  // The plain element maps (casts, transposes, the downsample re-orderings) run as ONE launch over a job
+  // table built on the first pack of each kind: mirror and extra never move, so the table is static.
+  // BTSBOT_AMD_PACK_UNBATCHED=1 keeps one launch per operand (A/B and parity).
+  static const bool unbatched = [] {
+    const char* e = getenv("BTSBOT_AMD_PACK_UNBATCHED");
+    return e != nullptr && e[0] == '1';
+  }();
+  const int kind = train_only ? 1 : 0;
+  std::vector<PackJob> jobs;
+  const bool build = !unbatched && h->pack_jobs[kind] == nullptr;
+  int status = BTSBOT_OK;
+  auto job = [&](int op, const float* src, const float* scale, void* dst, int R, int Cc) {
+    if (status != BTSBOT_OK) return;
+    if (!unbatched) {
+      if (build) jobs.push_back(PackJob{src, scale, dst, R, Cc, op, 0});
+      return;
+    }
+    switch (op) {
+      case PACK_CAST: status = launch_cast(c.precision, src, dst, R, st); break;
+      case PACK_TRANSPOSE_F32: status = launch_transpose_f32(src, reinterpret_cast<float*>(dst), R, Cc, st); break;
+      case PACK_TRANSPOSE_CAST: status = launch_transpose_cast(c.precision, src, scale, dst, R, Cc, st); break;
+      case PACK_DOWN: status = launch_pack_down(c.precision, src, dst, R, Cc, st); break;
+      default: status = launch_pack_down_t(c.precision, src, dst, R, Cc, st);
+    }
+  };
+  const bool convnext = h->has_image && !h->is_maxvit;
+  if (convnext) {
     if (h->stage0 || h->train_packs)
-      TRY(launch_cast(c.precision, m + h->stem_w, h->extra + h->p_stem16, (int64_t)c.dims[0] * 48,
-                      st));
+      job(PACK_CAST, m + h->stem_w, nullptr, h->extra + h->p_stem16, c.dims[0] * 48, 1);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
       if (i > 0) {
-        TRY(launch_pack_down(c.precision, m + h->down[i].w, h->extra + h->down[i].p_w, ch,
-                             c.dims[i - 1], st));
+        job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
         if (h->train_packs)
-          TRY(launch_pack_down_t(c.precision, m + h->down[i].w, h->extra + h->down[i].p_wt, ch,
-                                 c.dims[i - 1], st));
+          job(PACK_DOWN_T, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wt, ch, c.dims[i - 1]);
       }
       for (const BlockPk& b : h->blocks[i]) {
-        TRY(launch_transpose_f32(m + b.dw_w, reinterpret_cast<float*>(h->extra + b.p_dw), ch, 49,
-                                 st));
-        TRY(launch_cast(c.precision, m + b.fc1_w, h->extra + b.p_fc1, (int64_t)4 * ch * ch, st));
-        TRY(launch_cast(c.precision, m + b.fc2_w, h->extra + b.p_fc2, (int64_t)4 * ch * ch, st));
+        job(PACK_TRANSPOSE_F32, m + b.dw_w, nullptr, h->extra + b.p_dw, ch, 49);
+        job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
+        job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
+        if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
+          job(PACK_TRANSPOSE_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch, ch);
+          job(PACK_TRANSPOSE_CAST, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch, 4 * ch);
+        }
+      }
+    }
+  }
+  if (h->has_meta) {
+    job(PACK_TRANSPOSE_F32, m + h->m1_w, nullptr, h->extra + h->p_m1, c.meta_fc1, c.n_meta);
+    job(PACK_TRANSPOSE_F32, m + h->m2_w, nullptr, h->extra + h->p_m2, c.meta_fc2, c.meta_fc1);
+  }
+  for (int i = 0; i < h->n_comb; ++i)
+    job(PACK_TRANSPOSE_F32, m + h->comb_w[i], nullptr, h->extra + h->p_comb[i], h->comb_dims[i + 1],
+        h->comb_dims[i]);
+  TRY(status);
+  if (build && !jobs.empty()) {
+    int nb = 0;
+    for (PackJob& j : jobs) {
+      j.blk0 = nb;
+      nb += pack_job_blocks(j);
+    }
+    HIP_TRY(hipMalloc(&h->pack_jobs[kind], jobs.size() * sizeof(PackJob)));
+    HIP_TRY(hipMemcpy(h->pack_jobs[kind], jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    h->pack_njobs[kind] = (int)jobs.size();
+    h->pack_blocks[kind] = nb;
+  }
+  if (!unbatched)
+    TRY(launch_pack_jobs(c.precision, reinterpret_cast<const PackJob*>(h->pack_jobs[kind]), h->pack_njobs[kind],
+                         h->pack_blocks[kind], st));
+  // ... then the images that read the packed taps or have maps of their own
+  if (h->has_image && h->is_maxvit) {
+    TRY(maxvit_pack(h, st));
+  } else if (h->has_image) {
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.dims[i];
+      for (const BlockPk& b : h->blocks[i]) {
         if (!train_only)
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
@@ -373,12 +431,6 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s0par(reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
-        if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
-          TRY(launch_transpose_cast(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch,
-                                    ch, st));
-          TRY(launch_transpose_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch,
-                                    4 * ch, st));
-        }
         if (b.fused && !train_only)
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
                                     h->extra + b.p_fused, st));
@@ -386,17 +438,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     }
   }
   if (h->has_meta) {
-    TRY(launch_transpose_f32(m + h->m1_w, reinterpret_cast<float*>(h->extra + h->p_m1), c.meta_fc1,
-                             c.n_meta, st));
-    TRY(launch_transpose_f32(m + h->m2_w, reinterpret_cast<float*>(h->extra + h->p_m2), c.meta_fc2,
-                             c.meta_fc1, st));
     TRY(launch_bn_fold(m + h->bn_w, m + h->bn_b, m + h->bn_rm, m + h->bn_rv,
                        reinterpret_cast<float*>(h->extra + h->p_bn_scale),
                        reinterpret_cast<float*>(h->extra + h->p_bn_shift), c.n_meta, st));
   }
-  for (int i = 0; i < h->n_comb; ++i)
-    TRY(launch_transpose_f32(m + h->comb_w[i], reinterpret_cast<float*>(h->extra + h->p_comb[i]),
-                             h->comb_dims[i + 1], h->comb_dims[i], st));
   h->packed = true;
   h->packed_full = !train_only || !h->has_image || h->is_maxvit;
   return BTSBOT_OK;
@@ -834,6 +879,14 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
     if (!h->train_packs) {      // the dgrad transposes must be packed too from now on
       h->train_packs = true;
       h->packed = false;
+      for (int kd = 0; kd < 2; ++kd) {   // the job tables were built without the transposes: rebuild on the next pack
+        if (h->pack_jobs[kd]) {
+          HIP_TRY(hipDeviceSynchronize());
+          (void)hipFree(h->pack_jobs[kd]);
+        }
+        h->pack_jobs[kd] = nullptr;
+        h->pack_njobs[kd] = h->pack_blocks[kd] = 0;
+      }
     }
   }
   h->train_batch = 0;

@@ -165,8 +165,8 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
       // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
-      HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + (size_t)ch * H) - k.S) * 4, st));
-      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
+      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.S,
+                             (long)((k.G + (size_t)ch * H) - k.S)));
       TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, st));
@@ -187,8 +187,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
       const int cin = c.dims[i - 1], hwp = STAGE_HW[i - 1];
       const long prow = (long)B * hwp * hwp;
-      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st));
-      HIP_TRY(hipMemsetAsync(k.G, 0, (size_t)ch * 4 * cin * 4, st));
+      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.G, (long)ch * 4 * cin));
       TRYB(wgrad_cs(prec, k.dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin,
                     st));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));

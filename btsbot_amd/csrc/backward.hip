@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
 template <typename T>
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ in,
                                                          const float* __restrict__ scale,
-                                                         T* __restrict__ out, long n, int C) {
+                                                         T* __restrict__ out, long n, int C,
+                                                         float* __restrict__ zero, long zero_n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     out[i] = (T)(in[i] * (scale != nullptr ? scale[i % C] : 1.f));
+  // (the accumulators of the filter-gradient GEMM that consumes `out`: cleared here instead of by a memset launch)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = 0.f;
 }
 
 // out[r][c] = (T)(in[r][c] * rowscale[r])
@@ -515,20 +518,20 @@ int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_
 }
 
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
-                      hipStream_t st) {
+                      hipStream_t st, float* zero, long zero_n) {
   if (n <= 0) return BTSBOT_OK;
   switch (prec) {
     case BTSBOT_F32:
       hipLaunchKernelGGL(scale_cast_kernel<float>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<float*>(out), n, C);
+                         reinterpret_cast<float*>(out), n, C, zero, zero_n);
       break;
     case BTSBOT_BF16:
       hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<bf16_t*>(out), n, C);
+                         reinterpret_cast<bf16_t*>(out), n, C, zero, zero_n);
       break;
     case BTSBOT_F16:
       hipLaunchKernelGGL(scale_cast_kernel<f16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<f16_t*>(out), n, C);
+                         reinterpret_cast<f16_t*>(out), n, C, zero, zero_n);
       break;
     default:
       btsbot_set_error("scale_cast: bad precision %d", prec);

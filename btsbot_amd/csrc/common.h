@@ -244,7 +244,7 @@ int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
-                      hipStream_t st);
+                      hipStream_t st, float* zero = nullptr, long zero_n = 0);   // also zero[0..zero_n) = 0
 int launch_fc2_grads(const float* G, const float* S, const float* w2, const float* b2,
                      const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
                      hipStream_t st);
@@ -299,6 +299,19 @@ int launch_head(const HeadArgs& a, hipStream_t st);
 
 // parameter packing helpers
 int launch_cast(int prec, const float* src, void* dst, int64_t n, hipStream_t st);
+// One launch for a table of operand-packing jobs (the per-step re-pack of the training loop is ~75 of these,
+// each a 2-5 us kernel: launch-floor bound one by one).  The table lives in device memory; job j owns blocks
+// [blk0_j, blk0_{j+1}).  ops: the element maps of cast / transpose_f32 / transpose_cast / pack_down / pack_down_t.
+enum { PACK_CAST = 0, PACK_TRANSPOSE_F32 = 1, PACK_TRANSPOSE_CAST = 2, PACK_DOWN = 3, PACK_DOWN_T = 4 };
+struct PackJob {
+  const float* src;
+  const float* scale;   // PACK_TRANSPOSE_CAST: optional per-source-row scale
+  void* dst;
+  int R, Cc;            // CAST: R = element count, Cc = 1; DOWN / DOWN_T: R = Cout, Cc = Cin
+  int op, blk0;
+};
+int pack_job_blocks(const PackJob& j);
+int launch_pack_jobs(int prec, const PackJob* dev_jobs, int njobs, int total_blocks, hipStream_t st);
 // src [R][Cc] fp32 -> dst [Cc][R] fp32
 int launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
 // downsample filter [Cout][Cin][2][2] fp32 -> [Cout][(ky*2+kx)*Cin + cin] prec-typed

@@ -68,6 +68,8 @@ struct btsbot_ctx {
   // device memory
   float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
   unsigned char* extra = nullptr;   // transformed operands
+  void* pack_jobs[2] = {nullptr, nullptr};   // device tables of PackJob: [0] full pack, [1] training re-pack
+  int pack_njobs[2] = {0, 0}, pack_blocks[2] = {0, 0};
   size_t extra_bytes = 0;
   bool packed = false;
   bool packed_full = false;   // false after btsbot_pack_params_train(): inference-only operand images are stale

@@ -262,6 +262,64 @@ __global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, 
   }
 }
 
+// the five element maps above behind one launch: see PackJob in common.h
+template <typename T>
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {   // last job whose first block is <= this block (uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackJob jb = jobs[lo];
+  const int nblk = (lo + 1 < njobs ? jobs[lo + 1].blk0 : (int)gridDim.x) - jb.blk0;
+  const float* __restrict__ s = jb.src;
+  const int R = jb.R, Cc = jb.Cc;
+  const int64_t n = jb.op == PACK_DOWN || jb.op == PACK_DOWN_T ? (int64_t)R * Cc * 4 : (int64_t)R * Cc;
+  const int64_t i0 = (int64_t)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x, step = (int64_t)nblk * 256;
+  switch (jb.op) {
+    case PACK_CAST: {
+      T* d = reinterpret_cast<T*>(jb.dst);
+      for (int64_t i = i0; i < n; i += step) d[i] = (T)s[i];
+      break;
+    }
+    case PACK_TRANSPOSE_F32: {
+      float* d = reinterpret_cast<float*>(jb.dst);
+      for (int64_t i = i0; i < n; i += step) {
+        const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);
+        d[i] = s[(int64_t)r * Cc + c];
+      }
+      break;
+    }
+    case PACK_TRANSPOSE_CAST: {
+      T* d = reinterpret_cast<T*>(jb.dst);
+      for (int64_t i = i0; i < n; i += step) {
+        const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);
+        d[i] = (T)(s[(int64_t)r * Cc + c] * (jb.scale != nullptr ? jb.scale[r] : 1.f));
+      }
+      break;
+    }
+    case PACK_DOWN: {   // d[co][q][ci] <- s[co][ci][q]
+      T* d = reinterpret_cast<T*>(jb.dst);
+      for (int64_t i = i0; i < n; i += step) {
+        const int ci = (int)(i % Cc);
+        const int q = (int)((i / Cc) & 3);
+        const int co = (int)(i / (4 * (int64_t)Cc));
+        d[i] = (T)s[((int64_t)co * Cc + ci) * 4 + q];
+      }
+      break;
+    }
+    default: {          // PACK_DOWN_T: d[q*Cin + ci][co] <- s[co][ci][q]
+      T* d = reinterpret_cast<T*>(jb.dst);
+      for (int64_t i = i0; i < n; i += step) {
+        const int co = (int)(i % R);
+        const int k = (int)(i / R);
+        const int q = k / Cc, ci = k - q * Cc;
+        d[i] = (T)s[((int64_t)co * Cc + ci) * 4 + q];
+      }
+    }
+  }
+}
+
 inline int nblocks(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -289,6 +347,32 @@ int launch_head(const HeadArgs& a, hipStream_t st) {
     lds_attr = lds;
   }
   hipLaunchKernelGGL(head_kernel, dim3((a.B + HG - 1) / HG), dim3(HNT), lds, st, a);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int pack_job_blocks(const PackJob& j) {
+  const int64_t n = (j.op == PACK_DOWN || j.op == PACK_DOWN_T ? 4 : 1) * (int64_t)j.R * j.Cc;
+  const int64_t b = (n + 1023) / 1024;   // four elements per thread
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+int launch_pack_jobs(int prec, const PackJob* dev_jobs, int njobs, int total_blocks, hipStream_t st) {
+  if (njobs <= 0) return BTSBOT_OK;
+  switch (prec) {
+    case BTSBOT_F32:
+      hipLaunchKernelGGL(pack_jobs_kernel<float>, dim3(total_blocks), dim3(256), 0, st, dev_jobs, njobs);
+      break;
+    case BTSBOT_BF16:
+      hipLaunchKernelGGL(pack_jobs_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, dev_jobs, njobs);
+      break;
+    case BTSBOT_F16:
+      hipLaunchKernelGGL(pack_jobs_kernel<f16_t>, dim3(total_blocks), dim3(256), 0, st, dev_jobs, njobs);
+      break;
+    default:
+      btsbot_set_error("pack_jobs: bad precision %d", prec);
+      return BTSBOT_ERR_INVALID_ARG;
+  }
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
