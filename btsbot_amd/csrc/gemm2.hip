@@ -41,7 +41,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
+template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT, bool PRE>
 __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
                                                     const T* __restrict__ W,
                                                     const float* __restrict__ bias,
@@ -107,6 +107,31 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // The row-wise epilogue below reads one 16-byte (RESID: fp32 residual) or 8-byte (DGELU: pre-activation)
+  // piece per staged chunk from HBM.  Inside its store loop those loads cannot move above the previous
+  // iteration's store (out may alias resid), so each of the NIT iterations paid a full memory round trip;
+  // requested here, before the first k-tile, they arrive under the main loop (vmcnt retires in order: they are
+  // older than every LDS-DMA, so the counted waits below still mean what they say).
+  constexpr int CPR = TN * (int)sizeof(OT) / 16;   // 16-byte chunks per staged row
+  constexpr int EPC = 16 / (int)sizeof(OT);        // elements per chunk
+  constexpr int NIT = TM * CPR / 256;              // epilogue iterations per thread
+  static_assert((TM * CPR) % 256 == 0, "epilogue mapping");
+  typedef T __attribute__((ext_vector_type(4))) T4p;
+  constexpr bool PRE_R = PRE && EPI == EPI_RESID, PRE_D = PRE && EPI == EPI_DGELU;
+  float4 rpre[PRE_R ? NIT : 1];
+  T4p dpre[PRE_D ? NIT : 1];
+  if (PRE_R || PRE_D) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int ml = i / CPR, ch = i - ml * CPR;
+      const int m = min(m0 + ml, M - 1), n = min(n0 + ch * EPC, N - EPC);
+      const size_t o = (size_t)blockIdx.z * bsO + (size_t)m * N + n;
+      if (PRE_R) rpre[it] = *reinterpret_cast<const float4*>(resid + o);
+      if (PRE_D) dpre[it] = *reinterpret_cast<const T4p*>(reinterpret_cast<const T*>(resid) + o);
+    }
+  }
 
   const int nk = K / 64;
   const int lrow = lane & 15, lq = lane >> 4;
@@ -182,17 +207,17 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   }
   __syncthreads();
   // ---- epilogue stage 2: whole rows LDS -> HBM, 16 bytes per lane
-  constexpr int CPR = TN * (int)sizeof(OT) / 16;   // 16-byte chunks per row
-  constexpr int EPC = 16 / (int)sizeof(OT);        // elements per chunk
   if (EPI == EPI_RESID && ln_out != nullptr) {
     // RESID with the NEXT LayerNorm fused (host guarantees N == TN, so a row of the staged tile is a whole
     // row of the map): the row sits on CPR = TN/4 consecutive lanes -- one or two DPP rows
-    for (int i = tid; i < TM * CPR; i += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
       const int ml = i / CPR, ch = i - ml * CPR;
       const int m = min(m0 + ml, M - 1), n = ch * 4;
       const size_t o = (size_t)blockIdx.z * bsO + (size_t)m * N + n;
       float4 f = *reinterpret_cast<const float4*>(smem + ml * OPITCH + ch * 16);
-      const float4 r = *reinterpret_cast<const float4*>(resid + o);
+      const float4 r = PRE_R ? rpre[PRE_R ? it : 0] : *reinterpret_cast<const float4*>(resid + o);
       f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
       float s = group16_sum((f.x + f.y) + (f.z + f.w));
       if (CPR == 32) s += __shfl_xor(s, 16);
@@ -215,14 +240,16 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
     }
     return;
   }
-  for (int i = tid; i < TM * CPR; i += 256) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * 256;
     const int ml = i / CPR, ch = i - ml * CPR;
     const int m = m0 + ml, n = n0 + ch * EPC;
     if (m >= M || n >= N) continue;
     uint4 v = *reinterpret_cast<const uint4*>(smem + ml * OPITCH + ch * 16);
     const size_t o = (size_t)blockIdx.z * bsO + (size_t)m * N + n;
     if (EPI == EPI_RESID) {
-      const float4 r = *reinterpret_cast<const float4*>(resid + o);
+      const float4 r = PRE_R ? rpre[PRE_R ? it : 0] : *reinterpret_cast<const float4*>(resid + o);
       float4 f = *reinterpret_cast<float4*>(&v);
       f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = f;
@@ -238,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
       // backward: out = acc * gelu'(pre), pre read from aux (`resid`)
       typedef T __attribute__((ext_vector_type(4))) T4;
       const float4 f = *reinterpret_cast<float4*>(&v);
-      const T4 pre = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
+      const T4 pre = PRE_D ? dpre[PRE_D ? it : 0] : *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(resid) + o);
       T4 r;
       r[0] = (T)(f.x * gelu_grad_for<T>((float)pre[0]));
       r[1] = (T)(f.y * gelu_grad_for<T>((float)pre[1]));
@@ -251,15 +278,15 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
   }
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
-int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
+template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT, bool PRE>
+int launch_tile2p(const T* x, const T* w, const float* bias, const float* gamma,
                  const float* resid, void* out, int M, int N, int K, hipStream_t st, int batch = 1,
                  long bsX = 0, long bsW = 0, long bsO = 0, const float* ln_w = nullptr,
                  const float* ln_b = nullptr, void* ln_out = nullptr) {
   constexpr size_t ring = NSLOT * (size_t)(TM + TN) * 128;
   constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T || EPI == EPI_GELU_SAVE) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
-  auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT>;
+  auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT, PRE>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -271,6 +298,25 @@ int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
                      bsO, ln_w, ln_b, reinterpret_cast<T*>(ln_out));
   LAUNCH_CHECK();
   return BTSBOT_OK;
+}
+
+// BTSBOT_AMD_GEMM2_NO_PREFETCH=1: the epilogue's residual / pre-activation loads stay inside its store loop (A/B)
+template <typename T, int TM, int TN, int WM, int WN, int EPI, int NSLOT>
+int launch_tile2(const T* x, const T* w, const float* bias, const float* gamma,
+                 const float* resid, void* out, int M, int N, int K, hipStream_t st, int batch = 1,
+                 long bsX = 0, long bsW = 0, long bsO = 0, const float* ln_w = nullptr,
+                 const float* ln_b = nullptr, void* ln_out = nullptr) {
+  static const bool no_pre = [] {
+    const char* e = getenv("BTSBOT_AMD_GEMM2_NO_PREFETCH");
+    return e != nullptr && e[0] == '1';
+  }();
+  if constexpr (EPI == EPI_RESID || EPI == EPI_DGELU) {
+    if (!no_pre)
+      return launch_tile2p<T, TM, TN, WM, WN, EPI, NSLOT, true>(x, w, bias, gamma, resid, out, M, N, K, st, batch,
+                                                                bsX, bsW, bsO, ln_w, ln_b, ln_out);
+  }
+  return launch_tile2p<T, TM, TN, WM, WN, EPI, NSLOT, false>(x, w, bias, gamma, resid, out, M, N, K, st, batch, bsX,
+                                                             bsW, bsO, ln_w, ln_b, ln_out);
 }
 
 template <typename T, int EPI>
