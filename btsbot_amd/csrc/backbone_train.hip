@@ -23,6 +23,8 @@ struct BlkBuf {
   void* h;
 };
 
+constexpr size_t WPART_FLOATS = (size_t)16 << 20;   // 64 MB: every shape of the pico / nano schedule fits (else atomics)
+
 struct BBCache {
   float* xs[4];             // stage outputs [B*P_i*C_i] fp32
   void* patches[4];         // [B*P_i][4*C_{i-1}] operand type (i >= 1)
@@ -33,6 +35,7 @@ struct BBCache {
   float *G, *S;             // fp32 [max C*4C], [max 4C]
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
+  float* wpart;             // fp32 WPART_FLOATS: slice partials of the filter-gradient GEMMs (wgrad.hip)
   void* stem_patches;       // [B*225][48] operand type
   float* stem_pre;          // [B*225][C0] fp32
   size_t total;
@@ -81,6 +84,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
   k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
+  k.wpart = reinterpret_cast<float*>(take(WPART_FLOATS * 4));
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
   k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
   k.total = cur;
@@ -142,8 +146,8 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
 // range first.
 // out[n][k] += sum_m D[m][n] A[m][k] and cs[n] += sum_m D[m][n]; D and A in the mode's operand type
 static int wgrad_cs(int prec, const void* D, const void* A, float* out, float* cs, int M, int N,
-                    int K, int ldo, hipStream_t st) {
-  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st);
+                    int K, int ldo, hipStream_t st, float* part = nullptr) {
+  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS);
   const int rc = launch_wgrad(prec, D, A, out, M, N, K, ldo, st);
   return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
 }
@@ -167,14 +171,14 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
       TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.S,
                              (long)((k.G + (size_t)ch * H) - k.S)));
-      TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st));
+      TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st, k.wpart));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, st));
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, k.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), k.da, rows, H, ch, st));
       // ---- fc1:  dW1 += da^T xn,  db1 += colsum(da),  dxn = da W1
-      TRYB(wgrad_cs(prec, k.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, st));
+      TRYB(wgrad_cs(prec, k.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, st, k.wpart));
       TRYB(launch_gemm(prec, EPI_PLAIN, k.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
       // ---- LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
@@ -189,7 +193,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const long prow = (long)B * hwp * hwp;
       TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.G, (long)ch * 4 * cin));
       TRYB(wgrad_cs(prec, k.dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin,
-                    st));
+                    st, k.wpart));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));
       TRYB(launch_gemm(prec, EPI_PLAIN, k.dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
@@ -211,7 +215,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                        grads + h->stem_lnb, rows, c0, st));
     TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT, (long)rows * c0, c0, st));
     TRYB(wgrad_cs(prec, k.dyT, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
-                  st));
+                  st, k.wpart));
   }
   (void)esz;
   return BTSBOT_OK;

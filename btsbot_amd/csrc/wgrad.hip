@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
                                                      const T* __restrict__ A,
                                                      float* __restrict__ out,
                                                      float* __restrict__ colsum, int M, int N,
-                                                     int K, int ldo, int mslice) {
+                                                     int K, int ldo, int mslice,
+                                                     float* __restrict__ part) {
   constexpr int PN = TN * 2 + 64, PK = TK * 2 + 64;          // row pitch in bytes
   constexpr int DB = TM * PN, AB = TM * PK;                   // bytes per tile
   constexpr int FN = TN / 64, FK = TK / 64;                   // 32x32 fragments per wave
@@ -159,6 +160,21 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
 
   // C/D layout of 32x32: column = lane & 31 -> k, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n
   const int lc = lane & 31, lh = lane >> 5;
+  if (part != nullptr) {
+    // slice partial as a dense TN x TK tile (plain coalesced stores; wgrad_reduce_kernel adds the slices in a
+    // fixed order): an fp32 atomic per element per slice was the larger half of this kernel's time
+    float* pt = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TN * TK);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nl = wn * (TN / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int kl = wk * (TK / 2) + 32 * j + lc;
+          pt[nl * TK + kl] = acc[i][j][r];
+        }
+  } else
 #pragma unroll
   for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -183,56 +199,98 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
   }
 }
 
+// out[n][k] += sum over slices of the partial tiles (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ out, int N, int K, int ldo,
+                                                           int gx, int gy, int nsl, int TN, int TK) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int n = idx / K, k = idx - n * K;
+  const int tx = n / TN, ty = k / TK;
+  const float* p = part + ((size_t)ty * gx + tx) * (TN * TK) + (n - tx * TN) * TK + (k - ty * TK);
+  const size_t sstride = (size_t)gx * gy * TN * TK;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 3 < nsl; s += 4) {
+    s0 += p[(size_t)s * sstride];
+    s1 += p[(size_t)(s + 1) * sstride];
+    s2 += p[(size_t)(s + 2) * sstride];
+    s3 += p[(size_t)(s + 3) * sstride];
+  }
+  for (; s < nsl; ++s) s0 += p[(size_t)s * sstride];
+  out[(size_t)n * ldo + k] += (s0 + s1) + (s2 + s3);
+}
+
 template <typename T, int TN, int TK>
 int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M, int N, int K,
-                  int ldo, hipStream_t st) {
+                  int ldo, hipStream_t st, float* part, size_t part_floats) {
   const int gx = (N + TN - 1) / TN, gy = (K + TK - 1) / TK;
-  // slices of the reduction: ~384 workgroups in flight, at least 512 rows each (every slice ends in
-  // TN x TK fp32 atomics: fewer, longer slices beat more parallelism on the 9216-row stage-2 shapes)
-  static const int min_rows = [] {
-    const char* e = getenv("BTSBOT_AMD_WGRAD_MIN_ROWS");   // tuning knob (default 512; measured 256: +3 %, 1024: +4 %)
-    const int v = e ? atoi(e) : 512;
-    return v >= 32 ? v : 512;
+  // slices of the reduction.  Two-pass form (partial tiles + wgrad_reduce_kernel, when the caller lends scratch):
+  // ~512 workgroups, at least 256 rows each; atomic form (every slice ends in TN x TK fp32 atomics: fewer, longer
+  // slices win): ~384 workgroups, at least 512 rows.  Measured per 1024-alert step: 4.59 ms vs 4.67 ms.
+  static const int env_rows = [] {
+    const char* e = getenv("BTSBOT_AMD_WGRAD_MIN_ROWS");   // tuning knob (overrides both defaults)
+    const int v = e ? atoi(e) : 0;
+    return v >= 32 ? v : 0;
   }();
-  static const int target_wg = [] {
-    const char* e = getenv("BTSBOT_AMD_WGRAD_WGS");        // tuning knob (default 384)
-    const int v = e ? atoi(e) : 384;
-    return v >= 1 ? v : 384;
+  static const int env_wg = [] {
+    const char* e = getenv("BTSBOT_AMD_WGRAD_WGS");        // tuning knob (overrides both defaults)
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? v : 0;
   }();
-  int nsl = (target_wg + gx * gy - 1) / (gx * gy);
-  if (nsl > (M + min_rows - 1) / min_rows) nsl = (M + min_rows - 1) / min_rows;
-  if (nsl < 1) nsl = 1;
-  const int mslice = ((M + nsl - 1) / nsl + TM - 1) / TM * TM;
-  nsl = (M + mslice - 1) / mslice;
+  static const bool atomic_only = [] {
+    const char* e = getenv("BTSBOT_AMD_WGRAD_ATOMIC");     // 1: every slice adds its tile with fp32 atomics (A/B)
+    return e != nullptr && e[0] == '1';
+  }();
+  int nsl = 1, mslice = M;
+  auto slices = [&](int min_rows, int target_wg) {
+    nsl = (target_wg + gx * gy - 1) / (gx * gy);
+    if (nsl > (M + min_rows - 1) / min_rows) nsl = (M + min_rows - 1) / min_rows;
+    if (nsl < 1) nsl = 1;
+    mslice = ((M + nsl - 1) / nsl + TM - 1) / TM * TM;
+    nsl = (M + mslice - 1) / mslice;
+  };
+  bool two_pass = !atomic_only && part != nullptr;
+  if (two_pass) {
+    slices(env_rows ? env_rows : 256, env_wg ? env_wg : 512);
+    two_pass = nsl > 1 && (size_t)nsl * gx * gy * TN * TK <= part_floats;
+  }
+  if (!two_pass) slices(env_rows ? env_rows : 512, env_wg ? env_wg : 384);
   hipLaunchKernelGGL((wgrad2_kernel<T, TN, TK>), dim3(gx, gy, nsl), dim3(256), 0, st,
                      reinterpret_cast<const T*>(D), reinterpret_cast<const T*>(A), out, colsum, M,
-                     N, K, ldo, mslice);
+                     N, K, ldo, mslice, two_pass ? part : nullptr);
   LAUNCH_CHECK();
+  if (two_pass) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part, out, N, K, ldo,
+                       gx, gy, nsl, TN, TK);
+    LAUNCH_CHECK();
+  }
   return BTSBOT_OK;
 }
 
 template <typename T>
 int wgrad2_t(const void* D, const void* A, float* out, float* colsum, int M, int N, int K, int ldo,
-             hipStream_t st) {
-  if (N > 64 && K > 64) return wgrad2_launch<T, 128, 128>(D, A, out, colsum, M, N, K, ldo, st);
-  if (N > 64) return wgrad2_launch<T, 128, 64>(D, A, out, colsum, M, N, K, ldo, st);
-  if (K > 64) return wgrad2_launch<T, 64, 128>(D, A, out, colsum, M, N, K, ldo, st);
-  return wgrad2_launch<T, 64, 64>(D, A, out, colsum, M, N, K, ldo, st);
+             hipStream_t st, float* part, size_t pf) {
+  if (N > 64 && K > 64) return wgrad2_launch<T, 128, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
+  if (N > 64) return wgrad2_launch<T, 128, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
+  if (K > 64) return wgrad2_launch<T, 64, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
+  return wgrad2_launch<T, 64, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
 }
 
 }  // namespace
 
 // 16-bit modes only; N and K must be multiples of 8 and the operands 16-byte aligned.
+// part (optional): scratch for the slices' partial tiles -> two-pass reduction instead of atomics into `out`
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
-                   int K, int ldo, hipStream_t st) {
+                   int K, int ldo, hipStream_t st, float* part, size_t part_floats) {
   if (M <= 0) return BTSBOT_OK;
   if ((N & 7) || (K & 7) || ((uintptr_t)D & 15) || ((uintptr_t)A & 15)) {
     btsbot_set_error("wgrad16: N=%d K=%d / operand alignment not supported", N, K);
     return BTSBOT_ERR_INVALID_ARG;
   }
   switch (prec) {
-    case BTSBOT_BF16: return wgrad2_t<bf16_t>(D, A, out, colsum, M, N, K, ldo, st);
-    case BTSBOT_F16: return wgrad2_t<f16_t>(D, A, out, colsum, M, N, K, ldo, st);
+    case BTSBOT_BF16: return wgrad2_t<bf16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats);
+    case BTSBOT_F16: return wgrad2_t<f16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats);
     default:
       btsbot_set_error("wgrad16: precision %d is not a 16-bit mode", prec);
       return BTSBOT_ERR_INVALID_ARG;
