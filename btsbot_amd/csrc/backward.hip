@@ -662,12 +662,17 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
                   float* dbeta, long rows, int C, hipStream_t st) {
   if (rows <= 0) return BTSBOT_OK;
+  static const long cap = [] {
+    const char* e = getenv("BTSBOT_AMD_LNBWD_BLOCKS");   // tuning knob: workgroups (= same-address atomics per channel;
+    const long v = e ? atol(e) : 0;                      //  measured per step: 256 4.64 ms, 384/512 4.58, 1024 4.70, 2048 5.02)
+    return v >= 1 ? v : 512;
+  }();
   long blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;     // <= 512 same-address atomics per channel
+  if (blocks > cap) blocks = cap;     // <= cap same-address atomics per channel
   if (C == 64 || C == 128) {
     const int rpb = 4 * (C == 64 ? 4 : 2) * 2;   // rows per block pass
     long nb = (rows + rpb - 1) / rpb;
-    if (nb > 512) nb = 512;
+    if (nb > cap) nb = cap;
     if (C == 64)
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<16>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
                          dd, dg, dbeta, rows);
