@@ -450,6 +450,7 @@ def main():
                 "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc_traffic(dom, args),
+                "mfma_busy_pmc": pmc_mfma_busy(dom, args),
                 "flop_per_launch": flop_per_launch, "avg_launch_us": round(1e3 * ms / n, 2),
                 "launches_per_step": n // args.steps,
             },
@@ -487,6 +488,23 @@ def pmc_traffic(kernel, args):
     names = {kernel, kernel.replace("_kernel", "b_kernel")}
     hits = [v for v in ks.values() if v["family"] in names]
     return hits[0]["traffic_bytes"] if len(hits) == 1 else None
+
+
+def pmc_mfma_busy(kernel, args):
+    """Share of the MFMA pipes' cycles the kernel keeps busy, from the newest committed SQ-counter summary
+    (profiles/r*_mfma_util.json, tools/mfma_util.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8),
+    one rocprofv3 --pmc pass over this command).  Same caveat as pmc_traffic: null off the default workload."""
+    import glob
+    if args.precision != "bf16" or args.batch != PER_GPU_BATCH:
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_mfma_util.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        ks = json.load(f)["kernels"]
+    stems = {kernel.replace("_kernel", ""), kernel.replace("_kernel", "b")}
+    hits = [v for v in ks if v["kernel"].split("_kernel")[0] in stems]
+    return hits[0]["mfma_busy"] if len(hits) == 1 else None
 
 
 if __name__ == "__main__":

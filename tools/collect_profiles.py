@@ -44,6 +44,13 @@ json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 shutil.copy(newest("gpurun_out/final/trace/*/*_kernel_stats.csv"), f"profiles/{tag}_kernel_stats_bench_bf16_b1024.csv")
 shutil.copy(F, f"profiles/{tag}_pmc_fetch_size.csv")
 shutil.copy(W, f"profiles/{tag}_pmc_write_size.csv")
+try:   # training-step kernel stats and the MFMA-utilisation pass (tools/round_end.sh's last two runs)
+    shutil.copy(newest("gpurun_out/final/train_trace/*/*_kernel_stats.csv"), f"profiles/{tag}_kernel_stats_train_bf16_b1024.csv")
+    import subprocess
+    subprocess.run([sys.executable, "tools/mfma_util.py", "gpurun_out/final/mfma", f"profiles/{tag}_mfma_util.json"],
+                   check=True, stdout=subprocess.DEVNULL)
+except ValueError:
+    print("no train_trace / mfma pass under gpurun_out/final (older round_end.sh)")
 open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])
 for k, v in sorted(out["kernels"].items(), key=lambda x: -x[1]["traffic_bytes"] * x[1]["launches"])[:10]:
     print(f'{v["family"]:24s} launches {v["launches"]:4d}  fetch {v["fetch_bytes"]/1e6:8.2f} MB  write {v["write_bytes"]/1e6:8.2f} MB')
