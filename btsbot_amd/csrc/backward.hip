@@ -304,8 +304,11 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
     }
     for (int y = rg; y < HW; y += G) {
       float acc[HW];
+      // the row's addend pieces are requested before the taps run: `out` may be `addend` (dx = dy + conv), so inside
+      // the store loop below every load had to wait for the previous store -- HW exposed HBM round trips per row
 #pragma unroll
-      for (int xx = 0; xx < HW; ++xx) acc[xx] = b;
+      for (int xx = 0; xx < HW; ++xx)
+        acc[xx] = b + (addend != nullptr ? addend[base + (size_t)(y * HW + xx) * C + c] : 0.f);
 #pragma unroll KY_UNROLL
       for (int ky = 0; ky < 7; ++ky) {
         const int iy = y + ky - 3;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) {
         const size_t o = base + (size_t)(y * HW + xx) * C + c;
-        out[o] = acc[xx] + (addend != nullptr ? addend[o] : 0.f);
+        out[o] = acc[xx];
       }
     }
   }
