@@ -199,15 +199,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     gl[i] = c < C ? g[c] : 0.f;
     adg[i] = adb[i] = 0.f;
   }
-  for (long r = w0; r < rows; r += nw) {
-    float v[CPT], t[CPT];
-    float s = 0.f;
+  // dd may be dxn (in place): a load cannot move above an earlier store, so the NEXT row's pieces are requested
+  // explicitly before this row's stores (they arrive under the four wave reductions)
+  float nv[CPT], ndx[CPT];
+  auto fetch = [&](long r) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = lane + 64 * i;
-      v[i] = c < C ? d[r * C + c] : 0.f;
+      nv[i] = c < C ? d[r * C + c] : 0.f;
+      ndx[i] = c < C ? dxn[r * C + c] : 0.f;
+    }
+  };
+  if (w0 < rows) fetch(w0);
+  for (long r = w0; r < rows; r += nw) {
+    float v[CPT], t[CPT], dxr[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      v[i] = nv[i];
+      dxr[i] = ndx[i];
       s += v[i];
     }
+    if (r + nw < rows) fetch(r + nw);
     const float mean = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
@@ -220,8 +233,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float st = 0.f, stx = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = lane + 64 * i;
-      const float dx = c < C ? dxn[r * C + c] : 0.f;
+      const float dx = dxr[i];
       v[i] *= rstd;                     // xhat
       t[i] = dx * gl[i];
       st += t[i];
@@ -597,17 +609,29 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
     return v;
   };
   const long stride = (long)gridDim.x * 4 * R * 2;
-  for (long r0 = ((long)blockIdx.x * 4 + wv) * R * 2; r0 < rows; r0 += stride) {
+  // (dd may be dxn: the next pass's pieces are requested before this pass's stores, as in ln_bwd_kernel)
+  float4 nv[2], ndx[2];
+  auto fetch = [&](long r0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long r = r0 + u * R + sub;
+      const long rr = r < rows ? r : 0;
+      nv[u] = *reinterpret_cast<const float4*>(d + rr * C + 4 * l);
+      ndx[u] = *reinterpret_cast<const float4*>(dxn + rr * C + 4 * l);
+    }
+  };
+  const long rfirst = ((long)blockIdx.x * 4 + wv) * R * 2;
+  if (rfirst < rows) fetch(rfirst);
+  for (long r0 = rfirst; r0 < rows; r0 += stride) {
     float4 v[2], dx[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const long r = r0 + u * R + sub;
-      ok[u] = r < rows;
-      const long rr = ok[u] ? r : 0;
-      v[u] = *reinterpret_cast<const float4*>(d + rr * C + 4 * l);
-      dx[u] = *reinterpret_cast<const float4*>(dxn + rr * C + 4 * l);
+      ok[u] = r0 + u * R + sub < rows;
+      v[u] = nv[u];
+      dx[u] = ndx[u];
     }
+    if (r0 + stride < rows) fetch(r0 + stride);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const long r = r0 + u * R + sub;
