@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ 
   const int m = idx / N, n = idx - m * N;
   const float* ip = in + (size_t)m * ldi;
   const float* wp = wt + n;
-  float a0 = bias[n], a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains: the loads of a group overlap
+  float a0 = bias[n], a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains, two groups per trip: 16 loads in flight
   int k = 0;
+#pragma unroll 2
   for (; k + 3 < K; k += 4) {
     a0 = fmaf(ip[k], wp[(size_t)k * N], a0);
     a1 = fmaf(ip[k + 1], wp[(size_t)(k + 1) * N], a1);
@@ -82,9 +83,19 @@ __global__ __launch_bounds__(256) void lin_bwd_in_kernel(const float* __restrict
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * K) return;
   const int m = idx / K, k = idx - m * K;
-  float acc = 0.f;
-  for (int n = 0; n < N; ++n) acc = fmaf(dpre[(size_t)m * N + n], w[(size_t)n * K + k], acc);
-  din[(size_t)m * ldi + k] = acc;
+  const float* dp = dpre + (size_t)m * N;
+  const float* wp = w + k;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains, two groups per trip (one chain, one load pair in
+  int n = 0;                                       //  flight per trip: 64 us for the 1024 x 640 x 128 fusion layer)
+#pragma unroll 2
+  for (; n + 3 < N; n += 4) {
+    a0 = fmaf(dp[n], wp[(size_t)n * K], a0);
+    a1 = fmaf(dp[n + 1], wp[(size_t)(n + 1) * K], a1);
+    a2 = fmaf(dp[n + 2], wp[(size_t)(n + 2) * K], a2);
+    a3 = fmaf(dp[n + 3], wp[(size_t)(n + 3) * K], a3);
+  }
+  for (; n < N; ++n) a0 = fmaf(dp[n], wp[(size_t)n * K], a0);
+  din[(size_t)m * ldi + k] = (a0 + a1) + (a2 + a3);
 }
 
 // dw[n][k] = sum_m dpre[m][n] * in[m*ldi + k];  db[n] = sum_m dpre[m][n]
