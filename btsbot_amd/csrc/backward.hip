@@ -381,16 +381,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         float4* dx4 = reinterpret_cast<float4*>(xs);
         float4* dd4 = reinterpret_cast<float4*>(ds);
         const int n4 = P * C / 4;
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 512) {
-          float4 a[2], b[2];
+        // 16 pieces in flight per thread (two trips for a 15x15x64 map; with 4 in flight the 7 trips were 7 exposed
+        // HBM latencies per alert, most of this kernel's time: one workgroup per CU, nothing else to switch to)
+        constexpr int NB = 8;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * NB) {
+          float4 a[NB], b[NB];
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
+          for (int k = 0; k < NB; ++k) {
             const int ii = min(i0 + k * 256, n4 - 1);
             a[k] = sx[ii];
             b[k] = sd[ii];
           }
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
+          for (int k = 0; k < NB; ++k)
             if (i0 + k * 256 < n4) {
               dx4[i0 + k * 256] = a[k];
               dd4[i0 + k * 256] = b[k];

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const size_t sstride = (size_t)gx * gy * TN * TK;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int s = 0;
+#pragma unroll 2
   for (; s + 3 < nsl; s += 4) {
     s0 += p[(size_t)s * sstride];
     s1 += p[(size_t)(s + 1) * sstride];
