@@ -288,17 +288,17 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
       ws[i] = w[(flip ? 48 - t : t) * C + cc];
     }
   {
-    // 16-byte pieces, four in flight per thread before the first LDS store (the scalar copy loop waited
+    // 16-byte pieces, eight in flight per thread before the first LDS store (the scalar copy loop waited
     // for every 4-byte load: 56 exposed HBM latencies per workgroup at 15x15x64)
     const float4* src = reinterpret_cast<const float4*>(x + base);
     float4* dst = reinterpret_cast<float4*>(xs);
     const int n4 = P * C / 4;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
-      float4 v[4];
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 2048) {
+      float4 v[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + k * 256, n4 - 1)];   // (clamped: no conditional definition)
+      for (int k = 0; k < 8; ++k) v[k] = src[min(i0 + k * 256, n4 - 1)];   // (clamped: no conditional definition)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 8; ++k)
         if (i0 + k * 256 < n4) dst[i0 + k * 256] = v[k];
     }
   }
