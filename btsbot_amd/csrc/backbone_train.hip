@@ -162,6 +162,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   float* dy = k.dyA;
   float* dxn = k.dyB;
   HIP_TRY(hipMemcpyAsync(dy, dfeat, (size_t)B * c.dims[3] * 4, hipMemcpyDeviceToDevice, st));
+  // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type and
+  // clears the next filter-gradient accumulators -- the cast launch in front of the next block is then skipped
+  const bool fold_cast = prec != BTSBOT_F32;
+  bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
     for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
@@ -169,8 +173,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
       // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
-      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.S,
-                             (long)((k.G + (size_t)ch * H) - k.S)));
+      if (!dyT_ready)
+        TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.S,
+                               (long)((k.G + (size_t)ch * H) - k.S)));
+      dyT_ready = false;
       TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st, k.wpart));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, st));
@@ -185,13 +191,17 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
       // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
       TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
-      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st));
+      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, fold_cast ? k.dyT : nullptr, prec,
+                           fold_cast ? k.S : nullptr, fold_cast ? (long)((k.G + (size_t)ch * H) - k.S) : 0));
+      dyT_ready = fold_cast;
     }
     if (i > 0) {
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
       const int cin = c.dims[i - 1], hwp = STAGE_HW[i - 1];
       const long prow = (long)B * hwp * hwp;
-      TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.G, (long)ch * 4 * cin));
+      if (!dyT_ready)
+        TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.G, (long)ch * 4 * cin));
+      dyT_ready = false;
       TRYB(wgrad_cs(prec, k.dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin,
                     st, k.wpart));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));

@@ -271,8 +271,12 @@ template <int HW>
 __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ w, int flip,
                                                        const float* __restrict__ bias,
-                                                       const float* addend, float* out, int C) {
+                                                       const float* addend, float* out, int C,
+                                                       void* __restrict__ out16, int prec16,
+                                                       float* __restrict__ zero, long zero_n) {
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [HW*HW][C] map | [49][C] taps
+  // (the next filter-gradient GEMM's accumulators: cleared here, the launch that precedes it in the backward)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = 0.f;
   constexpr int P = HW * HW;
   float* ws = xs + P * C;
   const size_t base = (size_t)blockIdx.x * P * C;
@@ -345,6 +349,10 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
       for (int xx = 0; xx < HW; ++xx) {
         const size_t o = base + (size_t)(y * HW + xx) * C + c;
         out[o] = acc[xx];
+        if (out16 != nullptr) {   // the same values as the next block's 16-bit GEMM operand (was a cast launch)
+          if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[o] = (bf16_t)acc[xx];
+          else reinterpret_cast<f16_t*>(out16)[o] = (f16_t)acc[xx];
+        }
       }
     }
   }
@@ -732,7 +740,8 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
 }
 
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
-                    const float* addend, float* out, int B, int HW, int C, hipStream_t st) {
+                    const float* addend, float* out, int B, int HW, int C, hipStream_t st,
+                    void* out16, int prec16, float* zero, long zero_n) {
   if (B <= 0) return BTSBOT_OK;
   const size_t lds = ((size_t)HW * HW + 49) * C * sizeof(float);
 #define DWP(H)                                                                                 \
@@ -744,7 +753,7 @@ int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
       attr = lds;                                                                              \
     }                                                                                          \
     hipLaunchKernelGGL((dw_plain_kernel<H>), dim3(B), dim3(256), lds, st, x, w, flip, bias,    \
-                       addend, out, C);                                                        \
+                       addend, out, C, out16, prec16, zero, zero_n);                           \
   }
   if (HW == 15) DWP(15)
   else if (HW == 7) DWP(7)

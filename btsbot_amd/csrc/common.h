@@ -251,7 +251,9 @@ int launch_fc2_grads(const float* G, const float* S, const float* w2, const floa
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
                   float* dbeta, long rows, int C, hipStream_t st);
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
-                    const float* addend, float* out, int B, int HW, int C, hipStream_t st);
+                    const float* addend, float* out, int B, int HW, int C, hipStream_t st,
+                    void* out16 = nullptr, int prec16 = 0, float* zero = nullptr, long zero_n = 0);
+// (out16: also the result in the 16-bit operand type prec16 -- the next block's GEMM operand; zero: accumulators to clear)
 int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, float* partials,
                     int B, int HW, int C, hipStream_t st);   // partials: >= 256 * 50 * C floats
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
