@@ -1,7 +1,7 @@
 """Developer diagnostic: per-stage error of the HIP path against the oracle, all precisions."""
 import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from helpers import CONFIGS, seeded_state, build_model, run_model
 from btsbot_amd.synthetic import synthetic_batch

@@ -1,7 +1,7 @@
 """Developer diagnostic: per-tensor gradient error of the full backward vs autograd (fp32)."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from helpers import CONFIGS, seeded_state, build_model
 from btsbot_amd.synthetic import synthetic_batch

@@ -1,5 +1,5 @@
 """Developer check on the GPU box: MaxViT wirings vs the CPU oracle, with per-stage taps.
-usage: python tools/mv_check.py [B] [prec ...]"""
+usage: python tests/diag/mv_check.py [B] [prec ...]"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ import warnings
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import MM_MAXVIT, seeded_state_mv, build_model  # noqa: E402
