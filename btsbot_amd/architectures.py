@@ -13,7 +13,8 @@ There is NO CPU fallback: calling a model whose tensors are not on a HIP device 
 Covered: ``mm_ConvNeXt`` (:125-171), ``ConvNeXt`` (:104-122), ``um_nn`` (:277-293),
 ``frozen_fusion`` (:296-372) with ConvNeXt + um_nn branches; convnext_pico / convnext_nano
 backbones at 63x63; ``MaxViT`` (:25-55) and ``mm_MaxViT`` (:58-101) with the maxvit_tiny_rw_224
-backbone, inference only (eval mode).  ``mm_cnn`` / ``um_cnn`` raise NotImplementedError (legacy
+backbone in eval mode (inference; or, under ``model.train()``, a frozen branch put in eval mode whose heads and
+metadata branch train -- see ``_check_train_supported``).  ``mm_cnn`` / ``um_cnn`` raise NotImplementedError (legacy
 VGG-like CNNs, out of scope per SURVEY.md section 2).
 """
 from __future__ import annotations
@@ -278,11 +279,6 @@ class _HipModel(nn.Module):
              want_scores: bool = False):
         image, meta, batch, dev = self._check_inputs(image, meta)
         if self.training:
-            if getattr(self, "_inference_only", False):
-                raise NotImplementedError(
-                    f"btsbot_amd.{type(self).__name__}: only eval-mode inference is built for the MaxViT "
-                    "image branch (its BatchNorm2d batch statistics and backward are not); call "
-                    ".eval() first")
             return self._run_train(image, meta)
         if batch == 0:
             empty = torch.empty(0, 1, dtype=torch.float32, device=dev)
@@ -349,7 +345,34 @@ class _HipModel(nn.Module):
         return _TrainFn.apply(self, image, meta, masks, (trainable, keep_image),
                               *[g[0] for g in trainable])
 
+    def _image_bn_modules(self):
+        """Modules of the image branch that own BatchNorm running statistics (MaxViT's BatchNorm2d)."""
+        out = []
+        for (canon, *_), (key, parent, leaf, off, numel, shape, is_buf) in zip(self._table_rows, self._slots):
+            if is_buf and leaf == "running_mean" and not canon.startswith(("comb.", "meta.")):
+                out.append(parent)
+        return out
+
+    def _check_train_supported(self, keep_image: bool):
+        """The MaxViT image branch is built for eval mode only (BatchNorm2d running statistics folded into the
+        convolutions, no backward).  A training-mode forward is therefore served only with that branch frozen AND
+        in eval mode -- ``model.train(); model.<image branch>.eval()`` with ``requires_grad_(False)`` on its
+        parameters: heads (and the metadata branch) train over fixed image features, which is what the oracle's
+        ``training=True`` mode restates.  Anything else raises."""
+        if not getattr(self, "_inference_only", False):
+            return
+        if keep_image:
+            raise NotImplementedError(
+                f"btsbot_amd.{type(self).__name__}: the backward of the MaxViT image branch is not built; freeze "
+                "it (requires_grad_(False) on its parameters) to train the heads over it")
+        if any(m.training for m in self._image_bn_modules()):
+            raise NotImplementedError(
+                f"btsbot_amd.{type(self).__name__}: BatchNorm2d batch statistics of the MaxViT image branch are "
+                "not built; put the branch in eval mode (e.g. model.train(); model.maxvit_backbone.eval()) or "
+                "call .eval() on the whole model")
+
     def _forward_train_raw(self, image, meta, masks, keep_image: bool = False):
+        self._check_train_supported(keep_image)
         ref = image if image is not None else meta
         batch, dev = ref.shape[0], ref.device
         with torch.cuda.device(dev):
@@ -377,8 +400,8 @@ class _HipModel(nn.Module):
                 C.c_void_p(self._arena.data_ptr()), int(keep_image), C.c_void_p(stream)),
                 "btsbot_forward_train")
         # the kernel updated running_mean / running_var inside the arena
-        for mod in self.modules():
-            if "num_batches_tracked" in mod._buffers:
+        for mod in self.modules():   # (eval-mode BatchNorm does not count batches: a frozen MaxViT branch)
+            if "num_batches_tracked" in mod._buffers and mod.training:
                 mod._buffers["num_batches_tracked"] += 1
         self._packed_version = None
         return logits.view(batch, 1)

@@ -855,9 +855,11 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
     btsbot_set_error("reserve_train: bad argument");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (h->is_maxvit) {
-    btsbot_set_error("reserve_train: the MaxViT wirings are inference-only (BatchNorm2d batch statistics "
-                     "and the backward of the MaxViT image branch are not built)");
+  if (h->is_maxvit && with_image_grads) {
+    // a frozen, eval-mode MaxViT branch under trainable heads is served by the inference kernels (forward_train with
+    // keep_image_activations = 0); its own training is not built
+    btsbot_set_error("reserve_train: BatchNorm2d batch statistics and the backward of the MaxViT image branch "
+                     "are not built (heads over a frozen, eval-mode branch: with_image_grads = 0)");
     return BTSBOT_ERR_STATE;
   }
   const bool want_bb = with_image_grads && h->has_image;

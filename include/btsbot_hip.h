@@ -52,7 +52,9 @@ enum btsbot_wiring {
   BTSBOT_FROZEN_FUSION = 2, /* frozen_fusion   architectures.py:296-372 (ConvNeXt + um_nn, ReLU)*/
   BTSBOT_UM_NN = 3,         /* um_nn           architectures.py:277-293 (metadata only)         */
   BTSBOT_MM_MAXVIT = 4,     /* mm_MaxViT       architectures.py:58-101 (maxvit_tiny_rw_224 + GELU heads);
-                               inference only: reserve_train / forward_train return BTSBOT_ERR_STATE */
+                               the image branch runs in eval mode only (BatchNorm2d running statistics, no
+                               backward): reserve_train(with_image_grads = 1) returns BTSBOT_ERR_STATE;
+                               heads / metadata branch train over it with with_image_grads = 0           */
   BTSBOT_MAXVIT = 5,        /* MaxViT          architectures.py:25-55  (image only)             */
   BTSBOT_FROZEN_FUSION_MAXVIT = 6 /* frozen_fusion with a MaxViT image branch (head stripped to its global
                                pool, architectures.py:304-308) + um_nn metadata branch, ReLU fusion head:
@@ -151,7 +153,8 @@ int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* met
  * chunking, because of the batch statistics).  keep_image_activations != 0 runs the image branch
  * through the per-op training schedule that keeps, per block, x_in / LN output / fc1 pre-activation /
  * hidden activation (about 1.2 MB per alert) for a later btsbot_backward(need_image_grads=1);
- * otherwise the image branch runs the fused inference kernels. */
+ * otherwise the image branch runs the fused inference kernels.  The MaxViT wirings take only that second form:
+ * their BatchNorm2d layers use the running statistics (a frozen, eval-mode branch under trainable heads). */
 int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_image_grads);
 int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const float* meta,
                          float* logits, float* scores, int batch, const uint8_t* meta_keep_mask,

@@ -275,3 +275,79 @@ def test_process_wide_switches_in_a_child_process(cuda):
                         "tests/test_gpu_parity.py::test_forward_matches_oracle"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_heads_train_over_a_frozen_eval_mode_maxvit_branch(cuda):
+    """mm_MaxViT with its image branch frozen and in eval mode (``model.train(); model.maxvit_backbone.eval()``):
+    the metadata branch (BatchNorm1d batch statistics, dropout) and the fusion head train over fixed image
+    features.  Logits and the gradients of every trainable tensor against autograd through the oracle's
+    ``training=True`` restatement (eval-mode BatchNorm2d in the branch, architectures.py:58-101); fp32 mode."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    from oracle import maxvit_oracle as MO
+    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    sd = seeded_state_mv(kind, cfg, seed=3)
+    B = 6
+    img, meta, labels = synthetic_batch(B, seed=4)
+    masks = _masks(kind, cfg, B, seed=9)
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    for p in m.maxvit_backbone.parameters():
+        p.requires_grad_(False)
+    m.maxvit_backbone.eval()
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert trainable and not any(k.startswith("maxvit_backbone.") for k in trainable)
+    nbt = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+    logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+        logits, labels.to(cuda).float().unsqueeze(1))
+    loss.backward()
+    ref = {k: v.clone() for k, v in sd.items()}
+    for k in trainable:
+        ref[k].requires_grad_(True)
+    ref_logits = MO.forward(kind, ref, cfg, img, meta, training=True, masks=masks)
+    O.bce_with_logits(ref_logits, labels.float().unsqueeze(1), 2.0).backward()
+    _close(logits, ref_logits.detach(), "training-mode logits over the frozen branch")
+    got = dict(m.named_parameters())
+    for k in trainable:
+        a, b = got[k].grad.cpu().double(), ref[k].grad.double()
+        scale = max(b.abs().max().item(), 1e-7)
+        assert (a - b).abs().max().item() / scale <= 5e-4, k
+    # eval-mode BatchNorm2d neither moved its statistics nor counted the batch; the metadata BatchNorm1d did
+    after = m.state_dict()
+    for k, v in nbt.items():
+        want = v + (0 if k.startswith("maxvit_backbone.") else 1)
+        assert int(after[k]) == want, k
+    for k in after:
+        if k.startswith("maxvit_backbone.") and k.endswith("running_mean"):
+            assert torch.equal(after[k].cpu(), sd[k]), k
+
+
+def test_trainer_steps_over_a_frozen_maxvit_branch_bf16(cuda):
+    """Trainer.step (forward, BCE, backward, AdamW) on mm_MaxViT in the bf16 mode with the image branch frozen and
+    in eval mode: the loss is finite, head and metadata parameters move, no image-branch tensor does, and eval
+    after the steps still works (weights re-packed)."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    sd = seeded_state_mv(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "bf16").train()
+    for p in m.maxvit_backbone.parameters():
+        p.requires_grad_(False)
+    m.maxvit_backbone.eval()
+    tr = Trainer(m, lr=1e-3, betas=(0.99, 0.99), pos_weight=1.5, epochs=4, warmup_epochs=0)
+    losses = []
+    for step in range(2):
+        img, meta, labels = synthetic_batch(8, seed=30 + step)
+        losses.append(tr.step(img.to(cuda), meta.to(cuda), labels.to(cuda)).item())
+    assert all(np.isfinite(l) for l in losses), losses
+    out = m.state_dict()
+    moved = [k for k in sd if not k.startswith("maxvit_backbone.") and sd[k].dtype.is_floating_point
+             and not torch.equal(out[k].cpu(), sd[k])]
+    assert any(k.startswith("combined_head.") for k in moved) and any(k.startswith("metadata_branch.") for k in moved)
+    for k in sd:
+        if k.startswith("maxvit_backbone."):
+            assert torch.equal(out[k].cpu(), sd[k]), k
+    m.eval()
+    img, meta, _ = synthetic_batch(4, seed=40)
+    with torch.no_grad():
+        z = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    assert z.shape == (4, 1) and torch.isfinite(z).all()
