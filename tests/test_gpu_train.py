@@ -277,34 +277,48 @@ def test_process_wide_switches_in_a_child_process(cuda):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_heads_train_over_a_frozen_eval_mode_maxvit_branch(cuda):
-    """mm_MaxViT with its image branch frozen and in eval mode (``model.train(); model.maxvit_backbone.eval()``):
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit", "frozen_fusion_maxvit"])
+def test_heads_train_over_a_frozen_eval_mode_maxvit_branch(cuda, name):
+    """MaxViT wirings with the image branch frozen and in eval mode (``model.train(); model.<branch>.eval()``):
     the metadata branch (BatchNorm1d batch statistics, dropout) and the fusion head train over fixed image
     features.  Logits and the gradients of every trainable tensor against autograd through the oracle's
-    ``training=True`` restatement (eval-mode BatchNorm2d in the branch, architectures.py:58-101); fp32 mode."""
+    ``training=True`` restatement (eval-mode BatchNorm2d in the branch, architectures.py:25-101,296-372; the
+    frozen_fusion case freezes both branches as train.py:224-232 does); fp32 mode."""
     from helpers import MV_CONFIGS, seeded_state_mv
     from oracle import maxvit_oracle as MO
-    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    kind, cfg = MV_CONFIGS[name]
     sd = seeded_state_mv(kind, cfg, seed=3)
     B = 6
     img, meta, labels = synthetic_batch(B, seed=4)
-    masks = _masks(kind, cfg, B, seed=9)
+    if kind == "MaxViT":
+        mk = (torch.rand(B, cfg["fc2_neurons"], generator=torch.Generator().manual_seed(9)) >= cfg["dropout"]).float()
+        masks, omasks = {"comb": mk}, {"head": mk}
+    else:
+        masks = omasks = _masks(kind, cfg, B, seed=9)
     m = build_model(kind, cfg, sd, cuda, "f32").train()
     m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
-    for p in m.maxvit_backbone.parameters():
-        p.requires_grad_(False)
-    m.maxvit_backbone.eval()
+    branch = {"mm_MaxViT": "maxvit_backbone.", "MaxViT": "maxvit.", "frozen_fusion": "image_branch."}[kind]
+    frozen = lambda k: (k.startswith(branch) and ".head." not in k) or (kind == "frozen_fusion" and k.startswith("meta_branch."))
+    for k, p in m.named_parameters():
+        if frozen(k):
+            p.requires_grad_(False)
+    for mod_name, mod in m.named_modules():                    # eval mode for the branch's BatchNorm2d holders
+        if mod_name.startswith(branch.rstrip(".")) and "running_mean" in mod._buffers:
+            mod.eval()
     trainable = [k for k, p in m.named_parameters() if p.requires_grad]
-    assert trainable and not any(k.startswith("maxvit_backbone.") for k in trainable)
+    assert trainable and not any(frozen(k) for k in trainable)
     nbt = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
-    logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    if kind == "MaxViT":
+        logits = m(input_data=img.to(cuda))
+    else:
+        logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
     loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
         logits, labels.to(cuda).float().unsqueeze(1))
     loss.backward()
     ref = {k: v.clone() for k, v in sd.items()}
     for k in trainable:
         ref[k].requires_grad_(True)
-    ref_logits = MO.forward(kind, ref, cfg, img, meta, training=True, masks=masks)
+    ref_logits = MO.forward(kind, ref, cfg, img, meta, training=True, masks=omasks)
     O.bce_with_logits(ref_logits, labels.float().unsqueeze(1), 2.0).backward()
     _close(logits, ref_logits.detach(), "training-mode logits over the frozen branch")
     got = dict(m.named_parameters())
@@ -315,10 +329,9 @@ def test_heads_train_over_a_frozen_eval_mode_maxvit_branch(cuda):
     # eval-mode BatchNorm2d neither moved its statistics nor counted the batch; the metadata BatchNorm1d did
     after = m.state_dict()
     for k, v in nbt.items():
-        want = v + (0 if k.startswith("maxvit_backbone.") else 1)
-        assert int(after[k]) == want, k
+        assert int(after[k]) == v + (0 if k.startswith(branch) else 1), k
     for k in after:
-        if k.startswith("maxvit_backbone.") and k.endswith("running_mean"):
+        if k.startswith(branch) and k.endswith("running_mean"):
             assert torch.equal(after[k].cpu(), sd[k]), k
 
 
