@@ -300,7 +300,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="alerts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=5,
+    ap.add_argument("--train-steps", type=int, default=20,
                     help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
     ap.add_argument("--maxvit-steps", type=int, default=3,
@@ -378,7 +378,7 @@ def main():
         timg, tmeta, tlab = synthetic_batch(args.train_batch, seed=100 + rank)
         timg, tmeta, tlab = timg.to(dev), tmeta.to(dev), tlab.to(dev)
         tr = Trainer(tm, lr=1e-4, betas=(0.99, 0.99), pos_weight=1.0, epochs=8, warmup_epochs=2)
-        for _ in range(2):
+        for _ in range(3):
             tr.step(timg, tmeta, tlab)
         fence()
         t1 = time.perf_counter()
