@@ -203,3 +203,29 @@ def test_load_hf_model_maxvit_metadata_from_local_dir(tmp_path, monkeypatch):
               "meta_branch.network.4.weight", "combined_head.5.bias",
               "image_branch.maxvit.stages.2.blocks.4.attn_grid.attn.rel_pos.relative_position_bias_table"):
         assert torch.equal(got[k], sd[k]), k
+
+
+def test_maxvit_train_mode_gate_is_host_logic():
+    """Which training-mode calls of the MaxViT wirings are served is decided on the host before any kernel runs
+    (architectures._check_train_supported): refused while a BatchNorm2d holder of the image branch is in train
+    mode or the branch wants gradients; accepted once the branch is frozen and in eval mode.  No GPU needed."""
+    from helpers import MV_CONFIGS
+    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    m = _build(kind, cfg).train()
+    bn = m._image_bn_modules()
+    # stem norm1 + per block (pre-norm, norm1 after conv1, norm2 after the depthwise conv) + a norm in each of the
+    # four down-sampling shortcuts?  -- count them from the state dict instead of by recall:
+    n_bn = sum(1 for k in m.state_dict() if k.startswith("maxvit_backbone.") and k.endswith("running_mean"))
+    assert len(bn) == n_bn and n_bn > 30
+    assert all(b.training for b in bn)
+    with pytest.raises(NotImplementedError, match="BatchNorm2d"):
+        m._check_train_supported(False)
+    m.maxvit_backbone.eval()
+    assert m.training and not any(b.training for b in bn)
+    m._check_train_supported(False)                       # frozen eval-mode branch: served
+    with pytest.raises(NotImplementedError, match="backward"):
+        m._check_train_supported(True)                    # ... but not its own gradients
+    # the ConvNeXt wirings are not gated at all
+    from helpers import CONFIGS
+    kind2, cfg2 = CONFIGS["mm_pico"]
+    _build(kind2, cfg2).train()._check_train_supported(True)
