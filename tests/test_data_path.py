@@ -201,6 +201,69 @@ def test_prep_triplets_kernel_matches_reference_arithmetic(cuda):
     assert torch.equal(raw_only.cpu(), raw[:1]) and not d.any()
 
 
+def _fits_gz(arr, bitpix=-32, extra=()):
+    """An independent writer of the stamp format (gzip of a single-HDU FITS image, 80-character cards in
+    2880-byte blocks, big-endian samples, NAXIS1 = fastest axis): what alert packets carry as stampData."""
+    import gzip
+    cards = [f"{'SIMPLE':<8}= {'T':>20}", f"{'BITPIX':<8}= {bitpix:>20d}", f"{'NAXIS':<8}= {2:>20d}",
+             f"{'NAXIS1':<8}= {arr.shape[1]:>20d}", f"{'NAXIS2':<8}= {arr.shape[0]:>20d}",
+             f"{'OBJECT':<8}= 'ZTF / cutout'       / a quoted value with a slash"] + list(extra) + ["END"]
+    hdr = "".join(c.ljust(80) for c in cards)
+    hdr = hdr.ljust((len(hdr) + 2879) // 2880 * 2880)
+    data = arr.astype({-32: ">f4", -64: ">f8", 16: ">i2"}[bitpix]).tobytes()
+    data += b"\0" * ((-len(data)) % 2880)
+    return gzip.compress(hdr.encode("ascii") + data)
+
+
+def _alert(stamps):
+    return {f"cutout{n}": {"stampData": _fits_gz(np.asarray(s, dtype=np.float32))}
+            for n, s in zip(("Science", "Template", "Difference"), stamps)}
+
+
+def test_stamp_decoding_without_astropy():
+    """gunzip + FITS primary image (alert_utils.py:139-145): values, NaNs, shape (NAXIS2, NAXIS1), dtype as
+    astropy hands them over; scaled integers (BZERO / BSCALE) and float64 images; malformed input raises."""
+    from btsbot_amd import alert_utils
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((63, 63)).astype(np.float32)
+    a[3, 4] = np.nan
+    a[10, 0] = np.inf
+    out = alert_utils.decode_stamp(_fits_gz(a))
+    assert out.dtype == np.float32 and out.shape == (63, 63) and np.array_equal(out, a, equal_nan=True)
+    short = rng.standard_normal((61, 50)).astype(np.float32)       # NAXIS2 = 61 rows, NAXIS1 = 50 columns
+    assert np.array_equal(alert_utils.decode_stamp(_fits_gz(short)), short)
+    i16 = rng.integers(-100, 100, (5, 7)).astype(np.int16)
+    sc = alert_utils.decode_stamp(_fits_gz(i16, 16, [f"{'BZERO':<8}= {32768:>20d}", f"{'BSCALE':<8}= {2:>20d}"]))
+    assert np.array_equal(sc, i16.astype(np.float32) * 2 + 32768)
+    f64 = rng.standard_normal((4, 4))
+    assert np.array_equal(alert_utils.decode_stamp(_fits_gz(f64, -64)), f64)
+    trip = alert_utils.decode_alert(_alert([a, short, a * 2]))
+    assert np.array_equal(trip[1], short) and np.array_equal(trip[2], a * 2, equal_nan=True)
+    import gzip
+    with pytest.raises(ValueError):
+        alert_utils.decode_stamp(gzip.compress(b"not a fits file" * 300))
+    with pytest.raises(ValueError):
+        alert_utils.decode_fits_image(gzip.decompress(_fits_gz(a))[:2880 + 100])   # truncated data unit
+
+
+@pytest.mark.gpu
+def test_make_triplets_from_alert_packets(cuda):
+    """make_triplet end to end (alert_utils.py:110-196): alert packets -> host decode -> one kernel, against the
+    reference's own numpy calls on the same stamps (NaN / inf / short / empty cases included)."""
+    from btsbot_amd import alert_utils
+    cases = _stamp_cases()
+    alerts = [_alert(c) for c in cases]
+    got, drop = alert_utils.make_triplets(alerts, device=cuda)
+    got, drop = got.cpu().numpy(), drop.cpu().numpy()
+    assert got.shape == (len(cases), 3, 63, 63) and got.dtype == np.float32
+    for k, stamps in enumerate(cases):
+        want, wdrop = DO.make_triplet_arith(stamps)
+        want = np.transpose(want, (2, 0, 1)).astype(np.float32)
+        assert bool(drop[k]) == bool(wdrop), k
+        both_nan = np.isnan(got[k]) & np.isnan(want)
+        assert np.allclose(np.where(both_nan, 0, got[k]), np.where(both_nan, 0, want), rtol=3e-6, atol=1e-12), k
+
+
 # ---- examples/inference_example.py (the reference's harness, inference_example.py:47-95) ------------
 def _harness():
     import importlib.util
