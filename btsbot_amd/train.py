@@ -162,7 +162,7 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
     scheduler step -> ``best_model.pth`` when the validation loss improved by at least 0.5 % ->
     early stopping after ``patience`` epochs without improvement.  Checkpoints are state dicts only, like
     the reference's (no optimiser state); ``report.json`` carries ``config`` for
-    to_HF.prep_config.  Returns the run history dict (train/val loss and accuracy per epoch)."""
+    to_HF.prep_config, the history and the best epoch's alert-level ``val_summary``.  Returns the run history dict (train/val loss and accuracy per epoch)."""
     import json
     import os
     import numpy as np
@@ -194,7 +194,12 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
             if since >= patience:                                    # train.py:350-352
                 break
     out = {k: v[:done].tolist() for k, v in hist.items()}
+    # the alert-level numbers of the reference's val_summary (val.py:178-218 -> utils.make_report) for the best epoch;
+    # its figure and the per-source policy metrics need the candidate table and stay out of scope
+    from .val import alert_summary
+    summary = alert_summary(best_raw_preds, best_val_labels) if best_raw_preds is not None else {}
     with open(os.path.join(model_dir, "report.json"), "w") as f:
-        json.dump({"train_config": dict(config or {}), "Training history": out}, f, indent=2)
+        json.dump({"train_config": dict(config or {}), "Training history": out, "val_summary": summary}, f, indent=2)
     out["best_raw_preds"], out["best_val_labels"] = best_raw_preds, best_val_labels
+    out["val_summary"] = summary
     return out

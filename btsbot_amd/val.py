@@ -57,3 +57,41 @@ def run_val_tensors(model, images, metadata, labels, batch_size: int = 1024,
     loss, acc = device_metrics(all_logits, ds.labels, pw)
     raw_preds = torch.sigmoid(all_logits).squeeze(1).cpu().numpy()
     return loss.item(), acc.item(), raw_preds, ds.labels.float().cpu().numpy()
+
+
+def alert_summary(raw_preds, labels) -> dict:
+    """The alert-level part of the reference's validation summary (val.py:178-218; what train.py:404-411 logs and
+    report.json keeps under ``val_summary``): confusion counts at the 0.5 threshold (``np.rint``: 0.5 rounds to 0),
+    ``bts_acc`` / ``notbts_acc`` / ``bal_acc``, ``alert_precision`` / ``alert_recall`` (-999.0 when there is no true
+    positive or no true negative, as there) and ``roc_auc`` (area under sklearn's ``roc_curve``: the rank statistic
+    with tied scores sharing their average rank).  Everything is reduced on the tensors' device; one host read."""
+    p = torch.as_tensor(raw_preds).reshape(-1).to(torch.float64)
+    y = torch.as_tensor(labels, device=p.device).reshape(-1).to(torch.float64)
+    if p.numel() != y.numel():
+        raise ValueError("raw_preds / labels length mismatch")
+    pred = torch.round(p)                                  # half-to-even, as np.rint
+    tp = ((pred == 1) & (y == 1)).sum()
+    tn = ((pred == 0) & (y == 0)).sum()
+    fp = ((pred == 1) & (y == 0)).sum()
+    fn = ((pred == 0) & (y == 1)).sum()
+    # ROC AUC = P(score_pos > score_neg) + 0.5 P(tie): average ranks of the sorted scores
+    order = torch.argsort(p, stable=True)
+    ps = p[order]
+    uniq, inv, cnt = torch.unique_consecutive(ps, return_inverse=True, return_counts=True)
+    last = torch.cumsum(cnt, 0).to(torch.float64)          # rank of the last member of each tie group (1-based)
+    avg_rank = (last - (cnt.to(torch.float64) - 1) / 2)[inv]
+    n_pos, n_neg = y.sum(), (1 - y).sum()
+    rank_sum = (avg_rank * y[order]).sum()
+    vals = torch.stack([tp, tn, fp, fn, n_pos, n_neg, rank_sum]).to(torch.float64).cpu().tolist()
+    tp, tn, fp, fn, n_pos, n_neg, rank_sum = vals
+    nan = float("nan")
+    bts_acc = tp / (tp + fn) if tp + fn > 0 else nan
+    notbts_acc = tn / (tn + fp) if tn + fp > 0 else nan
+    if tp > 0 and tn > 0:
+        precision, recall = tp / (tp + fp), tp / (tp + fn)
+    else:
+        precision = recall = -999.0
+    auc = (rank_sum - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg) if n_pos > 0 and n_neg > 0 else nan
+    return {"roc_auc": auc, "bal_acc": (bts_acc + notbts_acc) / 2, "bts_acc": bts_acc, "notbts_acc": notbts_acc,
+            "alert_precision": precision, "alert_recall": recall,
+            "TP": int(tp), "TN": int(tn), "FP": int(fp), "FN": int(fn)}

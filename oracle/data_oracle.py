@@ -62,3 +62,27 @@ def make_triplet_arith(stamps, normalize: bool = True):
     triplet[:, :, 1] = cut["template"]
     triplet[:, :, 2] = cut["difference"]
     return triplet, drop
+
+
+def alert_summary(raw_preds, labels):
+    """val.py:178-218 on numpy with the reference's own calls (np.rint, bitwise masks, sklearn roc_curve + auc)."""
+    import numpy as np
+    from sklearn.metrics import roc_curve, auc
+    raw_preds = np.asarray(raw_preds)
+    preds = np.rint(raw_preds).astype(int)
+    labels = np.asarray(labels).astype(int)
+    fpr, tpr, _ = roc_curve(labels, raw_preds)
+    roc_auc = auc(fpr, tpr)
+    TP = int(np.bitwise_and(labels, preds).sum())
+    TN = int((1 - np.bitwise_or(labels, preds)).sum())
+    FP = int(np.bitwise_and(1 - labels, preds).sum())
+    FN = int(np.bitwise_and(labels, 1 - preds).sum())
+    bts_acc = TP / (TP + FN)
+    notbts_acc = TN / (TN + FP)
+    if TP > 0 and TN > 0:
+        precision, recall = TP / (TP + FP), TP / (TP + FN)
+    else:
+        precision = recall = -999.0
+    return {"roc_auc": float(roc_auc), "bal_acc": (bts_acc + notbts_acc) / 2, "bts_acc": bts_acc,
+            "notbts_acc": notbts_acc, "alert_precision": precision, "alert_recall": recall,
+            "TP": TP, "TN": TN, "FP": FP, "FN": FN}

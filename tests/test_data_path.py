@@ -201,6 +201,23 @@ def test_prep_triplets_kernel_matches_reference_arithmetic(cuda):
     assert torch.equal(raw_only.cpu(), raw[:1]) and not d.any()
 
 
+def test_alert_summary_matches_reference_formulas():
+    """val.py:178-218 (np.rint threshold, bitwise confusion masks, sklearn roc_curve + auc) against the torch
+    reduction of btsbot_amd.val.alert_summary: heavy ties, a score of exactly 0.5, and the -999 sentinel."""
+    from btsbot_amd.val import alert_summary
+    rng = np.random.default_rng(1)
+    y = (rng.random(5000) < 0.3).astype(np.float32)
+    p = np.round(np.clip(0.35 * y + rng.random(5000) * 0.7, 0, 1), 2).astype(np.float32)
+    p[:5] = 0.5
+    got, want = alert_summary(torch.from_numpy(p), torch.from_numpy(y)), DO.alert_summary(p, y)
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-12 * max(1.0, abs(want[k])), k
+    allneg = alert_summary(torch.full((8,), 0.2), torch.tensor([0, 1, 0, 1, 0, 0, 1, 0]))
+    assert allneg["alert_precision"] == -999.0 and allneg["alert_recall"] == -999.0 and allneg["TP"] == 0
+    assert allneg["roc_auc"] == 0.5 and allneg["notbts_acc"] == 1.0 and allneg["bts_acc"] == 0.0
+
+
 def _fits_gz(arr, bitpix=-32, extra=()):
     """An independent writer of the stamp format (gzip of a single-HDU FITS image, 80-character cards in
     2880-byte blocks, big-endian samples, NAXIS1 = fastest axis): what alert packets carry as stampData."""
@@ -335,5 +352,10 @@ def test_fit_loop_checkpoints_and_early_stopping(cuda, tmp_path):
         warnings.simplefilter("ignore")
         m2 = btsbot_amd.um_nn(cfg)
     m2.load_state_dict(best, strict=True)
-    assert json.load(open(tmp_path / "report.json"))["train_config"]["model_name"] == "um_nn"
+    report = json.load(open(tmp_path / "report.json"))
+    assert report["train_config"]["model_name"] == "um_nn"
     assert hist["best_raw_preds"] is not None and hist["best_raw_preds"].shape == (128,)
+    # the best epoch's alert-level summary (val.py:178-218) is in the report and equals the reference formulas
+    want = DO.alert_summary(hist["best_raw_preds"], hist["best_val_labels"])
+    for k, v in want.items():
+        assert abs(report["val_summary"][k] - v) <= 1e-9 * max(1.0, abs(v)), k
