@@ -19,8 +19,10 @@ differ from the reference's; the distribution of (permutation, flips, rotation) 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -57,6 +59,58 @@ def augment(images: torch.Tensor, index: Optional[torch.Tensor], ops: Optional[t
             C.c_void_p(ops.data_ptr() if ops is not None else 0), C.c_void_p(out.data_ptr()), n,
             C.c_void_p(st)), "btsbot_augment")
     return out
+
+
+IMAGE_ONLY_MODELS = ["um_cnn", "SwinV2", "MaxViT", "ConvNeXt"]            # train.py:40-44
+METADATA_ONLY_MODELS = ["um_nn"]
+MULTIMODAL_MODELS = ["mm_MaxViT", "mm_ConvNeXt", "mm_cnn", "frozen_fusion"]
+
+
+def model_needs(model_name: str):
+    """(need_triplets, need_metadata) of a reference model name (train.py:108-122)."""
+    need_triplets = model_name in IMAGE_ONLY_MODELS or model_name in MULTIMODAL_MODELS
+    need_metadata = model_name in METADATA_ONLY_MODELS or model_name in MULTIMODAL_MODELS
+    if not need_triplets and not need_metadata:
+        raise ValueError(f"{model_name} not categorized as image-only/metadata-only/multimodal.")
+    return need_triplets, need_metadata
+
+
+def load_split(data_base_dir: str, config: dict, split: str = "train"):
+    """The reference's on-disk split (train.py:133-172 for "train", val.py:82-101 for "val" / "test"):
+    ``{data_base_dir}data/{split}_cand_{version}_N{N_max}.csv`` (column ``label`` + the ``metadata_cols`` of the
+    config) and ``{split}_triplets_{version}_N{N_max}.npy`` (float64 NHWC [N,63,63,3]) ->
+    (triplets [N,3,63,63] float32 NCHW or None, metadata [N,M] float32 or None, labels [N] int64, cand DataFrame).
+    The training split drops alerts whose triplet holds a NaN -- from the triplets, the table and the labels alike --
+    and refuses NaNs in the metadata columns (ValueError), as the reference does; the other splits are taken as
+    they are.  Host tensors: hand them to ``DeviceDataset`` / ``run_val_tensors``, which move them to HBM once."""
+    import pandas as pd
+    need_triplets, need_metadata = model_needs(config["model_name"])
+    version = config["train_data_version"]
+    n_str = f"_N{config.get('N_max', 100)}"
+    metadata_cols = config.get("metadata_cols", None)
+    if need_metadata and metadata_cols is None:
+        raise ValueError("Metadata columns not found in config.")
+    base = os.path.join(f"{data_base_dir}data", f"{split}_")
+    cand = pd.read_csv(f"{base}cand_{version}{n_str}.csv", index_col=None)
+    triplets = None
+    if need_triplets:
+        path = f"{base}triplets_{version}{n_str}.npy"
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Triplets file not found for {split}: {path}")
+        trip = np.load(path).astype(np.float32)
+        if split == "train" and np.any(np.isnan(trip)):
+            bad = np.isnan(trip).any(axis=(1, 2, 3))
+            trip = trip[~bad]
+            cand = cand.loc[~bad].reset_index(drop=True)
+        triplets = torch.from_numpy(np.ascontiguousarray(np.transpose(trip, (0, 3, 1, 2))))
+    labels = torch.tensor(cand["label"].values, dtype=torch.long)
+    metadata = None
+    if need_metadata:
+        values = cand[metadata_cols].values.astype(np.float32)
+        if split == "train" and np.isnan(values).any():
+            raise ValueError("NaNs found in metadata columns")
+        metadata = torch.from_numpy(values)
+    return triplets, metadata, labels, cand
 
 
 class DeviceDataset:

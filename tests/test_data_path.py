@@ -201,6 +201,53 @@ def test_prep_triplets_kernel_matches_reference_arithmetic(cuda):
     assert torch.equal(raw_only.cpu(), raw[:1]) and not d.any()
 
 
+def test_load_split_reads_the_reference_layout(tmp_path):
+    """train.py:133-172 / val.py:82-101: file names, NHWC float64 -> NCHW float32, metadata column selection and
+    order, NaN triplets dropped from triplets + table + labels in the training split only, NaN metadata refused
+    there, uni-modal models skip the file they do not need."""
+    import pandas as pd
+    from btsbot_amd import data
+    from helpers import METADATA_COLS
+    rng = np.random.default_rng(3)
+    n = 12
+    trip = rng.random((n, 63, 63, 3))
+    trip[4, 10, 10, 1] = np.nan
+    cand = pd.DataFrame({c: rng.random(n) for c in METADATA_COLS[::-1]})      # file order != config order
+    cand["label"] = rng.integers(0, 2, n)
+    cand["objectId"] = [f"ZTF{i}" for i in range(n)]
+    d = tmp_path / "data"
+    d.mkdir()
+    for split in ("train", "val"):
+        np.save(d / f"{split}_triplets_v11_N100.npy", trip)
+        cand.to_csv(d / f"{split}_cand_v11_N100.csv", index=False)
+    cfg = dict(model_name="mm_ConvNeXt", train_data_version="v11", metadata_cols=METADATA_COLS)
+    base = str(tmp_path) + "/"
+    t, m, y, c = data.load_split(base, cfg, "train")
+    keep = np.arange(n) != 4
+    assert t.shape == (n - 1, 3, 63, 63) and t.dtype == torch.float32 and t.is_contiguous()
+    assert torch.equal(t, torch.from_numpy(np.transpose(trip[keep].astype(np.float32), (0, 3, 1, 2))))
+    assert torch.equal(m, torch.from_numpy(cand[METADATA_COLS].values[keep].astype(np.float32)))
+    assert torch.equal(y, torch.from_numpy(cand["label"].values[keep])) and y.dtype == torch.long
+    assert list(c["objectId"]) == [f"ZTF{i}" for i in range(n) if i != 4]
+    tv, mv, yv, _ = data.load_split(base, cfg, "val")                        # validation keeps every row
+    assert tv.shape[0] == n and torch.isnan(tv[4]).any() and yv.shape == (n,)
+    t1, m1, _, _ = data.load_split(base, dict(cfg, model_name="um_nn"), "train")
+    assert t1 is None and m1.shape == (n, len(METADATA_COLS))                # no triplets read, nothing dropped
+    t2, m2, _, _ = data.load_split(base, dict(cfg, model_name="ConvNeXt"), "train")
+    assert m2 is None and t2.shape[0] == n - 1
+    bad = cand.copy()
+    bad.loc[2, METADATA_COLS[3]] = np.nan
+    bad.to_csv(d / "train_cand_v11_N100.csv", index=False)
+    with pytest.raises(ValueError, match="NaNs found in metadata"):
+        data.load_split(base, cfg, "train")
+    with pytest.raises(ValueError):
+        data.load_split(base, dict(cfg, model_name="nonesuch"), "train")
+    with pytest.raises(ValueError, match="Metadata columns"):
+        data.load_split(base, dict(model_name="um_nn", train_data_version="v11"), "train")
+    with pytest.raises(FileNotFoundError):
+        data.load_split(base, dict(cfg, N_max=30), "train")
+
+
 def test_alert_summary_matches_reference_formulas():
     """val.py:178-218 (np.rint threshold, bitwise confusion masks, sklearn roc_curve + auc) against the torch
     reduction of btsbot_amd.val.alert_summary: heavy ties, a score of exactly 0.5, and the -999 sentinel."""
