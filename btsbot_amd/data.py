@@ -121,8 +121,16 @@ class DeviceDataset:
 
     def __init__(self, images, metadata, labels, batch_size: int, config: Optional[dict] = None,
                  device="cuda", shuffle: bool = True, drop_last: bool = True, augment: bool = True,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, shard: Optional[tuple] = None):
         config = config or {}
+        # shard = (rank, world): every rank holds the whole set and draws the SAME permutation (seed the
+        # generators alike); of each global batch it yields its contiguous rows [r*b/w, (r+1)*b/w) -- the
+        # reference's DataParallel scatter (train.py:238-240), without moving any alert between GPUs
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        if self.shard is not None:
+            r, w = self.shard
+            if not (0 <= r < w) or int(batch_size) % w != 0:
+                raise ValueError(f"shard {shard}: rank out of range or batch_size {batch_size} not divisible")
         self.device = torch.device(device)
         self.images = None if images is None else \
             torch.as_tensor(images).to(self.device, torch.float32).contiguous()
@@ -169,6 +177,10 @@ class DeviceDataset:
             else torch.arange(n, device=self.device)
         for i in range(len(self)):
             idx = order[i * self.batch_size:(i + 1) * self.batch_size]
+            if self.shard is not None:
+                r, w = self.shard
+                per = (idx.numel() + w - 1) // w            # (a ragged last batch, drop_last=False, shards unevenly)
+                idx = idx[r * per:(r + 1) * per]
             out = []
             if self.images is not None:
                 out.append(augment(self.images, idx, self.draw_ops(idx.numel())))

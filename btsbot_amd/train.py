@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -152,6 +153,11 @@ def train_epoch(trainer: Trainer, dataset, epoch_metrics: bool = True):
     if not epoch_metrics or not logits:
         return float("nan"), float("nan")
     loss, acc = device_metrics(torch.cat(logits), torch.cat(labels), trainer.pos_weight)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(trainer.group) > 1:
+        both = torch.stack([loss, acc])                   # equal shards: the mean of the ranks' means
+        dist.all_reduce(both, group=trainer.group)
+        loss, acc = both / dist.get_world_size(trainer.group)
     return loss.item(), acc.item()
 
 
@@ -168,7 +174,10 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
     import numpy as np
     from .to_HF import cpu_state_dict
     from .val import run_val_tensors
-    os.makedirs(model_dir, exist_ok=True)
+    import torch.distributed as dist
+    main = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0   # rank 0 writes the files
+    if main:
+        os.makedirs(model_dir, exist_ok=True)
     hist = {k: np.zeros(epochs) for k in ("train_loss", "train_accuracy", "val_loss", "val_accuracy")}
     best_raw_preds = best_val_labels = None
     since = 0
@@ -178,7 +187,8 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
         #  effect on the next epoch's learning rate)
         tl, ta = train_epoch(trainer, train_set)
         hist["train_loss"][epoch], hist["train_accuracy"][epoch] = tl, ta
-        torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "latest_model.pth"))
+        if main:
+            torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "latest_model.pth"))
         vl, va, raw, lab = run_val_tensors(trainer.model, val_images, val_metadata, val_labels,
                                            batch_size=val_batch_size, pos_weight=trainer.pos_weight)
         trainer.model.train()
@@ -186,7 +196,8 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
         done = epoch + 1
         prev_best = min([np.inf] + list(hist["val_loss"][:epoch]))
         if 1.005 * vl < prev_best:                                   # train.py:334-336
-            torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "best_model.pth"))
+            if main:
+                torch.save(cpu_state_dict(trainer.model), os.path.join(model_dir, "best_model.pth"))
             best_raw_preds, best_val_labels = np.copy(raw), np.copy(lab)
             since = 0
         else:
@@ -198,8 +209,66 @@ def fit(trainer: Trainer, train_set, val_images, val_metadata, val_labels, model
     # its figure and the per-source policy metrics need the candidate table and stay out of scope
     from .val import alert_summary
     summary = alert_summary(best_raw_preds, best_val_labels) if best_raw_preds is not None else {}
-    with open(os.path.join(model_dir, "report.json"), "w") as f:
-        json.dump({"train_config": dict(config or {}), "Training history": out, "val_summary": summary}, f, indent=2)
+    if main:
+        with open(os.path.join(model_dir, "report.json"), "w") as f:
+            json.dump({"train_config": dict(config or {}), "Training history": out, "val_summary": summary}, f,
+                      indent=2)
     out["best_raw_preds"], out["best_val_labels"] = best_raw_preds, best_val_labels
     out["val_summary"] = summary
     return out
+
+
+def run_training(config: dict, data_base_dir: str = "", run_name: str = "testing", device="cuda",
+                 precision: str = "bf16", models_root: str = "models"):
+    """train.py:75-440 (``run_training(config)``) on this framework, minus WandB and the diagnostic figure: seeds,
+    the split files (``data.load_split``), the model by name with the frozen_fusion freezing rule
+    (train.py:224-236), AdamW(lr, betas=(beta_1, beta_2)) under the warm-up + cosine schedule, BCE with
+    pos_weight = N_neg / N_pos of the training split (train.py:211-212), the epoch loop with latest / best
+    checkpoints and early stopping (``fit``), and the report.  Under ``torch.distributed`` (one process per GPU,
+    launched by torchrun) every rank trains its contiguous shard of each global batch and the gradients meet in one
+    all-reduce per step; rank 0 writes the files.  Config keys are the reference's: model_name, epochs,
+    batch_size, learning_rate, warmup_epochs, beta_1, beta_2, patience, random_seed, train_data_version, N_max,
+    metadata_cols, data_aug_*, plus the model's own.  Returns (history dict, model_dir)."""
+    import numpy as np
+    import torch.distributed as dist
+    from . import architectures
+    from .data import DeviceDataset, load_split
+    model_name = config["model_name"]
+    epochs, batch_size = int(config["epochs"]), int(config["batch_size"])
+    lr = float(config["learning_rate"])                    # "sometimes WandB makes LR a string" (train.py:85)
+    warmup = int(config.get("warmup_epochs", 0))
+    betas = (float(config["beta_1"]), float(config["beta_2"]))
+    patience, seed = int(config["patience"]), int(config["random_seed"])
+    version, n_str = config["train_data_version"], f"_N{config.get('N_max', 100)}"
+    dev = torch.device(device)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    timg, tmeta, tlab, _ = load_split(data_base_dir, config, "train")
+    vimg, vmeta, vlab, _ = load_split(data_base_dir, config, "val")
+    try:
+        model_type = getattr(architectures, model_name)
+    except AttributeError:
+        raise ValueError(f"Could not find model of name {model_name}") from None
+    model = model_type(config, precision=precision).to(dev).train()
+    if model_name == "frozen_fusion":                      # only the combined head is trained
+        for p in list(model.image_branch.parameters()) + list(model.meta_branch.parameters()):
+            p.requires_grad = False
+        for p in model.combined_head.parameters():
+            p.requires_grad = True
+        for m in model._image_bn_modules():                # a MaxViT branch is served in eval mode only
+            m.eval()
+    else:
+        for p in model.parameters():
+            p.requires_grad = True
+    gen = torch.Generator(device=dev).manual_seed(seed)    # the same permutations on every rank
+    train_set = DeviceDataset(timg, tmeta, tlab, batch_size, config=config, device=dev, generator=gen,
+                              shard=(rank, world) if world > 1 else None)
+    trainer = Trainer(model, lr=lr, betas=betas, pos_weight=train_set.pos_weight, epochs=epochs,
+                      warmup_epochs=warmup)
+    model_dir = os.path.join(models_root, f"{model_name}_{version}{n_str}_{dev.type}", run_name) + "/"
+    hist = fit(trainer, train_set, vimg, vmeta, vlab, model_dir, epochs=epochs, patience=patience,
+               val_batch_size=batch_size, config=config)
+    return hist, model_dir

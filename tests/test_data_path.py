@@ -406,3 +406,59 @@ def test_fit_loop_checkpoints_and_early_stopping(cuda, tmp_path):
     want = DO.alert_summary(hist["best_raw_preds"], hist["best_val_labels"])
     for k, v in want.items():
         assert abs(report["val_summary"][k] - v) <= 1e-9 * max(1.0, abs(v)), k
+
+
+@pytest.mark.gpu
+def test_sharded_device_dataset_is_the_dataparallel_scatter(cuda):
+    """shard=(rank, world): with equally seeded generators the ranks draw the same permutation and each yields its
+    contiguous slice of every global batch -- concatenated in rank order they ARE the unsharded batch."""
+    from btsbot_amd import data
+    img, meta, lab = synthetic_batch(200, seed=5)
+    mk = lambda **kw: data.DeviceDataset(img, meta, lab, 48, device=cuda, augment=False,
+                                         generator=torch.Generator(device=cuda).manual_seed(11), **kw)
+    full, r0, r1, r2 = mk(), mk(shard=(0, 3)), mk(shard=(1, 3)), mk(shard=(2, 3))
+    assert len(full) == len(r0) == 4
+    for epoch in range(2):                                   # the generators advance alike from epoch to epoch
+        for bf, b0, b1, b2 in zip(full, r0, r1, r2):
+            for k in range(3):
+                assert b0[k].shape[0] == 16
+                assert torch.equal(bf[k], torch.cat([b0[k], b1[k], b2[k]]))
+    with pytest.raises(ValueError):
+        mk(shard=(0, 5))                                     # 48 rows do not split five ways
+    with pytest.raises(ValueError):
+        mk(shard=(3, 3))
+
+
+@pytest.mark.gpu
+def test_run_training_driver_on_split_files(cuda, tmp_path):
+    """run_training (train.py:75-440 without WandB / figures) from the reference's split files: um_nn learns a
+    column threshold in a few epochs; models/<name>_<version>_N<N>_cuda/<run>/ holds latest / best checkpoints and
+    the report with history + val_summary; the best checkpoint loads strictly."""
+    import json
+    import pandas as pd
+    from btsbot_amd.train import run_training
+    from helpers import METADATA_COLS
+    _, meta, _ = synthetic_batch(768, seed=21)
+    lab = (meta[:, 5] > meta[:, 5].median()).long().numpy()
+    d = tmp_path / "data"
+    d.mkdir()
+    for split, sl in (("train", slice(0, 512)), ("val", slice(512, 768))):
+        df = pd.DataFrame(meta[sl].numpy(), columns=METADATA_COLS)
+        df["label"] = lab[sl]
+        df.to_csv(d / f"{split}_cand_v11_N100.csv", index=False)
+    cfg = dict(CONFIGS["um_nn"][1], model_name="um_nn", train_data_version="v11", epochs=5, batch_size=64,
+               learning_rate="3e-3", warmup_epochs=1, beta_1=0.9, beta_2=0.999, patience=3, random_seed=2)
+    hist, model_dir = run_training(cfg, data_base_dir=str(tmp_path) + "/", run_name="t0", device=cuda,
+                                   precision="f32", models_root=str(tmp_path / "models"))
+    assert model_dir.endswith("um_nn_v11_N100_cuda/t0/") and os.path.isfile(model_dir + "best_model.pth")
+    assert os.path.isfile(model_dir + "latest_model.pth")
+    n = len(hist["val_loss"])
+    assert 1 <= n <= 5 and (hist["val_loss"][-1] < 0.9 * hist["val_loss"][0] or n < 5)
+    rep = json.load(open(model_dir + "report.json"))
+    assert rep["train_config"]["model_name"] == "um_nn" and len(rep["Training history"]["train_loss"]) == n
+    assert 0.0 <= rep["val_summary"]["roc_auc"] <= 1.0 and rep["val_summary"]["TP"] + rep["val_summary"]["FN"] > 0
+    import btsbot_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2 = btsbot_amd.um_nn(cfg)
+    m2.load_state_dict(torch.load(model_dir + "best_model.pth"), strict=True)
