@@ -95,3 +95,26 @@ def alert_summary(raw_preds, labels) -> dict:
     return {"roc_auc": auc, "bal_acc": (bts_acc + notbts_acc) / 2, "bts_acc": bts_acc, "notbts_acc": notbts_acc,
             "alert_precision": precision, "alert_recall": recall,
             "TP": int(tp), "TN": int(tn), "FP": int(fp), "FN": int(fn)}
+
+
+def run_val(config: dict, model_dir: str, model_filename: str, bts_weight: float, data_base_dir: str = "",
+            split: str = "val", device="cuda", precision: str = "bf16"):
+    """val.py:31-168 (``run_val(config, model_dir, model_filename, bts_weight, ...)``): instantiate the model the
+    config names, load ``model_dir/model_filename`` strictly (a DataParallel ``module.`` prefix is accepted), read
+    the split files and run the validation pass.  ``need_triplets`` / ``need_metadata`` follow from the model
+    name as in train.py:108-122.  Returns (loss, accuracy, raw_preds, labels) like the reference."""
+    import os
+    from . import architectures
+    from .data import load_split
+    from .to_HF import strip_module_prefix
+    try:
+        model_type = getattr(architectures, config["model_name"])
+    except AttributeError:
+        raise ValueError(f"Could not find model of name {config['model_name']}") from None
+    model = model_type(config, precision=precision)
+    state = torch.load(os.path.join(model_dir, model_filename), map_location="cpu")
+    model.load_state_dict(strip_module_prefix(state), strict=True)
+    model = model.to(device).eval()
+    images, metadata, labels, _ = load_split(data_base_dir, config, split)
+    return run_val_tensors(model, images, metadata, labels, batch_size=int(config.get("batch_size", 1024)),
+                           pos_weight=float(bts_weight), device=device)

@@ -462,3 +462,12 @@ def test_run_training_driver_on_split_files(cuda, tmp_path):
         warnings.simplefilter("ignore")
         m2 = btsbot_amd.um_nn(cfg)
     m2.load_state_dict(torch.load(model_dir + "best_model.pth"), strict=True)
+    # val.py's run_val on the files the run left: the best epoch's validation loss / accuracy again
+    from btsbot_amd.val import run_val
+    pw = float((lab[:512] == 0).sum() / (lab[:512] == 1).sum())
+    vl, va, raw, vlab = run_val(cfg, model_dir, "best_model.pth", pw, data_base_dir=str(tmp_path) + "/",
+                                split="val", device=cuda, precision="f32")
+    best = int(np.argmin(np.array(hist["val_loss"]) * 1.0))
+    assert raw.shape == (256,) and np.array_equal(vlab, lab[512:768].astype(np.float32))
+    assert abs(vl - min(hist["val_loss"])) <= 1e-5 * max(1.0, vl) or abs(vl - hist["val_loss"][best]) <= 1e-5
+    assert np.allclose(raw, hist["best_raw_preds"], atol=1e-6)
