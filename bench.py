@@ -292,6 +292,43 @@ def cpu_baseline(sample_batch=256, budget_s=20.0):
                        f"fp32 torch-CPU oracle, median), ~{sum(times):.0f}s of CPU work")
 
 
+def train_leg(dev, rank, world, dist, fence, args):
+    """BASELINE.json configs[2]: the training step of mm_ConvNeXt, every parameter trainable."""
+    from btsbot_amd.train import Trainer
+    tcfg = dict(CONFIG, meta_dropout=0.25, comb_dropout=0.2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tm = btsbot_amd.mm_ConvNeXt(tcfg, precision=args.precision)
+    seeded_weights(tm)
+    tm = tm.to(dev).train()
+    timg, tmeta, tlab = synthetic_batch(args.train_batch, seed=100 + rank)
+    timg, tmeta, tlab = timg.to(dev), tmeta.to(dev), tlab.to(dev)
+    tr = Trainer(tm, lr=1e-4, betas=(0.99, 0.99), pos_weight=1.0, epochs=8, warmup_epochs=2)
+    for _ in range(3):
+        tr.step(timg, tmeta, tlab)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.train_steps):
+        tloss = tr.step(timg, tmeta, tlab)
+    fence()
+    tel = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([tel], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tel = t.item()
+    train = {
+        "workload": "BASELINE.json configs[2]: mm_ConvNeXt-pico training step (BCE pos_weight + "
+                    "backward + AdamW), every parameter trainable, one RCCL all-reduce of the "
+                    "flat gradient arena per step",
+        "value": round(args.train_batch * world * args.train_steps / tel, 1), "unit": "alerts/s",
+        "per_gpu_batch": args.train_batch, "global_batch": args.train_batch * world,
+        "steps": args.train_steps, "ms_per_step": round(1e3 * tel / args.train_steps, 3),
+        "loss_finite": bool(torch.isfinite(tloss).item()),
+    }
+    del tm, tr
+    return train
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,45 +402,22 @@ def main():
 
     # ---- training leg (BASELINE.json configs[2]): mm_ConvNeXt, every parameter trainable,
     #      BCE(pos_weight) + backward + one all-reduce of the flat gradient arena + AdamW per step
+    # The two secondary legs must not take the headline line down with them: a failure is reported in its place
+    # (an exception on ONE rank of a multi-GPU run can still strand the others in a collective -- nothing here
+    # hides that; it is for failures every rank shares, e.g. a reservation that does not fit)
+    del out
     train = None
     if args.train_steps > 0:
-        from btsbot_amd.train import Trainer
-        del out
-        tcfg = dict(CONFIG, meta_dropout=0.25, comb_dropout=0.2)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            tm = btsbot_amd.mm_ConvNeXt(tcfg, precision=args.precision)
-        seeded_weights(tm)
-        tm = tm.to(dev).train()
-        timg, tmeta, tlab = synthetic_batch(args.train_batch, seed=100 + rank)
-        timg, tmeta, tlab = timg.to(dev), tmeta.to(dev), tlab.to(dev)
-        tr = Trainer(tm, lr=1e-4, betas=(0.99, 0.99), pos_weight=1.0, epochs=8, warmup_epochs=2)
-        for _ in range(3):
-            tr.step(timg, tmeta, tlab)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.train_steps):
-            tloss = tr.step(timg, tmeta, tlab)
-        fence()
-        tel = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([tel], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tel = t.item()
-        train = {
-            "workload": "BASELINE.json configs[2]: mm_ConvNeXt-pico training step (BCE pos_weight + "
-                        "backward + AdamW), every parameter trainable, one RCCL all-reduce of the "
-                        "flat gradient arena per step",
-            "value": round(args.train_batch * world * args.train_steps / tel, 1), "unit": "alerts/s",
-            "per_gpu_batch": args.train_batch, "global_batch": args.train_batch * world,
-            "steps": args.train_steps, "ms_per_step": round(1e3 * tel / args.train_steps, 3),
-            "loss_finite": bool(torch.isfinite(tloss).item()),
-        }
-        del tm, tr
-
+        try:
+            train = train_leg(dev, rank, world, dist, fence, args)
+        except Exception as e:   # noqa: BLE001
+            train = {"error": f"{type(e).__name__}: {e}"}
     maxvit = None
     if args.maxvit_steps > 0:
-        maxvit = maxvit_leg(dev, rank, world, dist, fence, args)
+        try:
+            maxvit = maxvit_leg(dev, rank, world, dist, fence, args)
+        except Exception as e:   # noqa: BLE001
+            maxvit = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         work = family_work(args.batch, args.precision)
