@@ -357,8 +357,8 @@ class _HipModel(nn.Module):
         """The MaxViT image branch is built for eval mode only (BatchNorm2d running statistics folded into the
         convolutions, no backward).  A training-mode forward is therefore served only with that branch frozen AND
         in eval mode -- ``model.train(); model.<image branch>.eval()`` with ``requires_grad_(False)`` on its
-        parameters: heads (and the metadata branch) train over fixed image features, which is what the oracle's
-        ``training=True`` mode restates.  Anything else raises."""
+        parameters: heads (and the metadata branch) train over fixed image features (the regime the tests' CPU
+        checker restates with ``training=True``).  Anything else raises."""
         if not getattr(self, "_inference_only", False):
             return
         if keep_image:
