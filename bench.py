@@ -98,14 +98,10 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
         bytes=sum(d * (batch * p * c * (esz + 8) + 8 * c * c * esz)
                   for (d, p, c), f in zip(st, fused) if f))
     unf = [not f and not mega[i] for i, f in enumerate(fused)]
-    # stage 2 at C = 256: depthwise + LN + fc1 + GELU per block (stage2.hip) and fc2 as a GEMM; with
-    # BTSBOT_AMD_S2M=1 every block of the stage in one launch (stage2m.hip)
+    # stage 2 at C = 256: depthwise + LN + fc1 + GELU per block (stage2.hip) and fc2 as a GEMM
     s2 = precision != "f32" and dims[2] == 256
-    s2m = s2 and depths[2] <= 8 and os.environ.get("BTSBOT_AMD_S2M", "0") == "1"
-    w["stage2_kernel"] = dict(flop=2 * pw(*st[2]) if s2m else 0, bytes=batch * 9 * dims[2] * 4 * 2)
-    mega[2] = s2m
     w["s2_fc1_kernel"] = dict(
-        flop=pw(*st[2]) if s2 and not s2m else 0,
+        flop=pw(*st[2]) if s2 else 0,
         bytes=st[2][0] * (batch * 9 * dims[2] * 4 + batch * 9 * 4 * dims[2] * esz + 4 * dims[2] ** 2 * esz))
     unf = [u and not mega[i] for i, u in enumerate(unf)]
     unf1 = [u and not (s2 and i == 2) for i, u in enumerate(unf)]
@@ -134,7 +130,7 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     return w
 
 
-POINTWISE = ("stage0_kernel", "stage1_kernel", "stage2_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
+POINTWISE = ("stage0_kernel", "stage1_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
              "gemm_kernel<fc2,RESID>")
 
 

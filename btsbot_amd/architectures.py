@@ -353,6 +353,17 @@ class _HipModel(nn.Module):
                 out.append(parent)
         return out
 
+    def train(self, mode: bool = True):
+        """nn.Module.train, except that an inference-only image branch (MaxViT: BatchNorm2d folded from its
+        running statistics) keeps its BatchNorm containers in eval mode: ``model.train()`` after a validation
+        pass (train.py:332-340, val.py:55) would otherwise flip them back and the next step would refuse to
+        run.  Calling ``.train()`` on the branch itself still raises at the next forward."""
+        super().train(mode)
+        if mode and getattr(self, "_inference_only", False):
+            for m in self._image_bn_modules():
+                m.eval()
+        return self
+
     def _check_train_supported(self, keep_image: bool):
         """The MaxViT image branch is built for eval mode only (BatchNorm2d running statistics folded into the
         convolutions, no backward).  A training-mode forward is therefore served only with that branch frozen AND

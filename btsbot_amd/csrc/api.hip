@@ -11,7 +11,6 @@
 #include "ctx.h"
 #include "maxvit.h"
 #include "stage0.h"
-#include "stage2m.h"
 
 // ---------------------------------------------------------------------------------------
 // errors
@@ -103,7 +102,6 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc1 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
-        b.p_fc2gc = c.precision != BTSBOT_F32 ? bump(cur, (size_t)4 * ch * ch * esz) : 0;
         b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
                     : (i == 1 && ch == 128 && c.precision != BTSBOT_F32) ? bump(cur, s1par_bytes()) : 0;
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
@@ -260,12 +258,6 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_stage0 = !(ns != nullptr && ns[0] == '1');
   const char* n1 = getenv("BTSBOT_AMD_NO_STAGE1");
   h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
-  const char* n2m = getenv("BTSBOT_AMD_S2M");   // opt-in: at B = 1024 it only ties the per-block path
-  h->use_s2m = n2m != nullptr && n2m[0] == '1';
-  const char* n1b = getenv("BTSBOT_AMD_NO_S1B");
-  h->use_s1b = !(n1b != nullptr && n1b[0] == '1');
-  const char* n0b = getenv("BTSBOT_AMD_NO_S0B");
-  h->use_s0b = !(n0b != nullptr && n0b[0] == '1');
   const char* n2 = getenv("BTSBOT_AMD_NO_STAGE2");
   h->use_s2 = !(n2 != nullptr && n2[0] == '1');
   *out = h;
@@ -421,9 +413,6 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (!train_only)
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
-        if (c.precision != BTSBOT_F32 && !train_only)
-          TRY(launch_pack_w2_chunks(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2gc, ch,
-                                    4 * ch, st));
         if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
@@ -581,7 +570,6 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.blk[j].dw_b = m + b.dw_b;
         a.blk[j].ln_w = m + b.ln_w;
         a.blk[j].ln_b = m + b.ln_b;
-        a.blk[j].wpk = h->extra + b.p_fused;
         a.blk[j].b1 = m + b.fc1_b;
         a.blk[j].b2 = m + b.fc2_b;
         a.blk[j].gamma = m + b.gamma;
@@ -604,7 +592,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       a.stamps = h->stamps;
       a.wgt = h->stamps ? h->stamps + 32 : nullptr;
       TRY(timed(h, CAT_STAGE0, st, [&] {
-        return h->use_s0b ? launch_stage0b(c.precision, a, st) : launch_stage0(c.precision, a, st);
+        return launch_stage0b(c.precision, a, st);
       }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
@@ -644,8 +632,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].dw_b = m + b.dw_b;
           a.blk[j].ln_w = m + b.ln_w;
           a.blk[j].ln_b = m + b.ln_b;
-          a.blk[j].wpk = h->extra + b.p_fused;
-          a.blk[j].b1 = m + b.fc1_b;
+            a.blk[j].b1 = m + b.fc1_b;
           a.blk[j].b2 = m + b.fc2_b;
           a.blk[j].gamma = m + b.gamma;
           a.blk[j].w1 = h->extra + b.p_fc1;
@@ -666,43 +653,12 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.stamps = h->stamps ? h->stamps + 16 : nullptr;
         a.wgt = h->stamps ? h->stamps + 32 + 2 * 4096 : nullptr;
         TRY(timed(h, CAT_STAGE1, st, [&] {
-          return h->use_s1b ? launch_stage1b(c.precision, a, st) : launch_stage1(c.precision, a, st);
+          return launch_stage1b(c.precision, a, st);
         }));
         float* t = x;
         x = x2;
         x2 = t;
         down_done = true;
-        continue;
-      }
-      if (h->use_s2m && c.precision != BTSBOT_F32 && hw == 3 && ch == 256 &&
-          (int)h->blocks[i].size() <= stage2m_max_depth()) {
-        // every block of the 3x3 stage in one launch, the residual stream never leaves the CU
-        Stage2Args a;
-        memset(&a, 0, sizeof(a));
-        a.x_in = x;
-        a.out = x;
-        a.depth = (int)h->blocks[i].size();
-        a.B = nb;
-        {
-          const char* dg = getenv("BTSBOT_AMD_S2_DIAG");
-          a.diag = dg != nullptr ? atoi(dg) : 0;
-        }
-        for (int j = 0; j < a.depth; ++j) {
-          const BlockPk& b = h->blocks[i][j];
-          a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
-          a.blk[j].dw_b = m + b.dw_b;
-          a.blk[j].ln_w = m + b.ln_w;
-          a.blk[j].ln_b = m + b.ln_b;
-          a.blk[j].w1 = h->extra + b.p_fc1;
-          a.blk[j].w2g = h->extra + b.p_fc2gc;
-          a.blk[j].b1 = m + b.fc1_b;
-          a.blk[j].b2 = m + b.fc2_b;
-          a.blk[j].gamma = m + b.gamma;
-        }
-        TRY(timed(h, CAT_STAGE2, st, [&] { return launch_stage2m(c.precision, a, st); }));
-        if (h->debug)
-          HIP_TRY(hipMemcpyAsync(h->taps[i + 1], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice,
-                                 st));
         continue;
       }
       for (const BlockPk& b : h->blocks[i]) {

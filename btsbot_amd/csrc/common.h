@@ -45,19 +45,54 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// GELU for the 16-bit MFMA modes: x * sigmoid(p(x)), p odd quintic fitted (minimax, x clamped to
-// [-5,5]) to the exact erf form: max |error| 2.5e-5, below half an ulp of f16 at 0.05 and of bf16
-// at 0.006, at 9 VALU ops (2 transcendental) instead of erff's ~40.  The fp32 parity mode keeps
-// gelu_erf.  Coefficients carry the -log2(e) of exp -> v_exp_f32 (2^x).
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
-  const float x2 = xc * xc;
-  float t = fmaf(x2, 1.01426374e-3f, -1.06775727e-1f);   // -log2e * (c5, c3)
-  t = fmaf(x2, t, -2.30112134f);                          // -log2e * c1
-  const float e = __builtin_amdgcn_exp2f(xc * t);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
+// GELU for the 16-bit MFMA modes, one transcendental instead of erff's ~40 instructions:
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-a) = 2^q(a)  for a >= 0,
+// q = minimax polynomial of log2 Phi(-a) fitted so that |a 2^q(a) - a Phi(-a)| is smallest (tools/fit_gelu.py).
+// The leading coefficients are negative, so q -> -inf and the tail is exactly 0 for any |x|: no clamp.
+//   DEG 3: max |error| 5.8e-5 (below half an ulp of bf16 for |gelu| > 0.015), 3 fma + v_exp + v_max + fma;
+//   DEG 5: max |error| 4.7e-7 (f32-class), 2 more fma.
+// On gfx950 a v_exp_f32 issues in ~8 cycles, a plain VALU op in ~3: 24 / 30 cycles per wave-GELU against 42
+// for the x * sigmoid(quintic) form this replaces (v_exp + v_rcp + v_med3 + 6).  The fp32 parity mode keeps gelu_erf.
+template <int DEG> __device__ __forceinline__ float gelu_q(float a);
+template <> __device__ __forceinline__ float gelu_q<3>(float a) {
+  float t = fmaf(a, -0.024772998623334343f, -0.49926576060257244f);
+  t = fmaf(a, t, -1.1287482669759885f);
+  return fmaf(a, t, -1.0036805164077327f);
 }
-template <typename T> __device__ __forceinline__ float gelu_for(float x) { return gelu_fast(x); }
+template <> __device__ __forceinline__ float gelu_q<5>(float a) {
+  float t = fmaf(a, -0.0004726569791655389f, 0.007079169600613161f);
+  t = fmaf(a, t, -0.05181158088529847f);
+  t = fmaf(a, t, -0.46001256950698816f);
+  t = fmaf(a, t, -1.1507770495088248f);
+  return fmaf(a, t, -1.000039487932206f);
+}
+template <int DEG> __device__ __forceinline__ float gelu_poly(float x) {
+  const float a = __builtin_fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(gelu_q<DEG>(a));
+  return fmaf(-a, e, fmaxf(x, 0.0f));
+}
+// d/dx of gelu_poly: with E = 2^q(a), D = E (1 + a ln2 q'(a)):  x > 0: 1 - D,  x < 0: D  (x = 0: 1/2 either way
+// up to the fit error).  The 16-bit training forward applies gelu_poly, so its backward differentiates gelu_poly.
+template <int DEG> __device__ __forceinline__ float gelu_dq(float a);
+template <> __device__ __forceinline__ float gelu_dq<3>(float a) {
+  float t = fmaf(a, 3.0f * -0.024772998623334343f, 2.0f * -0.49926576060257244f);
+  return fmaf(a, t, -1.1287482669759885f);
+}
+template <> __device__ __forceinline__ float gelu_dq<5>(float a) {
+  float t = fmaf(a, 5.0f * -0.0004726569791655389f, 4.0f * 0.007079169600613161f);
+  t = fmaf(a, t, 3.0f * -0.05181158088529847f);
+  t = fmaf(a, t, 2.0f * -0.46001256950698816f);
+  return fmaf(a, t, -1.1507770495088248f);
+}
+template <int DEG> __device__ __forceinline__ float gelu_poly_grad(float x) {
+  const float a = __builtin_fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(gelu_q<DEG>(a));
+  const float d = e * fmaf(a * 0.6931471805599453f, gelu_dq<DEG>(a), 1.0f);
+  return x > 0.0f ? 1.0f - d : d;
+}
+template <typename T> struct GeluDeg { static constexpr int value = 5; };     // f16 operands: f32-class GELU
+template <> struct GeluDeg<bf16_t> { static constexpr int value = 3; };       // bf16 operands
+template <typename T> __device__ __forceinline__ float gelu_for(float x) { return gelu_poly<GeluDeg<T>::value>(x); }
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 
 // d/dx of the exact erf GELU: Phi(x) + x * phi(x)
@@ -76,22 +111,9 @@ __device__ __forceinline__ float silu_fast(float x) {
 template <typename T> __device__ __forceinline__ float silu_for(float x) { return silu_fast(x); }
 template <> __device__ __forceinline__ float silu_for<float>(float x) { return silu_f(x); }
 
-// d/dx of gelu_fast (the function the 16-bit forward actually applies): with u(x) = xc * t(xc), e = 2^u,
-// s = 1 / (1 + e):  d(x s)/dx = s - x s (1 - s) ln2 u'(x),  u' = a1 + 3 a3 x^2 + 5 a5 x^4 inside the clamp, 0
-// outside.  ~14 VALU ops (2 transcendental) instead of erff + expf (~60); the fp32 mode keeps gelu_grad.
-__device__ __forceinline__ float gelu_fast_grad(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
-  const float x2 = xc * xc;
-  float t = fmaf(x2, 1.01426374e-3f, -1.06775727e-1f);
-  t = fmaf(x2, t, -2.30112134f);
-  const float e = __builtin_amdgcn_exp2f(xc * t);
-  const float s = __builtin_amdgcn_rcpf(1.0f + e);
-  float du = fmaf(x2, 5.0f * 1.01426374e-3f, 3.0f * -1.06775727e-1f);
-  du = fmaf(x2, du, -2.30112134f);
-  du = (x == xc) ? du : 0.0f;
-  return fmaf(x * s * (1.0f - s), -0.6931471805599453f * du, s);
+template <typename T> __device__ __forceinline__ float gelu_grad_for(float x) {
+  return gelu_poly_grad<GeluDeg<T>::value>(x);
 }
-template <typename T> __device__ __forceinline__ float gelu_grad_for(float x) { return gelu_fast_grad(x); }
 template <> __device__ __forceinline__ float gelu_grad_for<float>(float x) { return gelu_grad(x); }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
@@ -170,19 +192,6 @@ int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const flo
                                int N, int K, hipStream_t st, const float* ln_w = nullptr,
                                const float* ln_b = nullptr, void* ln_out = nullptr);
 
-// persistent variant with the filter panel resident in LDS (gemm4.hip): 16-bit modes, K in {128,256},
-// N % 128 == 0, typed-output epilogues SILU / GELU / BIAS_T
-bool gemm4_supported(int prec, int epi, int M, int N, int K);
-int launch_gemm4(int prec, int epi, const void* X, const void* W, const float* bias, void* out, int M,
-                 int N, int K, hipStream_t st);
-
-// LDS-free streaming variant for K in {64,128} (gemm3.hip): filter slice in registers, activation rows
-// fetched as MFMA fragments; 16-bit modes, N % 32 == 0, epilogues SILU / BIAS_T / GELU / RESID / BIAS
-bool gemm3_supported(int prec, int epi, int M, int N, int K);
-int launch_gemm3(int prec, int epi, const void* X, const void* W, const float* bias,
-                 const float* gamma, const float* resid, void* out, int M, int N, int K,
-                 hipStream_t st);
-
 // stem: conv 4x4 s4 (+bias) + LayerNorm over C0.  img [B,3,63,63] fp32 -> out [B,225,C0] fp32.
 int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
                 const float* lnb, float* out, int B, int C0, hipStream_t st);
@@ -211,21 +220,15 @@ int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const flo
                      void* post_out = nullptr, const float* pw = nullptr, const float* pb = nullptr,
                      int post_mode = 0);
 
-// stage-0 megakernel (stage0.hip): stem + 2 blocks + downsample in one launch, 16-bit modes, C0 = 64
+// stage-0 megakernel (stage0b.hip): stem + 2 blocks + downsample in one launch, 16-bit modes, C0 = 64
 struct Stage0Args;
 bool stage0_supported(int prec, int c0);
-int launch_stage0(int prec, const Stage0Args& a, hipStream_t st);
 
 // backward kernels (backward.hip)
 int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
                  hipStream_t st);                                  // out[n][k] += sum_m D[m][n] A[m][k]
 struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
-struct Stage2Args;
-int launch_stage2m(int prec, const Stage2Args& a, hipStream_t st);   // stage2m.hip: all 3x3 blocks, one launch
-int stage2m_max_depth();
-int launch_pack_w2_chunks(int prec, const float* w2, const float* gamma, void* dst, int Cc, int H,
-                          hipStream_t st);   // gamma-scaled fc2 filter, chunk-major [H/32][Cc][32]
 struct Stage1Args;
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.hip
 size_t s1par_bytes();
@@ -265,9 +268,7 @@ int launch_pack_down_t(int prec, const float* src, void* dst, int Cout, int Cin,
 // Gd [Cout][4][Cin] (q-major patches order) accumulated into dst [Cout][Cin][4] (master layout)
 int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st);
 
-struct Stage1Args;
-bool stage1_supported(int prec, int c1, int c2);
-int launch_stage1(int prec, const Stage1Args& a, hipStream_t st);
+bool stage1_supported(int prec, int c1, int c2);   // stage1b.hip
 
 struct HeadArgs {
   // image feature part

@@ -17,7 +17,6 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
-  size_t p_fc2gc;          // diag(gamma) W2, chunk-major [4C/32][C][32] (megakernel LDS-DMA source)
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
@@ -84,9 +83,6 @@ struct btsbot_ctx {
   std::vector<int> prof_cat;
   size_t prof_used = 0;
 
-  bool use_s2m = false;    // BTSBOT_AMD_S2M=1: all stage-2 blocks in one launch (stage2m.hip) instead of per-block launches
-  bool use_s1b = true;     // BTSBOT_AMD_NO_S1B=1: stage1.hip's layout instead of stage1b.hip
-  bool use_s0b = true;     // BTSBOT_AMD_NO_S0B=1: stage0.hip's one-workgroup-per-CU layout instead of stage0b.hip
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
   bool stage1 = false;     // stage 1 + second downsample as one kernel

@@ -170,10 +170,10 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
-          const float v0 = gelu_fast(hacc[4 * q + 0] + bv.x);
-          const float v1 = gelu_fast(hacc[4 * q + 1] + bv.y);
-          const float v2 = gelu_fast(hacc[4 * q + 2] + bv.z);
-          const float v3 = gelu_fast(hacc[4 * q + 3] + bv.w);
+          const float v0 = gelu_for<T>(hacc[4 * q + 0] + bv.x);
+          const float v1 = gelu_for<T>(hacc[4 * q + 1] + bv.y);
+          const float v2 = gelu_for<T>(hacc[4 * q + 2] + bv.z);
+          const float v3 = gelu_for<T>(hacc[4 * q + 3] + bv.w);
           hf[q >> 1][(q & 1) * 4 + 0] = (T)v0;
           hf[q >> 1][(q & 1) * 4 + 1] = (T)v1;
           hf[q >> 1][(q & 1) * 4 + 2] = (T)v2;

@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const T* __restrict__ X,
       if (EPI == EPI_GELU) {
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
-        v[0] = (T)gelu_fast(a[0] + bv.x);
-        v[1] = (T)gelu_fast(a[1] + bv.y);
-        v[2] = (T)gelu_fast(a[2] + bv.z);
-        v[3] = (T)gelu_fast(a[3] + bv.w);
+        v[0] = (T)gelu_for<T>(a[0] + bv.x);
+        v[1] = (T)gelu_for<T>(a[1] + bv.y);
+        v[2] = (T)gelu_for<T>(a[2] + bv.z);
+        v[3] = (T)gelu_for<T>(a[3] + bv.w);
         *reinterpret_cast<T4*>(dst) = v;
       } else if (EPI == EPI_SILU || EPI == EPI_BIAS_T || EPI == EPI_GELU_SAVE) {
         // (GELU_SAVE stages the rounded pre-activation; stage 2 writes it and its GELU)

@@ -9,6 +9,8 @@
 //
 // Sizes are tiny (B x {25,128,128,640,128,32,1}); kernels are plain fp32 tiles, one launch per
 // layer, deterministic summation order (no atomics).
+#include <algorithm>
+
 #include "ctx.h"
 
 #define TRY_RET(call)               \
@@ -252,6 +254,17 @@ inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 // ---------------------------------------------------------------------------------------
 // cache layout (floats) for a batch of M alerts
 // ---------------------------------------------------------------------------------------
+// Row width of the three backward scratch buffers: the widest tensor any of them ever holds -- d(z) of the
+// concatenated fusion input, a fusion layer's input gradient, or the metadata branch's d(a2) / d(h1) / d(x).
+static size_t train_dwidth(const btsbot_ctx* h) {
+  const btsbot_config& c = h->cfg;
+  size_t w = 64;
+  for (int i = 0; i <= h->n_comb; ++i) w = std::max(w, (size_t)h->comb_dims[i]);
+  if (h->has_image) w = std::max(w, (size_t)c.dims[3]);
+  if (h->has_meta) w = std::max(std::max(w, (size_t)c.n_meta), std::max((size_t)c.meta_fc1, (size_t)c.meta_fc2));
+  return (w + 3) / 4 * 4;
+}
+
 size_t train_cache_floats(const btsbot_ctx* h, int M) {
   const btsbot_config& c = h->cfg;
   const size_t F = h->has_image ? c.dims[3] : 0;
@@ -260,7 +273,7 @@ size_t train_cache_floats(const btsbot_ctx* h, int M) {
   if (h->has_meta) n += (size_t)M * (2 * c.n_meta + 2 * c.meta_fc1 + c.meta_fc2) + c.n_meta;
   n += (size_t)M * h->comb_dims[0];                     // z
   for (int i = 0; i < h->n_comb; ++i) n += 2 * (size_t)M * h->comb_dims[i + 1];   // pre + act
-  n += 3 * (size_t)M * 768;                             // backward scratch (d-buffers)
+  n += 3 * (size_t)M * train_dwidth(h);                 // backward scratch (d-buffers)
   return n + 1024;
 }
 
@@ -294,9 +307,10 @@ static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
     p.pre[i] = take((size_t)M * h->comb_dims[i + 1]);
     p.actv[i] = take((size_t)M * h->comb_dims[i + 1]);
   }
-  p.d0 = take((size_t)M * 768);
-  p.d1 = take((size_t)M * 768);
-  p.dm = take((size_t)M * 768);
+  const size_t dw = train_dwidth(h);
+  p.d0 = take((size_t)M * dw);
+  p.d1 = take((size_t)M * dw);
+  p.dm = take((size_t)M * dw);
   return p;
 }
 
@@ -309,11 +323,6 @@ int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* lo
   TrainPtrs p = carve(h, cache, M);
   const int F = h->has_image ? c.dims[3] : 0;
   const int zd = h->comb_dims[0];
-  for (int i = 1; i <= h->n_comb; ++i)
-    if (h->comb_dims[i] > 768 || zd > 4096) {
-      btsbot_set_error("train: head widths exceed the training scratch (768)");
-      return BTSBOT_ERR_INVALID_ARG;
-    }
   if (h->has_image) {
     hipLaunchKernelGGL(feat_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, p.feat, F,
                        h->hn_w >= 0 ? m + h->hn_w : nullptr, h->hn_b >= 0 ? m + h->hn_b : nullptr,

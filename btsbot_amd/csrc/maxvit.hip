@@ -56,13 +56,11 @@ struct MaxVit {
   size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr, o_wg;
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
   bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
-  bool no_gemm3 = true;     // BTSBOT_AMD_MV_GEMM3=1: LDS-free streaming GEMM (gemm3.hip) for the K = 64 / 128 shapes
                             // (measured slower than gemm2 on these shapes: opt-in, kept as the record)
   bool gated_gemm = false;  // BTSBOT_AMD_MV_GATED_GEMM=1: register-staged gated GEMM for every conv3 (f32 mode's path)
   bool no_front = false;    // BTSBOT_AMD_MV_NO_FRONT=1: conv1 GEMM + depthwise kernel instead of the fused MBConv front
   bool no_ln_fuse = false;  // BTSBOT_AMD_MV_NO_LN_FUSE=1: separate LayerNorm launches everywhere
   bool no_attn_block = false;  // BTSBOT_AMD_MV_NO_ATTN_BLOCK=1: qkv GEMM + attention + proj GEMM at C = 64 too
-  bool no_gemm4 = true;     // BTSBOT_AMD_MV_GEMM4=1: persistent GEMM with the filter panel resident in LDS (gemm4.hip)
                             // for the K = 128 / 256 wide-N shapes (measured 20-25 % slower than gemm2: opt-in)
   bool dw_plain = false;    // BTSBOT_AMD_MV_DW_PLAIN=1: per-pixel depthwise kernel + separate pool pass
   bool attn_valu = false;   // BTSBOT_AMD_MV_ATTN_VALU=1: the one-query-per-lane kernel in the 16-bit modes too
@@ -150,8 +148,6 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->dw_plain = d != nullptr && d[0] == '1';
     const char* s2 = getenv("BTSBOT_AMD_MV_STEM_IM2COL");
     mv->stem_im2col = s2 != nullptr && s2[0] == '1';
-    const char* g3 = getenv("BTSBOT_AMD_MV_GEMM3");
-    mv->no_gemm3 = !(g3 != nullptr && g3[0] == '1');
     const char* gg = getenv("BTSBOT_AMD_MV_GATED_GEMM");
     mv->gated_gemm = gg != nullptr && gg[0] == '1';
     const char* nf = getenv("BTSBOT_AMD_MV_NO_FRONT");
@@ -160,8 +156,6 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_ln_fuse = lf != nullptr && lf[0] == '1';
     const char* ab = getenv("BTSBOT_AMD_MV_NO_ATTN_BLOCK");
     mv->no_attn_block = ab != nullptr && ab[0] == '1';
-    const char* g4 = getenv("BTSBOT_AMD_MV_GEMM4");
-    mv->no_gemm4 = !(g4 != nullptr && g4[0] == '1');
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
   }
@@ -313,10 +307,6 @@ size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk) {
 // GEMM dispatch of the MaxViT schedule: the LDS-free streaming kernel where it applies (K = 64 / 128)
 static int mv_gemm(const MaxVit* mv, int prec, int epi, const void* X, const void* W, const float* bias,
                    const float* gamma, const float* resid, void* out, int M, int N, int K, hipStream_t st) {
-  if (!mv->no_gemm4 && gemm4_supported(prec, epi, M, N, K))
-    return launch_gemm4(prec, epi, X, W, bias, out, M, N, K, st);
-  if (!mv->no_gemm3 && gemm3_supported(prec, epi, M, N, K))
-    return launch_gemm3(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
   return launch_gemm(prec, epi, X, W, bias, gamma, resid, out, M, N, K, st);
 }
 

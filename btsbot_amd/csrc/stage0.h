@@ -1,4 +1,4 @@
-// Argument block of the stage-0 megakernel (stage0.hip).
+// Argument blocks of the stage-0 / stage-1 megakernels (stage0b.hip, stage1b.hip).
 #pragma once
 
 struct Stage0Blk {
@@ -6,7 +6,6 @@ struct Stage0Blk {
   const float* dw_b;
   const float* ln_w;
   const float* ln_b;
-  const unsigned char* wpk;   // fused_mlp packed image (FusedGeom<64>)
   const float* b1;
   const float* b2;
   const float* gamma;
@@ -36,10 +35,10 @@ struct Stage0Args {
 };
 
 
-// Argument block of the stage-1 megakernel (stage1.hip): 4 alerts per workgroup, C = 128.
+// Stage-1 megakernel (stage1b.hip): two alerts per workgroup, C = 128.
 struct Stage1Args {
   const float* x_in;      // [B][49][128] f32 (stage-0 output after its downsample)
-  Stage0Blk blk[2];       // dw_w is [49][128]; wpk is the FusedGeom<128> image
+  Stage0Blk blk[2];       // dw_w is [49][128]
   const float* ds_lnw;
   const float* ds_lnb;
   const void* ds_w;       // [256][512] 16-bit, k = (ky*2+kx)*128 + c

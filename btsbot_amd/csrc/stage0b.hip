@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
           for (int s2 = 0; s2 < 2; ++s2) {
             frag hf;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_fast(hacc[t][8 * s2 + r]);
+            for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_for<T>(hacc[t][8 * s2 + r]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) x[t][ct] = SBM<T>::run(a2[ct][s2], hf, x[t][ct]);
           }
@@ -541,6 +541,10 @@ int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, c
                      ln_b, b1, b2, gamma, reinterpret_cast<float*>(out));
   LAUNCH_CHECK();
   return BTSBOT_OK;
+}
+
+bool stage0_supported(int prec, int c0) {
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c0 == 64;
 }
 
 // Needs Stage0Blk::par, ::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.

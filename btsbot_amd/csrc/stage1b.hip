@@ -1,5 +1,5 @@
 // Stage-1 megakernel, second layout (gfx950): TWO alerts' 7x7x128 maps per 256-thread workgroup,
-// two workgroups per CU -- the re-cut of stage1.hip that stage0b.hip is of stage0.hip:
+// two workgroups per CU (same scheme as stage0b.hip):
 //
 //   2 x [ dwconv 7x7 + LN -> fc1 -> GELU -> fc2 -> layer-scale -> +x ]  ->  LN + conv 2x2 s2 (128 -> 256)
 //
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         for (int s2 = 0; s2 < 2; ++s2) {
           frag hf;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_fast(hacc[8 * s2 + r]);
+          for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_for<T>(hacc[8 * s2 + r]);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][s2], hf, x[ct]);
         }
@@ -488,6 +488,10 @@ int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const floa
   }
   LAUNCH_CHECK();
   return BTSBOT_OK;
+}
+
+bool stage1_supported(int prec, int c1, int c2) {
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c1 == 128 && c2 == 256;
 }
 
 // Needs Stage0Blk::par (launch_pack_s1par), ::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit.

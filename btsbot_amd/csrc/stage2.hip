@@ -85,25 +85,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// gelu_fast (common.h) on two values: v_pk_mul / v_pk_fma where the math allows
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-  f32x2 xc;
-  xc[0] = __builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f);
-  xc[1] = __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f);
-  const f32x2 x2 = xc * xc;
-  f32x2 t = __builtin_elementwise_fma(x2, (f32x2)(1.01426374e-3f), (f32x2)(-1.06775727e-1f));
-  t = __builtin_elementwise_fma(x2, t, (f32x2)(-2.30112134f));
-  const f32x2 z = xc * t;
-  f32x2 e;
-  e[0] = __builtin_amdgcn_exp2f(z[0]);
-  e[1] = __builtin_amdgcn_exp2f(z[1]);
-  const f32x2 d = e + (f32x2)(1.0f);
-  f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(d[0]);
-  r[1] = __builtin_amdgcn_rcpf(d[1]);
-  return x * r;
-}
-
 template <typename T>
 __global__ __launch_bounds__(NT) void s2_fc1_kernel(S2Fc1Args a) {
   using frag = typename M2<T>::frag;
@@ -254,16 +235,13 @@ __global__ __launch_bounds__(NT) void s2_fc1_kernel(S2Fc1Args a) {
   {
     const int nl = wave * 16 + lq * 4;
     const float4 bv = *reinterpret_cast<const float4*>(a.b1 + n0 + nl);
-    const f32x2 b0 = {bv.x, bv.y}, b1 = {bv.z, bv.w};
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const f32x2 y0 = gelu_fast2(f32x2{acc[mi][0], acc[mi][1]} + b0);
-      const f32x2 y1 = gelu_fast2(f32x2{acc[mi][2], acc[mi][3]} + b1);
       T4 o;
-      o[0] = (T)y0[0];
-      o[1] = (T)y0[1];
-      o[2] = (T)y1[0];
-      o[3] = (T)y1[1];
+      o[0] = (T)gelu_for<T>(acc[mi][0] + bv.x);
+      o[1] = (T)gelu_for<T>(acc[mi][1] + bv.y);
+      o[2] = (T)gelu_for<T>(acc[mi][2] + bv.z);
+      o[3] = (T)gelu_for<T>(acc[mi][3] + bv.w);
       *reinterpret_cast<T4*>(smem + (mi * 16 + lrow) * OPITCH + nl * 2) = o;
     }
   }
