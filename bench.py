@@ -28,7 +28,50 @@ import sys
 import time
 import warnings
 
-import torch
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--batch", type=int, default=1024, help="alerts per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the f16 / f32 precision legs and the parity object (profiling runs)")
+    ap.add_argument("--train-steps", type=int, default=20,
+                    help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
+    ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
+    ap.add_argument("--maxvit-steps", type=int, default=3,
+                    help="steps of the MaxViT inference leg (BASELINE.json configs[3]); 0 = skip")
+    ap.add_argument("--maxvit-batch", type=int, default=1024, help="alerts per GPU per MaxViT step")
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what
+    `python -m torch.distributed.run --nproc-per-node N` would do), one process per GPU, and exit with the
+    worst child's code.  Runs before torch or the package is imported: nothing in THIS process has touched
+    the GPU, the children are ordinary child processes (no exec of a GPU-initialised process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _n = parse_args().gpus
+    if _n > 1:
+        sys.exit(spawn_ranks(_n))
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -288,6 +331,52 @@ def cpu_baseline(sample_batch=256, budget_s=20.0):
                        f"fp32 torch-CPU oracle, median), ~{sum(times):.0f}s of CPU work")
 
 
+def parity_vs_oracle(model, img, meta, n=256):
+    """max |dlogit| / |dscore| of THIS model (the benchmarked weights and precision) on the first n alerts of the
+    benchmarked batch against the fp32 CPU oracle (checker only; outside every timed region)."""
+    from oracle import convnext_oracle as O   # checker only
+    n = min(n, img.shape[0])
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = O.forward("mm_ConvNeXt", sd, CONFIG, img[:n].cpu(), meta[:n].cpu())
+        out = model(image_input=img[:n].contiguous(), metadata_input=meta[:n].contiguous()).cpu()
+    return dict(alerts=n, max_abs_dlogit=float((out - ref).abs().max()),
+                max_abs_dscore=float((torch.sigmoid(out) - torch.sigmoid(ref)).abs().max()),
+                oracle="oracle/convnext_oracle.py, fp32 CPU, same weights")
+
+
+def precision_leg(precision, dev, img, meta, steps, warmup, fence, dist, world, with_parity=True):
+    """The same workload in another MFMA operand mode (f16: same matrix rate as bf16, scores within 1e-4 of the
+    oracle; f32: the exact-fp32 parity mode), with its own parity figures."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.mm_ConvNeXt(CONFIG, precision=precision)
+    seeded_weights(m)
+    m = m.to(dev).eval()
+
+    def step():
+        with torch.no_grad():
+            return m(image_input=img, metadata_input=meta)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    leg = dict(value=round(img.shape[0] * world * steps / el, 1), unit="alerts/s", steps=steps,
+               ms_per_step=round(1e3 * el / steps, 4))
+    if with_parity:
+        leg["parity"] = parity_vs_oracle(m, img, meta)
+    return leg
+
+
 def train_leg(dev, rank, world, dist, fence, args):
     """BASELINE.json configs[2]: the training step of mm_ConvNeXt, every parameter trainable."""
     from btsbot_amd.train import Trainer
@@ -326,26 +415,15 @@ def train_leg(dev, rank, world, dist, fence, args):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="alerts per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=20,
-                    help="steps of the training leg (BASELINE.json configs[2]); 0 = skip")
-    ap.add_argument("--train-batch", type=int, default=1024, help="alerts per GPU per training step")
-    ap.add_argument("--maxvit-steps", type=int, default=3,
-                    help="steps of the MaxViT inference leg (BASELINE.json configs[3]); 0 = skip")
-    ap.add_argument("--maxvit-batch", type=int, default=1024, help="alerts per GPU per MaxViT step")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPUs visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -395,6 +473,19 @@ def main():
         step()
     prof = model.collect_profile()
     model.set_profile(False)
+
+    # ---- parity of the benchmarked model / weights / precision, and the other operand modes on the same batch
+    parity, legs = None, {}
+    if not args.no_extra_legs:
+        parity = parity_vs_oracle(model, img, meta) if rank == 0 else None
+        for prec in ("f16", "bf16", "f32"):
+            if prec == args.precision:
+                continue
+            try:
+                legs[prec] = precision_leg(prec, dev, img, meta, max(5, args.steps // (5 if prec == "f32" else 1)),
+                                           3, fence, dist, world, with_parity=(rank == 0))
+            except Exception as e:   # noqa: BLE001
+                legs[prec] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- training leg (BASELINE.json configs[2]): mm_ConvNeXt, every parameter trainable,
     #      BCE(pos_weight) + backward + one all-reduce of the flat gradient arena + AdamW per step
@@ -468,6 +559,13 @@ def main():
             "flop_per_alert": 133701376 + 210000,
             "whole_net_tflops": round((133701376 + 210000) * total_alerts / elapsed / 1e12, 2),
         }
+        if parity is not None:
+            line["parity"] = parity
+        if legs:
+            line["precision_legs"] = legs
+        if dist is not None:
+            line["collective"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
+                                      note="inference: no data-path collective; training leg: bucketed all-reduce")
         if train is not None:
             line["train"] = train
         if maxvit is not None:

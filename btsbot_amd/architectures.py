@@ -311,9 +311,9 @@ class _HipModel(nn.Module):
             dest.append((t, off, numel, shape))
         return comb, meta, image
 
-    def _dropout_masks(self, batch: int, dev):
-        """uint8 keep-masks [B, meta_fc1] and [B, comb_fc2] drawn from torch's device RNG (or the
-        ones a test planted in ``_forced_masks``)."""
+    def _dropout_masks(self, batch: int, dev, generator=None):
+        """uint8 keep-masks [B, meta_fc1] and [B, comb_fc2] drawn from torch's device RNG (or `generator`, or
+        the ones a test planted in ``_forced_masks``)."""
         forced = getattr(self, "_forced_masks", None)
         a = self._cfg_args
         out = []
@@ -324,7 +324,7 @@ class _HipModel(nn.Module):
             elif forced is not None and name in forced:
                 out.append(forced[name].to(device=dev, dtype=torch.uint8).contiguous())
             else:
-                out.append((torch.rand(batch, width, device=dev) >= p).to(torch.uint8))
+                out.append((torch.rand(batch, width, device=dev, generator=generator) >= p).to(torch.uint8))
         return out
 
     def _run_train(self, image, meta):
@@ -430,6 +430,17 @@ class _HipModel(nn.Module):
                 self._handle.ptr, C.c_void_p(dl.data_ptr()), C.c_void_p(self._grad_arena.data_ptr()),
                 int(need_meta), int(need_image), C.c_void_p(stream)), "btsbot_backward")
         return self._grad_arena
+
+    def _grad_buckets(self):
+        """Arena ranges [(lo, hi)] in the order btsbot_backward() completes them (btsbot_grad_buckets)."""
+        lo, hi = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        n = _lib.check(_lib.lib().btsbot_grad_buckets(self._handle.ptr, 8, lo, hi), "btsbot_grad_buckets")
+        return [(int(lo[i]), int(hi[i])) for i in range(n)]
+
+    def _wait_grad_bucket(self, bucket: int, stream: int):
+        """Make the HIP stream `stream` wait for bucket `bucket` of the last backward (no host sync)."""
+        _lib.check(_lib.lib().btsbot_wait_grad_bucket(self._handle.ptr, int(bucket), C.c_void_p(stream)),
+                   "btsbot_wait_grad_bucket")
 
     def set_profile(self, on: bool = True):
         """Bracket every kernel launch of forward() with HIP events (bench.py's roofline leg)."""

@@ -139,6 +139,18 @@ int build_tables(btsbot_ctx* h) {
     h->p_comb[i] = bump(cur, (size_t)h->comb_dims[i + 1] * h->comb_dims[i] * 4);
   }
   h->extra_bytes = cur;
+  // gradient buckets, in the order the backward pass completes them
+  if (h->has_image && !h->is_maxvit) {
+    const int64_t s3 = h->down[3].ln_w, s2 = h->down[2].ln_w;
+    h->n_buckets = 3;
+    h->bucket_lo[0] = s3; h->bucket_hi[0] = h->total_floats;
+    h->bucket_lo[1] = s2; h->bucket_hi[1] = s3;
+    h->bucket_lo[2] = 0;  h->bucket_hi[2] = s2;
+  } else {
+    h->n_buckets = 1;
+    h->bucket_lo[0] = 0;
+    h->bucket_hi[0] = h->total_floats;
+  }
   return BTSBOT_OK;
 }
 
@@ -277,6 +289,8 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->bucket_ev)
+    if (e) (void)hipEventDestroy(e);
   delete h;
   return BTSBOT_OK;
 }
@@ -416,8 +430,8 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
-        if (i == 0 && ch == 64 && !train_only)   // (after the tap-major transpose above: same stream)
-          TRY(launch_pack_s0par(reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
+        if (i == 0 && ch == 64 && c.precision != BTSBOT_F32 && !train_only)   // (after the tap-major transpose above: same stream)
+          TRY(launch_pack_s0par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
         if (b.fused && !train_only)
@@ -933,11 +947,42 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
   }
   if (need_img)   // image-branch gradients are accumulated with atomics
     HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
+  for (int i = 0; i < h->n_buckets; ++i)
+    if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
   float* dfeat = nullptr;
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));
-  if (need_img)
-    TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));
+  if (need_img) {
+    TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));   // records the bucket events
+  } else {
+    for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));
+  }
+  h->bucket_recorded = true;
+  return BTSBOT_OK;
+}
+
+extern "C" int btsbot_grad_buckets(btsbot_handle h, int capacity, int64_t* lo, int64_t* hi) {
+  if (h == nullptr || lo == nullptr || hi == nullptr || capacity < h->n_buckets) {
+    btsbot_set_error("grad_buckets: NULL argument or room for fewer than %d buckets", h ? h->n_buckets : 0);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < h->n_buckets; ++i) {
+    lo[i] = h->bucket_lo[i];
+    hi[i] = h->bucket_hi[i];
+  }
+  return h->n_buckets;
+}
+
+extern "C" int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream) {
+  if (h == nullptr || bucket < 0 || bucket >= h->n_buckets) {
+    btsbot_set_error("wait_grad_bucket: bad handle or bucket %d", bucket);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (!h->bucket_recorded) {
+    btsbot_set_error("wait_grad_bucket: btsbot_backward() has not run on this handle");
+    return BTSBOT_ERR_STATE;
+  }
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->bucket_ev[bucket], 0));
   return BTSBOT_OK;
 }
 

@@ -212,6 +212,8 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_ln_bwd(k.xs[i - 1], dxn, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
                          grads + h->down[i].ln_b, prow, cin, st));
     }
+    // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete here
+    if (i >= 2 && h->n_buckets == 3) HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], st));
   }
   // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]
   {
@@ -227,6 +229,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
     TRYB(wgrad_cs(prec, k.dyT, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
                   st, k.wpart));
   }
+  if (h->n_buckets == 3) HIP_TRY(hipEventRecord(h->bucket_ev[2], st));
   (void)esz;
   return BTSBOT_OK;
 }

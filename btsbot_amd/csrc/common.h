@@ -66,10 +66,17 @@ template <> __device__ __forceinline__ float gelu_q<5>(float a) {
   t = fmaf(a, t, -1.1507770495088248f);
   return fmaf(a, t, -1.000039487932206f);
 }
+// max(x, 0) as ONE v_max_f32 (fmaxf costs two: hipcc canonicalises the operand first for its NaN rule; here a
+// NaN input gives 0 + NaN * e = NaN from the fma anyway)
+__device__ __forceinline__ float relu_f(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 template <int DEG> __device__ __forceinline__ float gelu_poly(float x) {
   const float a = __builtin_fabsf(x);
   const float e = __builtin_amdgcn_exp2f(gelu_q<DEG>(a));
-  return fmaf(-a, e, fmaxf(x, 0.0f));
+  return fmaf(-a, e, relu_f(x));
 }
 // d/dx of gelu_poly: with E = 2^q(a), D = E (1 + a ln2 q'(a)):  x > 0: 1 - D,  x < 0: D  (x = 0: 1/2 either way
 // up to the fit error).  The 16-bit training forward applies gelu_poly, so its backward differentiates gelu_poly.
@@ -235,7 +242,7 @@ size_t s1par_bytes();
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
                       const float* ln_b, void* out, hipStream_t st);
 size_t s0par_bytes();
-int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
+int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
                       const float* b1, const float* b2, const float* gamma, void* out,
                       hipStream_t st);
 int launch_s2_fc1(int prec, const float* x, const float* dw_w, const float* dw_b, const float* ln_w,

@@ -101,6 +101,12 @@ struct btsbot_ctx {
   const uint8_t* t_meta_mask = nullptr;
   const uint8_t* t_comb_mask = nullptr;
 
+  // gradient buckets in the order btsbot_backward() completes them (btsbot_grad_buckets / btsbot_wait_grad_bucket)
+  int n_buckets = 0;
+  int64_t bucket_lo[3] = {0, 0, 0}, bucket_hi[3] = {0, 0, 0};
+  hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+  bool bucket_recorded = false;
+
   unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1
   bool debug = false;
   float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

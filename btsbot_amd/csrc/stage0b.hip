@@ -32,40 +32,62 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T> struct SBM;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 template <> struct SBM<bf16_t> {
   using frag = bf16x8;
+  using frag4 = s16x4;
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  // 16 independent 4x4x4 products (one per channel): lane = (block, row of A / column of B and D)
+  static __device__ __forceinline__ f32x4 run4(frag4 a, frag4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0);
   }
 };
 template <> struct SBM<f16_t> {
   using frag = f16x8;
+  using frag4 = f16x4;
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 run4(frag4 a, frag4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0);
   }
 };
 
 constexpr int C = 64, HW = 15, P = 225, CT = 2, HID = 256;
-constexpr int PITCH = 2 * C + 16;                 // 144 bytes per map row
-constexpr int MAPB = 256 * PITCH;                 // 36864
+constexpr int PITCH = 2 * C + 16;                 // [pixel][channel] image: 144 bytes per pixel row
+static_assert(256 * PITCH <= C * 800, "the [pixel][channel] image overlays the planar one");
+// planar image for the depthwise phase: [channel][x quad 0..3][row -3..18][4 x] in the operand type.
+// 8-byte entries (4 consecutive x of one row); 22 rows of a quad are contiguous, so the four lanes j of a
+// 4x4x4 MFMA block read 4 consecutive entries; the channel stride (100 entries) is 4 mod 32, which spreads
+// the 8 blocks x 4 rows of a 32-lane half over all 32 eight-byte bank slots: ds_read_b64 without conflicts.
+constexpr int PL_ROWS = 22, PL_XQ = PL_ROWS * 8, PL_CH = 800;
+constexpr int PLB = C * PL_CH;                    // 51200 (the [pixel][channel] image overlays it)
 constexpr int CHUNKB = 8192, NCH = HID / 32, NSLOT = 3;
 constexpr int RINGB = NSLOT * CHUNKB;             // 24576
-// per-block fp32 parameter image (packed once by launch_pack_s0par, fetched by LDS-DMA):
-// [49][64] depthwise taps | dw bias | LN weight | LN bias | fc1 bias [256] | gamma*b2 [64] | pad
-constexpr int PAR_DWB = 49 * C, PAR_LNW = PAR_DWB + C, PAR_LNB = PAR_LNW + C, PAR_B1 = PAR_LNB + C,
-              PAR_B2 = PAR_B1 + HID, PAR_FLOATS = 4096;
-static_assert(PAR_B2 + C <= PAR_FLOATS, "parameter image layout");
-constexpr int PARB = PAR_FLOATS * 4;              // 16384 = 16 LDS-DMA pieces, 4 per wave
-constexpr int OFF_RING = MAPB;
-constexpr int OFF_PAR = OFF_RING + RINGB;
-constexpr int OFF_B1 = OFF_PAR + PARB;            // 256 + 64 floats: this block's fc1 bias, gamma*b2
-constexpr int OFF_RED = OFF_B1 + (HID + C) * 4;   // 4 waves x 32 floats
-constexpr int LDS_BYTES = OFF_RED + 4 * 32 * 4;   // 79616: two workgroups per CU
+// per-block parameter image in HBM (launch_pack_s0par):
+//   Toeplitz taps, operand type: [r = ky * 3 + (rb + 1)][channel][i][k] = W[channel][ky][4 rb + k - i + 3] (0 outside
+//   the 7 taps): the A operand of the 4x4x4 MFMA that maps input columns 4 (xb + rb) + k to outputs 4 xb + i;
+//   then fp32: dw bias [64] | LN weight [64] | LN bias [64] | fc1 bias [256] | gamma * fc2 bias [64]
+constexpr int TW_R = 21, TW_BYTES = TW_R * C * 4 * 4 * 2;   // 43008
+constexpr int PF_DWB = 0, PF_LNW = C, PF_LNB = 2 * C, PF_B1 = 3 * C, PF_B2 = PF_B1 + HID, PF_FLOATS = 512;
+static_assert(PF_B2 + C == PF_FLOATS, "parameter image layout");
+constexpr int PARB = TW_BYTES + PF_FLOATS * 4;    // 45056
+constexpr int OFF_RING = PLB;
+constexpr int OFF_B1 = OFF_RING + RINGB;          // 256 + 64 floats: this block's fc1 bias, gamma*b2
+constexpr int OFF_ST = OFF_B1 + (HID + C) * 4;    // LayerNorm (rstd, -mean * rstd) per padded pixel slot: 2 x 256 floats
+constexpr int LDS_BYTES = OFF_ST + 2 * 256 * 4;   // 79104: two workgroups per CU
+static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
 constexpr float LN_EPS = 1e-6f;
 
 #define SB_STAMP(i)                                                                \
   do {                                                                             \
-    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {             \
+      a.stamps[i] = clock64();                                                     \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* keep the counted waits of the DMA ring exact */ \
+    }                                                                              \
     if (a.wgt != nullptr && threadIdx.x == 0 && ((i) == 0 || (i) == 13))           \
       a.wgt[2 * blockIdx.x + ((i) == 13)] = wall_clock64();                        \
   } while (0)
@@ -86,16 +108,6 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// 16 values per lane -> v[0..3] = 64-lane totals of values (lane>>4)*4 + j
-__device__ __forceinline__ void treduce16(float (&v)[16]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = swap_add32(v[i], v[i + 8]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = swap_add16(v[i], v[i + 4]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = group16_sum(v[i]);
-}
-
 // LayerNorm over the 64 channels of this lane's pixel (x[2][16] here + the partner lane ^ 32)
 __device__ __forceinline__ void ln_regs(const f32x16 (&x)[CT], const float* __restrict__ w,
                                         const float* __restrict__ b, int h, f32x16 (&y)[CT]) {
@@ -132,7 +144,7 @@ __device__ __forceinline__ void ln_regs(const f32x16 (&x)[CT], const float* __re
 
 template <typename T>
 __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char* map, int p, int h) {
-  typedef T __attribute__((ext_vector_type(4))) T4;
+  typedef T T4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -146,6 +158,19 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
     }
 }
 
+// this lane's pixel (32 of its 64 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
+// image; the zero padding around the 15x15 map is never touched
+template <typename T>
+__device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
+  const int y = p / HW, xx = p - y * HW;
+  unsigned char* dst = pl + (xx >> 2) * PL_XQ + (y + 3) * 8 + (xx & 3) * 2 + h * 4 * PL_CH;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = (T)x[ct][r];
+}
+
 __device__ __forceinline__ void regs_to_tap(const f32x16 (&x)[CT], float* tap, int h) {
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -155,17 +180,47 @@ __device__ __forceinline__ void regs_to_tap(const f32x16 (&x)[CT], float* tap, i
           make_float4(x[ct][4 * qd], x[ct][4 * qd + 1], x[ct][4 * qd + 2], x[ct][4 * qd + 3]);
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Transposing sum over the 16 blocks (lane bits 2..5) of 64 values per lane (SQ: of their squares): level by
+// level the lanes of a pair split the values between them, so 32 + 16 + 8 + 4 adds instead of 4 x 64.
+// out[0..3] = the 16-lane totals of values 16 (lane >> 4) + 4 ((lane >> 2) & 3) + 0..3.
+template <bool SQ> __device__ __forceinline__ void block_reduce64(const float (&v)[64], int lane, float (&out)[4]) {
+  float w[32];
+#pragma unroll
+  for (int n = 0; n < 32; ++n)
+    w[n] = SQ ? swap_add32(v[n] * v[n], v[n + 32] * v[n + 32]) : swap_add32(v[n], v[n + 32]);
+#pragma unroll
+  for (int n = 0; n < 16; ++n) w[n] = swap_add16(w[n], w[n + 16]);
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const float own = b3 ? w[n + 8] : w[n], send = b3 ? w[n] : w[n + 8];
+    w[n] = own + dpp_mov<0x128>(send);                       // row_ror:8 = lane ^ 8
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const float own = b2 ? w[n + 4] : w[n], send = b2 ? w[n] : w[n + 4];
+    const float lo = dpp_mov<0x124>(send), hi = dpp_mov<0x12C>(send);   // row_ror:4 / :12 = lane - 4 / lane + 4
+    out[n] = own + (b2 ? lo : hi);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   using frag = typename SBM<T>::frag;
-  typedef T T8 __attribute__((ext_vector_type(8)));
+  using frag4 = typename SBM<T>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* map = smem;
+  unsigned char* map = smem;     // [pixel][channel] image (MLP operand, downsample input)
+  unsigned char* pl = smem;      // planar image (depthwise operand): same bytes, never live together
   unsigned char* ring = smem + OFF_RING;
-  const float* par = reinterpret_cast<const float*>(smem + OFF_PAR);
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
   float* b2s = b1s + HID;
-  float* red = reinterpret_cast<float*>(smem + OFF_RED);
+  float* part = reinterpret_cast<float*>(ring + 2 * CHUNKB);   // LayerNorm partial sums [2][4 waves][256 slots]:
+                                                               // ring slot 2 is idle until the MLP's first chunk
+  float* st = reinterpret_cast<float*>(smem + OFF_ST);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
@@ -177,19 +232,33 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
     pix[t] = wave * 64 + t * 32 + lr;     // this lane's pixel slot of column block t
     live[t] = pix[t] < P;
   }
+  // depthwise roles: lane = (block b = channel 16 wave + b, row offset j)
+  const int dj = lane & 3, dch = wave * 16 + (lane >> 2);
+  const int dyb = lane >> 4, dxb = (lane >> 2) & 3;   // where this lane's LayerNorm sums end up
 
   SB_STAMP(0);
-  // per-block parameter image: 16 pieces, wave w takes w, w+4, w+8, w+12
-  auto issue_params = [&](int j) {
+  // a block's Toeplitz taps (16 channels x 4 rows x 21 fragments per wave, lane-linear 8-byte loads) and its
+  // per-lane scalars: requested one phase ahead of the depthwise convolution that needs them
+  frag4 tw[TW_R];
+  float dwbias, lng, lnb2, b1v, b2v;
+  auto load_block_params = [&](int j) {
+    const Stage0Blk& bk = a.blk[j];
+    const uint2* src = reinterpret_cast<const uint2*>(bk.par) + wave * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.blk[j].par + (wave + 4 * i) * 1024 + lane * 16),
-                                       (lptr_t)(smem + OFF_PAR + (wave + 4 * i) * 1024), 16, 0, 0);
+    for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, src[r * 256]);
+    const float* pf = reinterpret_cast<const float*>(bk.par + TW_BYTES);
+    dwbias = pf[PF_DWB + dch];
+    lng = pf[PF_LNW + dch];
+    lnb2 = pf[PF_LNB + dch];
+    b1v = pf[PF_B1 + tid];
+    b2v = pf[PF_B2 + (tid & 63)];
   };
-  issue_params(0);   // lands under the stem
-  // rows 225..255 of the image are padding: keep them finite
-  for (int i = tid; i < (256 - P) * PITCH / 4; i += 256)
-    reinterpret_cast<unsigned*>(map + P * PITCH)[i] = 0u;
+  load_block_params(0);   // lands under the stem
+  auto zero_planar = [&]() {
+    for (int i = tid; i < PLB / 16; i += 256) reinterpret_cast<uint4*>(pl)[i] = make_uint4(0u, 0u, 0u, 0u);
+  };
+  zero_planar();
+  __syncthreads();
 
   // ============================ stem: conv 4x4 s4 + LN =====================================
   f32x16 x[2][CT];
@@ -231,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         for (int ct = 0; ct < CT; ++ct) x[t][ct] = SBM<T>::run(af[ci][ct], bf, x[t][ct]);
       }
       ln_regs(x[t], a.stem_lnw, a.stem_lnb, h, x[t]);
-      regs_to_map<T>(x[t], map, pix[t], h);
+      if (live[t]) regs_to_planar<T>(x[t], pl, pix[t], h);
       if (a.tap_stem != nullptr && live[t])
         regs_to_tap(x[t], a.tap_stem + ((size_t)alert * P + pix[t]) * C, h);
     }
@@ -239,14 +308,13 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   SB_STAMP(1);   // stem done
 
   // ============================ two ConvNeXt blocks ========================================
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < 2; ++j) {
     const Stage0Blk& bk = a.blk[j];
     SB_STAMP(2 + 5 * j);
-    wait_vm<0>();      // this wave's quarter of the block's parameter image has landed
-    __syncthreads();   // ... everyone's; map complete (stem / previous MLP); ring free
-    b1s[tid] = par[PAR_B1 + tid];                  // the MLP reads these while the NEXT block's
-    if (tid < C) b2s[tid] = par[PAR_B2 + tid];     // image is already arriving
+    __syncthreads();   // planar image complete (stem / previous MLP); ring free; b1s / st idle
+    b1s[tid] = b1v;
+    if (tid < C) b2s[tid] = b2v;
 
     // ---- pointwise filters: chunk = 32 hidden units = 8 pieces of 1 KiB, 2 per wave.
     //      pieces 0..3: W1 rows (LDS row m <- hidden unit 32*ch + swap23(m)), 128-byte rows,
@@ -275,91 +343,98 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
                                          (lptr_t)(ring + (ch % NSLOT) * CHUNKB + (wave * 2 + i) * 1024),
                                          16, 0, 0);
     };
-    issue(0);
-    issue(1);
     SB_STAMP(3 + 5 * j);
-    const float dwbias = par[PAR_DWB + lane], lng = par[PAR_LNW + lane], lnb2 = par[PAR_LNB + lane];
 
-    // ---- depthwise 7x7 + bias + LN: lane = channel, wave = map rows wave, wave+4, ...; the LN
-    //      outputs wait in registers (xnv) until every wave is done reading the image
-    T8 xnv[4][2];
+    // ---- depthwise 7x7 on the matrix pipe: per channel (= MFMA block) and output tile (4 rows yb, 4 columns xb)
+    //      D[i][j] = out[4 yb + j][4 xb + i] = sum over ky, rb, k of  W[ky][4 rb + k - i + 3] * in[4 yb + j + ky - 3][4 (xb + rb) + k]
+    //      A = the Toeplitz taps (registers), B = 4 consecutive x of 4 consecutive rows (one ds_read_b64 per lane);
+    //      a row step s = 4 yb + ky serves every (yb, ky) pair with that sum: 76 reads, 280 MFMAs per wave.
+    float v[64];
     {
-      const T* mi = reinterpret_cast<const T*>(map);
-      float* myred = red + wave * 32;
+      f32x4 acc[4][4];
 #pragma unroll
-      for (int rd = 0; rd < 4; ++rd) {
-        const int y = rd * 4 + wave;
-        const bool valid = y < HW;
-        float acc[16];
+      for (int yb = 0; yb < 4; ++yb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = (i < HW) ? dwbias : 0.f;
-        if (valid) {
+        for (int xb = 0; xb < 4; ++xb) acc[yb][xb] = f32x4{dwbias, dwbias, dwbias, dwbias};
+      const unsigned char* lb = pl + dch * PL_CH + dj * 8;
 #pragma unroll
-          for (int ky = 0; ky < 7; ++ky) {
-            const int iy = y + ky - 3;
-            if (iy < 0 || iy >= HW) continue;
-            const T* row = mi + (iy * HW) * (PITCH / 2) + lane;
-            float in[HW], w[7];
+      for (int s = 0; s < 19; ++s) {
+        frag4 bq[4];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) w[kx] = par[(ky * 7 + kx) * C + lane];
-#pragma unroll
-            for (int xx = 0; xx < HW; ++xx) in[xx] = (float)row[xx * (PITCH / 2)];
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-              for (int xx = 0; xx < HW; ++xx) {
-                const int ix = xx + kx - 3;
-                if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[kx], acc[xx]);
-              }
-          }
+        for (int q = 0; q < 4; ++q)
+          bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + s * 8));
+        if (s == 0) {
+          // the taps are in registers by now: only now queue the filter chunks (a wait for an ordinary load
+          // placed behind an LDS-DMA would wait for the DMA too)
+          __builtin_amdgcn_sched_barrier(0);
+          issue(0);
+          issue(1);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        // LN over the 64 channels (= lanes) of each of the row's 15 pixels: transposing reduction,
-        // totals broadcast through this wave's own LDS words (no workgroup barrier)
-        float s[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = acc[i];
-        treduce16(s);
-        if ((lane & 15) == 0) {
+        for (int yb = 0; yb < 4; ++yb) {
+          const int ky = s - 4 * yb;
+          if (ky < 0 || ky > 6) continue;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) myred[(lane >> 4) * 4 + jj] = s[jj];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local hand-off through LDS
+          for (int rbi = 0; rbi < 3; ++rbi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          acc[i] -= myred[i] * (1.0f / C);
-          s[i] = acc[i] * acc[i];
-        }
-        treduce16(s);
-        if ((lane & 15) == 0) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) myred[16 + (lane >> 4) * 4 + jj] = s[jj];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int xx = 0; xx < 16; ++xx) {
-          const float rstd = rsqrtf(myred[16 + xx] * (1.0f / C) + LN_EPS);
-          xnv[rd][xx >> 3][xx & 7] = (T)(acc[xx] * rstd * lng + lnb2);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one round at a time: registers (see stage1b.hip)
-      }
-    }
-    __syncthreads();   // nobody reads the image (or the taps) any more
-    if (j == 0) issue_params(1);   // lands under this block's MLP
-    {
-      T* mo = reinterpret_cast<T*>(map);
-#pragma unroll
-      for (int rd = 0; rd < 4; ++rd) {
-        const int y = rd * 4 + wave;
-        if (y < HW) {
-          T* dst = mo + (y * HW) * (PITCH / 2) + lane;
-#pragma unroll
-          for (int xx = 0; xx < HW; ++xx) dst[xx * (PITCH / 2)] = xnv[rd][xx >> 3][xx & 7];
+            for (int xb = 0; xb < 4; ++xb) {
+              const int q = xb + rbi - 1;
+              if (q < 0 || q > 3) continue;
+              acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+            }
         }
       }
+#pragma unroll
+      for (int yb = 0; yb < 4; ++yb)
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[yb * 16 + xb * 4 + i] = acc[yb][xb][i];
     }
     SB_STAMP(4 + 5 * j);   // depthwise done
-    __syncthreads();   // LN image complete
+    // ---- LayerNorm over the 64 channels of a pixel: 16 blocks of this wave (transposing lane reduction), then
+    //      the 4 waves through LDS; single-pass variance
+    {
+      float s1[4], s2[4];
+      block_reduce64<false>(v, lane, s1);
+      block_reduce64<true>(v, lane, s2);
+      const int slot = (4 * dyb + dj) * 16 + 4 * dxb;
+      *reinterpret_cast<float4*>(part + wave * 256 + slot) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(part + 1024 + wave * 256 + slot) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+    __syncthreads();   // partial sums complete; nobody reads the planar image any more
+    {
+      const float t1 = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid];
+      const float t2 = part[1024 + tid] + part[1280 + tid] + part[1536 + tid] + part[1792 + tid];
+      const float mean = t1 * (1.0f / C);
+      const float rstd = rsqrtf(fmaxf(t2 * (1.0f / C) - mean * mean, 0.0f) + LN_EPS);
+      st[tid] = rstd;
+      st[256 + tid] = -mean * rstd;
+    }
+    __syncthreads();
+    {
+      T* mo = reinterpret_cast<T*>(map) + dch;
+#pragma unroll
+      for (int yb = 0; yb < 4; ++yb)
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb) {
+          const int slot = (4 * yb + dj) * 16 + 4 * xb;
+          const float4 r4 = *reinterpret_cast<const float4*>(st + slot);
+          const float4 m4 = *reinterpret_cast<const float4*>(st + 256 + slot);
+          const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+          if (yb < 3 || dj < 3) {   // row 15 is padding
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (xb == 3 && i == 3) continue;   // column 15 is padding
+              const float y = fmaf(fmaf(v[yb * 16 + xb * 4 + i], rr[i], mm[i]), lng, lnb2);
+              mo[((4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = (T)y;
+            }
+          }
+        }
+    }
     SB_STAMP(5 + 5 * j);
+    __syncthreads();   // LN image complete
 
     // ---- fc1 -> GELU -> fc2 over 8 chunks; fc2 accumulates into x (gamma is in the filter)
     {
@@ -384,12 +459,13 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         }
 #pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
-        // this wave's pieces of chunk ch have landed once only the younger chunks are outstanding
-        // (VM order of a wave: chunk 0, chunk 1, [block 0: next parameter image, 4], chunk 2, ...)
-        if (ch < 2 && j == 0) wait_vm<6>();
-        else if (ch + 1 < NCH) wait_vm<2>();
+        // this wave's pieces of chunk ch have landed once only the younger chunk is outstanding
+        if (ch + 1 < NCH) wait_vm<2>();
         else wait_vm<0>();
         __syncthreads();   // ... everyone's; chunk ch-1 is read out (and xf is loaded, ch == 0)
+        // the LN image is dead once every wave holds its xf: clear it for the next block's planar image
+        // (whose padding must read as zero) while the matrix pipe works
+        if (ch == 1 && j == 0) zero_planar();
         const unsigned char* w1s = ring + (ch % NSLOT) * CHUNKB;
         const unsigned char* w2s = w1s + 4096;
         frag a1[4], a2[CT][2];
@@ -436,10 +512,12 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
           }
         }
       }
-      // the LN image was last read (xf) before the first chunk barrier: free to overwrite
+      // next block's depthwise operand (the region was cleared during this MLP)
       if (j == 0) {
+        load_block_params(1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) regs_to_map<T>(x[t], map, pix[t], h);
+        for (int t = 0; t < 2; ++t)
+          if (live[t]) regs_to_planar<T>(x[t], pl, pix[t], h);
       }
     }
     SB_STAMP(6 + 5 * j);   // MLP done
@@ -452,17 +530,19 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 
   // ============================ downsample: LN + conv 2x2 s2 (64 -> 128) ====================
   {
+    // wave -> 32 output channels (cot = wave) x the 49 output pixels (2 column blocks); K = 4 x 64
+    // (filter fragments requested first: their L2 latency passes under the LayerNorm below)
+    const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(wave * 32 + lr) * 256 + h * 8;
+    frag af[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const frag*>(dw + ks * 16);
+    // (every wave loaded its xf from the last block's LN image before that MLP's second barrier)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x16 xn[CT];
       ln_regs(x[t], a.ds_lnw, a.ds_lnb, h, xn);
       regs_to_map<T>(xn, map, pix[t], h);
     }
-    // wave -> 32 output channels (cot = wave) x the 49 output pixels (2 column blocks); K = 4 x 64
-    const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(wave * 32 + lr) * 256 + h * 8;
-    frag af[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const frag*>(dw + ks * 16);
     __syncthreads();
     SB_STAMP(12);
 #pragma unroll
@@ -499,21 +579,30 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   }
 }
 
-// one block's fp32 parameter image (see PAR_* above)
+// one block's parameter image (layout at TW_R / PF_* above); taps tap-major [49][64] fp32
+template <typename T>
 __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                   const float* __restrict__ b1, const float* __restrict__ b2,
-                                  const float* __restrict__ gamma, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PAR_FLOATS) return;
-  float v = 0.f;
-  if (i < PAR_DWB) v = taps[i];
-  else if (i < PAR_LNW) v = dw_b[i - PAR_DWB];
-  else if (i < PAR_LNB) v = ln_w[i - PAR_LNW];
-  else if (i < PAR_B1) v = ln_b[i - PAR_LNB];
-  else if (i < PAR_B2) v = b1[i - PAR_B1];
-  else if (i < PAR_B2 + C) v = gamma[i - PAR_B2] * b2[i - PAR_B2];
-  out[i] = v;
+                                  const float* __restrict__ gamma, unsigned char* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NTW = TW_R * C * 16;
+  if (idx < NTW) {
+    const int k = idx & 3, i = (idx >> 2) & 3, c = (idx >> 4) & (C - 1), r = idx >> 10;
+    const int ky = r / 3, rb = r % 3 - 1, kx = 4 * rb + k - i + 3;
+    const float w = (kx >= 0 && kx < 7) ? taps[(ky * 7 + kx) * C + c] : 0.f;
+    reinterpret_cast<T*>(out)[idx] = (T)w;
+    return;
+  }
+  const int f = idx - NTW;
+  if (f >= PF_FLOATS) return;
+  float v;
+  if (f < PF_LNW) v = dw_b[f - PF_DWB];
+  else if (f < PF_LNB) v = ln_w[f - PF_LNW];
+  else if (f < PF_B1) v = ln_b[f - PF_LNB];
+  else if (f < PF_B2) v = b1[f - PF_B1];
+  else v = gamma[f - PF_B2] * b2[f - PF_B2];
+  reinterpret_cast<float*>(out + TW_BYTES)[f] = v;
 }
 
 template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
@@ -534,11 +623,18 @@ template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) 
 size_t s0par_bytes() { return PARB; }
 
 // taps: the block's depthwise filter tap-major [49][64] fp32; the others the master parameters
-int launch_pack_s0par(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
-                      const float* b1, const float* b2, const float* gamma, void* out,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(pack_s0par_kernel, dim3(PAR_FLOATS / 256), dim3(256), 0, st, taps, dw_b, ln_w,
-                     ln_b, b1, b2, gamma, reinterpret_cast<float*>(out));
+int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
+                      const float* b1, const float* b2, const float* gamma, void* out, hipStream_t st) {
+  const dim3 grid((TW_R * C * 16 + PF_FLOATS + 255) / 256), blk(256);
+  unsigned char* o = reinterpret_cast<unsigned char*>(out);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(pack_s0par_kernel<bf16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(pack_s0par_kernel<f16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
+  else {
+    btsbot_set_error("pack_s0par: precision %d is not a 16-bit mode", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

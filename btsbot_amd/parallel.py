@@ -2,12 +2,19 @@
 
 Replaces torch.nn.parallel.DataParallel at /root/reference/btsbot/train.py:238-240: instead of
 re-broadcasting every parameter and scattering inputs from device 0 each step, every rank keeps a
-persistent replica and its own shard of alerts; the only collective is ONE all-reduce of the flat
-gradient arena per step (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
+persistent replica (made equal ONCE, ``broadcast_`` at ``Trainer`` construction) and its own shard of
+alerts; the only collective of a step is the all-reduce (SUM) of the trainable part of the flat gradient
+arena -- RCCL over xGMI when the backend is "nccl", gloo in the CPU tests.  The arena is exchanged in a few
+buckets in the order ``btsbot_backward`` finishes them (fusion head / metadata branch / last image stage
+first, stem last), each on a side stream as soon as the library signals it, so the collectives run under
+the rest of the backward pass.
+
+Everything here is host logic over plain tensors (no HIP call): the CPU tests drive the same code with
+gloo at world sizes 2 and 3.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -21,11 +28,93 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _world(group=None) -> int:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def trainable_ranges(slots: Iterable[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """Merged arena ranges [lo, hi) of the tensors that are trained.  `slots` = (offset, numel) of every
+    tensor with requires_grad; tensors are 4-float aligned in the arena (the padding carries zero gradient),
+    so neighbours merge; frozen tensors and BatchNorm buffers leave gaps."""
+    out: List[List[int]] = []
+    for lo, n in sorted(slots):
+        hi = (lo + n + 3) // 4 * 4
+        if out and lo <= out[-1][1]:
+            out[-1][1] = max(hi, out[-1][1])
+        else:
+            out.append([lo, hi])
+    return [(a, b) for a, b in out]
+
+
+def plan_exchange(ranges: Sequence[Tuple[int, int]],
+                  buckets: Optional[Sequence[Tuple[int, int]]] = None) -> List[Tuple[int, int, int]]:
+    """One (bucket index, lo, hi) per collective: the trainable span inside each bucket, in the buckets'
+    (readiness) order.  A bucket's span runs from its first to its last trainable float -- the frozen gaps
+    inside it (zero gradient) ride along rather than splitting the collective; a bucket with nothing
+    trainable is skipped.  Without buckets: one span over everything trainable."""
+    if not ranges:
+        return []
+    if not buckets:
+        buckets = [(ranges[0][0], ranges[-1][1])]
+    plan = []
+    for bi, (blo, bhi) in enumerate(buckets):
+        inside = [(max(lo, blo), min(hi, bhi)) for lo, hi in ranges if lo < bhi and hi > blo]
+        if inside:
+            plan.append((bi, inside[0][0], inside[-1][1]))
+    return plan
+
+
+class GradExchange:
+    """The exchange step of one training iteration over a flat gradient arena.
+
+    ``exchange(grads, wait_bucket)`` issues one all-reduce per planned span.  On a HIP device the collectives
+    go to a side stream: ``wait_bucket(bucket, stream)`` (``btsbot_wait_grad_bucket``) makes that stream wait
+    for the bucket's gradients, and the caller's stream waits for every collective before it returns to the
+    optimiser.  On CPU tensors (gloo) the calls are synchronous and ``wait_bucket`` is not used.
+    """
+
+    def __init__(self, ranges: Sequence[Tuple[int, int]],
+                 buckets: Optional[Sequence[Tuple[int, int]]] = None, group=None):
+        self.group = group
+        self.plan = plan_exchange(ranges, buckets)
+        self._side = None
+
+    def exchange(self, grads: torch.Tensor,
+                 wait_bucket: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
+        if _world(self.group) <= 1 or not self.plan:
+            return grads
+        import torch.distributed as dist
+        if grads.device.type != "cuda":
+            for _b, lo, hi in self.plan:
+                dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            return grads
+        dev = grads.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        works = []
+        with torch.cuda.stream(self._side):
+            for b, lo, hi in self.plan:
+                if wait_bucket is not None:
+                    wait_bucket(b, self._side.cuda_stream)     # the side stream waits for the bucket's kernels
+                else:
+                    self._side.wait_stream(main)
+                works.append(dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+        for w in works:
+            w.wait()                                            # the caller's stream waits for the collective
+        main.wait_stream(self._side)
+        return grads
+
+
 def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """Sum `flat` over ranks in place.  The local gradients are already scaled by 1/B_global
     (btsbot_bce_fwd_bwd's n_global), so the SUM is the gradient of the global-batch mean loss."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _world(group) > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
@@ -34,6 +123,6 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     """Make every replica start from rank `src`'s parameters (what DataParallel's per-step
     broadcast guaranteed implicitly)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _world(group) > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat

@@ -52,7 +52,7 @@ def lr_schedule(lr: float, epochs: int, warmup_epochs: int) -> Sequence[float]:
 class Trainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, pos_weight: float = 1.0, epochs: int = 1,
-                 warmup_epochs: int = 0, group=None):
+                 warmup_epochs: int = 0, group=None, dropout_seed: int = 0):
         self.model = model
         self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pos_weight = float(pos_weight)
@@ -64,17 +64,21 @@ class Trainer:
         self.need_image = any(t.requires_grad for t, *_ in image)
         self.need_meta = any(t.requires_grad for t, *_ in meta)
         # contiguous arena ranges of the trainable tensors (padding between tensors has zero grad)
-        slots = sorted((off, off + numel) for t, off, numel, _s in image + meta + comb
-                       if t.requires_grad)
-        self.ranges = []
-        for lo, hi in slots:
-            hi = (hi + 3) // 4 * 4
-            if self.ranges and lo <= self.ranges[-1][1]:
-                self.ranges[-1][1] = max(hi, self.ranges[-1][1])
-            else:
-                self.ranges.append([lo, hi])
+        self.ranges = parallel.trainable_ranges(
+            (off, numel) for t, off, numel, _s in image + meta + comb if t.requires_grad)
+        # the exchange step: one all-reduce per gradient bucket, in the order btsbot_backward() finishes them
+        self.exchange = parallel.GradExchange(self.ranges, model._grad_buckets(), group)
         self.exp_avg = None
         self.exp_avg_sq = None
+        import torch.distributed as dist
+        self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        self.dropout_seed = int(dropout_seed)
+        self._rng = None
+        # replicas start from rank 0's parameters and buffers (what DataParallel's per-step broadcast did
+        # implicitly at train.py:238-240); from here on identical gradients keep them identical
+        if parallel._world(group) > 1:
+            parallel.broadcast_(model._arena, 0, group)
+            model.mark_weights_dirty()
 
     @property
     def lr(self) -> float:
@@ -92,11 +96,19 @@ class Trainer:
         if not m.training:
             raise RuntimeError("Trainer.step: put the model in train mode first (model.train())")
         images, meta, batch, dev = m._check_inputs(images, meta)
-        import torch.distributed as dist
-        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if labels.numel() != batch:
+            raise ValueError(f"Trainer.step: {labels.numel()} labels for a batch of {batch} alerts")
+        if batch < 2 and m._cfg_args["n_meta"] > 0:
+            # nn.BatchNorm1d in train mode: "Expected more than 1 value per channel when training"
+            raise ValueError("Trainer.step: BatchNorm1d batch statistics need more than one alert per rank")
+        world = parallel._world(self.group)
         n_global = int(global_batch) if global_batch is not None else batch * world
+        if self._rng is None or self._rng.device != dev:
+            # every rank draws its own dropout masks (seed + rank)
+            self._rng = torch.Generator(device=dev)
+            self._rng.manual_seed(self.dropout_seed + 7919 * self.rank)
         with torch.no_grad():
-            masks = m._dropout_masks(batch, dev)
+            masks = m._dropout_masks(batch, dev, self._rng if world > 1 else None)
             logits = m._forward_train_raw(images, meta, masks, self.need_image).reshape(-1)
             y = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
             loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -113,9 +125,8 @@ class Trainer:
                 self.exp_avg = torch.zeros_like(m._arena)
                 self.exp_avg_sq = torch.zeros_like(m._arena)
             if world > 1:
-                # one exchange per step: the trainable slice of the flat gradient arena
-                lo, hi = self.ranges[0][0], self.ranges[-1][1]
-                parallel.allreduce_mean_(grads[lo:hi], self.group)
+                # the one exchange of the step (local gradients are already scaled by 1 / n_global)
+                self.exchange.exchange(grads, m._wait_grad_bucket)
             self.t += 1
             with torch.cuda.device(dev):
                 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

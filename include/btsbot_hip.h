@@ -170,6 +170,18 @@ int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const floa
 int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, int need_meta_grads,
                     int need_image_grads, void* stream);
 
+/* Replaces the gradient reduction of torch.nn.DataParallel (train.py:238-240; SURVEY.md section 8b's
+ * btsbot_allreduce_grads) -- split in two, because the communicator belongs to the host's process group
+ * (torch.distributed over RCCL), not to this library: the library says WHICH parts of the gradient arena
+ * btsbot_backward() finishes WHEN, the host issues one all-reduce per part on a side stream.
+ * btsbot_grad_buckets: up to `capacity` arena ranges [lo[i], hi[i]) (floats) in the order btsbot_backward()
+ * completes them -- ConvNeXt wirings: {last image stage + head LayerNorm + metadata branch + fusion head},
+ * {stage 2}, {stem + stages 0-1}; every other wiring: one range over the whole arena.  Returns the count.
+ * btsbot_wait_grad_bucket: makes `stream` wait (hipStreamWaitEvent) until the kernels of the LAST
+ * btsbot_backward() call that write bucket `bucket` have finished; no host synchronisation. */
+int btsbot_grad_buckets(btsbot_handle h, int capacity, int64_t* lo, int64_t* hi);
+int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
+
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and
  * stage outputs (call before btsbot_reserve()). */
 int btsbot_set_debug(btsbot_handle h, int on);

@@ -217,6 +217,12 @@ def test_maxvit_train_mode_gate_is_host_logic():
     # four down-sampling shortcuts?  -- count them from the state dict instead of by recall:
     n_bn = sum(1 for k in m.state_dict() if k.startswith("maxvit_backbone.") and k.endswith("running_mean"))
     assert len(bn) == n_bn and n_bn > 30
+    # model.train() leaves the inference-only branch's BatchNorm2d holders in eval mode (a validation pass
+    # followed by model.train() must not switch batch statistics on: train.py:332-340) ...
+    assert m.training and not any(b.training for b in bn)
+    m._check_train_supported(False)
+    # ... asking for batch statistics explicitly is refused
+    m.maxvit_backbone.train()
     assert all(b.training for b in bn)
     with pytest.raises(NotImplementedError, match="BatchNorm2d"):
         m._check_train_supported(False)

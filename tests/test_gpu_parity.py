@@ -267,7 +267,8 @@ def test_maxvit_chunking_independence_and_modes(cuda):
     perm = torch.randperm(10, generator=torch.Generator().manual_seed(0)).to(cuda)
     assert torch.equal(run_model(kind, m, img[perm].contiguous(), meta[perm].contiguous()), full[perm])
     assert run_model(kind, m, img[:0], meta[:0]).shape == (0, 1)
-    m.train()                                       # BatchNorm2d batch statistics of the branch: not built
+    m.train()
+    m.maxvit_backbone.train()                       # BatchNorm2d batch statistics of the branch: not built
     with pytest.raises(NotImplementedError):
         m(image_input=img, metadata_input=meta)
     m.maxvit_backbone.eval()                        # eval-mode branch, but its parameters still want gradients
