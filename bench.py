@@ -130,10 +130,10 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     down_flop = lambda i: 2 * batch * STAGE_P[i] * 4 * dims[i - 1] * dims[i]
     # MFMA-executed algorithmic FLOP only (stem, 2 x (fc1 + fc2), downsample); the depthwise conv
     # (2 x 2*49*225*64 FLOP per alert, VALU) is not counted against the MFMA roofline
-    w["stage0_kernel"] = dict(
+    w["stage0b_kernel"] = dict(
         flop=(stem_flop + 2 * pw(*st[0]) + down_flop(1)) if s0 else 0,
         bytes=batch * (3 * 63 * 63 * 4 + 49 * dims[1] * 4))
-    w["stage1_kernel"] = dict(
+    w["stage1b_kernel"] = dict(
         flop=(2 * pw(*st[1]) + down_flop(2)) if s1 else 0,
         bytes=batch * (49 * dims[1] * 4 + 9 * dims[2] * 4))
     w["fused_mlp_kernel"] = dict(
@@ -143,6 +143,14 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     unf = [not f and not mega[i] for i, f in enumerate(fused)]
     # stage 2 at C = 256: depthwise + LN + fc1 + GELU per block (stage2.hip) and fc2 as a GEMM
     s2 = precision != "f32" and dims[2] == 256
+    # ... or, by default, the whole stage and the last downsample in one persistent launch (stage2p.hip)
+    s2p = s2 and dims[3] == 512 and depths[2] <= 8 and os.environ.get("BTSBOT_AMD_NO_S2P", "0") != "1" and \
+        os.environ.get("BTSBOT_AMD_NO_STAGE2", "0") != "1"
+    w["stage2p_kernel"] = dict(
+        flop=(2 * pw(*st[2]) + down_flop(3)) if s2p else 0,
+        bytes=batch * (9 * dims[2] * 4 + dims[3] * 4) + depths[2] * 8 * dims[2] ** 2 * esz + 4 * dims[2] * dims[3] * esz)
+    mega[2] = s2p
+    s2 = s2 and not s2p
     w["s2_fc1_kernel"] = dict(
         flop=pw(*st[2]) if s2 else 0,
         bytes=st[2][0] * (batch * 9 * dims[2] * 4 + batch * 9 * 4 * dims[2] * esz + 4 * dims[2] ** 2 * esz))
@@ -173,7 +181,7 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     return w
 
 
-POINTWISE = ("stage0_kernel", "stage1_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
+POINTWISE = ("stage0b_kernel", "stage1b_kernel", "stage2p_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
              "gemm_kernel<fc2,RESID>")
 
 

@@ -11,6 +11,7 @@
 #include "ctx.h"
 #include "maxvit.h"
 #include "stage0.h"
+#include "stage2p.h"
 
 // ---------------------------------------------------------------------------------------
 // errors
@@ -71,6 +72,7 @@ int build_tables(btsbot_ctx* h) {
     h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
     h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
     h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
+    h->stage2p = stage2p_supported(c.precision, c.dims[2], c.dims[3], c.depths[2]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
@@ -84,6 +86,7 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
         h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
+        if (i == 3 && h->stage2p) h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
       }
       for (int j = 0; j < c.depths[i]; ++j) {
         snprintf(buf, sizeof buf, "stages.%d.blocks.%d.", i, j);
@@ -104,6 +107,10 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
                     : (i == 1 && ch == 128 && c.precision != BTSBOT_F32) ? bump(cur, s1par_bytes()) : 0;
+        if (i == 2 && h->stage2p) {
+          b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
+          b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
+        }
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
         b.fused = fused_mlp_supported(c.precision, ch);
@@ -272,6 +279,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
   const char* n2 = getenv("BTSBOT_AMD_NO_STAGE2");
   h->use_s2 = !(n2 != nullptr && n2[0] == '1');
+  const char* n2p = getenv("BTSBOT_AMD_NO_S2P");
+  h->use_s2p = h->use_s2 && !(n2p != nullptr && n2p[0] == '1');
   *out = h;
   return BTSBOT_OK;
 }
@@ -427,6 +436,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (!train_only)
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
+        if (i == 2 && h->stage2p && !train_only) {
+          TRY(launch_pack_s2p(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, st));
+          TRY(launch_pack_s2p(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, st));
+        }
         if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
@@ -440,6 +453,9 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       }
     }
   }
+  if (convnext && h->stage2p && !train_only)
+    TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
+                        c.dims[2], st));
   if (h->has_meta) {
     TRY(launch_bn_fold(m + h->bn_w, m + h->bn_b, m + h->bn_rm, m + h->bn_rv,
                        reinterpret_cast<float*>(h->extra + h->p_bn_scale),
@@ -669,6 +685,43 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         TRY(timed(h, CAT_STAGE1, st, [&] {
           return launch_stage1b(c.precision, a, st);
         }));
+        float* t = x;
+        x = x2;
+        x2 = t;
+        down_done = true;
+        continue;
+      }
+      if (i == 2 && h->stage2p && h->use_s2p) {
+        // every block of the 3x3 stage and the last downsample in one launch: x [nb][9][256] -> x2 [nb][512]
+        Stage2pArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x_in = x;
+        a.depth = (int)h->blocks[2].size();
+        for (int j = 0; j < a.depth; ++j) {
+          const BlockPk& b = h->blocks[2][j];
+          a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+          a.blk[j].dw_b = m + b.dw_b;
+          a.blk[j].ln_w = m + b.ln_w;
+          a.blk[j].ln_b = m + b.ln_b;
+          a.blk[j].b1 = m + b.fc1_b;
+          a.blk[j].b2 = m + b.fc2_b;
+          a.blk[j].gamma = m + b.gamma;
+          a.blk[j].w1p = h->extra + b.p_w1p;
+          a.blk[j].w2p = h->extra + b.p_w2p;
+        }
+        a.ds_lnw = m + h->down[3].ln_w;
+        a.ds_lnb = m + h->down[3].ln_b;
+        a.ds_wp = h->extra + h->down[3].p_wp;
+        a.ds_b = m + h->down[3].b;
+        a.out = x2;
+        a.tap_stage = h->debug ? h->taps[3] : nullptr;
+        a.B = nb;
+        {
+          const char* dg = getenv("BTSBOT_AMD_S2P_DIAG");
+          a.diag = dg != nullptr ? atoi(dg) : 0;
+        }
+        a.stamps = h->stamps ? h->stamps + 32 + 16384 : nullptr;
+        TRY(timed(h, CAT_STAGE2, st, [&] { return launch_stage2p(c.precision, a, st); }));
         float* t = x;
         x = x2;
         x2 = t;

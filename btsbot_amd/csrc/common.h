@@ -66,12 +66,13 @@ template <> __device__ __forceinline__ float gelu_q<5>(float a) {
   t = fmaf(a, t, -1.1507770495088248f);
   return fmaf(a, t, -1.000039487932206f);
 }
-// max(x, 0) as ONE v_max_f32 (fmaxf costs two: hipcc canonicalises the operand first for its NaN rule; here a
-// NaN input gives 0 + NaN * e = NaN from the fma anyway)
+// max(x, 0) as ONE instruction: v_max_i32 on the bits (a positive float is a positive integer, anything with the
+// sign bit set is negative).  fmaxf costs two (hipcc canonicalises the operand first for its NaN rule), and an
+// inline-asm v_max_f32 is invisible to the compiler's hazard recogniser: scheduled right behind the MFMA that
+// produces x it read the register before the matrix pipe had written it (stage2p.hip, first cut).
 __device__ __forceinline__ float relu_f(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
 }
 template <int DEG> __device__ __forceinline__ float gelu_poly(float x) {
   const float a = __builtin_fabsf(x);
@@ -238,6 +239,14 @@ struct Stage0Args;
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st);   // stage0b.hip
 struct Stage1Args;
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.hip
+// persistent stage 2 (+ stages[3].downsample) for C = 256 -> 512, 16-bit modes (stage2p.hip)
+struct Stage2pArgs;
+bool stage2p_supported(int prec, int c2, int c3, int depth);
+int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
+// fp32 [rows][K] (reorder_down: a [Cout][Cin][2][2] downsample filter, K = 4 Cin) -> 16x16x32 A fragments
+// [row tile][k-step][lane][8], optionally scaled per row
+int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
+                    int cin, hipStream_t st);
 size_t s1par_bytes();
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
                       const float* ln_b, void* out, hipStream_t st);

@@ -18,12 +18,14 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   size_t p_dw, p_fc1, p_fc2, p_fused;
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
+  size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip: fc1 / gamma * fc2 filters as MFMA A fragments
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
 };
 struct DownPk {
   int64_t ln_w, ln_b, w, b;
   size_t p_w, p_wt;        // p_wt: [4*Cin][Cout] transpose of the packed filter (dgrad)
+  size_t p_wp = 0;         // stage2p.hip: the filter as MFMA A fragments
 };
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
@@ -33,8 +35,8 @@ enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD
        CAT_MV_G_FC2, CAT_MV_FUSED, CAT_MV_FRONT, CAT_MV_ABLK, CAT_MV_ELT, CAT_MV_DW, CAT_MV_SE, CAT_MV_LN, CAT_MV_ATTN, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
-                                     "head_kernel", "fused_mlp_kernel", "stage0_kernel", "stage1_kernel",
-                                     "s2_fc1_kernel", "stage2_kernel",
+                                     "head_kernel", "fused_mlp_kernel", "stage0b_kernel", "stage1b_kernel",
+                                     "s2_fc1_kernel", "stage2p_kernel",
                                      "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
                                      "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
                                      "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
@@ -84,6 +86,8 @@ struct btsbot_ctx {
   size_t prof_used = 0;
 
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
+  bool use_s2p = true;     // BTSBOT_AMD_NO_S2P=1: per-block launches (stage2.hip + fc2 GEMM) instead of stage2p.hip
+  bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
   bool stage1 = false;     // stage 1 + second downsample as one kernel
   bool use_stage0 = true;

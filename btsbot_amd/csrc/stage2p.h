@@ -1,0 +1,31 @@
+// Argument block of the persistent stage-2 kernel (stage2p.hip).
+#pragma once
+
+constexpr int S2P_ALERTS = 4;      // alerts resident per workgroup
+constexpr int S2P_MAX_DEPTH = 8;   // blocks of the stage (pico: 6, nano would be 8 at another width)
+
+struct Stage2pBlk {
+  const float* dw_w;     // [49][256] tap-major fp32
+  const float* dw_b;
+  const float* ln_w;
+  const float* ln_b;
+  const float* b1;       // [1024]
+  const float* b2;       // [256]
+  const float* gamma;    // [256]
+  const void* w1p;       // fc1 filter as MFMA A fragments: [hidden tile 64][k-step 8][lane 64][8]
+  const void* w2p;       // gamma * fc2 filter as A fragments: [channel tile 16][k-step 32][lane 64][8]
+};
+struct Stage2pArgs {
+  const float* x_in;     // [B][9][256] f32 (stage-1 output after its downsample)
+  Stage2pBlk blk[S2P_MAX_DEPTH];
+  int depth;
+  const float* ds_lnw;   // stages[3].downsample: LayerNorm2d(256) + Conv2d(256, 512, 2, 2)
+  const float* ds_lnb;
+  const void* ds_wp;     // A fragments: [output tile 32][k-step 32][lane 64][8], k = (2 ky + kx) * 256 + c
+  const float* ds_b;
+  float* out;            // [B][512] f32
+  float* tap_stage;      // optional [B][9][256] f32 copy of the stage output (validation)
+  int B;
+  unsigned long long* stamps;   // optional: workgroup 0 / thread 0 stores the shader clock per phase (64 entries)
+  int diag;              // developer switches (BTSBOT_AMD_S2P_DIAG): 1 barrier at every chunk start, 2 drain loads there
+};

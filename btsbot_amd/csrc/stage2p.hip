@@ -1,0 +1,408 @@
+// Stage 2 (3x3 maps, C = 256) as ONE persistent launch (gfx950, 16-bit modes):
+//
+//   depth x [ dwconv 7x7 + LN -> fc1 -> GELU -> fc2 -> layer-scale -> +x ]  ->  LN + conv 2x2 s2 (256 -> 512)
+//
+// (timm ConvNeXt stages[2].blocks / stages[3].downsample, reached from
+// /root/reference/btsbot/architectures.py:108,132).  HBM sees [9][256] f32 in and [512] f32 out per alert;
+// the residual stream, the LayerNorm outputs and the 1024-wide hidden activations never leave the CU.
+//
+// Why this shape.  At the benchmark's 1024 alerts stage 2 has 9216 pixel rows against 1 MB of filters per
+// block: too few rows to amortise the filters inside one workgroup, too many launches (12 + 2) to keep them
+// short.  What this chip does well is let EVERY CU stream the SAME bytes out of L2: 125 GB/s per CU, 32 TB/s
+// chip-wide, straight into registers (tools/unit/l2stream.hip).  So: one 512-thread workgroup per CU keeps
+// G = 4 alerts (36 pixel rows, padded to 48 = three 16-column MFMA blocks) resident for the whole stage and
+// streams all 6 x 1 MB of filters past them, 8.4 us per block at the measured rate, which is also about
+// what the 48-column products cost on the matrix pipe (6 us): the two overlap.
+//
+//   * filters are packed per MFMA fragment (launch_pack_s2p): a wave's A operand for one k-step is ONE
+//     contiguous 1 KiB global_load_dwordx4, no LDS staging, no barrier between load and use.  fc1 chunk of
+//     128 hidden units: wave w takes hidden tile 8 ch + w (8 k-steps); fc2: wave w owns output channels
+//     32 w .. 32 w + 31 (2 tiles x 4 k-steps of the chunk).  Two register sets: a chunk's fragments are requested
+//     one whole chunk ahead.
+//   * the residual stream IS the fc2 accumulator: 32 channels x 48 pixels per wave in the 16x16 C/D layout
+//     (24 registers), layer scale folded into the packed fc2 filter, gamma * b2 added once per block;
+//   * fc1's B operand is the LayerNorm output ([pixel][channel] in LDS, re-read per chunk: the registers it would
+//     take are the second fragment set); its result goes through GELU into a double-buffered [pixel][hidden]
+//     LDS image that is fc2's B operand: one barrier per chunk;
+//   * depthwise + LayerNorm: the map goes to LDS in fp32, thread = (channel, alert pair) applies the central
+//     5 x 5 taps (all a 3 x 3 map can touch) in place, wave = pixel normalises (two wave reductions);
+//   * the downsample's 4 MB-per-launch GEMM (M = alerts) runs here as 16-column products with 4 live columns:
+//     wasteful on the matrix pipe, free in time -- it is the 1 MB filter stream that bounds it.
+#include <type_traits>
+
+#include "common.h"
+#include "stage2p.h"
+
+namespace {
+
+template <typename T> struct MP;
+template <> struct MP<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MP<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int C = 256, HID = 1024, G = S2P_ALERTS, NPX = 9 * G, NCOL = 48, NB = NCOL / 16;   // 36 live of 48 columns
+constexpr int NT = 512, NW = NT / 64;                 // 8 waves: 2 per SIMD
+constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;      // hidden units per fc1 / fc2 step
+constexpr int KS1 = C / 32;                           // 8 k-steps of fc1
+constexpr int KS2 = CHUNK / 32;                       // 4 k-steps of fc2 per chunk
+constexpr int CO = 512, KD = 4 * C, KSD = KD / 32;    // downsample: 512 outputs, K = 1024
+constexpr int XLP = C;                                // fp32 map: floats per pixel row
+constexpr int XNP = C * 2 + 16;                       // 16-bit LN image: bytes per pixel row (528)
+constexpr int HP = CHUNK * 2 + 16;                    // hidden image: bytes per pixel row (272)
+constexpr int OFF_XL = 0;                             // [48][256] f32 (rows >= 36 stay zero)
+constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;       // 49152
+constexpr int OFF_H = OFF_XN + NCOL * XNP;            // + 25344
+constexpr int OFF_B1 = OFF_H + 2 * NCOL * HP;         // + 26112: fc1 bias [1024] f32
+constexpr int LDS_BYTES = OFF_B1 + HID * 4;           // 104704
+constexpr float LN_EPS = 1e-6f;
+#define S2P_STAMP(i)                                                                      \
+  do {                                                                                    \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+  } while (0)
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
+  using frag = typename MP<T>::frag;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xl = reinterpret_cast<float*>(smem + OFF_XL);
+  unsigned char* xn = smem + OFF_XN;
+  unsigned char* hb = smem + OFF_H;
+  float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kg = lane >> 4;
+  const int alert0 = blockIdx.x * G;
+  const int nlive = min(G, a.B - alert0) * 9;        // live pixel rows of this workgroup
+
+  S2P_STAMP(0);
+  // pad rows of the operand images: zero once (they are never written again)
+  for (int i = tid; i < (NCOL - NPX) * XNP / 4; i += NT) reinterpret_cast<unsigned*>(xn + NPX * XNP)[i] = 0u;
+  for (int i = tid; i < NCOL * XLP; i += NT) xl[i] = 0.f;
+
+  // ---- residual stream: this wave's 32 channels x 48 pixels, acc[m][n][r] = x[16 n + col][32 wave + 16 m + 4 kg + r]
+  f32x4 acc[2][NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int p = 16 * n + col;
+      acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p < nlive)
+        acc[m][n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + 32 * wave + 16 * m + 4 * kg);
+    }
+  __syncthreads();   // zero fill done before the first map is written
+
+  // this wave's fragment streams: fc1 tile (8 ch + wave) of a chunk: 8 KiB contiguous; fc2 tiles 2 wave, 2 wave + 1:
+  // 2 x 4 KiB.  Two register sets: a chunk's fragments are requested one whole chunk ahead (the loads of all 256
+  // CUs hit the same L2 lines at about the same time: ~1.1k cycles of transfer per 64 KB burst per CU on top of
+  // the L2 latency -- a half-chunk of lookahead measured 20 us per block, the transfer time of the filters is 8.4).
+  frag a1[2][KS1], a2[2][2][KS2];
+  auto load_chunk = [&](auto P, const Stage2pBlk& bk, int ch) {
+    constexpr int p = decltype(P)::value;
+    const frag* src1 = reinterpret_cast<const frag*>(bk.w1p) + ((size_t)(ch * NW + wave) * KS1) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) a1[p][s] = src1[s * 64];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const frag* src2 = reinterpret_cast<const frag*>(bk.w2p) +
+                         ((size_t)(2 * wave + m) * (HID / 32) + ch * KS2) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) a2[p][m][s] = src2[s * 64];
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  if (a.depth > 0) load_chunk(P0{}, a.blk[0], 0);
+
+#pragma unroll 1
+  for (int j = 0; j < a.depth; ++j) {
+    const Stage2pBlk& bk = a.blk[j];
+    S2P_STAMP(1 + 8 * j);
+    // ---- residual + gamma * b2 (the bias of the folded fc2), and the map to LDS in fp32
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int c0 = 32 * wave + 16 * m + 4 * kg;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(bk.gamma + c0);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk.b2 + c0);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int p = 16 * n + col;
+        if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
+        acc[m][n] += g4 * b4;
+      }
+    }
+    b1s[tid] = bk.b1[tid];
+    b1s[tid + NT] = bk.b1[tid + NT];
+    __syncthreads();
+    S2P_STAMP(2 + 8 * j);
+    // ---- depthwise 7x7 on the 3x3 maps, in place: thread = (channel, alert pair)
+    {
+      const int c = tid & (C - 1), half = tid >> 8;
+      float w[25];
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + c];
+      const float bias = bk.dw_b[c];
+#pragma unroll
+      for (int g = 0; g < G / 2; ++g) {
+        float* px = xl + (size_t)((half * (G / 2) + g) * 9) * XLP + c;
+        float in[9], o[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) in[i] = px[i * XLP];
+#pragma unroll
+        for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+          for (int ox = 0; ox < 3; ++ox) {
+            float s = bias;
+#pragma unroll
+            for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+              for (int ix = 0; ix < 3; ++ix) s = fmaf(w[(iy - oy + 2) * 5 + (ix - ox + 2)], in[iy * 3 + ix], s);
+            o[oy * 3 + ox] = s;
+          }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) px[i * XLP] = o[i];
+      }
+    }
+    __syncthreads();
+    S2P_STAMP(3 + 8 * j);
+    // ---- LayerNorm over the 256 channels of a pixel: wave = pixel, lane = 4 channels
+    {
+      const f32x4 lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 4 * lane);
+      const f32x4 lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 4 * lane);
+      for (int p = wave; p < NPX; p += NW) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * lane);
+        const float mean = wave_sum(d[0] + d[1] + d[2] + d[3]) * (1.0f / C);
+        const f32x4 e = d - mean;
+        const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]) * (1.0f / C);
+        const float rstd = rsqrtf(var + LN_EPS);
+        T4 y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = (T)(e[i] * rstd * lw[i] + lb[i]);
+        *reinterpret_cast<T4*>(xn + p * XNP + 8 * lane) = y;
+      }
+    }
+    __syncthreads();
+    S2P_STAMP(4 + 8 * j);
+
+    // one chunk of 128 hidden units; P = register set that holds its fragments.  The next chunk's 16 fragment
+    // loads are spread over this chunk's k-steps: issued in one burst they hold every wave at the CU's one
+    // vector-memory port for ~2k cycles before its first product (measured: 4.6k cycles per chunk, MFMA work 1.5k).
+    auto chunk = [&](auto P, int ch) {
+      constexpr int p = decltype(P)::value;
+      // (after the stage's last chunk the loads below re-read this block's first chunk: an unconditional load
+      //  keeps the k-step loops free of branches -- hipcc waits vmcnt(0) behind every conditional load)
+      const Stage2pBlk& nb = ch + 1 < NCHUNK ? bk : a.blk[j + 1 < a.depth ? j + 1 : j];
+      const int nch = ch + 1 < NCHUNK ? ch + 1 : 0;
+      const frag* src1 = reinterpret_cast<const frag*>(nb.w1p) + ((size_t)(nch * NW + wave) * KS1) * 64 + lane;
+      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + nch * KS2) * 64 + lane;
+#ifdef S2P_DIAG
+      if (a.diag & 1) __syncthreads();
+      if (a.diag & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]
+      f32x4 hacc[NB];
+      {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + ch * CHUNK + 16 * wave + 4 * kg);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) hacc[n] = bv;
+      }
+      frag xb[2][NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) xb[0][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (8 * kg) * 2);
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        if (s + 1 < KS1) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            xb[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * 2);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[p][s], xb[s & 1][n], hacc[n]);
+        a1[1 - p][s] = src1[s * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // GELU -> hidden image [pixel][hidden of this chunk]; rows (hidden) 4 kg .. + 3 of tile `wave`
+      unsigned char* hcur = hb + p * (NCOL * HP);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        T4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (T)gelu_for<T>(hacc[n][r]);
+        *reinterpret_cast<T4*>(hcur + (16 * n + col) * HP + (16 * wave + 4 * kg) * 2) = hv;
+      }
+      __syncthreads();   // hidden image complete (the other buffer was last read a barrier ago)
+      // fc2: out channels 32 wave .. + 31, K = this chunk's 128 hidden units; accumulates into the residual
+      frag hbf[2][NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hcur + (16 * n + col) * HP + (8 * kg) * 2);
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        if (s + 1 < KS2) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hcur + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[p][m][s], hbf[s & 1][n], acc[m][n]);
+        a2[1 - p][0][s] = src2[s * 64];
+        a2[1 - p][1][s] = src2[((size_t)(HID / 32) + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll 1
+    for (int ch = 0; ch < NCHUNK; ch += 2) {
+      chunk(P0{}, ch);
+      chunk(P1{}, ch + 1);
+      if (ch == 0) S2P_STAMP(5 + 8 * j);
+      if (ch == 2) S2P_STAMP(6 + 8 * j);
+    }
+    S2P_STAMP(7 + 8 * j);
+  }
+
+  S2P_STAMP(56);
+  // ---- stage output (validation copy), then the downsample: LN per pixel + conv 2x2 s2 on pixels 0, 1, 3, 4
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c0 = 32 * wave + 16 * m + 4 * kg;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int p = 16 * n + col;
+      if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
+      if (a.tap_stage != nullptr && p < nlive)
+        *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
+    }
+  }
+  __syncthreads();
+  {
+    const f32x4 lw = *reinterpret_cast<const f32x4*>(a.ds_lnw + 4 * lane);
+    const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ds_lnb + 4 * lane);
+    for (int p = wave; p < NPX; p += NW) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * lane);
+      const float mean = wave_sum(d[0] + d[1] + d[2] + d[3]) * (1.0f / C);
+      const f32x4 e = d - mean;
+      const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]) * (1.0f / C);
+      const float rstd = rsqrtf(var + LN_EPS);
+      T4 y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = (T)(e[i] * rstd * lw[i] + lb[i]);
+      *reinterpret_cast<T4*>(xn + p * XNP + 8 * lane) = y;
+    }
+  }
+  __syncthreads();
+  {
+    S2P_STAMP(57);
+    // out[alert][co] = b[co] + sum_k Wd[co][k] patch[alert][k],  k = (2 ky + kx) * 256 + c  ->  pixel 3 ky + kx.
+    // Column = alert (4 live of 16); wave w: output tiles 4 w .. 4 w + 3 (16 channels each), 32 k-steps.
+    const int al = col < G ? col : 0;
+    // this wave's 4 tiles x 32 k-steps = 128 fragments, contiguous in memory (tile-major): a ring of 16 in flight
+    const frag* src = reinterpret_cast<const frag*>(a.ds_wp) + (size_t)(4 * wave) * KSD * 64 + lane;
+    constexpr int RING = 16, NSTEP = 4 * KSD;
+    frag wq[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) wq[i] = src[i * 64];
+    f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (4 * wave) + 4 * kg);
+#pragma unroll 1
+    for (int g = 0; g < NSTEP / RING; ++g) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) {
+        const int st = g * RING + i, s = st & (KSD - 1), tile = 4 * wave + (st >> 5);
+        const int q = s >> 3, pq = 3 * (q >> 1) + (q & 1);
+        const frag bf = *reinterpret_cast<const frag*>(xn + (9 * al + pq) * XNP + (32 * (s & 7) + 8 * kg) * 2);
+        o = MP<T>::run(wq[i], bf, o);
+        if (st + RING < NSTEP) wq[i] = src[(size_t)(st + RING) * 64];
+        if (s == KSD - 1) {   // tile finished (every 32 steps = two ring rounds)
+          if (col < G && alert0 + col < a.B)
+            *reinterpret_cast<f32x4*>(a.out + (size_t)(alert0 + col) * CO + 16 * tile + 4 * kg) = o;
+          if (st + 1 < NSTEP) o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (tile + 1) + 4 * kg);
+        }
+      }
+    }
+  }
+  S2P_STAMP(58);
+}
+
+// ---- operand packing: one 16x16x32 A fragment = 64 lanes x 8 elements = 1 KiB, lane l holds row (l & 15),
+//      k = 32 s + 8 (l >> 4) + j of its tile
+template <typename T>
+__global__ void pack_frag_kernel(const float* __restrict__ w, const float* __restrict__ rowscale, T* __restrict__ out,
+                                 int rows, int K, int reorder_down, int cin) {
+  // element index -> (tile, k-step, lane, j); out is tile-major, k-step next: a tile's k-steps are contiguous
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)rows * K;
+  if (i >= total) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;                 // fragment index = tile * (K / 32) + s
+  const int ksteps = K / 32;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  const int row = 16 * tile + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+  float v;
+  if (reorder_down) {
+    // downsample filter [Cout][Cin][2][2] -> k = (2 ky + kx) * Cin + c
+    const int q = k / cin, c = k - q * cin;
+    v = w[((long)row * cin + c) * 4 + q];
+  } else {
+    v = w[(long)row * K + k];
+  }
+  if (rowscale != nullptr) v *= rowscale[row];
+  out[i] = (T)v;
+}
+
+template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+  auto kern = stage2p_kernel<T>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), LDS_BYTES, st, a);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+}  // namespace
+
+bool stage2p_supported(int prec, int c2, int c3, int depth) {
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c2 == C && c3 == CO && depth >= 1 && depth <= S2P_MAX_DEPTH;
+}
+
+// src [rows][K] fp32 (row-major; reorder_down: a [Cout][Cin][2][2] downsample filter) -> MFMA A fragments
+int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
+                    int cin, hipStream_t st) {
+  const long total = (long)rows * K;
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(pack_frag_kernel<bf16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<bf16_t*>(dst), rows, K,
+                       reorder_down, cin);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(pack_frag_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
+                       reorder_down, cin);
+  else {
+    btsbot_set_error("pack_s2p: precision %d is not a 16-bit mode", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
+  if (a.B <= 0) return BTSBOT_OK;
+  if (prec == BTSBOT_BF16) return launch_stage2p_t<bf16_t>(a, st);
+  if (prec == BTSBOT_F16) return launch_stage2p_t<f16_t>(a, st);
+  btsbot_set_error("stage2p: unsupported precision %d", prec);
+  return BTSBOT_ERR_INVALID_ARG;
+}

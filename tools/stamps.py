@@ -38,21 +38,12 @@ for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
     print("   duration deciles", np.percentile(dur, [10, 30, 50, 70, 90]).round(1))
     print("   start deciles   ", np.percentile(st, [10, 30, 50, 70, 90]).round(1))
 
-s2 = t[32 + 16384:32 + 16384 + 8]
-print("s2_fc1 (last block of stage 2) total cycles", s2[7] - s2[0])
-for i, nm in enumerate(["loads + filter DMA issued", "tap table barrier", "depthwise + LN (1 alert / wave)", "image barrier",
-                        "main loop", "GELU + staging", "rows stored"]):
-    print(f"   {nm:32s} +{s2[i + 1] - s2[i]:8d}")
-
-base = 32 + 16384
-for off, nm in ((16, "prologue end"), (32, "main loop end"), (48, "GELU end")):
-    print(f"   per wave {nm:14s}", [t[base + off + w] - s2[0] for w in range(16)])
-
-n = ((B + 15) // 16 + 7) // 8 * 8 * 4
-w = np.array(t[base + 64:base + 64 + 2 * n]).reshape(n, 2)
-w = w[w[:, 0] > 0]
-t0 = w[:, 0].min()
-dur = (w[:, 1] - w[:, 0]) / 100.0
-st = (w[:, 0] - t0) / 100.0
-print(f"s2_fc1 workgroups {len(w)}: kernel span {(w[:,1].max()-t0)/100.0:.1f} us; WG duration us min/median/max "
-      f"{dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f}; start deciles", np.percentile(st, [10, 50, 90, 100]).round(1))
+s2 = t[32 + 16384:32 + 16384 + 64]
+print("stage2p (workgroup 0) total cycles", s2[58] - s2[0])
+print(f"   prologue (zero fill, x load)    +{s2[1] - s2[0]:8d}")
+for j in range(6):
+    b = 1 + 8 * j
+    nxt = s2[1 + 8 * (j + 1)] if j < 5 else s2[56]
+    print(f"   block {j}: map->LDS +{s2[b+1]-s2[b]:6d}  depthwise +{s2[b+2]-s2[b+1]:6d}  LN +{s2[b+3]-s2[b+2]:6d}  "
+          f"chunks 0-1 +{s2[b+4]-s2[b+3]:6d}  2-3 +{s2[b+5]-s2[b+4]:6d}  4-7 +{s2[b+6]-s2[b+5]:6d}  (block {nxt - s2[b]:7d})")
+print(f"   downsample: LN +{s2[57]-s2[56]:6d}  conv +{s2[58]-s2[57]:6d}")
