@@ -69,6 +69,14 @@ constexpr float LN_EPS = 1e-6f;
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
   } while (0)
 
+// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63 separately); every lane ends with its half's total
+__device__ __forceinline__ float half_sum(float v) {
+  v = group16_sum(v);
+  float w = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  return v + w;
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   using frag = typename MP<T>::frag;
@@ -128,35 +136,42 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   for (int j = 0; j < a.depth; ++j) {
     const Stage2pBlk& bk = a.blk[j];
     S2P_STAMP(1 + 8 * j);
-    // ---- residual + gamma * b2 (the bias of the folded fc2), and the map to LDS in fp32
+    // ---- every small parameter of the block is requested first: the L2 latency passes under the phases below
+    f32x4 g4[2], b4[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 32 * wave + 16 * m + 4 * kg);
+      b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 32 * wave + 16 * m + 4 * kg);
+    }
+    const float b1a = bk.b1[tid], b1b = bk.b1[tid + NT];
+    const int dc = tid & (C - 1), dhalf = tid >> 8;      // depthwise role: (channel, alert pair)
+    float w[25];
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + dc];
+    const float dbias = bk.dw_b[dc];
+    const f32x4 lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
+    const f32x4 lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
+    const f32x4 lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
+    const f32x4 lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
+    // ---- the map to LDS in fp32
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int c0 = 32 * wave + 16 * m + 4 * kg;
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(bk.gamma + c0);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk.b2 + c0);
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         const int p = 16 * n + col;
         if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
-        acc[m][n] += g4 * b4;
       }
     }
-    b1s[tid] = bk.b1[tid];
-    b1s[tid + NT] = bk.b1[tid + NT];
     __syncthreads();
     S2P_STAMP(2 + 8 * j);
     // ---- depthwise 7x7 on the 3x3 maps, in place: thread = (channel, alert pair)
     {
-      const int c = tid & (C - 1), half = tid >> 8;
-      float w[25];
-#pragma unroll
-      for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + c];
-      const float bias = bk.dw_b[c];
 #pragma unroll
       for (int g = 0; g < G / 2; ++g) {
-        float* px = xl + (size_t)((half * (G / 2) + g) * 9) * XLP + c;
+        float* px = xl + (size_t)((dhalf * (G / 2) + g) * 9) * XLP + dc;
         float in[9], o[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) in[i] = px[i * XLP];
@@ -164,37 +179,46 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         for (int oy = 0; oy < 3; ++oy)
 #pragma unroll
           for (int ox = 0; ox < 3; ++ox) {
-            float s = bias;
+            float sum = dbias;
 #pragma unroll
             for (int iy = 0; iy < 3; ++iy)
 #pragma unroll
-              for (int ix = 0; ix < 3; ++ix) s = fmaf(w[(iy - oy + 2) * 5 + (ix - ox + 2)], in[iy * 3 + ix], s);
-            o[oy * 3 + ox] = s;
+              for (int ix = 0; ix < 3; ++ix) sum = fmaf(w[(iy - oy + 2) * 5 + (ix - ox + 2)], in[iy * 3 + ix], sum);
+            o[oy * 3 + ox] = sum;
           }
 #pragma unroll
         for (int i = 0; i < 9; ++i) px[i * XLP] = o[i];
       }
     }
+    b1s[tid] = b1a;            // (last read by the previous block's last fc1, two barriers ago)
+    b1s[tid + NT] = b1b;
     __syncthreads();
     S2P_STAMP(3 + 8 * j);
-    // ---- LayerNorm over the 256 channels of a pixel: wave = pixel, lane = 4 channels
-    {
-      const f32x4 lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 4 * lane);
-      const f32x4 lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 4 * lane);
-      for (int p = wave; p < NPX; p += NW) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * lane);
-        const float mean = wave_sum(d[0] + d[1] + d[2] + d[3]) * (1.0f / C);
-        const f32x4 e = d - mean;
-        const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]) * (1.0f / C);
-        const float rstd = rsqrtf(var + LN_EPS);
-        T4 y;
+    // ---- LayerNorm over the 256 channels of a pixel: half wave = pixel, lane = 8 channels
+    for (int p = 2 * wave + (lane >> 5); p < NPX; p += 2 * NW) {
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31));
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31) + 4);
+      const float mean = half_sum(d0[0] + d0[1] + d0[2] + d0[3] + d1[0] + d1[1] + d1[2] + d1[3]) * (1.0f / C);
+      const f32x4 e0 = d0 - mean, e1 = d1 - mean;
+      const float var = half_sum(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2] + e0[3] * e0[3] + e1[0] * e1[0] +
+                                 e1[1] * e1[1] + e1[2] * e1[2] + e1[3] * e1[3]) * (1.0f / C);
+      const float rstd = rsqrtf(var + LN_EPS);
+      typedef T T8 __attribute__((ext_vector_type(8)));
+      T8 y;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = (T)(e[i] * rstd * lw[i] + lb[i]);
-        *reinterpret_cast<T4*>(xn + p * XNP + 8 * lane) = y;
+      for (int i = 0; i < 4; ++i) {
+        y[i] = (T)(e0[i] * rstd * lw[i] + lb[i]);
+        y[4 + i] = (T)(e1[i] * rstd * lw2[i] + lb2[i]);
       }
+      *reinterpret_cast<T8*>(xn + p * XNP + 16 * (lane & 31)) = y;
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
+    // residual + gamma * b2 (the bias of the folded fc2)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[m][n] += g4[m] * b4[m];
 
     // one chunk of 128 hidden units; P = register set that holds its fragments.  The next chunk's 16 fragment
     // loads are spread over this chunk's k-steps: issued in one burst they hold every wave at the CU's one
