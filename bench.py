@@ -418,6 +418,13 @@ def train_leg(dev, rank, world, dist, fence, args):
         "steps": args.train_steps, "ms_per_step": round(1e3 * tel / args.train_steps, 3),
         "loss_finite": bool(torch.isfinite(tloss).item()),
     }
+    # whole-step roofline: forward + input gradients + filter gradients = 3 x the forward's algorithmic FLOP
+    step_flop = 3.0 * (133701376 + 210000) * args.train_batch
+    achieved = step_flop / (tel / args.train_steps) / 1e12
+    train["roofline"] = {"kernel": "whole training step (forward, backward, AdamW; ~260 launches)", "bound": "mfma",
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4),
+                         "flop_per_step": step_flop}
     del tm, tr
     return train
 
@@ -586,41 +593,49 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, args):
-    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
-    (profiles/r*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    same command, FETCH_SIZE doubled per the gfx950 calibration in tools/pmc_calib).  PMC counters
-    cannot be sampled from inside this process, so the figure is only reported for the workload the
-    summary was collected on (default precision and batch); otherwise null."""
+def _newest_profile(pattern):
     import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(kernel, args):
+    """HBM-side bytes per launch of `kernel`, NOT measured in this run: PMC counters cannot be sampled from inside
+    the process, so the figure comes from the newest committed summary (profiles/r*_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH_SIZE doubled per the gfx950
+    calibration in tools/pmc_calib) and is tagged with that file.  Only for the workload the summary was collected
+    on (default precision and batch) and only when the file knows this kernel symbol; otherwise null."""
     if args.precision != "bf16" or args.batch != PER_GPU_BATCH:
         return None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    if not files:
+    f = _newest_profile("r*_pmc_traffic.json")
+    if f is None:
         return None
-    with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    # (the stage megakernels are profiled under their category names; their symbols carry a 'b')
-    names = {kernel, kernel.replace("_kernel", "b_kernel")}
-    hits = [v for v in ks.values() if v["family"] in names]
-    return hits[0]["traffic_bytes"] if len(hits) == 1 else None
+    with open(f) as fh:
+        ks = json.load(fh)["kernels"]
+    hits = [v for v in ks.values() if v["family"] == kernel]
+    if len(hits) != 1:
+        return None
+    return {"bytes_per_launch": hits[0]["traffic_bytes"], "source": "profiles/" + os.path.basename(f),
+            "measured_in_this_run": False}
 
 
 def pmc_mfma_busy(kernel, args):
     """Share of the MFMA pipes' cycles the kernel keeps busy, from the newest committed SQ-counter summary
     (profiles/r*_mfma_util.json, tools/mfma_util.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8),
-    one rocprofv3 --pmc pass over this command).  Same caveat as pmc_traffic: null off the default workload."""
-    import glob
+    one rocprofv3 --pmc pass over this command).  Same caveats and tagging as pmc_traffic."""
     if args.precision != "bf16" or args.batch != PER_GPU_BATCH:
         return None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_mfma_util.json")))
-    if not files:
+    f = _newest_profile("r*_mfma_util.json")
+    if f is None:
         return None
-    with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    stems = {kernel.replace("_kernel", ""), kernel.replace("_kernel", "b")}
-    hits = [v for v in ks if v["kernel"].split("_kernel")[0] in stems]
-    return hits[0]["mfma_busy"] if len(hits) == 1 else None
+    with open(f) as fh:
+        ks = json.load(fh)["kernels"]
+    stem = kernel.replace("_kernel", "")
+    hits = [v for v in ks if v["kernel"].split("_kernel")[0] == stem]
+    if len(hits) != 1:
+        return None
+    return {"busy_share": hits[0]["mfma_busy"], "source": "profiles/" + os.path.basename(f),
+            "measured_in_this_run": False}
 
 
 if __name__ == "__main__":

@@ -86,7 +86,7 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
         h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
-        if (i == 3 && h->stage2p) h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
+        if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
       }
       for (int j = 0; j < c.depths[i]; ++j) {
         snprintf(buf, sizeof buf, "stages.%d.blocks.%d.", i, j);
@@ -453,6 +453,8 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       }
     }
   }
+  if (convnext && h->stage1 && !train_only)
+    TRY(launch_pack_frag32(c.precision, m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
   if (convnext && h->stage2p && !train_only)
     TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], st));
@@ -671,9 +673,10 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         }
         a.ds_lnw = m + h->down[2].ln_w;
         a.ds_lnb = m + h->down[2].ln_b;
-        a.ds_w = h->extra + h->down[2].p_w;
+        a.ds_w = h->extra + h->down[2].p_wp;
         a.ds_b = m + h->down[2].b;
         a.out = x2;
+        a.scratch = x2 + (((size_t)nb * 9 * c.dims[2] + 63) / 64) * 64;   // behind the output rows (x2 holds 225 * 64 floats per alert)
         a.tap_stage = h->debug ? h->taps[2] : nullptr;
         a.B = nb;
         {

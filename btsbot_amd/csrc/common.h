@@ -248,6 +248,7 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
                     int cin, hipStream_t st);
 size_t s1par_bytes();
+int launch_pack_frag32(int prec, const float* src, void* dst, int cout, int cin, hipStream_t st);   // stage1b.hip
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
                       const float* ln_b, void* out, hipStream_t st);
 size_t s0par_bytes();

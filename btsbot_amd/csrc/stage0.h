@@ -41,9 +41,10 @@ struct Stage1Args {
   Stage0Blk blk[2];       // dw_w is [49][128]
   const float* ds_lnw;
   const float* ds_lnb;
-  const void* ds_w;       // [256][512] 16-bit, k = (ky*2+kx)*128 + c
+  const void* ds_w;       // 32x32x16 A fragments of the [256][512] filter, k = (ky*2+kx)*128 + c (launch_pack_frag32)
   const float* ds_b;
   float* out;             // [B][9][256] f32
+  float* scratch;         // [B][49][128] f32: the residual stream between the two blocks (stage1b.hip)
   float* tap_stage;       // optional [B][49][128] f32 copy of the stage output (validation)
   int B;
   unsigned long long* stamps;   // optional phase timestamps (workgroup 0, thread 0)

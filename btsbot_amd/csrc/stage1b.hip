@@ -1,26 +1,27 @@
-// Stage-1 megakernel, second layout (gfx950): TWO alerts' 7x7x128 maps per 256-thread workgroup,
-// two workgroups per CU (same scheme as stage0b.hip):
+// Stage-1 megakernel (gfx950): TWO alerts' 7x7x128 maps per 256-thread workgroup, two workgroups per CU:
 //
 //   2 x [ dwconv 7x7 + LN -> fc1 -> GELU -> fc2 -> layer-scale -> +x ]  ->  LN + conv 2x2 s2 (128 -> 256)
 //
 // (timm ConvNeXt stages[1].blocks / stages[2].downsample, reached from
 // /root/reference/btsbot/architectures.py:108,132).  HBM sees [49][128] f32 in and [9][256] f32
 // out per alert.  At B = 1024 the 512 workgroups are all resident at once (2 per CU) and drift
-// apart, so one's depthwise phase (VALU + LDS) runs under the other's MLP (MFMA + GELU).
+// apart, so one's depthwise phase runs under the other's MLP (MFMA + GELU).
 //   * residual stream fp32 in registers, 32x32 MFMA accumulator layout: wave = 32 pixel slots of
 //     the 98, lane half h and 64 registers = the 128 channels;
-//   * a 16-bit map image in LDS ([98 px][128 ch], 272-byte rows) holds x for the depthwise phase
-//     (lane = channel, wave = (alert, channel half), 7 rounds = rows); its LN outputs go to a
-//     second image that borrows ring slots 0..1 until the MLP has loaded its B operand from it;
-//     LayerNorm sums meet the other channel half's through LDS, one barrier per round
-//     (single-pass variance);
-//   * the depthwise taps (in the operand type) arrive by LDS-DMA in ring slot 2, which the filter
-//     ring only needs from the MLP's third chunk on: 7 tap registers instead of 49, which is what
-//     keeps the residual tile out of scratch;
+//   * depthwise 7x7 on the matrix pipe, as in stage0b.hip: the 16-block 4x4x4 MFMA, one block per channel,
+//     A = Toeplitz taps in registers (21 fragments per group of 16 channels), B = 4 consecutive x of 4
+//     consecutive rows read with one ds_read_b64 from a planar image [alert][x quad][row][channel][4 x]: the
+//     channel-minor order with a 136-entry row pitch makes the 8 blocks x 4 rows of a half wave hit 32 different
+//     8-byte bank slots.  Rows outside the map are one shared zero row (per-lane row offsets), column 7 of
+//     the second quad is kept zero.  Wave = 2 channel groups x both alerts: 224 MFMAs, 88 reads per block
+//     (the VALU form this replaces: 25k cycles per block, 2 x 49 x 7 FMAs per lane plus conversions);
+//   * LayerNorm: transposing lane reduction over the 16 blocks, the 4 waves meet through LDS (stage0b.hip);
+//     its 16-bit output is the MLP's B operand image, in ring slots 0..1 until the MLP has loaded it;
 //   * pointwise filters: 16 KB chunks of 32 hidden units (W1 rows + gamma*W2 columns) through a
 //     3-slot LDS-DMA ring straight from the plain row-major filters; the per-lane source address
 //     applies the bank swizzles and the bit-2/bit-3 row swap that makes the fc1 accumulator the
-//     fc2 B operand in plain k order (stage0b.hip); fc2 accumulates into the residual registers.
+//     fc2 B operand in plain k order (stage0b.hip); fc2 accumulates into the residual registers.  Ring slot 2
+//     shares its bytes with the planar image (dead once the depthwise phase is over).
 #include "common.h"
 #include "stage0.h"
 
@@ -31,36 +32,48 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T> struct SCM;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 template <> struct SCM<bf16_t> {
   using frag = bf16x8;
+  using frag4 = s16x4;
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 run4(frag4 a, frag4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0);
   }
 };
 template <> struct SCM<f16_t> {
   using frag = f16x8;
+  using frag4 = f16x4;
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 run4(frag4 a, frag4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0);
   }
 };
 
 constexpr int C = 128, HW = 7, PA = 49, G = 2, NPX = G * PA, CT = 4, HID = 512, KS1 = 8;
 constexpr int CN = 256, PO = 9;                   // downsample: output channels, pixels per alert
-constexpr int PITCH = 2 * C + 16;                 // 272 bytes per map row
-constexpr int MAPB = NPX * PITCH;                 // 26656
+constexpr int PITCH = 2 * C + 16;                 // [pixel][channel] image: 272 bytes per pixel row
+constexpr int MAPB = NPX * PITCH;                 // 26656: lives in ring slots 0..1
 constexpr int CHUNKB = 16384, NCH = HID / 32, NSLOT = 3;
-constexpr int OFF_RING = MAPB;
-constexpr int OFF_B1 = OFF_RING + NSLOT * CHUNKB; // 512 floats fc1 bias + 128 floats gamma*b2
-constexpr int OFF_RED = OFF_B1 + (HID + C) * 4;   // [2 parities][4 waves][16]
-constexpr int LDS_BYTES = OFF_RED + 2 * 4 * 16 * 4;   // 78880: two workgroups per CU
-static_assert(MAPB % 16 == 0 && LDS_BYTES <= 80 * 1024, "LDS layout");
+// planar image of the depthwise phase: [alert][x quad 0..1][row 0..6, 7 = zeros][channel, pitch 136][4 x]
+constexpr int PL_ROW = 136 * 8, PL_XQ = 8 * PL_ROW, PL_AL = 2 * PL_XQ, PLB = G * PL_AL;   // 1088, 8704, 17408, 34816
+constexpr int OFF_PL = 2 * CHUNKB;                // ring slots 0, 1 | planar image = ring slot 2 + 18 KB
+constexpr int OFF_B1 = OFF_PL + PLB;              // 512 floats fc1 bias + 128 floats gamma*b2
+constexpr int OFF_PART = OFF_B1 + (HID + C) * 4;  // LayerNorm partial sums [2][4 waves][128 slots]
+constexpr int OFF_ST = OFF_PART + 2 * 4 * 128 * 4;   // (rstd, -mean * rstd) per padded pixel slot [2][128]
+constexpr int LDS_BYTES = OFF_ST + 2 * 128 * 4;   // 75264: two workgroups per CU
+static_assert(MAPB <= 2 * CHUNKB && CHUNKB <= PLB && LDS_BYTES <= 80 * 1024, "LDS layout");
 constexpr float LN_EPS = 1e-6f;
-// per-block depthwise parameter image (launch_pack_s1par), fetched by LDS-DMA into ring slot 2,
-// which the filter ring does not need before the MLP's first chunk is consumed:
-// [49][128] taps in the operand type | dw bias | LN weight | LN bias (fp32) | zero pad to 16 KiB
-constexpr int TAPB = 49 * C * 2;                  // 12544
-constexpr int PARB = CHUNKB;                      // 16384 = 16 pieces, 4 per wave
-static_assert(TAPB + 3 * C * 4 <= PARB, "parameter image layout");
+// per-block parameter image in HBM (launch_pack_s1par): Toeplitz taps in the operand type
+//   [r = ky * 3 + (rb + 1)][channel][i][k] = W[channel][ky][4 rb + k - i + 3]   (0 outside the 7 taps)
+// then fp32: dw bias [128] | LN weight [128] | LN bias [128]
+constexpr int TW_R = 21, TW_BYTES = TW_R * C * 4 * 4 * 2;   // 86016
+constexpr int PARB = TW_BYTES + 3 * C * 4;        // 87552
 
 #define SC_STAMP(i)                                                                \
   do {                                                                             \
@@ -83,14 +96,28 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// 16 values per lane -> v[0..3] = 64-lane totals of values (lane>>4)*4 + j
-__device__ __forceinline__ void treduce16(float (&v)[16]) {
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// Transposing sum over the 16 blocks (lane bits 2..5) of 32 values per lane: out[0..1] = the 16-lane totals of
+// values 16 (lane >> 5) + 8 ((lane >> 4) & 1) + 4 ((lane >> 3) & 1) + 2 ((lane >> 2) & 1) + 0..1  (stage0b.hip)
+__device__ __forceinline__ void block_reduce32(float (&w)[32], int lane, float (&out)[2]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = swap_add32(v[i], v[i + 8]);
+  for (int n = 0; n < 16; ++n) w[n] = swap_add32(w[n], w[n + 16]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = swap_add16(v[i], v[i + 4]);
+  for (int n = 0; n < 8; ++n) w[n] = swap_add16(w[n], w[n + 8]);
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = group16_sum(v[i]);
+  for (int n = 0; n < 4; ++n) {
+    const float own = b3 ? w[n + 4] : w[n], send = b3 ? w[n] : w[n + 4];
+    w[n] = own + dpp_mov<0x128>(send);                       // row_ror:8 = lane ^ 8
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const float own = b2 ? w[n + 2] : w[n], send = b2 ? w[n] : w[n + 2];
+    const float lo = dpp_mov<0x124>(send), hi = dpp_mov<0x12C>(send);   // row_ror:4 / :12 = lane - 4 / lane + 4
+    out[n] = own + (b2 ? lo : hi);
+  }
 }
 
 // LayerNorm over the 128 channels of this lane's pixel (x[4][16] here + the partner lane ^ 32)
@@ -143,16 +170,32 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
     }
 }
 
+// this lane's pixel (64 of its 128 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
+// image; p = alert * 49 + y * 7 + x
+template <typename T>
+__device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
+  const int al = p >= PA ? 1 : 0, pp = p - al * PA;
+  const int y = pp / HW, xx = pp - y * HW;
+  unsigned char* dst = pl + al * PL_AL + (xx >> 2) * PL_XQ + y * PL_ROW + (xx & 3) * 2 + h * 32;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = (T)x[ct][r];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   using frag = typename SCM<T>::frag;
-  typedef T T8 __attribute__((ext_vector_type(8)));
+  using frag4 = typename SCM<T>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* map = smem;
-  unsigned char* ring = smem + OFF_RING;
+  unsigned char* pl = smem + OFF_PL;                 // planar image; its first 16 KB double as ring slot 2
+  unsigned char* stg = smem;                         // LN image [98][PITCH] in ring slots 0..1
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
   float* b2s = b1s + HID;
-  float* red = reinterpret_cast<float*>(smem + OFF_RED);
+  float* part = reinterpret_cast<float*>(smem + OFF_PART);
+  float* st = reinterpret_cast<float*>(smem + OFF_ST);
+  auto slot_ptr = [&](int sl) { return sl < 2 ? smem + sl * CHUNKB : smem + OFF_PL; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
@@ -162,53 +205,72 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   const bool live = p < nal * PA;
   const bool inmap = p < NPX;
   const int pm = inmap ? p : 0;                      // row to read for slots beyond the image
-
+  // depthwise roles: lane = (block b, row offset j); wave = channel groups 2 wave, 2 wave + 1 of both alerts
+  const int dj = lane & 3, db = lane >> 2;
   SC_STAMP(0);
-  unsigned char* pimg = ring + 2 * CHUNKB;          // parameter image = ring slot 2 (see PARB)
-  auto issue_params = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.blk[j].par + (wave * 4 + i) * 1024 + lane * 16),
-                                       (lptr_t)(pimg + (wave * 4 + i) * 1024), 16, 0, 0);
+  // what the live writes never touch and the depthwise products read: the zero rows and column 7
+  auto zero_pads = [&]() {
+    for (int i = tid; i < 4 * PL_ROW / 16; i += 256) {
+      const int blk = i / (PL_ROW / 16), o = i - blk * (PL_ROW / 16);
+      *reinterpret_cast<uint4*>(pl + (blk >> 1) * PL_AL + (blk & 1) * PL_XQ + 7 * PL_ROW + o * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int i = tid; i < G * HW * C; i += 256) {
+      const int al = i / (HW * C), r = (i / C) % HW, c = i % C;
+      *reinterpret_cast<unsigned short*>(pl + al * PL_AL + PL_XQ + r * PL_ROW + c * 8 + 6) = 0;
+    }
   };
-  issue_params(0);   // lands under the input load
-  // ---- stage input -> registers (accumulator layout) and the 16-bit map image
-  f32x16 x[CT];
-  {
-    const float* src = a.x_in + ((size_t)a0 * PA + (live ? p : 0)) * C;
+  zero_pads();
+  // ---- the residual stream does NOT stay in registers through the depthwise phase (64 registers next to that
+  //      phase's 64 outputs and 42 tap registers spill): it is re-read at the start of each MLP, from the stage
+  //      input for block 0 and from a scratch copy (written by the same lanes, L2-resident) for block 1
+  const float* xsrc = a.x_in + ((size_t)a0 * PA + (live ? p : 0)) * C;
+  float* xscr = a.scratch + ((size_t)a0 * PA + (live ? p : 0)) * C;
+  auto load_x = [&](const float* src, f32x16 (&x)[CT]) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const float4 v = *reinterpret_cast<const float4*>(src + ct * 32 + 8 * qd + 4 * h);
-        x[ct][4 * qd + 0] = live ? v.x : 0.f;
-        x[ct][4 * qd + 1] = live ? v.y : 0.f;
-        x[ct][4 * qd + 2] = live ? v.z : 0.f;
-        x[ct][4 * qd + 3] = live ? v.w : 0.f;
+        const float4 v4 = *reinterpret_cast<const float4*>(src + ct * 32 + 8 * qd + 4 * h);
+        x[ct][4 * qd + 0] = live ? v4.x : 0.f;
+        x[ct][4 * qd + 1] = live ? v4.y : 0.f;
+        x[ct][4 * qd + 2] = live ? v4.z : 0.f;
+        x[ct][4 * qd + 3] = live ? v4.w : 0.f;
       }
-    if (inmap) regs_to_map<T>(x, map, p, h);
+  };
+  {
+    f32x16 x0[CT];
+    load_x(xsrc, x0);
+    if (inmap) regs_to_planar<T>(x0, pl, p, h);
   }
   SC_STAMP(1);
 
+  f32x16 x[CT];   // (written in full at the start of every MLP: dead through the depthwise phases)
   const int rot = (blockIdx.x * 5 + (blockIdx.x >> 4)) & (NCH - 1);   // chunk rotation, see issue()
-  const int half = wave & 1;                         // channel half owned in the depthwise phase
-  const int cdw = half * 64 + lane;
 #pragma unroll 1
   for (int j = 0; j < 2; ++j) {
     const Stage0Blk& bk = a.blk[j];
-    // ---- fc1 bias and gamma*b2: ordinary loads, issued BEFORE the block's first filter DMA
-    //      (vmcnt retires in order: a load younger than a DMA would have to wait for it)
+    // ---- ordinary loads first (vmcnt retires in order: a load younger than a DMA would wait for it): fc1 bias,
+    //      gamma*b2, the first channel group's Toeplitz taps and both groups' per-channel scalars
     const float b1v0 = bk.b1[tid], b1v1 = bk.b1[256 + tid];
     const float b2v = bk.gamma[tid & (C - 1)] * bk.b2[tid & (C - 1)];
+    const uint2* twsrc = reinterpret_cast<const uint2*>(bk.par) + (2 * wave) * 64 + lane;
+    frag4 tw[TW_R];
+#pragma unroll
+    for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, twsrc[r * 512]);
+    const float* pf = reinterpret_cast<const float*>(bk.par + TW_BYTES);
+    float dwbias[2], lng[2], lnb2[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int c = 16 * (2 * wave + gi) + db;
+      dwbias[gi] = pf[c];
+      lng[gi] = pf[C + c];
+      lnb2[gi] = pf[2 * C + c];
+    }
     SC_STAMP(2 + 5 * j);
-    wait_vm<0>();      // this wave's quarter of the parameter image (and the loads above) landed
-    __syncthreads();   // ... everyone's; map complete (input / previous MLP); ring slots 0, 1 free
+    __syncthreads();   // planar image complete (input / previous MLP + zero pads); ring slots 0, 1 free
     b1s[tid] = b1v0;
     b1s[256 + tid] = b1v1;
     if (tid < C) b2s[tid] = b2v;
-    const T* taps = reinterpret_cast<const T*>(pimg) + cdw;
-    const float* pf = reinterpret_cast<const float*>(pimg + TAPB);
-    const float dwbias = pf[cdw], lng = pf[C + cdw], lnb2 = pf[2 * C + cdw];
 
     // ---- pointwise filters: chunk = 32 hidden units = 16 pieces of 1 KiB, 4 per wave.
     //      pieces 0..7 : W1 rows (LDS row m <- hidden unit 32*ch + swap23(m)), 256-byte rows,
@@ -236,73 +298,131 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((ch + rot) & (NCH - 1)) * wstep0),
-                                         (lptr_t)(ring + ((ch + 2) % NSLOT) * CHUNKB + (wave * 4 + i) * 1024),
+                                         (lptr_t)(slot_ptr((ch + 2) % NSLOT) + (wave * 4 + i) * 1024),
                                          16, 0, 0);
     };
     SC_STAMP(3 + 5 * j);
 
-    // ---- depthwise 7x7 + bias + LN: wave = (alert, channel half), round = map row (a real loop:
-    //      unrolled, the seven rounds cost ~36 live registers each and the residual tile went to
-    //      scratch).  The LN outputs go straight to a second image in ring slots 0..1, which the
-    //      filter ring only claims after the MLP has taken its B operand from it.
-    unsigned char* stg = ring;                       // [98][PITCH] = 26656 B <= 2 slots
-    {
-      const T* mi = reinterpret_cast<const T*>(map);
-      const int g = wave >> 1;                       // alert
-#pragma unroll 1
-      for (int y = 0; y < HW; ++y) {
-        float acc[8];
+    // ---- depthwise 7x7 on the matrix pipe.  Per channel (= block) and output tile (rows 4 yb + j, columns 4 xb + i):
+    //        D[i][j] = sum over ky, rb, k of  W[ky][4 rb + k - i + 3] * in[4 yb + j + ky - 3][4 (xb + rb) + k]
+    //      a row step s = 4 yb + ky serves both yb with that sum: 22 reads, 56 MFMAs per (channel group, alert)
+    // padded rows of the planar image: rofs[s] = byte offset of input row s + j - 3 (row 7 = zeros when outside)
+    int rofs[11];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = (i < HW) ? dwbias : 0.f;
+    for (int sx = 0; sx < 11; ++sx) {
+      const int r = sx + dj - 3;
+      rofs[sx] = ((unsigned)r < (unsigned)HW ? r : 7) * PL_ROW;
+    }
+    float v[2][2][16];   // [group][alert][yb * 8 + xb * 4 + i]
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-          const int iy = y + ky - 3;
-          if (iy < 0 || iy >= HW) continue;          // wave-uniform
-          const T* row = mi + ((g * HW + iy) * HW) * (PITCH / 2) + cdw;
-          float in[HW], w[7];
+    for (int gi = 0; gi < 2; ++gi) {
+      if (gi == 1) {   // the second group's taps into the same registers (their last use is behind us)
 #pragma unroll
-          for (int kx = 0; kx < 7; ++kx) w[kx] = (float)taps[(ky * 7 + kx) * C];
+        for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, twsrc[r * 512 + 64]);
+      }
 #pragma unroll
-          for (int xx = 0; xx < HW; ++xx) in[xx] = (float)row[xx * (PITCH / 2)];
+      for (int al = 0; al < G; ++al) {
+        f32x4 acc[2][2];
 #pragma unroll
-          for (int kx = 0; kx < 7; ++kx)
+        for (int yb = 0; yb < 2; ++yb)
 #pragma unroll
-            for (int xx = 0; xx < HW; ++xx) {
-              const int ix = xx + kx - 3;
-              if (ix >= 0 && ix < HW) acc[xx] = fmaf(in[ix], w[kx], acc[xx]);
-            }
+          for (int xb = 0; xb < 2; ++xb) acc[yb][xb] = f32x4{dwbias[gi], dwbias[gi], dwbias[gi], dwbias[gi]};
+        const unsigned char* lb = pl + al * PL_AL + (16 * (2 * wave + gi) + db) * 8;
+#pragma unroll
+        for (int sx = 0; sx < 11; ++sx) {
+          frag4 bq[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + rofs[sx]));
+#pragma unroll
+          for (int yb = 0; yb < 2; ++yb) {
+            const int ky = sx - 4 * yb;
+            if (ky < 0 || ky > 6) continue;
+#pragma unroll
+            for (int rbi = 0; rbi < 3; ++rbi)
+#pragma unroll
+              for (int xb = 0; xb < 2; ++xb) {
+                const int q = xb + rbi - 1;
+                if (q < 0 || q > 1) continue;
+                acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+              }
+          }
         }
-        // LN over 128 channels = this wave's 64 lanes + the partner wave's: sums and sums of
-        // squares of the 7 pixels in one transposing reduction, exchanged through LDS
-        float s[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          s[i] = acc[i];
-          s[8 + i] = acc[i] * acc[i];
-        }
-        treduce16(s);
-        float* myred = red + ((y & 1) * 4 + wave) * 16;
-        if ((lane & 15) == 0) {
+        for (int yb = 0; yb < 2; ++yb)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) myred[(lane >> 4) * 4 + jj] = s[jj];
-        }
-        __syncthreads();
-        const float* pred = red + ((y & 1) * 4 + (wave ^ 1)) * 16;
-        T* dst = reinterpret_cast<T*>(stg) + ((g * HW + y) * HW) * (PITCH / 2) + cdw;
+          for (int xb = 0; xb < 2; ++xb)
 #pragma unroll
-        for (int xx = 0; xx < HW; ++xx) {
-          const float mean = (myred[xx] + pred[xx]) * (1.0f / C);
-          const float var = (myred[8 + xx] + pred[8 + xx]) * (1.0f / C) - mean * mean;
-          dst[xx * (PITCH / 2)] = (T)((acc[xx] - mean) * rsqrtf(var + LN_EPS) * lng + lnb2);
-        }
+            for (int i = 0; i < 4; ++i) v[gi][al][yb * 8 + xb * 4 + i] = acc[yb][xb][i];
       }
     }
     SC_STAMP(4 + 5 * j);   // depthwise done
-    __syncthreads();   // LN image complete; the taps (ring slot 2) are dead
-    issue(0);          // chunk ch lives in slot (ch + 2) % 3: chunk 0 can start right away
+    // ---- LayerNorm over the 128 channels of a pixel: this wave's 2 groups in the lane, its 16 blocks by the
+    //      transposing lane reduction, the 4 waves through LDS; single-pass variance
+    {
+      float o1[2], o2[2];
+      {
+        float s1[32];
+#pragma unroll
+        for (int al = 0; al < G; ++al)
+#pragma unroll
+          for (int n = 0; n < 16; ++n) s1[al * 16 + n] = v[0][al][n] + v[1][al][n];
+        block_reduce32(s1, lane, o1);
+      }
+      {
+        float s2[32];
+#pragma unroll
+        for (int al = 0; al < G; ++al)
+#pragma unroll
+          for (int n = 0; n < 16; ++n) s2[al * 16 + n] = fmaf(v[0][al][n], v[0][al][n], v[1][al][n] * v[1][al][n]);
+        block_reduce32(s2, lane, o2);
+      }
+      // padded pixel slot [alert][row 0..7][column 0..7] of this lane's two totals
+      const int slot = (lane >> 5) * 64 + (4 * ((lane >> 4) & 1) + dj) * 8 + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1);
+      *reinterpret_cast<float2*>(part + wave * 128 + slot) = make_float2(o1[0], o1[1]);
+      *reinterpret_cast<float2*>(part + 512 + wave * 128 + slot) = make_float2(o2[0], o2[1]);
+    }
+    __syncthreads();   // partial sums complete; nobody reads the planar image any more
+    if (tid < 128) {
+      const float t1 = part[tid] + part[128 + tid] + part[256 + tid] + part[384 + tid];
+      const float t2 = part[512 + tid] + part[640 + tid] + part[768 + tid] + part[896 + tid];
+      const float mean = t1 * (1.0f / C);
+      const float rstd = rsqrtf(fmaxf(t2 * (1.0f / C) - mean * mean, 0.0f) + LN_EPS);
+      st[tid] = rstd;
+      st[128 + tid] = -mean * rstd;
+    }
+    __syncthreads();
+    {
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        T* mo = reinterpret_cast<T*>(stg) + 16 * (2 * wave + gi) + db;
+#pragma unroll
+        for (int al = 0; al < G; ++al)
+#pragma unroll
+          for (int yb = 0; yb < 2; ++yb)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+              const int slot = al * 64 + (4 * yb + dj) * 8 + 4 * xb;
+              const float4 r4 = *reinterpret_cast<const float4*>(st + slot);
+              const float4 m4 = *reinterpret_cast<const float4*>(st + 128 + slot);
+              const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+              if (yb < 1 || dj < 3) {   // row 7 is padding
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (xb == 1 && i == 3) continue;   // column 7 is padding
+                  const float y = fmaf(fmaf(v[gi][al][yb * 8 + xb * 4 + i], rr[i], mm[i]), lng[gi], lnb2[gi]);
+                  mo[(al * PA + (4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = (T)y;
+                }
+              }
+            }
+      }
+    }
+    __syncthreads();   // LN image complete
+    issue(0);          // chunk 0 lives in slot 2 = the (dead) planar image's first 16 KB
     SC_STAMP(5 + 5 * j);
 
     // ---- fc1 -> GELU -> fc2 over 16 chunks; fc2 accumulates into x (gamma is in the filter)
+    load_x(j == 0 ? xsrc : xscr, x);
     {
       frag xf[KS1];
 #pragma unroll
@@ -329,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         else if (ch + 1 < NCH) wait_vm<4>();
         else wait_vm<0>();
         __syncthreads();   // chunk ch has landed for everyone; chunk ch-1 is read out
-        const unsigned char* w1s = ring + ((ch + 2) % NSLOT) * CHUNKB;
+        const unsigned char* w1s = slot_ptr((ch + 2) % NSLOT);
         const unsigned char* w2s = w1s + 8192;
         frag a1[KS1], a2[CT][2];
 #pragma unroll
@@ -369,12 +489,19 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
           for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][s2], hf, x[ct]);
         }
       }
-      if (j == 0) {      // next block's parameter image -> ring slot 2 (chunk 15 must be read out)
+      if (j == 0) {      // next block's depthwise operand; chunk 15 (slot 2 = the same bytes) must be read out first
         __syncthreads();
-        issue_params(1);
+        zero_pads();
+        if (inmap) regs_to_planar<T>(x, pl, p, h);
+        if (live) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              *reinterpret_cast<float4*>(xscr + ct * 32 + 8 * qd + 4 * h) =
+                  make_float4(x[ct][4 * qd], x[ct][4 * qd + 1], x[ct][4 * qd + 2], x[ct][4 * qd + 3]);
+        }
       }
-      // the map still holds the block's INPUT; the next block's depthwise phase wants the new x
-      if (j == 0 && inmap) regs_to_map<T>(x, map, p, h);
     }
     SC_STAMP(6 + 5 * j);   // MLP done
   }
@@ -390,11 +517,20 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 
   // ---- downsample: LN + conv 2x2 s2 (128 -> 256): 18 output pixels x 256 channels, K = 512
   {
+    __syncthreads();   // every wave is out of the MLP: ring slots 0..1 take the LN image
     {
       f32x16 xn[CT];
       ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn);
-      if (inmap) regs_to_map<T>(xn, map, p, h);   // (the image was last read before chunk 0's barrier)
+      if (inmap) regs_to_map<T>(xn, stg, p, h);
     }
+    // this wave's output tiles wave, wave + 4 (32 channels each) x 32 k-steps: 64 filter fragments packed as
+    // MFMA A operands (1 KiB each, launch_pack_frag32), a ring of 16 in flight
+    constexpr int KSD = 4 * C / 16, RING = 16, NSTEP = 2 * KSD;
+    const frag* wsrc = reinterpret_cast<const frag*>(a.ds_w) + lane;
+    auto fsrc = [&](int stp) { return wsrc + (size_t)((wave + 4 * (stp >> 5)) * KSD + (stp & (KSD - 1))) * 64; };
+    frag wq[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) wq[i] = *fsrc(i);
     __syncthreads();
     SC_STAMP(12);
     const int o = lr;                                // output pixel slot: 18 of 32 used
@@ -402,34 +538,30 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     const int oc = o < G * PO ? o : 0;
     const int g = oc / PO, oo = oc - g * PO;
     const int oy = oo / 3, ox = oo - oy * 3;
+    f32x16 acc;
 #pragma unroll 1
-    for (int tl = 0; tl < 2; ++tl) {
-      const int cot = wave + 4 * tl;                 // 8 output-channel tiles of 32 over 4 waves
-      const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(cot * 32 + lr) * (4 * C) + h * 8;
-      f32x16 acc;
+    for (int rd = 0; rd < NSTEP / RING; ++rd) {
+      const int cot = wave + 4 * (rd >> 1);
+      if ((rd & 1) == 0) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.ds_b + cot * 32 + 8 * qd + 4 * h);
-        acc[4 * qd + 0] = bv.x;
-        acc[4 * qd + 1] = bv.y;
-        acc[4 * qd + 2] = bv.z;
-        acc[4 * qd + 3] = bv.w;
-      }
-#pragma unroll 1
-      for (int kh = 0; kh < 2; ++kh) {               // two halves of K: 16 filter fragments in flight
-        frag af[16];
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) af[k2] = *reinterpret_cast<const frag*>(dw + (kh * 16 + k2) * 16);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          const int ks = kh * 16 + k2;
-          const int q = ks >> 3;                     // tap (ky*2 + kx): 8 k-steps of 16 channels each
-          const int pin = g * PA + (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
-          const frag bf = *reinterpret_cast<const frag*>(map + pin * PITCH + (ks & 7) * 32 + h * 16);
-          acc = SCM<T>::run(af[k2], bf, acc);
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 bv = *reinterpret_cast<const float4*>(a.ds_b + cot * 32 + 8 * qd + 4 * h);
+          acc[4 * qd + 0] = bv.x;
+          acc[4 * qd + 1] = bv.y;
+          acc[4 * qd + 2] = bv.z;
+          acc[4 * qd + 3] = bv.w;
         }
       }
-      if (olive) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) {
+        const int stp = rd * RING + i, ks = stp & (KSD - 1);
+        const int q = ks >> 3;                     // tap (ky*2 + kx): 8 k-steps of 16 channels each
+        const int pin = g * PA + (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
+        const frag bf = *reinterpret_cast<const frag*>(stg + pin * PITCH + (ks & 7) * 32 + h * 16);
+        acc = SCM<T>::run(wq[i], bf, acc);
+        if (stp + RING < NSTEP) wq[i] = *fsrc(stp + RING);
+      }
+      if ((rd & 1) == 1 && olive) {
         float* dst = a.out + ((size_t)a0 * PO + o) * CN + cot * 32 + 4 * h;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
@@ -441,20 +573,43 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   }
 }
 
-// one block's depthwise parameter image (see TAPB / PARB above); taps: tap-major [49][128] fp32
+// one block's parameter image (layout at TW_R above); taps: tap-major [49][128] fp32
 template <typename T>
 __global__ void pack_s1par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                   unsigned char* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 49 * C) reinterpret_cast<T*>(out)[i] = (T)taps[i];
-  if (i < (PARB - TAPB) / 4) {
-    float v = 0.f;
-    if (i < C) v = dw_b[i];
-    else if (i < 2 * C) v = ln_w[i - C];
-    else if (i < 3 * C) v = ln_b[i - 2 * C];
-    reinterpret_cast<float*>(out + TAPB)[i] = v;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NTW = TW_R * C * 16;
+  if (idx < NTW) {
+    const int k = idx & 3, i = (idx >> 2) & 3, c = (idx >> 4) & (C - 1), r = idx / (16 * C);
+    const int ky = r / 3, rb = r % 3 - 1, kx = 4 * rb + k - i + 3;
+    const float w = (kx >= 0 && kx < 7) ? taps[(ky * 7 + kx) * C + c] : 0.f;
+    reinterpret_cast<T*>(out)[idx] = (T)w;
+    return;
   }
+  const int f = idx - NTW;
+  if (f >= 3 * C) return;
+  float v;
+  if (f < C) v = dw_b[f];
+  else if (f < 2 * C) v = ln_w[f - C];
+  else v = ln_b[f - 2 * C];
+  reinterpret_cast<float*>(out + TW_BYTES)[f] = v;
+}
+
+// fp32 downsample filter [Cout][Cin][2][2] -> 32x32x16 A fragments [row tile][k-step][lane][8], lane l holds row
+// (l & 31), k = 16 s + 8 (l >> 5) + j of its tile, k = (2 ky + kx) * Cin + c
+template <typename T>
+__global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = 4 * cin;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 16;
+  const int sk = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  const int row = 32 * tile + (l & 31), k = 16 * sk + 8 * (l >> 5) + j;
+  const int q = k / cin, c = k - q * cin;
+  out[i] = (T)w[((long)row * cin + c) * 4 + q];
 }
 
 template <typename T> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
@@ -477,7 +632,7 @@ size_t s1par_bytes() { return PARB; }
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
                       const float* ln_b, void* out, hipStream_t st) {
   unsigned char* o = reinterpret_cast<unsigned char*>(out);
-  const dim3 grid((49 * C + 255) / 256), blk(256);
+  const dim3 grid((TW_R * C * 16 + 3 * C + 255) / 256), blk(256);
   if (prec == BTSBOT_BF16)
     hipLaunchKernelGGL(pack_s1par_kernel<bf16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
   else if (prec == BTSBOT_F16)
@@ -490,11 +645,28 @@ int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const floa
   return BTSBOT_OK;
 }
 
+// downsample filter [Cout][Cin][2][2] fp32 -> 32x32x16 MFMA A fragments (stage1b.hip's / stage0b.hip's last phase)
+int launch_pack_frag32(int prec, const float* src, void* dst, int cout, int cin, hipStream_t st) {
+  const long total = (long)cout * 4 * cin;
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(pack_frag32_kernel<bf16_t>, grid, blk, 0, st, src, reinterpret_cast<bf16_t*>(dst), cout, cin);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(pack_frag32_kernel<f16_t>, grid, blk, 0, st, src, reinterpret_cast<f16_t*>(dst), cout, cin);
+  else {
+    btsbot_set_error("pack_frag32: precision %d is not a 16-bit mode", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 bool stage1_supported(int prec, int c1, int c2) {
   return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c1 == 128 && c2 == 256;
 }
 
-// Needs Stage0Blk::par (launch_pack_s1par), ::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit.
+// Needs Stage0Blk::par (launch_pack_s1par), ::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit,
+// and Stage1Args::ds_w as MFMA fragments (launch_pack_frag32).
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage1b_t<bf16_t>(a, st);

@@ -2,10 +2,15 @@
 btsbot_amd modules, against the CPU oracle and the committed reference-wrapper goldens.
 
 Tolerances (the reference's own notion of "same output" is rtol 1e-4 / atol 1e-5 on fp32 logits,
-/root/reference/btsbot/to_onnx.py:135-137; the north star asks for scores within 1e-4):
-  f32  mode: |dlogit| <= 1e-4 * max(1, max|logit|)  and  |dscore| <= 1e-5   (measured ~1e-5 / ~1e-6)
-  f16  mode: |dscore| <= 1e-3   (measured ~1.3e-4 with worst-case layer-scale gamma ~ 1)
-  bf16 mode: |dscore| <= 1e-2   (measured ~1.1e-3, same weights)
+/root/reference/btsbot/to_onnx.py:135-137; the north star asks for scores within 1e-4).  Every bound is at most
+twice what is measured on these seeds, so a numerical regression fails the suite:
+  f32  mode: |dlogit| <= 1e-4 * max(1, max|logit|)  and  |dscore| <= 1e-5   (measured 7e-6 / 2e-6)
+  f16  mode: |dscore| <= 3e-4   (measured 1.4e-4 at B = 39, 1.7e-4 at B = 1024 with layer-scale gamma ~ 1;
+             5e-5 with gamma ~ 0.1, test_f16_meets_1e4_at_trained_like_layer_scale)
+  bf16 mode: |dscore| <= 2.5e-3 (measured 1.0e-3 .. 1.3e-3, gamma ~ 1)
+What owns the 16-bit error is the operand rounding itself (CPU emulation, tools/error_budget.py: LayerNorm
+outputs 9e-5, filters 7e-5, hidden activations 6e-5 of the f16 mode's 1.7e-4), not a kernel: a mode that
+feeds 16-bit operands to the matrix pipe cannot do better at gamma ~ 1.
 Weights are seeded random with layer-scale gamma ~ 1 (a trained checkpoint has |gamma| << 1, which
 damps the low-precision error of every block); no trained checkpoint exists offline.
 """
@@ -22,7 +27,7 @@ from oracle import convnext_oracle as O   # checker only
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL_SCORE = {"f32": 1e-5, "f16": 1e-3, "bf16": 1e-2}
+TOL_SCORE = {"f32": 1e-5, "f16": 3e-4, "bf16": 2.5e-3}
 
 
 def _oracle(kind, cfg, sd, img, meta):
@@ -154,6 +159,70 @@ def test_large_batch_properties(cuda):
     hi = run_model(kind, m, img[512:].contiguous(), meta[512:].contiguous())
     assert torch.equal(full, torch.cat([lo, hi]))
     assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_full_size_batch_matches_oracle(cuda, prec):
+    """BASELINE.json configs[1] at its full size (B = 1024, the batch bench.py times) against the oracle -- every
+    alert, not a self-comparison."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(1024, seed=2)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    ds = _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
+    print(f"B=1024 {prec}: max|dscore| {ds:.3e}")
+
+
+def test_f16_meets_1e4_at_trained_like_layer_scale(cuda):
+    """With layer scale ~0.1 (timm initialises it to 1e-6; trained ConvNeXts keep it well below 1) the f16 mode
+    is inside the north star's 1e-4 on every alert of a 256-alert batch (measured 5e-5); gamma ~ 1, the
+    stress case of the other tests, doubles every block's contribution to the error."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3, gamma=0.1)
+    img, meta, _ = synthetic_batch(256, seed=2)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, "f16")
+    out = run_model(kind, m, img.to(cuda), meta.to(cuda)).cpu()
+    ds = (torch.sigmoid(out) - torch.sigmoid(ref)).abs().max().item()
+    assert ds <= 1e-4, f"f16, gamma 0.1: max|dscore| {ds}"
+
+
+def test_trained_checkpoint_reproduces_expected_scores(cuda):
+    """Auto-activating: the only vector the reference holds for this path is the `expected_scores` column of
+    example_data/usage_candidates.csv (inference_example.py:47-95; 8 of its 39 alerts are committed in
+    tests/golden/example8.npz).  The published checkpoints cannot be fetched offline; as soon as one is placed
+    under models/BTSbot-*/ (pytorch_model.bin + train_config.json, the layout load_HF_model reads), this test
+    loads it through the drop-in entry point and requires |score - expected| <= 1e-4 on those alerts for at
+    least one of the checkpoints found (the csv does not say which model produced the column)."""
+    import glob
+    import warnings
+    import btsbot_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dirs = [d for d in sorted(glob.glob(os.path.join(root, "models", "BTSbot-*")))
+            if os.path.isfile(os.path.join(d, "pytorch_model.bin"))
+            and os.path.isfile(os.path.join(d, "train_config.json"))]
+    if not dirs:
+        pytest.skip("no trained checkpoint under models/BTSbot-*/ (no network here): parity against "
+                    "expected_scores stays unpinned")
+    ex = np.load(os.path.join(GOLD, "example8.npz"))
+    img = torch.from_numpy(ex["triplets"]).to(cuda)
+    meta = torch.from_numpy(ex["metadata"]).to(cuda)
+    expected = torch.from_numpy(ex["expected_scores"]).float()
+    errs = {}
+    for d in dirs:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = btsbot_amd.from_HF.load_checkpoint_dir(d, cuda).eval()
+        m.set_precision("f32")
+        m = m.to(cuda).eval()
+        with torch.no_grad():
+            try:
+                out = m(image_input=img, metadata_input=meta)
+            except TypeError:
+                out = m(input_data=img)
+        errs[os.path.basename(d)] = (torch.sigmoid(out).cpu().reshape(-1) - expected).abs().max().item()
+    assert min(errs.values()) <= 1e-4, f"no checkpoint reproduces expected_scores: {errs}"
 
 
 def test_bce_kernel(cuda):

@@ -98,6 +98,32 @@ def test_training_forward_and_head_gradients(cuda, name):
             assert int(out_sd[k]) == int(sd[k]) + 1
 
 
+def test_head_gradients_with_a_wide_fused_input(cuda):
+    """The backward scratch of the heads is sized from the widths in use: convnext_nano (640 image features) with
+    a 256-wide metadata branch gives an 896-wide fusion input (wider than the old fixed 768-float rows, which
+    d(z) overran into the neighbouring buffer)."""
+    kind, cfg = CONFIGS["mm_nano_ls"]
+    cfg = dict(cfg, meta_fc2_neurons=256, meta_fc1_neurons=192)
+    sd = seeded_state(kind, cfg, seed=3)
+    B = 12
+    img, meta, labels = synthetic_batch(B, seed=4)
+    masks = _masks(kind, cfg, B, seed=9)
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    trainable = [k for k, p in m.named_parameters()]
+    logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+        logits, labels.to(cuda).float().unsqueeze(1))
+    loss.backward()
+    ref_logits, _l, ref_grads, _ = _oracle_train(kind, cfg, sd, img, meta, labels, masks, 2.0, trainable)
+    _close(logits, ref_logits, "training-mode logits")
+    got = dict(m.named_parameters())
+    for k in trainable:
+        a, b = got[k].grad.cpu().double(), ref_grads[k].double()
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-7)
+        assert err <= 5e-4, f"grad {k}: rel err {err:.3e}"
+
+
 @pytest.mark.parametrize("name", ["mm_pico", "convnext", "mm_nano_ls"])
 def test_full_backward_matches_autograd(cuda, name):
     """Every parameter trainable (train.py:233-236): gradients of the whole model -- stem, every
@@ -226,7 +252,7 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
     assert not torch.equal(want, run_model(kind, build_model(kind, cfg, sd, cuda, "bf16"), img, meta))
 
 
-@pytest.mark.parametrize("prec,bound", [("f16", 1.5e-2), ("bf16", 8e-2)])
+@pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, prec, bound):
     """The 16-bit training schedule (LDS-DMA GEMMs with the GELU_SAVE / DGELU / PLAIN epilogues, the MFMA
     filter-gradient GEMM with its two-pass slice reduction, depthwise / LayerNorm backward on saved maps)
