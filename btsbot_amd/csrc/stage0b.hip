@@ -462,7 +462,10 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         // this wave's pieces of chunk ch have landed once only the younger chunk is outstanding
         if (ch + 1 < NCH) wait_vm<2>();
         else wait_vm<0>();
-        __syncthreads();   // ... everyone's; chunk ch-1 is read out (and xf is loaded, ch == 0)
+        // raw barrier: __syncthreads() would also wait vmcnt(0) while an LDS-DMA is in flight and so drain the two
+        // chunks this ring keeps ahead (the chunk time then IS the DMA latency, ~2k cycles for ~1k of work)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // chunk ch has landed for everyone; chunk ch-1 is read out
         // the LN image is dead once every wave holds its xf: clear it for the next block's planar image
         // (whose padding must read as zero) while the matrix pipe works
         if (ch == 1 && j == 0) zero_planar();
@@ -479,20 +482,26 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
             const int r = ct * 32 + lr;
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
+        // (inline asm: behind a compiler-visible ds_read of anything but the ring hipcc waits vmcnt(0) -- it cannot
+        //  tell that the bias words are not an LDS-DMA destination -- and the ring's two chunks in flight are gone)
+        f32x4 bq[4];
+        {
+          const unsigned baddr = (unsigned)(size_t)(lptr_t)(b1s + ch * 32 + 8 * h);
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\t"
+                       "ds_read_b128 %3, %4 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]) : "v"(baddr) : "memory");
+        }
+        // every fragment read is queued before the first product (see stage1b.hip)
+        __builtin_amdgcn_sched_barrier(0);
         // both column blocks' fc1 first: the second one's MFMAs run under the first one's GELU
         f32x16 hacc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // accumulator row (r&3) + 8(r>>2) + 4h holds hidden unit 32ch + (r&3) + 4((r>>2)&1) + 8h + 16(r>>3)
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const float4 bv = *reinterpret_cast<const float4*>(b1s + ch * 32 + 4 * (qd & 1) + 8 * h +
-                                                               16 * (qd >> 1));
-            hacc[t][4 * qd + 0] = bv.x;
-            hacc[t][4 * qd + 1] = bv.y;
-            hacc[t][4 * qd + 2] = bv.z;
-            hacc[t][4 * qd + 3] = bv.w;
-          }
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hacc[t][4 * qd + e] = bq[qd][e];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
         }

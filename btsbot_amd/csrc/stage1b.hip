@@ -17,13 +17,16 @@
 //     (the VALU form this replaces: 25k cycles per block, 2 x 49 x 7 FMAs per lane plus conversions);
 //   * LayerNorm: transposing lane reduction over the 16 blocks, the 4 waves meet through LDS (stage0b.hip);
 //     its 16-bit output is the MLP's B operand image, in ring slots 0..1 until the MLP has loaded it;
-//   * pointwise filters: 16 KB chunks of 32 hidden units (W1 rows + gamma*W2 columns) through a
-//     3-slot LDS-DMA ring straight from the plain row-major filters; the per-lane source address
-//     applies the bank swizzles and the bit-2/bit-3 row swap that makes the fc1 accumulator the
-//     fc2 B operand in plain k order (stage0b.hip); fc2 accumulates into the residual registers.  Ring slot 2
-//     shares its bytes with the planar image (dead once the depthwise phase is over).
+//   * pointwise filters: chunks of 32 hidden units (8 KB of W1 rows + 8 KB of gamma*W2 columns) through two
+//     3-slot LDS-DMA rings straight from the plain row-major filters (waves 0, 1 load W1, waves 2, 3 load W2); the
+//     per-lane source address applies the bank swizzles and the bit-2/bit-3 row swap that makes the fc1 accumulator
+//     the fc2 B operand in plain k order (stage0b.hip); fc2 accumulates into the residual registers.  The rings
+//     live in the planar image's and the LN image's bytes (dead by then).  The chunk loop is software-pipelined
+//     inside the wave: W1 fragments and the fc1 bias of chunk ch+1 are in registers before step ch starts, its fc1
+//     MFMAs issue between the GELUs of chunk ch, chunk ch's fc2 MFMAs between the second half's GELUs.
 #include "common.h"
 #include "stage0.h"
+#include <type_traits>
 
 namespace {
 
@@ -59,7 +62,7 @@ constexpr int C = 128, HW = 7, PA = 49, G = 2, NPX = G * PA, CT = 4, HID = 512, 
 constexpr int CN = 256, PO = 9;                   // downsample: output channels, pixels per alert
 constexpr int PITCH = 2 * C + 16;                 // [pixel][channel] image: 272 bytes per pixel row
 constexpr int MAPB = NPX * PITCH;                 // 26656: lives in ring slots 0..1
-constexpr int CHUNKB = 16384, NCH = HID / 32, NSLOT = 3;
+constexpr int CHUNKB = 16384, HALFB = CHUNKB / 2, NCH = HID / 32, NSLOT = 3;
 // planar image of the depthwise phase: [alert][x quad 0..1][row 0..6, 7 = zeros][channel, pitch 136][4 x]
 constexpr int PL_ROW = 136 * 8, PL_XQ = 8 * PL_ROW, PL_AL = 2 * PL_XQ, PLB = G * PL_AL;   // 1088, 8704, 17408, 34816
 constexpr int OFF_PL = 2 * CHUNKB;                // ring slots 0, 1 | planar image = ring slot 2 + 18 KB
@@ -67,7 +70,7 @@ constexpr int OFF_B1 = OFF_PL + PLB;              // 512 floats fc1 bias + 128 f
 constexpr int OFF_PART = OFF_B1 + (HID + C) * 4;  // LayerNorm partial sums [2][4 waves][128 slots]
 constexpr int OFF_ST = OFF_PART + 2 * 4 * 128 * 4;   // (rstd, -mean * rstd) per padded pixel slot [2][128]
 constexpr int LDS_BYTES = OFF_ST + 2 * 128 * 4;   // 75264: two workgroups per CU
-static_assert(MAPB <= 2 * CHUNKB && CHUNKB <= PLB && LDS_BYTES <= 80 * 1024, "LDS layout");
+static_assert(MAPB <= 2 * CHUNKB && 4 * HALFB <= PLB && LDS_BYTES <= 80 * 1024, "LDS layout");
 constexpr float LN_EPS = 1e-6f;
 // per-block parameter image in HBM (launch_pack_s1par): Toeplitz taps in the operand type
 //   [r = ky * 3 + (rb + 1)][channel][i][k] = W[channel][ky][4 rb + k - i + 3]   (0 outside the 7 taps)
@@ -195,18 +198,20 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
   float* b2s = b1s + HID;
   float* part = reinterpret_cast<float*>(smem + OFF_PART);
   float* st = reinterpret_cast<float*>(smem + OFF_ST);
-  auto slot_ptr = [&](int sl) { return sl < 2 ? smem + sl * CHUNKB : smem + OFF_PL; };
+  // filter rings, 3 slots of 8 KB each: the W1 slots and W2 slot 0 lie in the planar image (dead once the depthwise
+  // phase is over, so the first chunk is requested under the LayerNorm), W2 slots 1, 2 in the LN image's bytes
+  auto w1slot = [&](int sl) { return pl + sl * HALFB; };
+  auto w2slot = [&](int sl) { return sl == 0 ? pl + 3 * HALFB : smem + (sl - 1) * HALFB; };
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
+  const bool w1wave = wave < 2;
   const int a0 = blockIdx.x * G;
   const int nal = min(G, a.B - a0);
   const int p = wave * 32 + lr;                      // this lane's pixel slot (MFMA phases)
   const bool live = p < nal * PA;
   const bool inmap = p < NPX;
   const int pm = inmap ? p : 0;                      // row to read for slots beyond the image
-  // depthwise roles: lane = (block b, row offset j); wave = channel groups 2 wave, 2 wave + 1 of both alerts
-  const int dj = lane & 3, db = lane >> 2;
   SC_STAMP(0);
   // what the live writes never touch and the depthwise products read: the zero rows and column 7
   auto zero_pads = [&]() {
@@ -246,14 +251,21 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 
   f32x16 x[CT];   // (written in full at the start of every MLP: dead through the depthwise phases)
   const int rot = (blockIdx.x * 5 + (blockIdx.x >> 4)) & (NCH - 1);   // chunk rotation, see issue()
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < 2; ++j) {
     const Stage0Blk& bk = a.blk[j];
+    // depthwise roles: lane = (block b, row offset j); wave = channel groups 2 wave, 2 wave + 1 of both alerts.
+    // (The lane id is laundered per block: with the block loop unrolled hipcc otherwise computes every address of
+    //  BOTH blocks' depthwise / LayerNorm phases once, keeps them across the first MLP and starves its filter
+    //  fragments of registers -- fc1 then waits for an LDS read in front of every MFMA.)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int dj = ln & 3, db = ln >> 2;
     // ---- ordinary loads first (vmcnt retires in order: a load younger than a DMA would wait for it): fc1 bias,
     //      gamma*b2, the first channel group's Toeplitz taps and both groups' per-channel scalars
     const float b1v0 = bk.b1[tid], b1v1 = bk.b1[256 + tid];
     const float b2v = bk.gamma[tid & (C - 1)] * bk.b2[tid & (C - 1)];
-    const uint2* twsrc = reinterpret_cast<const uint2*>(bk.par) + (2 * wave) * 64 + lane;
+    const uint2* twsrc = reinterpret_cast<const uint2*>(bk.par) + (2 * wave) * 64 + ln;
     frag4 tw[TW_R];
 #pragma unroll
     for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, twsrc[r * 512]);
@@ -290,16 +302,17 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         wsrc[i] = bk.w2g + (size_t)r * (HID * 2) + (((lane & 3) ^ swz4(r)) << 4);
       }
     }
-    // chunk ch adds 32 W1 rows (8192 B) resp. 32 W2 columns (64 B)
-    const int wstep0 = wave < 2 ? 32 * C * 2 : 64;
+    // chunk k adds 32 W1 rows (8192 B) resp. 32 W2 columns (64 B)
+    const int wstep0 = w1wave ? 32 * C * 2 : 64;
     // (every workgroup walks the 16 chunks in its own rotation -- fc2 sums over the hidden units,
     //  so the order is free -- which keeps the 512 workgroups off the same L2 lines)
-    auto issue = [&](int ch) {
+    // waves 0, 1 load the W1 half of chunk k into W1 slot k % 3, waves 2, 3 the W2 half into W2 slot k % 3
+    auto issue = [&](int k) {
+      unsigned char* dst = (w1wave ? w1slot(k % NSLOT) : w2slot(k % NSLOT)) + (wave & 1) * 4096;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((ch + rot) & (NCH - 1)) * wstep0),
-                                         (lptr_t)(slot_ptr((ch + 2) % NSLOT) + (wave * 4 + i) * 1024),
-                                         16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
+                                         (lptr_t)(dst + i * 1024), 16, 0, 0);
     };
     SC_STAMP(3 + 5 * j);
 
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         for (int al = 0; al < G; ++al)
 #pragma unroll
           for (int n = 0; n < 16; ++n) s1[al * 16 + n] = v[0][al][n] + v[1][al][n];
-        block_reduce32(s1, lane, o1);
+        block_reduce32(s1, ln, o1);
       }
       {
         float s2[32];
@@ -375,10 +388,10 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         for (int al = 0; al < G; ++al)
 #pragma unroll
           for (int n = 0; n < 16; ++n) s2[al * 16 + n] = fmaf(v[0][al][n], v[0][al][n], v[1][al][n] * v[1][al][n]);
-        block_reduce32(s2, lane, o2);
+        block_reduce32(s2, ln, o2);
       }
       // padded pixel slot [alert][row 0..7][column 0..7] of this lane's two totals
-      const int slot = (lane >> 5) * 64 + (4 * ((lane >> 4) & 1) + dj) * 8 + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1);
+      const int slot = (ln >> 5) * 64 + (4 * ((ln >> 4) & 1) + dj) * 8 + 4 * ((ln >> 3) & 1) + 2 * ((ln >> 2) & 1);
       *reinterpret_cast<float2*>(part + wave * 128 + slot) = make_float2(o1[0], o1[1]);
       *reinterpret_cast<float2*>(part + 512 + wave * 128 + slot) = make_float2(o2[0], o2[1]);
     }
@@ -421,7 +434,13 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     issue(0);          // chunk 0 lives in slot 2 = the (dead) planar image's first 16 KB
     SC_STAMP(5 + 5 * j);
 
-    // ---- fc1 -> GELU -> fc2 over 16 chunks; fc2 accumulates into x (gamma is in the filter)
+    // ---- fc1 -> GELU -> fc2 over 16 chunks, software-pipelined inside the wave: step ch issues chunk ch+1's fc1 MFMAs
+    //      between the GELUs of chunk ch (one element per MFMA: ~7 VALU instructions pass while the matrix pipe
+    //      works on a 32-cycle product), then chunk ch's fc2 MFMAs between the second half's GELUs.  Without this a
+    //      wave runs LDS reads -> 8 dependent MFMAs -> 120 VALU -> 8 MFMAs strictly one after the other (2.9k cycles per
+    //      chunk).  What bounds the loop now is the LDS port: every wave reads the whole 16 KB chunk for its 32 pixel
+    //      slots, 2 x 80 KB per CU and step = 1.3k cycles at 128 B/clk (measured: 41k cycles per block when both
+    //      workgroups of the CU are in their MLP, 27k when one is).  fc2 accumulates into x (gamma is in the filter).
     load_x(j == 0 ? xsrc : xscr, x);
     {
       frag xf[KS1];
@@ -439,22 +458,68 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
           x[ct][4 * qd + 3] += bv.w;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // xf is in registers
-      __syncthreads();   // ... everyone's: slots 0..1 may be overwritten
+      __syncthreads();   // ... everyone's: the LN image's bytes may take the W2 ring's slots 1, 2
       issue(1);
-      issue(2);
-#pragma unroll 1
-      for (int ch = 0; ch < NCH; ++ch) {
-        // VM order of a wave: chunk 0, chunk 1, chunk 2, then chunk ch+2 at iteration ch >= 1
-        if (ch == 0) wait_vm<8>();
-        else if (ch + 1 < NCH) wait_vm<4>();
-        else wait_vm<0>();
-        __syncthreads();   // chunk ch has landed for everyone; chunk ch-1 is read out
-        const unsigned char* w1s = slot_ptr((ch + 2) % NSLOT);
-        const unsigned char* w2s = w1s + 8192;
-        frag a1[KS1], a2[CT][2];
+      if (w1wave) issue(2);
+      // fc1 bias of chunk k into an accumulator: row (r&3) + 8(r>>2) + 4h holds hidden unit
+      // 32k + (r&3) + 4((r>>2)&1) + 8h + 16(r>>3).  (Read as 16-bit vectors like the filter fragments: behind an LDS
+      // read of float type hipcc waits vmcnt(0) while an LDS-DMA is in flight -- its type-based alias test takes the
+      // DMA for a possible writer of those words -- and the chunks this ring keeps ahead are drained.)
+      auto bias_acc = [&](int k, f32x16& acc) {
+        const float* bp = b1s + ((k + rot) & (NCH - 1)) * 32 + 8 * h;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 bv = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(bp + 4 * (qd & 1) + 16 * (qd >> 1)));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * qd + e] = bv[e];
+        }
+      };
+      auto read_a1 = [&](int k, frag (&a1)[KS1]) {
+        const unsigned char* w1s = w1slot(k % NSLOT);
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks)
           a1[ks] = *reinterpret_cast<const frag*>(w1s + lr * 256 + (((ks * 2 + h) ^ (lr & 15)) << 4));
+      };
+#ifdef S1_LOOPSTAMP
+      unsigned long long lts[16];
+#define LS(i) do { __builtin_amdgcn_sched_barrier(0); if (ch == 6 || ch == 7) lts[i + 8 * (ch - 6)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LS(i)
+#endif
+      // Register pipeline: entering step ch the wave holds hc = fc1 of chunk ch, hn = the fc1 bias of chunk ch + 1 and
+      // a1 = the W1 fragments of chunk ch + 1 (both requested in the middle of step ch - 1, so their LDS latency --
+      // 400+ cycles when eight waves read 20 KB each -- is not in anybody's way).
+      f32x16 hacc[2];
+      frag a1[KS1];
+      {   // prologue: chunk 0's fc1, then the operands of step 0
+        wait_vm<4>();   // W1(0) (and x) landed; at most this wave's youngest group is still out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bias_acc(0, hacc[0]);
+        read_a1(0, a1);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) hacc[0] = SCM<T>::run(a1[ks], xf[ks], hacc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm<0>();   // W1(1), W1(2) / W2(1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // ... for everyone, and W1 slot 0 is read out
+        bias_acc(1, hacc[1]);
+        read_a1(1, a1);
+        if (w1wave) issue(3);
+      }
+      // one step: hc = fc1 of chunk ch (complete), hn = bias of chunk ch + 1 <- fc1 of chunk ch + 1; hc <- bias of ch + 2
+      auto step = [&](auto last_c, int ch, f32x16& hc, f32x16& hn) {
+        constexpr bool LAST = decltype(last_c)::value;
+        LS(0);
+        // VM order of a wave: W1 waves W1(0..ch+3), W2 waves W2(0..ch+1); both need all but their youngest group
+        wait_vm<4>();
+        LS(1);
+        // raw barrier: __syncthreads() would also wait vmcnt(0) while an LDS-DMA is in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the last step is home
+        __builtin_amdgcn_s_barrier();   // W1(ch+2), W2(ch) have landed for everyone; W1(ch+1), W2(ch-1) are read out
+        LS(2);
+        frag a2[CT][2];
+        const unsigned char* w2s = w2slot(ch % NSLOT);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -462,33 +527,50 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
             const int r = ct * 32 + lr;
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
-        f32x16 hacc;
-        // accumulator row (r&3) + 8(r>>2) + 4h holds hidden unit 32ch + (r&3) + 4((r>>2)&1) + 8h + 16(r>>3)
+        LS(3);
+        issue(ch + (w1wave ? 4 : 2));   // (indices past the last chunk wrap: harmless reloads into dead slots)
+        __builtin_amdgcn_sched_barrier(0);
+        LS(4);
+        float g[16];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const float4 bv = *reinterpret_cast<const float4*>(b1s + ((ch + rot) & (NCH - 1)) * 32 +
-                                                             4 * (qd & 1) + 8 * h + 16 * (qd >> 1));
-          hacc[4 * qd + 0] = bv.x;
-          hacc[4 * qd + 1] = bv.y;
-          hacc[4 * qd + 2] = bv.z;
-          hacc[4 * qd + 3] = bv.w;
+        for (int r = 0; r < 8; ++r) {
+          if (!LAST) hn = SCM<T>::run(a1[r], xf[r], hn);
+          g[r] = gelu_for<T>(hc[r]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        LS(5);
+        if (!LAST) read_a1(ch + 2, a1);
+        frag hf;
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) hacc = SCM<T>::run(a1[ks], xf[ks], hacc);
-        // the next chunk's LDS-DMA is issued HERE: an LDS-DMA holds the issuing wave for ~90 cycles
-        // per instruction, which now passes while the fc1 MFMA chain drains
-        if (ch >= 1 && ch + 2 < NCH) issue(ch + 2);
-        // GELU in two halves, each followed by the fc2 MFMAs that consume it: the first half's
-        // MFMAs run while the second half's GELU issues
+        for (int r = 0; r < 8; ++r) hf[r] = (T)g[r];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          frag hf;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_for<T>(hacc[8 * s2 + r]);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][s2], hf, x[ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          x[ct] = SCM<T>::run(a2[ct][0], hf, x[ct]);
+          g[8 + 2 * ct] = gelu_for<T>(hc[8 + 2 * ct]);
+          g[9 + 2 * ct] = gelu_for<T>(hc[9 + 2 * ct]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (!LAST) bias_acc(ch + 2, hc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) hf[r] = (T)g[8 + r];
+        LS(6);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][1], hf, x[ct]);
+        LS(7);
+      };
+#pragma unroll 1
+      for (int ch = 0; ch < NCH - 2; ch += 2) {
+        step(std::false_type{}, ch, hacc[0], hacc[1]);
+        step(std::false_type{}, ch + 1, hacc[1], hacc[0]);
       }
+      step(std::false_type{}, NCH - 2, hacc[0], hacc[1]);
+      step(std::true_type{}, NCH - 1, hacc[1], hacc[0]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last prefetches (unused) are not left in flight
+#ifdef S1_LOOPSTAMP
+      if (a.wgt != nullptr && blockIdx.x == 0 && tid == 0 && j == 0)
+        for (int i = 0; i < 16; ++i) a.wgt[4096 + i] = lts[i];
+#endif
+      wait_vm<0>();   // the wrapped reloads: nothing may land in the ring once its bytes are reused
       if (j == 0) {      // next block's depthwise operand; chunk 15 (slot 2 = the same bytes) must be read out first
         __syncthreads();
         zero_pads();

@@ -27,7 +27,7 @@ for base, tag in ((0, "stage0"), (16, "stage1")):
         print(f"   {names[i]:22s} +{t[base + i] - t[base + i - 1]:8d}")
 
 import numpy as np
-for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
+for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 1) // 2)):
     w = np.array(t[off:off + 2 * n]).reshape(n, 2)
     t0 = w[:, 0].min()
     dur = (w[:, 1] - w[:, 0]) / 100.0
@@ -38,6 +38,9 @@ for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 3) // 4)):
     print("   duration deciles", np.percentile(dur, [10, 30, 50, 70, 90]).round(1))
     print("   start deciles   ", np.percentile(st, [10, 30, 50, 70, 90]).round(1))
 
+ls = t[32 + 8192 + 4096:32 + 8192 + 4096 + 16]
+if any(ls):
+    print("stage1 loop stamps (steps 6, 7):", [ls[i + 1] - ls[i] for i in range(15)])
 s2 = t[32 + 16384:32 + 16384 + 64]
 print("stage2p (workgroup 0) total cycles", s2[58] - s2[0])
 print(f"   prologue (zero fill, x load)    +{s2[1] - s2[0]:8d}")
