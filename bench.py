@@ -154,6 +154,15 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
     w["s2_fc1_kernel"] = dict(
         flop=pw(*st[2]) if s2 else 0,
         bytes=st[2][0] * (batch * 9 * dims[2] * 4 + batch * 9 * 4 * dims[2] * esz + 4 * dims[2] ** 2 * esz))
+    # stage 3 (1x1 maps) at C in {512, 640}: two fragment-streaming launches per block (stage3.hip)
+    s3 = precision != "f32" and dims[3] in (512, 640) and os.environ.get("BTSBOT_AMD_NO_S3", "0") != "1"
+    w["s3_fc1_kernel"] = dict(
+        flop=pw(*st[3]) if s3 else 0,
+        bytes=st[3][0] * (batch * dims[3] * 4 + batch * 4 * dims[3] * esz + 4 * dims[3] ** 2 * esz))
+    w["s3_fc2_kernel"] = dict(
+        flop=pw(*st[3]) if s3 else 0,
+        bytes=st[3][0] * (batch * 4 * dims[3] * esz + 2 * batch * dims[3] * 4 + 4 * dims[3] ** 2 * esz))
+    mega[3] = s3
     unf = [u and not mega[i] for i, u in enumerate(unf)]
     unf1 = [u and not (s2 and i == 2) for i, u in enumerate(unf)]
     w["gemm_kernel<fc1,GELU>"] = dict(
@@ -178,10 +187,12 @@ def family_work(batch, precision, depths=(2, 2, 6, 2), dims=(64, 128, 256, 512))
                             bytes=batch * (3 * 63 * 63 * 4 + 225 * dims[0] * 4))
     w["head_kernel"] = dict(flop=2 * batch * (25 * 128 + 128 * 128 + 640 * 128 + 128 * 32 + 32),
                             bytes=batch * (dims[3] * 4 + 25 * 4 + 8))
+    w["head16_kernel"] = dict(w["head_kernel"])   # the same head on the matrix pipe (16-bit modes)
     return w
 
 
-POINTWISE = ("stage0b_kernel", "stage1b_kernel", "stage2p_kernel", "s2_fc1_kernel", "fused_mlp_kernel", "gemm_kernel<fc1,GELU>",
+POINTWISE = ("stage0b_kernel", "stage1b_kernel", "stage2p_kernel", "s3_fc1_kernel", "s3_fc2_kernel", "s2_fc1_kernel", "fused_mlp_kernel",
+             "gemm_kernel<fc1,GELU>",
              "gemm_kernel<fc2,RESID>")
 
 

@@ -12,6 +12,8 @@
 #include "maxvit.h"
 #include "stage0.h"
 #include "stage2p.h"
+#include "stage3.h"
+#include "head16.h"
 
 // ---------------------------------------------------------------------------------------
 // errors
@@ -73,6 +75,7 @@ int build_tables(btsbot_ctx* h) {
     h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
     h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(c.precision, c.dims[2], c.dims[3], c.depths[2]);
+    h->stage3 = stage3_supported(c.precision, c.dims[3], c.depths[3]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
@@ -107,7 +110,7 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
                     : (i == 1 && ch == 128 && c.precision != BTSBOT_F32) ? bump(cur, s1par_bytes()) : 0;
-        if (i == 2 && h->stage2p) {
+        if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
         }
@@ -144,6 +147,15 @@ int build_tables(btsbot_ctx* h) {
     h->comb_w[i] = add_param(h, p + "weight", {h->comb_dims[i + 1], h->comb_dims[i]});
     h->comb_b[i] = add_param(h, p + "bias", {h->comb_dims[i + 1]});
     h->p_comb[i] = bump(cur, (size_t)h->comb_dims[i + 1] * h->comb_dims[i] * 4);
+  }
+  h->head16 = head16_supported(c.precision, h->has_image ? c.dims[3] : 0, h->has_meta ? c.n_meta : 0, c.meta_fc1, c.meta_fc2,
+                               h->n_comb, h->comb_dims);
+  if (h->head16) {
+    if (h->has_meta) {
+      h->p_m1h = bump(cur, head16_packed_bytes(c.meta_fc1, c.n_meta));
+      h->p_m2h = bump(cur, head16_packed_bytes(c.meta_fc2, c.meta_fc1));
+    }
+    for (int i = 0; i < h->n_comb; ++i) h->p_combh[i] = bump(cur, head16_packed_bytes(h->comb_dims[i + 1], h->comb_dims[i]));
   }
   h->extra_bytes = cur;
   // gradient buckets, in the order the backward pass completes them
@@ -183,7 +195,12 @@ void ws_layout(const btsbot_ctx* h, int chunk, size_t* ox, size_t* ox2, size_t* 
     *ox = bump(cur, x_el * chunk * 4);
     *ox2 = bump(cur, x_el * chunk * 4);
     *oxn = bump(cur, xn_el * chunk * h->esz());
-    *oh = bump(cur, h_el * chunk * h->esz());
+    size_t h_bytes = h_el * chunk * h->esz();
+    if (h->stage3) {   // stage3.hip keeps GELU(fc1) in fragment order, alerts rounded up to its 64-row tiles
+      const size_t s3 = stage3_hfrag_bytes(c.precision, c.dims[3], chunk);
+      h_bytes = s3 > h_bytes ? s3 : h_bytes;
+    }
+    *oh = bump(cur, h_bytes);
   }
   *total = cur > 256 ? cur : 256;
 }
@@ -281,6 +298,14 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_s2 = !(n2 != nullptr && n2[0] == '1');
   const char* n2p = getenv("BTSBOT_AMD_NO_S2P");
   h->use_s2p = h->use_s2 && !(n2p != nullptr && n2p[0] == '1');
+  {
+    const char* nh = getenv("BTSBOT_AMD_NO_HEAD16");
+    h->use_head16 = !(nh != nullptr && nh[0] == '1');
+  }
+  {
+    const char* n3 = getenv("BTSBOT_AMD_NO_S3");
+    h->use_s3 = !(n3 != nullptr && n3[0] == '1');
+  }
   *out = h;
   return BTSBOT_OK;
 }
@@ -440,6 +465,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s2p(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, st));
           TRY(launch_pack_s2p(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, st));
         }
+        if (i == 3 && h->stage3 && !train_only) {
+          TRY(launch_pack_s3(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 1, st));
+          TRY(launch_pack_s3(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, st));
+        }
         if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
@@ -458,6 +487,14 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   if (convnext && h->stage2p && !train_only)
     TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], st));
+  if (h->head16) {
+    if (h->has_meta) {
+      TRY(launch_pack_h16(c.precision, m + h->m1_w, h->extra + h->p_m1h, c.meta_fc1, c.n_meta, st));
+      TRY(launch_pack_h16(c.precision, m + h->m2_w, h->extra + h->p_m2h, c.meta_fc2, c.meta_fc1, st));
+    }
+    for (int i = 0; i < h->n_comb; ++i)
+      TRY(launch_pack_h16(c.precision, m + h->comb_w[i], h->extra + h->p_combh[i], h->comb_dims[i + 1], h->comb_dims[i], st));
+  }
   if (h->has_meta) {
     TRY(launch_bn_fold(m + h->bn_w, m + h->bn_b, m + h->bn_rm, m + h->bn_rv,
                        reinterpret_cast<float*>(h->extra + h->p_bn_scale),
@@ -731,6 +768,35 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         down_done = true;
         continue;
       }
+      if (i == 3 && hw == 1 && h->stage3 && h->use_s3) {
+        // the 1x1 stage: two launches per block, x updated in place
+        Stage3Args a;
+        memset(&a, 0, sizeof(a));
+        a.x = x;
+        a.depth = (int)h->blocks[3].size();
+        for (int j = 0; j < a.depth; ++j) {
+          const BlockPk& b = h->blocks[3][j];
+          a.blk[j].dw_c = reinterpret_cast<const float*>(h->extra + b.p_dw) + 24 * ch;   // tap-major [49][C]: the centre row
+          a.blk[j].dw_b = m + b.dw_b;
+          a.blk[j].ln_w = m + b.ln_w;
+          a.blk[j].ln_b = m + b.ln_b;
+          a.blk[j].w1p = h->extra + b.p_w1p;
+          a.blk[j].b1 = m + b.fc1_b;
+          a.blk[j].w2p = h->extra + b.p_w2p;
+          a.blk[j].b2 = m + b.fc2_b;
+          a.blk[j].gamma = m + b.gamma;
+        }
+        a.hfrag = hb;
+        a.B = nb;
+        a.stamps = h->stamps ? h->stamps + 32 + 16384 + 64 : nullptr;
+        for (int j = 0; j < a.depth; ++j) {
+          TRY(timed(h, CAT_S3FC1, st, [&] { return launch_stage3(c.precision, ch, a, j, 0, st); }));
+          TRY(timed(h, CAT_S3FC2, st, [&] { return launch_stage3(c.precision, ch, a, j, 1, st); }));
+        }
+        if (h->debug)
+          HIP_TRY(hipMemcpyAsync(h->taps[4], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice, st));
+        continue;
+      }
       for (const BlockPk& b : h->blocks[i]) {
         if (h->use_s2 && c.precision != BTSBOT_F32 && hw == 3 && ch == 256) {
           // depthwise + LN + fc1 + GELU in one launch (stage2.hip), then the fc2 GEMM
@@ -782,6 +848,33 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
   const float* m = h->mirror;
   float* x = nullptr;
   if (h->has_image) TRY(backbone_chunk(h, img, nb, st, &x));
+  if (h->head16 && h->use_head16) {
+    Head16Args g;
+    memset(&g, 0, sizeof(g));
+    g.feat = h->has_image ? x : nullptr;
+    g.feat_dim = h->has_image ? c.dims[3] : 0;
+    g.hn_w = h->hn_w >= 0 ? m + h->hn_w : nullptr;
+    g.hn_b = h->hn_b >= 0 ? m + h->hn_b : nullptr;
+    if (h->has_meta) {
+      g.meta = meta;
+      g.n_meta = c.n_meta;
+      g.bn_scale = reinterpret_cast<const float*>(h->extra + h->p_bn_scale);
+      g.bn_shift = reinterpret_cast<const float*>(h->extra + h->p_bn_shift);
+      g.m1 = H16Layer{h->extra + h->p_m1h, m + h->m1_b, c.n_meta, c.meta_fc1, h->act};
+      g.m2 = H16Layer{h->extra + h->p_m2h, m + h->m2_b, c.meta_fc1, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE};
+    }
+    g.n_layers = h->n_comb;
+    for (int i = 0; i < h->n_comb; ++i)
+      g.comb[i] = H16Layer{h->extra + h->p_combh[i], m + h->comb_b[i], h->comb_dims[i], h->comb_dims[i + 1],
+                           i + 1 < h->n_comb ? h->act : ACT_NONE};
+    g.logits = logits;
+    g.scores = scores;
+    g.B = nb;
+    g.stamps = h->stamps ? h->stamps + 32 + 16384 + 64 + 1500 : nullptr;
+    TRY(timed(h, CAT_HEAD16, st, [&] { return launch_head16(c.precision, g, st); }));
+    h->last_chunk = nb;
+    return BTSBOT_OK;
+  }
   HeadArgs a;
   memset(&a, 0, sizeof(a));
   a.feat = h->has_image ? x : nullptr;

@@ -18,7 +18,7 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   size_t p_dw, p_fc1, p_fc2, p_fused;
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
-  size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip: fc1 / gamma * fc2 filters as MFMA A fragments
+  size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip / stage3.hip: fc1 / gamma * fc2 filters as MFMA A fragments
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
 };
@@ -30,13 +30,13 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_S2FC1, CAT_STAGE2,
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_S2FC1, CAT_STAGE2, CAT_S3FC1, CAT_S3FC2, CAT_HEAD16,
        CAT_MV_STEM, CAT_MV_G_STEM, CAT_MV_G_CONV1, CAT_MV_G_CONV3, CAT_MV_G_SC, CAT_MV_G_QKV, CAT_MV_G_PROJ, CAT_MV_G_FC1,
        CAT_MV_G_FC2, CAT_MV_FUSED, CAT_MV_FRONT, CAT_MV_ABLK, CAT_MV_ELT, CAT_MV_DW, CAT_MV_SE, CAT_MV_LN, CAT_MV_ATTN, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
                                      "head_kernel", "fused_mlp_kernel", "stage0b_kernel", "stage1b_kernel",
-                                     "s2_fc1_kernel", "stage2p_kernel",
+                                     "s2_fc1_kernel", "stage2p_kernel", "s3_fc1_kernel", "s3_fc2_kernel", "head16_kernel",
                                      "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
                                      "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
                                      "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
@@ -64,6 +64,9 @@ struct btsbot_ctx {
   int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
   int64_t comb_w[3], comb_b[3];
   size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift, p_stem16 = 0;
+  size_t p_m1h = 0, p_m2h = 0, p_combh[3] = {0, 0, 0};   // head16.hip: the Linear filters as split A fragments
+  bool head16 = false;     // the 16-bit modes run the head on the matrix pipe (head16.hip)
+  bool use_head16 = true;  // BTSBOT_AMD_NO_HEAD16=1: the fp32 VALU head (head.hip) instead
   bool stage0 = false;     // stem + stage 0 + first downsample as one kernel
 
   // device memory
@@ -88,6 +91,8 @@ struct btsbot_ctx {
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
   bool use_s2p = true;     // BTSBOT_AMD_NO_S2P=1: per-block launches (stage2.hip + fc2 GEMM) instead of stage2p.hip
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
+  bool stage3 = false;     // stage3.hip: the 1x1 stage as two fragment-streaming launches per block
+  bool use_s3 = true;      // BTSBOT_AMD_NO_S3=1: dwconv_ln + the generic GEMMs instead
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
   bool stage1 = false;     // stage 1 + second downsample as one kernel
   bool use_stage0 = true;

@@ -1,0 +1,306 @@
+// Stage-3 pointwise kernels (gfx950).  The last ConvNeXt stage works on 1x1 maps, so a block
+//
+//     x += gamma * fc2( GELU( fc1( LN( dwconv7x7(x) ) ) ) )
+//
+// (timm ConvNeXtBlock, reached from /root/reference/btsbot/architectures.py:108,132) is two GEMMs over the batch:
+// [B x C] x [C x 4C] and [B x 4C] x [4C x C], with the depthwise filter reduced to its centre tap.  Two launches per
+// block, 256 workgroups of 8 waves each at B = 1024, every global operand a 1 KiB contiguous MFMA fragment:
+//   s3_fc1  tile = 32 alerts x 256 hidden units, wave = 32 hidden units.  The 32 rows are requested first, then the
+//           wave's filter fragments (straight into registers, all of them): centre tap + bias + LayerNorm of the rows
+//           (4 per wave; redone by the 8 tiles that share them: 32 x C values, cheaper than a launch of its own) runs
+//           while the filter streams in; 16-bit rows in LDS are the B operand.  Epilogue bias + GELU; the filter rows
+//           are packed with bits 2/3 of the row index swapped, so a lane's accumulator holds 2 x 8 consecutive hidden
+//           units of its alert = exactly fc2's B fragment: h leaves as [alert block][k-step][lane][8], 1 KiB per store.
+//   s3_fc2  tile = 64 alerts x 32 channels, the 8 waves split K = 4C; A (gamma * W2) and B (h) fragments are all
+//           requested up front (48 per wave); the partial tiles meet in LDS, + gamma * b2 + x, in place.
+// Bound: what one CU can pull through its TA port, ~64 B/clk: 320 KB per fc1 tile, 384 KB per fc2 tile = 5k / 6k
+// cycles, behind one MALL round trip (the L2s start every kernel empty); algorithmic FLOPs 2 x 2.1 GFLOP per block.
+// (One cooperative launch for the whole stage was tried: a grid-wide barrier costs 8-20 us on this part -- 256
+//  same-address device-scope atomics, or cooperative_groups' grid.sync() -- against ~3 us for a kernel boundary.)
+#include "common.h"
+#include "stage3.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename T> struct S3M;
+template <> struct S3M<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct S3M<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+#define S3_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+  } while (0)
+
+constexpr int NT = 512;           // threads per workgroup (8 waves)
+constexpr int M1 = 32, N1 = 256;  // fc1 tile: alerts x hidden units
+constexpr int M2 = 64, N2 = 32;   // fc2 tile: alerts x channels
+constexpr float LN_EPS = 1e-6f;
+constexpr int RED_BYTES = 8 * 2 * 4 * 64 * 16;   // fc2: 8 K slices x 2 alert blocks x 4 quads x 64 lanes x float4
+
+template <typename T, int C>
+__device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& bk, int ab, int nt, unsigned char* smem) {
+  using frag = typename S3M<T>::frag;
+  constexpr int HID = 4 * C, KS = C / 16, NV = C / 128, RING = KS > 32 ? KS / 2 : KS;
+  static_assert(RING % 4 == 0, "ring quarters");
+  constexpr int PITCH = C * 2 + 16;     // bytes per LDS row: C 16-bit values + 16 (8 rows cover the 32 banks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int ht = nt * (N1 / 32) + wave;                 // this wave's tile of 32 hidden units
+  // ---- the 32 rows first (4 per wave; lane = channels 128 i + 2 lane + {0, 1}), then the per-channel constants
+  float2 v[4][NV];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int al = ab * M1 + 4 * wave + u;
+    const float* src = a.x + (size_t)(al < a.B ? al : a.B - 1) * C + 2 * lane;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[u][i] = *reinterpret_cast<const float2*>(src + 128 * i);
+  }
+  float2 wc[NV], bc[NV], lw[NV], lb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 128 * i + 2 * lane;
+    wc[i] = *reinterpret_cast<const float2*>(bk.dw_c + c);
+    bc[i] = *reinterpret_cast<const float2*>(bk.dw_b + c);
+    lw[i] = *reinterpret_cast<const float2*>(bk.ln_w + c);
+    lb[i] = *reinterpret_cast<const float2*>(bk.ln_b + c);
+  }
+  // ---- the wave's filter fragments, a quarter in front of each row's LayerNorm: the requests queue at the TA port
+  //      (a wave cannot run ahead of its own unissued loads) while the VALU works on the row before
+  const frag* wsrc = reinterpret_cast<const frag*>(bk.w1p) + (size_t)ht * KS * 64 + lane;
+  frag wq[RING];
+  S3_STAMP(9);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int i = u * (RING / 4); i < (u + 1) * (RING / 4); ++i) wq[i] = wsrc[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[u][i].x = fmaf(v[u][i].x, wc[i].x, bc[i].x);
+      v[u][i].y = fmaf(v[u][i].y, wc[i].y, bc[i].y);
+      s += v[u][i].x + v[u][i].y;
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[u][i].x -= mean;
+      v[u][i].y -= mean;
+      q = fmaf(v[u][i].x, v[u][i].x, fmaf(v[u][i].y, v[u][i].y, q));
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
+    unsigned char* row = smem + (4 * wave + u) * PITCH + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      typedef T __attribute__((ext_vector_type(2))) T2;
+      T2 o;
+      o[0] = (T)fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x);
+      o[1] = (T)fmaf(v[u][i].y * rstd, lw[i].y, lb[i].y);
+      *reinterpret_cast<T2*>(row + 256 * i) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  S3_STAMP(10);
+  // ---- fc1 bias into the accumulator: register r of a lane = hidden unit 32 ht + (r & 7) + 8 h + 16 (r >> 3)
+  f32x16 acc;
+  {
+    const float* bp = bk.b1 + 32 * ht + 8 * h;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * (qd & 1) + 16 * (qd >> 1));
+      acc[4 * qd + 0] = bv.x;
+      acc[4 * qd + 1] = bv.y;
+      acc[4 * qd + 2] = bv.z;
+      acc[4 * qd + 3] = bv.w;
+    }
+  }
+  __syncthreads();
+  S3_STAMP(11);
+  const unsigned char* bp = smem + lr * PITCH + h * 16;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const frag bf = *reinterpret_cast<const frag*>(bp + ks * 32);
+    acc = S3M<T>::run(wq[ks % RING], bf, acc);
+    if (ks + RING < KS) wq[ks % RING] = wsrc[(ks + RING) * 64];
+  }
+  S3_STAMP(12);
+  // ---- GELU, out as fc2's B fragments: lane (alert lr, half h) holds k = 16 ks2 + 8 h + 0..7 of k-step ks2 = 2 ht + hh
+  frag* hout = reinterpret_cast<frag*>(a.hfrag);
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (T)gelu_for<T>(acc[8 * hh + j]);
+    hout[((size_t)ab * (HID / 16) + 2 * ht + hh) * 64 + lane] = o;
+  }
+  __syncthreads();   // the rows in LDS are read out: the next tile may overwrite them
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
+  using frag = typename S3M<T>::frag;
+  constexpr int HID = 4 * C, KSA = HID / 16, KSW = KSA / 8, RING = KSW <= 16 ? KSW : KSW / 2;
+  static_assert(KSW % RING == 0, "k-steps per wave");
+  float4* red = reinterpret_cast<float4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = mt * M2;
+  const frag* wsrc = reinterpret_cast<const frag*>(bk.w2p) + ((size_t)ct * KSA + wave * KSW) * 64 + lane;
+  const frag* h0 = reinterpret_cast<const frag*>(a.hfrag) + ((size_t)(m0 / 32) * KSA + wave * KSW) * 64 + lane;
+  const frag* h1 = h0 + (size_t)KSA * 64;
+  frag wa[RING], ha[RING], hb[RING];
+#pragma unroll
+  for (int i = 0; i < RING; ++i) {
+    wa[i] = wsrc[i * 64];
+    ha[i] = h0[i * 64];
+    hb[i] = h1[i * 64];
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc sinks the loads to their MFMAs: ~10 in flight instead of 48)
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KSW; ++ks) {
+    acc[0] = S3M<T>::run(wa[ks % RING], ha[ks % RING], acc[0]);
+    acc[1] = S3M<T>::run(wa[ks % RING], hb[ks % RING], acc[1]);
+    if (ks + RING < KSW) {
+      wa[ks % RING] = wsrc[(ks + RING) * 64];
+      ha[ks % RING] = h0[(ks + RING) * 64];
+      hb[ks % RING] = h1[(ks + RING) * 64];
+    }
+  }
+  S3_STAMP(13);
+  // ---- the eight K slices meet in LDS; register r = channel 32 ct + (r & 3) + 8 (r >> 2) + 4 h of alert (lane & 31)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      red[((wave * 2 + t) * 4 + qd) * 64 + lane] =
+          make_float4(acc[t][4 * qd], acc[t][4 * qd + 1], acc[t][4 * qd + 2], acc[t][4 * qd + 3]);
+  __syncthreads();
+  {
+    const int q = tid, t = q >> 8, qd = (q >> 6) & 3, ln = q & 63;
+    const int al = m0 + 32 * t + (ln & 31), c = 32 * ct + 8 * qd + 4 * (ln >> 5);
+    float4 s = red[q];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      const float4 p = red[w * 512 + q];
+      s.x += p.x;
+      s.y += p.y;
+      s.z += p.z;
+      s.w += p.w;
+    }
+    if (al < a.B) {
+      float* xp = a.x + (size_t)al * C + c;
+      const float4 xv = *reinterpret_cast<const float4*>(xp);
+      const float4 g = *reinterpret_cast<const float4*>(bk.gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(bk.b2 + c);
+      *reinterpret_cast<float4*>(xp) = make_float4(xv.x + fmaf(g.x, b.x, s.x), xv.y + fmaf(g.y, b.y, s.y),
+                                                   xv.z + fmaf(g.z, b.z, s.z), xv.w + fmaf(g.w, b.w, s.w));
+    }
+  }
+  S3_STAMP(14);
+  __syncthreads();   // the partial sums are read out
+}
+
+
+template <typename T, int C>
+__global__ __launch_bounds__(NT) void s3_fc1_kernel(Stage3Args a, int j) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTL = 4 * C / N1;
+  // (blockIdx % 8 = the XCD: consecutive workgroups take different hidden tiles of one alert block, so an XCD's L2
+  //  holds 1/8 of the filter)
+  fc1_tile<T, C>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(NT) void s3_fc2_kernel(Stage3Args a, int j) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTL = C / N2;
+  fc2_tile<T, C>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
+}
+
+// fp32 [rows][K] (x rowscale[row]) -> 32x32x16 A fragments [row tile][k-step][lane][8]: lane l holds tile row (l & 31),
+// k = 16 s + 8 (l >> 5) + j; with swap23 tile row r carries source row (r with bits 2 and 3 exchanged)
+template <typename T>
+__global__ void pack_s3_kernel(const float* __restrict__ w, const float* __restrict__ rowscale, T* __restrict__ out,
+                               int rows, int K, int swap23) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 16;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  int r = l & 31;
+  if (swap23) r = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const int row = 32 * tile + r, k = 16 * s + 8 * (l >> 5) + j;
+  float v = w[(long)row * K + k];
+  if (rowscale != nullptr) v *= rowscale[row];
+  out[i] = (T)v;
+}
+
+template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
+  constexpr int LDS1 = M1 * (C * 2 + 16);
+  if (phase == 0) {
+    hipLaunchKernelGGL((s3_fc1_kernel<T, C>), dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
+  } else {
+    auto kern = s3_fc2_kernel<T, C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RED_BYTES));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((a.B + M2 - 1) / M2) * (C / N2)), dim3(NT), RED_BYTES, st, a, j);
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+}  // namespace
+
+bool stage3_supported(int prec, int c3, int depth) {
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (c3 == 512 || c3 == 640) && depth >= 1 && depth <= S3_MAX_DEPTH;
+}
+
+size_t stage3_hfrag_bytes(int prec, int c3, int B) {
+  return (size_t)((B + M2 - 1) / M2) * M2 * 4 * c3 * (prec == BTSBOT_F32 ? 4 : 2);
+}
+
+int launch_stage3(int prec, int c3, const Stage3Args& a, int block, int phase, hipStream_t st) {
+  if (a.B <= 0) return BTSBOT_OK;
+  if (prec == BTSBOT_BF16 && c3 == 512) return launch_t<bf16_t, 512>(a, block, phase, st);
+  if (prec == BTSBOT_F16 && c3 == 512) return launch_t<f16_t, 512>(a, block, phase, st);
+  if (prec == BTSBOT_BF16 && c3 == 640) return launch_t<bf16_t, 640>(a, block, phase, st);
+  if (prec == BTSBOT_F16 && c3 == 640) return launch_t<f16_t, 640>(a, block, phase, st);
+  btsbot_set_error("stage3: precision %d / width %d not supported", prec, c3);
+  return BTSBOT_ERR_INVALID_ARG;
+}
+
+int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int swap23,
+                   hipStream_t st) {
+  const long total = (long)rows * K;
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  if (prec == BTSBOT_BF16)
+    hipLaunchKernelGGL(pack_s3_kernel<bf16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<bf16_t*>(dst), rows, K,
+                       swap23);
+  else if (prec == BTSBOT_F16)
+    hipLaunchKernelGGL(pack_s3_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
+                       swap23);
+  else {
+    btsbot_set_error("pack_s3: precision %d is not a 16-bit mode", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}

@@ -50,3 +50,25 @@ for j in range(6):
     print(f"   block {j}: map->LDS +{s2[b+1]-s2[b]:6d}  depthwise +{s2[b+2]-s2[b+1]:6d}  LN +{s2[b+3]-s2[b+2]:6d}  "
           f"chunks 0-1 +{s2[b+4]-s2[b+3]:6d}  2-3 +{s2[b+5]-s2[b+4]:6d}  4-7 +{s2[b+6]-s2[b+5]:6d}  (block {nxt - s2[b]:7d})")
 print(f"   downsample: LN +{s2[57]-s2[56]:6d}  conv +{s2[58]-s2[57]:6d}")
+
+s3 = t[32 + 16384 + 64:32 + 16384 + 64 + 16]
+if any(s3):
+    print("stage3 (workgroup 0) total cycles", s3[8] - s3[0] if s3[8] else s3[7] - s3[0])
+    lab = ["fc1", "sync", "fc2", "sync"]
+    for j in range(2):
+        print("   block", j, "  ".join(f"{lab[i]} +{s3[1 + 4 * j + i] - s3[4 * j + i]:6d}" for i in range(4)))
+    print("   last fc1 tile: loads issued", s3[9] - s3[4], " LN done +", s3[10] - s3[9], " barrier +", s3[11] - s3[10], " MFMA loop +", s3[12] - s3[11],
+          " | last fc2 tile: MFMA loop done", s3[13] - s3[6], " reduced/stored +", s3[14] - s3[13])
+    w = np.array(t[32 + 16384 + 64 + 16:32 + 16384 + 64 + 16 + 5 * 256]).reshape(256, 5)
+    t0 = w[:, 0].min()
+    for k, nm in enumerate(["start", "fc1 done", "sync done", "fc2 done", "sync done"]):
+        d = (w[:, k] - t0) / 100.0
+        print(f"   {nm:10s} us after first start: min {d.min():6.1f} median {np.median(d):6.1f} max {d.max():6.1f}")
+
+hs = t[32 + 16384 + 64 + 1500:32 + 16384 + 64 + 1500 + 10]
+if any(hs):
+    print("head16 (workgroup 0) total cycles", hs[8] - hs[0])
+    for i, nm in enumerate(["loads issued", "feature LN", "meta in", "step 0", "step 1", "step 2", "step 3", "step 4"]):
+        print(f"   {nm:14s} +{hs[i + 1] - hs[i]:7d}")
+    d = t[32 + 16384 + 64 + 1500 + 10:32 + 16384 + 64 + 1500 + 15]
+    print("   inside meta fc2: ring+bias issued/arrived", d[1] - d[0], " MFMA loop", d[2] - d[1], " barrier", d[3] - d[2], " epilogue", d[4] - d[3], " (entry at +", d[0] - hs[4], ")")
