@@ -1,6 +1,6 @@
 // Fused classifier heads on the matrix pipe (gfx950, the 16-bit modes): optional head LayerNorm on the 1x1 image
 // feature, metadata branch (BatchNorm1d folded to scale/shift -> Linear -> act -> Linear [-> act]), concat (image
-// first, then metadata), fusion MLP, logits + sigmoid scores -- one launch, 32 alerts per workgroup, nothing but the
+// first, then metadata), fusion MLP, logits + sigmoid scores -- one launch, 16 alerts per workgroup, nothing but the
 // logits leaves the CU.  Same wirings as head.hip (which stays the fp32 mode's head):
 // /root/reference/btsbot/architectures.py:146-171 (mm_ConvNeXt, GELU), :109-122 (ConvNeXt head), :282-293 (um_nn,
 // ReLU), :299-313,358-372 (frozen_fusion); sigmoid: inference_example.py:91.
@@ -9,27 +9,29 @@
 // MFMAs per k-step: activations and filters are split into a 16-bit head and a 16-bit remainder,
 //     a w  ~  a_hi w_hi + a_lo w_hi + a_hi w_lo          (what is dropped is below 2^-16 of the product, bf16),
 // which keeps the head out of the precision mode's error budget.  Layout per layer: filters packed as
-// 32x32x16 A fragments [hi | lo][row tile of 32][k-step][lane][8] (rows bit-2/3 swapped, zero padded), activations
-// [alert][k] 16-bit rows in LDS as the B operand; a wave owns row tiles, its accumulator holds 2 x 8 consecutive
-// outputs of the lane's alert, written straight into the next layer's rows.
+// 16x16x32 A fragments [hi | lo][row tile of 16][k-step][lane][8] (zero padded), activations [alert][k] 16-bit rows in
+// LDS as the B operand; a wave owns a row tile (and, where a layer has fewer tiles than the workgroup has waves, a
+// slice of K), its accumulator holds 4 consecutive outputs of the lane's alert, written straight into the next
+// layer's rows.  16 alerts per workgroup rather than 32: the chain's length is instructions per wave, not FLOPs.
+// (Single f16 filters with split activations were tried: frozen_fusion's unnormalised features put the bf16 mode's
+//  score error at 3.3e-3 against 2e-3 with the filters' remainder kept.)
 #include "common.h"
 #include "head16.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <typename T> struct HM;
 template <> struct HM<bf16_t> {
   using frag = bf16x8;
-  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
 template <> struct HM<f16_t> {
   using frag = f16x8;
-  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
 };
 
@@ -38,14 +40,14 @@ template <> struct HM<f16_t> {
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
   } while (0)
 
-constexpr int HA = 32;            // alerts per workgroup
+constexpr int HA = 16;            // alerts per workgroup (the column block of the 16x16x32 MFMA)
 constexpr int HNT = 512, HNW = HNT / 64;
 constexpr float HN_EPS = 1e-6f;
 
 __host__ __device__ constexpr int rup(int v, int m) { return (v + m - 1) / m * m; }
-constexpr int KGRAN = 4;          // every layer's K is padded to a multiple of 4 k-steps (64 inputs)
-__host__ __device__ constexpr int kpad(int K) { return rup(K, 16 * KGRAN); }
-__host__ __device__ constexpr size_t head16_bytes(int N, int K) { return (size_t)2 * rup(N, 32) * kpad(K) * 2; }
+constexpr int KGRAN = 2;          // every layer's K is padded to a multiple of 2 k-steps of 32 (64 inputs)
+__host__ __device__ constexpr int kpad(int K) { return rup(K, 32 * KGRAN); }
+__host__ __device__ constexpr size_t head16_bytes(int N, int K) { return (size_t)2 * rup(N, 16) * kpad(K) * 2; }
 
 // an activation buffer in LDS: hi rows then lo rows, `pitch` bytes per alert row
 struct Rows {
@@ -68,7 +70,7 @@ __device__ __forceinline__ float head_act(float x, int act) {
 }
 
 // out[alert][col0 + n] = act(bias[n] + sum_k in[alert][k] W[n][k]),  n < Np (rows past N come out as act(0) = 0).
-// Jobs: (row tile of 32 outputs, K part).  With fewer row tiles than waves the k-steps of a tile are split over 2, 4
+// Jobs: (row tile of 16 outputs, K part).  With fewer row tiles than waves the k-steps of a tile are split over 2, 4
 // or 8 waves (a layer is a chain of dependent MFMAs: 3 per k-step on one accumulator) and the parts meet in LDS.
 // K is padded to KGRAN k-steps with zero filters / zero activations.
 template <typename T>
@@ -77,25 +79,27 @@ __device__ __forceinline__ void dense16(const Rows& in, const H16Layer& L, const
 #define D_STAMP(i) do { if (stamps != nullptr && col0 != 0 && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = clock64(); } while (0)
   D_STAMP(10);
   using frag = typename HM<T>::frag;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
-  const int KS = kpad(L.K) / 16, tiles = rup(L.N, 32) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane & 15, q = lane >> 4;
+  const int KS = kpad(L.K) / 32, tiles = rup(L.N, 16) / 16;
   int split = 1;
   while (split * 2 * tiles <= HNW && KS % (split * 2 * KGRAN) == 0 && tiles * (split * 2 - 1) <= red_slots) split *= 2;
   const int rt = wave % tiles, part = wave / tiles;      // (tiles <= HNW: head16_supported)
   const bool job = part < split;
   const int ksp = KS / split, k0 = (job ? part : 0) * ksp;
-  f32x16 acc;
+  f32x4 acc;
   if (job) {
-    const unsigned char* bh = in.hi + lr * in.pitch + h * 16;
+    // B fragment of k-step ks: lane (alert lc, quarter q) holds k = 32 ks + 8 q + 0..7
+    const unsigned char* bh = in.hi + lc * in.pitch + q * 16;
     const unsigned char* bl = bh + HA * in.pitch;
     const frag* whi = reinterpret_cast<const frag*>(L.w) + (size_t)rt * KS * 64 + lane;
     const frag* wlo = whi + (size_t)tiles * KS * 64;
     // A part is G groups of KGRAN k-steps; the next group's filter fragments are requested before this group's
-    // products (one group in flight: a head layer is short, and the code has to stay short too -- this kernel runs
-    // every instruction once per workgroup, so a fully unrolled version spent its time in instruction fetch: 58 KB of
-    // code streamed at ~1 byte per cycle).  Three independent accumulators (hi.hi, lo.hi, hi.lo) and the B fragments
-    // of the group's four k-steps requested at once: on one accumulator with the LDS reads in line a k-step is a chain
-    // of two LDS round trips and three dependent MFMAs.
+    // products (a loop with one group in flight: a head layer is short, and the code has to stay short too -- this
+    // kernel runs every instruction once per workgroup, so a fully unrolled version spent its time in instruction
+    // fetch: 58 KB of code streamed at ~1 byte per cycle; a ring of four groups was no faster and its clamped
+    // re-reads cost the short layers ~1.4k cycles each).  Three independent accumulators (hi.hi, lo.hi, hi.lo) and
+    // the B fragments of the group's k-steps requested at once: on one accumulator with the LDS reads in line a
+    // k-step is a chain of two LDS round trips and three dependent MFMAs.
     const int G = ksp / KGRAN;
     frag ah[KGRAN], al[KGRAN];
 #pragma unroll
@@ -103,18 +107,15 @@ __device__ __forceinline__ void dense16(const Rows& in, const H16Layer& L, const
       ah[j] = whi[(k0 + j) * 64];
       al[j] = wlo[(k0 + j) * 64];
     }
-    // register r of a lane = output 32 rt + 8 h + (r & 7) + 16 (r >> 3)
-    const int n0 = 32 * rt + 8 * h;
+    // register r of a lane = output 16 rt + 4 q + r of alert lc
+    const int n0 = 16 * rt + 4 * q;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + (r & 7) + 16 * (r >> 3);
-      acc[r] = L.bias[n < L.N ? n : L.N - 1];   // (unconditional load; masked below)
-    }
+    for (int r = 0; r < 4; ++r) acc[r] = L.bias[n0 + r < L.N ? n0 + r : L.N - 1];   // (unconditional load; masked below)
     __builtin_amdgcn_sched_barrier(0);   // one round trip for the first group and the bias
-    f32x16 acc1, acc2;
+    f32x4 acc1, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (part != 0 || n0 + (r & 7) + 16 * (r >> 3) >= L.N) acc[r] = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      if (part != 0 || n0 + r >= L.N) acc[r] = 0.f;
       acc1[r] = acc2[r] = 0.f;
     }
 #pragma unroll 1
@@ -128,8 +129,8 @@ __device__ __forceinline__ void dense16(const Rows& in, const H16Layer& L, const
       }
 #pragma unroll
       for (int j = 0; j < KGRAN; ++j) {
-        xh[j] = *reinterpret_cast<const frag*>(bh + (kg + j) * 32);
-        xl[j] = *reinterpret_cast<const frag*>(bl + (kg + j) * 32);
+        xh[j] = *reinterpret_cast<const frag*>(bh + (kg + j) * 64);
+        xl[j] = *reinterpret_cast<const frag*>(bl + (kg + j) * 64);
       }
 #pragma unroll
       for (int j = 0; j < KGRAN; ++j) {
@@ -144,49 +145,47 @@ __device__ __forceinline__ void dense16(const Rows& in, const H16Layer& L, const
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];
+    for (int r = 0; r < 4; ++r) acc[r] += acc1[r] + acc2[r];
     D_STAMP(12);
     if (part != 0) {
-      float* dst = red + ((size_t)(rt * (split - 1) + part - 1) * 16) * 64 + lane;
+      float* dst = red + ((size_t)(rt * (split - 1) + part - 1) * 4) * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
+      for (int r = 0; r < 4; ++r) dst[r * 64] = acc[r];
     }
   }
   if (split > 1) __syncthreads();
   D_STAMP(13);
   if (job && part == 0) {
     for (int p = 1; p < split; ++p) {
-      const float* src = red + ((size_t)(rt * (split - 1) + p - 1) * 16) * 64 + lane;
+      const float* src = red + ((size_t)(rt * (split - 1) + p - 1) * 4) * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += src[r * 64];
+      for (int r = 0; r < 4; ++r) acc[r] += src[r * 64];
     }
-    if (logits != nullptr) {   // the last layer: output 0 of tile 0 = register 0 of the lanes with h = 0
-      if (rt == 0 && h == 0 && b0 + lr < B) {
+    if (logits != nullptr) {   // the last layer: output 0 of tile 0 = register 0 of the lanes with q = 0
+      if (rt == 0 && q == 0 && b0 + lc < B) {
         const float zz = acc[0];
-        logits[b0 + lr] = zz;
-        if (scores != nullptr) scores[b0 + lr] = 1.0f / (1.0f + expf(-zz));
+        logits[b0 + lc] = zz;
+        if (scores != nullptr) scores[b0 + lc] = 1.0f / (1.0f + expf(-zz));
       }
     } else {
+      typedef T __attribute__((ext_vector_type(4))) T4;
+      T4 oh, ol;
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        frag oh, ol;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = head_act(acc[8 * hh + j], L.act);
-          const T hv = (T)v;
-          oh[j] = hv;
-          ol[j] = (T)(v - (float)hv);
-        }
-        const int off = lr * out.pitch + (col0 + 32 * rt + 16 * hh + 8 * h) * 2;
-        *reinterpret_cast<frag*>(out.hi + off) = oh;
-        *reinterpret_cast<frag*>(out.lo() + off) = ol;
+      for (int r = 0; r < 4; ++r) {
+        const float v = head_act(acc[r], L.act);
+        const T hv = (T)v;
+        oh[r] = hv;
+        ol[r] = (T)(v - (float)hv);
       }
+      const int off = lc * out.pitch + (col0 + 16 * rt + 4 * q) * 2;
+      *reinterpret_cast<T4*>(out.hi + off) = oh;
+      *reinterpret_cast<T4*>(out.lo() + off) = ol;
     }
   }
   D_STAMP(14);
   // columns between the padded row tiles and the next layer's padded K read as zero
   if (logits == nullptr) {
-    const int c0 = col0 + 32 * tiles, c1 = col0 + kpad(L.N);
+    const int c0 = col0 + 16 * tiles, c1 = col0 + kpad(L.N);
     for (int i = threadIdx.x; i < HA * (c1 - c0); i += HNT) {
       const int g = i / (c1 - c0), c = c0 + i % (c1 - c0);
       split_store<T>(out.hi + g * out.pitch + c * 2, out.lo() + g * out.pitch + c * 2, 0.f);
@@ -264,7 +263,7 @@ template <typename T> __global__ __launch_bounds__(HNT) void head16_kernel(Head1
   }
   // ---- metadata branch -> z[:, feat_dim : feat_dim + f2]
   if (a.n_meta > 0) {
-    // (n_meta <= 32: element e = tid + 512 i is column e % 32 of alert e / 32; the loads go out together)
+    // (n_meta <= 32: thread e is column e % 32 of alert e / 32)
     const int mk = kpad(a.n_meta);
     constexpr int EPT = HA * 32 / HNT;
     float mv[EPT], sc[EPT], sh[EPT];
@@ -297,29 +296,28 @@ template <typename T> __global__ __launch_bounds__(HNT) void head16_kernel(Head1
   for (int si = 0; si < a.n_steps; ++si) {
     const H16Step st = a.steps[si];
     const bool last = si + 1 == a.n_steps;
-    // K-split partial tiles (4 KB each) go to whichever of the three buffers the layer neither reads nor writes
+    // K-split partial tiles (1 KB each) go to whichever of the three buffers the layer neither reads nor writes
     const Rows rb = buf(st.red_buf);
     dense16<T>(buf(st.in_buf), st.L, buf(st.out_buf), st.col0, reinterpret_cast<float*>(rb.hi),
-               st.red_buf >= 0 ? 2 * HA * rb.pitch / 4096 : 0, last ? a.logits : nullptr, a.scores, b0, a.B, a.stamps);
+               st.red_buf >= 0 ? 2 * HA * rb.pitch / 1024 : 0, last ? a.logits : nullptr, a.scores, b0, a.B, a.stamps);
     __syncthreads();
     H_STAMP(4 + si);
   }
 }
 
-// fp32 [N][K] -> [hi | lo][row tile][k-step][lane][8] A fragments, rows bit-2/3 swapped, zero padded to 32 x 16
+// fp32 [N][K] -> [hi | lo][row tile of 16][k-step of 32][lane][8] A fragments of the 16x16x32 MFMA (lane l: row l & 15,
+// k = 8 (l >> 4) + 0..7), zero padded
 template <typename T>
 __global__ void pack_h16_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int K) {
-  const int Kp = kpad(K), Np = rup(N, 32);
+  const int Kp = kpad(K), Np = rup(N, 16);
   const long half = (long)Np * Kp;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= half) return;
   const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
   const long fs = i >> 9;
-  const int ksteps = Kp / 16;
+  const int ksteps = Kp / 32;
   const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
-  int r = l & 31;
-  r = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-  const int row = 32 * tile + r, k = 16 * s + 8 * (l >> 5) + j;
+  const int row = 16 * tile + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
   const float v = (row < N && k < K) ? w[(long)row * K + k] : 0.f;
   const T hv = (T)v;
   out[i] = hv;
@@ -333,14 +331,14 @@ size_t head16_packed_bytes(int N, int K) { return head16_bytes(N, K); }
 bool head16_supported(int prec, int feat_dim, int n_meta, int f1, int f2, int n_layers, const int* dims) {
   if (prec != BTSBOT_BF16 && prec != BTSBOT_F16) return false;
   if (feat_dim > 768 || (feat_dim & 7) != 0 || n_layers < 1 || n_layers > 3) return false;
-  if (n_meta > 0 && (f1 > 32 * HNW || f2 > 32 * HNW || n_meta > 32)) return false;
+  if (n_meta > 0 && (f1 > 16 * HNW || f2 > 16 * HNW || n_meta > 32)) return false;
   for (int i = 1; i <= n_layers; ++i)
-    if (dims[i] > 32 * HNW) return false;
+    if (dims[i] > 16 * HNW) return false;
   return dims[n_layers] == 1;
 }
 
 int launch_pack_h16(int prec, const float* w, void* dst, int N, int K, hipStream_t st) {
-  const long half = (long)rup(N, 32) * kpad(K);
+  const long half = (long)rup(N, 16) * kpad(K);
   const dim3 grid((unsigned)((half + 255) / 256)), blk(256);
   if (prec == BTSBOT_BF16)
     hipLaunchKernelGGL(pack_h16_kernel<bf16_t>, grid, blk, 0, st, w, reinterpret_cast<bf16_t*>(dst), N, K);
