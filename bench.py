@@ -32,10 +32,13 @@ import warnings
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--batch", type=int, default=1024, help="alerts per GPU per step")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="batches in flight on alternating HIP streams in the timed loop (btsbot_amd.ScoreStream); "
+                         "1 = plain model(...) calls on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the f16 / f32 precision legs and the parity object (profiling runs)")
@@ -504,18 +507,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def timed(run):
+        run(args.warmup)
+        fence()
+        t0 = time.perf_counter()
+        last = run(args.steps)
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el, last
+
+    def run_serial(n):
+        o = None
+        for _ in range(n):
+            o = step()
+        return o
+
+    # one stream, one model(...) call after the other
+    serial_elapsed, out = timed(run_serial)
+    elapsed = serial_elapsed
+    if args.pipeline_depth > 1:
+        # the scoring loop as the library runs it over a sequence of batches: consecutive batches on alternating HIP
+        # streams (btsbot_amd.ScoreStream), every batch a full pass of the same kernels, all K finished inside the
+        # timed region
+        scorer = btsbot_amd.ScoreStream(model, depth=args.pipeline_depth, inputs_ready=True)   # (resident, fenced)
+
+        def run_pipelined(n):
+            o = None
+            for o in scorer.map((img, meta) for _ in range(n)):
+                pass
+            return o
+
+        elapsed, out = timed(run_pipelined)
+        del scorer
     if not os.environ.get("BTSBOT_AMD_S0_DIAG"):
         assert torch.isfinite(out).all()
 
@@ -610,7 +637,11 @@ def main():
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                 "precision": args.precision, "weights": "seeded random, layer-scale ~1",
                 "parallelism": f"{world} independent replicas, batch-sharded, no collective",
+                "pipeline_depth": args.pipeline_depth,
             },
+            "serial": {"note": "the same K steps as plain model(...) calls on one stream",
+                       "value": round(total_alerts / serial_elapsed, 1), "unit": "alerts/s",
+                       "ms_per_step": round(1e3 * serial_elapsed / args.steps, 4)},
             "roofline": {
                 "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

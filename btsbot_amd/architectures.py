@@ -521,6 +521,7 @@ class mm_ConvNeXt(_HipModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         _warn_pretrained(config)
         table = _convnext_table(config.get("model_kind", _DEFAULT_KIND))
         self.convnext_feature_dim = table[1][-1]
@@ -545,6 +546,7 @@ class ConvNeXt(_HipModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         _warn_pretrained(config)
         table = _convnext_table(config.get("model_kind", _DEFAULT_KIND))
         self._setup(
@@ -565,6 +567,7 @@ class um_nn(_HipModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         self._setup(
             table=None, head_norm=False, n_meta=len(config.get("metadata_cols", [])),
             meta_fc=(config["meta_fc1_neurons"], config["meta_fc2_neurons"]), comb_fc=(0, 0),
@@ -593,6 +596,7 @@ class frozen_fusion(_HipModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         icfg = self._branch_config(config, "image")
         mcfg = self._branch_config(config, "meta")
         if icfg["model_name"] not in ("ConvNeXt", "MaxViT") or mcfg["model_name"] != "um_nn":
@@ -697,6 +701,7 @@ class MaxViT(_MaxVitModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         _warn_pretrained(config)
         model_kind = config.get("model_kind", _MAXVIT_DEFAULT_KIND)
         self.image_size = get_model_image_size(model_kind)
@@ -718,6 +723,7 @@ class mm_MaxViT(_MaxVitModel):
 
     def __init__(self, config, precision: Optional[str] = None):
         super().__init__()
+        self._init_config = dict(config)
         _warn_pretrained(config)
         model_kind = config.get("model_kind", _MAXVIT_DEFAULT_KIND)
         self.image_size = get_model_image_size(model_kind)

@@ -235,3 +235,22 @@ def test_maxvit_train_mode_gate_is_host_logic():
     from helpers import CONFIGS
     kind2, cfg2 = CONFIGS["mm_pico"]
     _build(kind2, cfg2).train()._check_train_supported(True)
+
+
+def test_score_stream_host_checks():
+    """ScoreStream (btsbot_amd/pipeline.py) refuses what it cannot run: depth < 1, a training-mode model, a model that
+    is not on the GPU (no CPU fallback)."""
+    import warnings
+    import btsbot_amd
+    from helpers import CONFIGS
+    kind, cfg = CONFIGS["um_nn"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = getattr(btsbot_amd, kind)(cfg)
+    with pytest.raises(ValueError):
+        btsbot_amd.ScoreStream(m.eval(), depth=0)
+    with pytest.raises(RuntimeError, match="eval"):
+        btsbot_amd.ScoreStream(m.train(), depth=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        btsbot_amd.ScoreStream(m.eval(), depth=2)
+    assert m._init_config["meta_fc1_neurons"] == cfg["meta_fc1_neurons"]
