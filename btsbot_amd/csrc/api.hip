@@ -487,7 +487,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   if (convnext && h->stage2p && !train_only)
     TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], st));
-  if (h->head16) {
+  if (h->head16 && !train_only) {
     if (h->has_meta) {
       TRY(launch_pack_h16(c.precision, m + h->m1_w, h->extra + h->p_m1h, c.meta_fc1, c.n_meta, st));
       TRY(launch_pack_h16(c.precision, m + h->m2_w, h->extra + h->p_m2h, c.meta_fc2, c.meta_fc1, st));

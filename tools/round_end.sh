@@ -1,16 +1,18 @@
 #!/bin/bash
 # Round-end measurement recipe (run on the MI355X box through gpurun from the repo root).
-# Writes everything under gpurun_out/final/; copy what should be judged into profiles/.
+# Writes everything under gpurun_out/final/; copy what should be judged into profiles/ (tools/collect_profiles.py).
+# Every step has its own time limit and the chain stops at the first step that fails or is killed.
 set -u
 O=gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
-python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
-( time python bench.py ) > $O/bench_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --train-steps 0 > $O/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 --maxvit-steps 1 --maxvit-batch 256 > $O/mfma.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 20 --maxvit-steps 0 > $O/train_trace.log 2>&1
-find $O -name "*.csv" | head -50
-tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -2; tail -5 $O/bench_default.log
+PROF="--pipeline-depth 1 --no-extra-legs"   # profiled runs: one stream, so a kernel's duration is its own
+timeout -k 10 420 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1 &&
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 &&
+( time timeout -k 10 400 python bench.py ) > $O/bench_default.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --train-steps 0 $PROF > $O/trace.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 $PROF > $O/pmc_fetch.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 $PROF > $O/pmc_write.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 --maxvit-steps 1 --maxvit-batch 256 $PROF > $O/mfma.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 20 --maxvit-steps 0 $PROF > $O/train_trace.log 2>&1
+echo "chain rc=$?" > $O/chain.log
+tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -5 $O/bench_default.log | cut -c1-400; cat $O/chain.log
