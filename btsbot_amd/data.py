@@ -121,7 +121,8 @@ class DeviceDataset:
 
     def __init__(self, images, metadata, labels, batch_size: int, config: Optional[dict] = None,
                  device="cuda", shuffle: bool = True, drop_last: bool = True, augment: bool = True,
-                 generator: Optional[torch.Generator] = None, shard: Optional[tuple] = None):
+                 generator: Optional[torch.Generator] = None, shard: Optional[tuple] = None,
+                 check_nan: bool = True):
         config = config or {}
         # shard = (rank, world): every rank holds the whole set and draws the SAME permutation (seed the
         # generators alike); of each global batch it yields its contiguous rows [r*b/w, (r+1)*b/w) -- the
@@ -131,13 +132,18 @@ class DeviceDataset:
             r, w = self.shard
             if not (0 <= r < w) or int(batch_size) % w != 0:
                 raise ValueError(f"shard {shard}: rank out of range or batch_size {batch_size} not divisible")
+            if not drop_last:
+                # a ragged last batch can leave a rank with no alerts, and n_global = batch * world is then wrong
+                raise ValueError("shard needs drop_last=True")
         self.device = torch.device(device)
         self.images = None if images is None else \
             torch.as_tensor(images).to(self.device, torch.float32).contiguous()
         self.metadata = None if metadata is None else \
             torch.as_tensor(metadata).to(self.device, torch.float32).contiguous()
         self.labels = torch.as_tensor(labels).to(self.device)
-        if self.metadata is not None and torch.isnan(self.metadata).any():
+        # the reference refuses NaN metadata for the training split only (train.py:170); a validation / test split
+        # is taken as it is (val.py:96-99 prints and goes on): those callers pass check_nan=False
+        if check_nan and self.metadata is not None and torch.isnan(self.metadata).any():
             raise ValueError("NaNs found in metadata columns")         # train.py:170
         self.batch_size = int(batch_size)
         self.shuffle, self.drop_last = shuffle, drop_last

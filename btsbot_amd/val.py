@@ -41,7 +41,7 @@ def run_val_tensors(model, images, metadata, labels, batch_size: int = 1024,
                     pos_weight: Optional[float] = None, device="cuda"):
     """val.py:117-168.  ``pos_weight`` defaults to N_neg / N_pos of this split (val.py:60-62)."""
     ds = DeviceDataset(images, metadata, labels, batch_size, device=device, shuffle=False,
-                       drop_last=False, augment=False)
+                       drop_last=False, augment=False, check_nan=False)
     pw = ds.pos_weight if pos_weight is None else float(pos_weight)
     was_training = model.training
     model.eval()

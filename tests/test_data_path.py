@@ -68,6 +68,9 @@ def test_device_dataset_refuses_cpu_and_nans():
     bad[0, 0] = float("nan")
     with pytest.raises(ValueError, match="NaNs"):
         data.DeviceDataset(img, bad, lab, 4, device="cpu")
+    data.DeviceDataset(None, bad, lab, 4, device="cpu", check_nan=False)     # a validation split is taken as it is
+    with pytest.raises(ValueError, match="drop_last"):
+        data.DeviceDataset(None, meta, lab, 4, device="cpu", shard=(0, 2), drop_last=False)
     ds = data.DeviceDataset(None, meta, lab, 3, device="cpu")
     assert len(ds) == 2 and abs(ds.pos_weight - ds.num_notbts / max(ds.num_bts, 1)) < 1e-12
     batches = list(ds)                       # metadata-only sets need no kernel
