@@ -130,7 +130,17 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  if (a.depth > 0) load_chunk(P0{}, a.blk[0], 0);
+  if (a.depth > 0) {
+    load_chunk(P0{}, a.blk[0], 0);
+    // (a step multiplies the PREVIOUS chunk's fc2 fragments and refills their slots with the chunk after this one:
+    //  chunk 1's go in ahead, every later one is fetched two steps before its use)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const frag* src2 = reinterpret_cast<const frag*>(a.blk[0].w2p) + ((size_t)(2 * wave + m) * (HID / 32) + 1 * KS2) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) a2[1][m][s] = src2[s * 64];
+    }
+  }
 
 #pragma unroll 1
   for (int j = 0; j < a.depth; ++j) {
@@ -220,21 +230,22 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[m][n] += g4[m] * b4[m];
 
-    // one chunk of 128 hidden units; P = register set that holds its fragments.  The next chunk's 16 fragment
-    // loads are spread over this chunk's k-steps: issued in one burst they hold every wave at the CU's one
-    // vector-memory port for ~2k cycles before its first product (measured: 4.6k cycles per chunk, MFMA work 1.5k).
-    auto chunk = [&](auto P, int ch) {
+    // One step = fc1 of chunk ch, then GELU of chunk ch BETWEEN the fc2 products of chunk ch - 1 (software pipeline
+    // inside the wave: the two waves of a SIMD meet at the same barrier every chunk, so they are in the same phase
+    // all the time and nothing overlaps unless a wave overlaps its own VALU and MFMA work; with fc1 -> GELU -> barrier
+    // -> fc2 in line a chunk took 3.35k cycles against 1.5k of MFMA work and a 2.3k filter-streaming floor).
+    // P = register set of chunk ch's fc1 fragments; chunk ch - 1's fc2 fragments sit in the OTHER set's a2 slots.
+    // The next chunk's 16 fragment loads are spread over the k-steps: issued in one burst they hold every wave at the
+    // CU's one vector-memory port for ~2k cycles before its first product.
+    auto step = [&](auto P, auto FIRST, int ch) {
       constexpr int p = decltype(P)::value;
-      // (after the stage's last chunk the loads below re-read this block's first chunk: an unconditional load
+      constexpr bool first = decltype(FIRST)::value;
+      // (after the stage's last chunk the loads below re-read this block's first chunks: an unconditional load
       //  keeps the k-step loops free of branches -- hipcc waits vmcnt(0) behind every conditional load)
       const Stage2pBlk& nb = ch + 1 < NCHUNK ? bk : a.blk[j + 1 < a.depth ? j + 1 : j];
       const int nch = ch + 1 < NCHUNK ? ch + 1 : 0;
       const frag* src1 = reinterpret_cast<const frag*>(nb.w1p) + ((size_t)(nch * NW + wave) * KS1) * 64 + lane;
       const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + nch * KS2) * 64 + lane;
-#ifdef S2P_DIAG
-      if (a.diag & 1) __syncthreads();
-      if (a.diag & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
       // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]
       f32x4 hacc[NB];
       {
@@ -257,43 +268,77 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         a1[1 - p][s] = src1[s * 64];
         __builtin_amdgcn_sched_barrier(0);
       }
-      // GELU -> hidden image [pixel][hidden of this chunk]; rows (hidden) 4 kg .. + 3 of tile `wave`
+      // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
+      // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
       unsigned char* hcur = hb + p * (NCOL * HP);
+      const unsigned char* hprev = hb + (1 - p) * (NCOL * HP);
+      frag hbf[2][NB];
+      if (!first) {
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        T4 hv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (T)gelu_for<T>(hacc[n][r]);
-        *reinterpret_cast<T4*>(hcur + (16 * n + col) * HP + (16 * wave + 4 * kg) * 2) = hv;
+        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * 2);
       }
-      __syncthreads();   // hidden image complete (the other buffer was last read a barrier ago)
-      // fc2: out channels 32 wave .. + 31, K = this chunk's 128 hidden units; accumulates into the residual
+      static_assert(NB <= KS2, "one GELU column block per fc2 k-step");
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        if (!first) {
+          if (s + 1 < KS2) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[1 - p][m][s], hbf[s & 1][n], acc[m][n]);
+          a2[1 - p][0][s] = src2[s * 64];
+          a2[1 - p][1][s] = src2[((size_t)(HID / 32) + s) * 64];
+        }
+        if (s < NB) {
+          T4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = (T)gelu_for<T>(hacc[s][r]);
+          *reinterpret_cast<T4*>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * 2) = hv;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();   // image hb[p] complete; hb[1 - p] is read out
+    };
+    // the fc2 half of a step of its own: the block's last chunk (the residual must be complete before the next
+    // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 1
+    auto fc2_tail = [&]() {
+      const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
+      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + 1 * KS2) * 64 + lane;
+      const unsigned char* hprev = hb + 1 * (NCOL * HP);   // chunk NCHUNK - 1 is odd: image 1, fragments in set 1
       frag hbf[2][NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hcur + (16 * n + col) * HP + (8 * kg) * 2);
+      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * 2);
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         if (s + 1 < KS2) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hcur + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
+            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[p][m][s], hbf[s & 1][n], acc[m][n]);
-        a2[1 - p][0][s] = src2[s * 64];
-        a2[1 - p][1][s] = src2[((size_t)(HID / 32) + s) * 64];
+          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[1][m][s], hbf[s & 1][n], acc[m][n]);
+        a2[1][0][s] = src2[s * 64];
+        a2[1][1][s] = src2[((size_t)(HID / 32) + s) * 64];
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    static_assert(NCHUNK % 2 == 0, "the last chunk runs in register set 1");
+    step(P0{}, std::true_type{}, 0);
+    step(P1{}, std::false_type{}, 1);
+    S2P_STAMP(5 + 8 * j);
 #pragma unroll 1
-    for (int ch = 0; ch < NCHUNK; ch += 2) {
-      chunk(P0{}, ch);
-      chunk(P1{}, ch + 1);
-      if (ch == 0) S2P_STAMP(5 + 8 * j);
+    for (int ch = 2; ch < NCHUNK; ch += 2) {
+      step(P0{}, std::false_type{}, ch);
+      step(P1{}, std::false_type{}, ch + 1);
       if (ch == 2) S2P_STAMP(6 + 8 * j);
     }
+    fc2_tail();
     S2P_STAMP(7 + 8 * j);
   }
 
