@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32", "fp8"])
     ap.add_argument("--batch", type=int, default=1024, help="alerts per GPU per step")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches in flight on alternating HIP streams in the timed loop (btsbot_amd.ScoreStream); "
@@ -84,7 +84,7 @@ from btsbot_amd.synthetic import METADATA_COLS, synthetic_batch  # noqa: E402
 
 METRIC = "alerts/sec (63×63×3 triplet + 25 meta) train+infer, 1/2/4/8 MI355X"
 PER_GPU_BATCH = 1024
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "fp8": 2500.0}   # (fp8 mode: most FLOPs still bf16)
 HBM_PEAK_GBS = 8000.0
 STAGE_P = (225, 49, 9, 1)
 
@@ -565,15 +565,47 @@ def main():
                                            3, fence, dist, world, with_parity=(rank == 0))
             except Exception as e:   # noqa: BLE001
                 legs[prec] = {"error": f"{type(e).__name__}: {e}"}
-        # BASELINE.json configs[4] (batch 8192, streaming nightly-alert-rate throughput) in the benchmarked precision:
-        # the library has no fp8 operand mode (out of scope), so this is that configuration's batch size at
-        # bf16/f16 -- the library works through it in chunks of 2048 alerts
+        # BASELINE.json configs[4] (fp8 MFMA inference, batch 8192, streaming throughput): the fp8 mode = stages 2-3's
+        # pointwise convolutions on fp8 operands, everything else as in bf16; first this batch size in the
+        # benchmarked precision, then the fp8 mode on the benched batch (with its parity) and on 8192 alerts per call
+        # through the two-stream scoring loop.  The library works through a call in chunks of 2048 alerts
         try:
             big_img, big_meta, _ = synthetic_batch(8192, seed=3 + rank)
             big_img, big_meta = big_img.to(dev), big_meta.to(dev)
             leg = precision_leg_on(model, big_img, big_meta, max(5, args.steps // 5), 2, fence, dist, world)
-            leg["workload"] = "BASELINE.json configs[4] batch size (8192 alerts per call) at %s, fp8 not implemented" % args.precision
+            leg["workload"] = "BASELINE.json configs[4] batch size (8192 alerts per call) at %s, serial calls" % args.precision
             legs["batch8192"] = leg
+            if args.precision != "fp8":
+                legs["fp8"] = precision_leg("fp8", dev, img, meta, args.steps, 3, fence, dist, world, with_parity=(rank == 0))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    m8 = btsbot_amd.mm_ConvNeXt(CONFIG, precision="fp8")
+                seeded_weights(m8)
+                m8 = m8.to(dev).eval()
+                sc8 = btsbot_amd.ScoreStream(m8, depth=2, inputs_ready=True)
+
+                def run8(n):
+                    o = None
+                    for o in sc8.map((big_img, big_meta) for _ in range(n)):
+                        pass
+                    return o
+
+                run8(3)
+                fence()
+                t8 = time.perf_counter()
+                n8 = max(6, args.steps // 8)
+                run8(n8)
+                fence()
+                e8 = time.perf_counter() - t8
+                if dist is not None:
+                    tt = torch.tensor([e8], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    e8 = tt.item()
+                legs["fp8_batch8192"] = dict(
+                    value=round(8192 * world * n8 / e8, 1), unit="alerts/s", steps=n8, ms_per_step=round(1e3 * e8 / n8, 4),
+                    workload="BASELINE.json configs[4]: mm_ConvNeXt-pico, fp8 MFMA in stages 2-3, 8192 synthetic alerts per "
+                             "call, two calls in flight (ScoreStream)")
+                del sc8, m8
             del big_img, big_meta
         except Exception as e:   # noqa: BLE001
             legs["batch8192"] = {"error": f"{type(e).__name__}: {e}"}

@@ -89,7 +89,10 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
         h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
-        if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
+        if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) {
+          h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
+          h->down[i].p_scale = bump(cur, 64);
+        }
       }
       for (int j = 0; j < c.depths[i]; ++j) {
         snprintf(buf, sizeof buf, "stages.%d.blocks.%d.", i, j);
@@ -113,6 +116,7 @@ int build_tables(btsbot_ctx* h) {
         if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
+          b.p_scales = bump(cur, 64);
         }
         b.p_fc1t = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2t = bump(cur, (size_t)4 * ch * ch * esz);
@@ -217,13 +221,17 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
                      BTSBOT_ABI_VERSION);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_F16 ||
+  if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_FP8 ||
       cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_FROZEN_FUSION_MAXVIT) {
     btsbot_set_error("create: bad precision %d or wiring %d", cfg->precision, cfg->wiring);
     return BTSBOT_ERR_INVALID_ARG;
   }
   btsbot_ctx* h = new btsbot_ctx();
   h->cfg = *cfg;
+  if (cfg->precision == BTSBOT_FP8) {   // everything but the fragment-streaming stages reads the bf16 schedule
+    h->fp8 = true;
+    h->cfg.precision = BTSBOT_BF16;
+  }
   const int w = cfg->wiring;
   h->has_image = (w != BTSBOT_UM_NN);
   h->has_meta = (w != BTSBOT_CONVNEXT && w != BTSBOT_MAXVIT);
@@ -462,12 +470,14 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
         if (i == 2 && h->stage2p && !train_only) {
-          TRY(launch_pack_s2p(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, st));
-          TRY(launch_pack_s2p(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, st));
+          float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
+          TRY(launch_pack_s2p(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, sc, st));
+          TRY(launch_pack_s2p(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, sc + 2, st));
         }
         if (i == 3 && h->stage3 && !train_only) {
-          TRY(launch_pack_s3(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 1, st));
-          TRY(launch_pack_s3(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, st));
+          float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
+          TRY(launch_pack_s3(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 1, sc, st));
+          TRY(launch_pack_s3(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, sc + 2, st));
         }
         if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
           TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
@@ -486,7 +496,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     TRY(launch_pack_frag32(c.precision, m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
   if (convnext && h->stage2p && !train_only)
     TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
-                        c.dims[2], st));
+                        c.dims[2], nullptr, st));
   if (h->head16 && !train_only) {
     if (h->has_meta) {
       TRY(launch_pack_h16(c.precision, m + h->m1_w, h->extra + h->p_m1h, c.meta_fc1, c.n_meta, st));
@@ -748,6 +758,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].gamma = m + b.gamma;
           a.blk[j].w1p = h->extra + b.p_w1p;
           a.blk[j].w2p = h->extra + b.p_w2p;
+          a.blk[j].scales = h->fp8 ? reinterpret_cast<const float*>(h->extra + b.p_scales) : nullptr;
         }
         a.ds_lnw = m + h->down[3].ln_w;
         a.ds_lnb = m + h->down[3].ln_b;
@@ -761,7 +772,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.diag = dg != nullptr ? atoi(dg) : 0;
         }
         a.stamps = h->stamps ? h->stamps + 32 + 16384 : nullptr;
-        TRY(timed(h, CAT_STAGE2, st, [&] { return launch_stage2p(c.precision, a, st); }));
+        TRY(timed(h, CAT_STAGE2, st, [&] { return launch_stage2p(h->prec_tail(), a, st); }));
         float* t = x;
         x = x2;
         x2 = t;
@@ -785,13 +796,14 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].w2p = h->extra + b.p_w2p;
           a.blk[j].b2 = m + b.fc2_b;
           a.blk[j].gamma = m + b.gamma;
+          a.blk[j].scales = h->fp8 ? reinterpret_cast<const float*>(h->extra + b.p_scales) : nullptr;
         }
         a.hfrag = hb;
         a.B = nb;
         a.stamps = h->stamps ? h->stamps + 32 + 16384 + 64 : nullptr;
         for (int j = 0; j < a.depth; ++j) {
-          TRY(timed(h, CAT_S3FC1, st, [&] { return launch_stage3(c.precision, ch, a, j, 0, st); }));
-          TRY(timed(h, CAT_S3FC2, st, [&] { return launch_stage3(c.precision, ch, a, j, 1, st); }));
+          TRY(timed(h, CAT_S3FC1, st, [&] { return launch_stage3(h->prec_tail(), ch, a, j, 0, st); }));
+          TRY(timed(h, CAT_S3FC2, st, [&] { return launch_stage3(h->prec_tail(), ch, a, j, 1, st); }));
         }
         if (h->debug)
           HIP_TRY(hipMemcpyAsync(h->taps[4], x, (size_t)rows * ch * 4, hipMemcpyDeviceToDevice, st));

@@ -8,6 +8,7 @@
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
+struct fp8_t { unsigned char v; };   // tag of the fp8 (OCP e4m3) operand mode of stage2p.hip / stage3.hip
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -246,7 +247,7 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
 // fp32 [rows][K] (reorder_down: a [Cout][Cin][2][2] downsample filter, K = 4 Cin) -> 16x16x32 A fragments
 // [row tile][k-step][lane][8], optionally scaled per row
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
-                    int cin, hipStream_t st);
+                    int cin, float* scale, hipStream_t st);   // scale: fp8 mode only ({S, 1/S}, device)
 size_t s1par_bytes();
 int launch_pack_frag32(int prec, const float* src, void* dst, int cout, int cin, hipStream_t st);   // stage1b.hip
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,

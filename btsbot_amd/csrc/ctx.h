@@ -19,6 +19,7 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip / stage3.hip: fc1 / gamma * fc2 filters as MFMA A fragments
+  size_t p_scales = 0;           // fp8 mode: {S1, 1/S1, S2, 1/S2} of those two
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
 };
@@ -26,6 +27,7 @@ struct DownPk {
   int64_t ln_w, ln_b, w, b;
   size_t p_w, p_wt;        // p_wt: [4*Cin][Cout] transpose of the packed filter (dgrad)
   size_t p_wp = 0;         // stage2p.hip: the filter as MFMA A fragments
+  size_t p_scale = 0;      // fp8 mode: {S, 1/S} of it
 };
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
@@ -91,6 +93,8 @@ struct btsbot_ctx {
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
   bool use_s2p = true;     // BTSBOT_AMD_NO_S2P=1: per-block launches (stage2.hip + fc2 GEMM) instead of stage2p.hip
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
+  bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
+  int prec_tail() const { return fp8 ? BTSBOT_FP8 : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip
   bool stage3 = false;     // stage3.hip: the 1x1 stage as two fragment-streaming launches per block
   bool use_s3 = true;      // BTSBOT_AMD_NO_S3=1: dwconv_ln + the generic GEMMs instead
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)

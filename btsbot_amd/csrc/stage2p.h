@@ -14,6 +14,7 @@ struct Stage2pBlk {
   const float* gamma;    // [256]
   const void* w1p;       // fc1 filter as MFMA A fragments: [hidden tile 64][k-step 8][lane 64][8]
   const void* w2p;       // gamma * fc2 filter as A fragments: [channel tile 16][k-step 32][lane 64][8]
+  const float* scales;   // fp8 mode: {S1, 1/S1, S2, 1/S2} (device): the powers of two the two filters were packed with
 };
 struct Stage2pArgs {
   const float* x_in;     // [B][9][256] f32 (stage-1 output after its downsample)
@@ -21,7 +22,7 @@ struct Stage2pArgs {
   int depth;
   const float* ds_lnw;   // stages[3].downsample: LayerNorm2d(256) + Conv2d(256, 512, 2, 2)
   const float* ds_lnb;
-  const void* ds_wp;     // A fragments: [output tile 32][k-step 32][lane 64][8], k = (2 ky + kx) * 256 + c
+  const void* ds_wp;     // (16-bit in the fp8 mode too) A fragments: [output tile 32][k-step 32][lane 64][8], k = (2 ky + kx) * 256 + c
   const float* ds_b;
   float* out;            // [B][512] f32
   float* tap_stage;      // optional [B][9][256] f32 copy of the stage output (validation)

@@ -32,22 +32,60 @@
 
 #include "common.h"
 #include "stage2p.h"
+#include "stage3.h"
 
 namespace {
 
+// operand traits: fragment (8 elements per lane), element size, MFMA, conversions from fp32
 template <typename T> struct MP;
-template <> struct MP<bf16_t> {
-  using frag = bf16x8;
+template <typename T> struct MP16 {
+  static constexpr int ESZ = 2;
+  typedef T frag __attribute__((ext_vector_type(8)));
+  typedef T quad __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
+    frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
+    return o;
+  }
+  static __device__ __forceinline__ quad pack4(const float (&v)[4]) {
+    quad o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+    return o;
+  }
+};
+template <> struct MP<bf16_t> : MP16<bf16_t> {
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
-template <> struct MP<f16_t> {
-  using frag = f16x8;
+template <> struct MP<f16_t> : MP16<f16_t> {
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
 };
+// fp8 (OCP e4m3): 8 elements = one 64-bit register pair; activations clamped to +-448 before the conversion (beyond
+// its largest finite value the format has only NaN).  Filters carry one power-of-two scale each (stage3.hip).
+template <> struct MP<fp8_t> {
+  static constexpr int ESZ = 1;
+  typedef long frag;
+  typedef unsigned quad;
+  static __device__ __forceinline__ float c8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+  static __device__ __forceinline__ quad pack4(const float (&v)[4]) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c8(v[0]), c8(v[1]), 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c8(v[2]), c8(v[3]), w, true);
+  }
+  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
+    const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+    return (long)(((unsigned long)pack4(b) << 32) | pack4(a));
+  }
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+  }
+};
+template <typename T> struct GeluOf2 { using type = T; };
+template <> struct GeluOf2<fp8_t> { using type = bf16_t; };   // fp8 rides on the bf16 schedule's GELU
 
 constexpr int C = 256, HID = 1024, G = S2P_ALERTS, NPX = 9 * G, NCOL = 48, NB = NCOL / 16;   // 36 live of 48 columns
 constexpr int NT = 512, NW = NT / 64;                 // 8 waves: 2 per SIMD
@@ -56,12 +94,12 @@ constexpr int KS1 = C / 32;                           // 8 k-steps of fc1
 constexpr int KS2 = CHUNK / 32;                       // 4 k-steps of fc2 per chunk
 constexpr int CO = 512, KD = 4 * C, KSD = KD / 32;    // downsample: 512 outputs, K = 1024
 constexpr int XLP = C;                                // fp32 map: floats per pixel row
-constexpr int XNP = C * 2 + 16;                       // 16-bit LN image: bytes per pixel row (528)
-constexpr int HP = CHUNK * 2 + 16;                    // hidden image: bytes per pixel row (272)
+constexpr int XNP2 = C * 2 + 16;                      // 16-bit LN image: bytes per pixel row (528)
+constexpr int HP2 = CHUNK * 2 + 16;                   // hidden image: bytes per pixel row (272)
 constexpr int OFF_XL = 0;                             // [48][256] f32 (rows >= 36 stay zero)
 constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;       // 49152
-constexpr int OFF_H = OFF_XN + NCOL * XNP;            // + 25344
-constexpr int OFF_B1 = OFF_H + 2 * NCOL * HP;         // + 26112: fc1 bias [1024] f32
+constexpr int OFF_H = OFF_XN + NCOL * XNP2;           // + 25344
+constexpr int OFF_B1 = OFF_H + 2 * NCOL * HP2;        // + 26112: fc1 bias [1024] f32
 constexpr int LDS_BYTES = OFF_B1 + HID * 4;           // 104704
 constexpr float LN_EPS = 1e-6f;
 #define S2P_STAMP(i)                                                                      \
@@ -80,11 +118,15 @@ __device__ __forceinline__ float half_sum(float v) {
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   using frag = typename MP<T>::frag;
-  typedef T T4 __attribute__((ext_vector_type(4)));
+  using quad = typename MP<T>::quad;
+  constexpr int ESZ = MP<T>::ESZ;
+  constexpr bool F8 = std::is_same<T, fp8_t>::value;
+  // operand images: bytes per pixel row (the regions keep their 16-bit sizes)
+  constexpr int XNP = C * ESZ + 16, HP = CHUNK * ESZ + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
   unsigned char* xn = smem + OFF_XN;
-  unsigned char* hb = smem + OFF_H;
+  unsigned char* hb = smem + OFF_H;   // two hidden images, NCOL * HP2 bytes apart
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -213,14 +255,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const float var = half_sum(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2] + e0[3] * e0[3] + e1[0] * e1[0] +
                                  e1[1] * e1[1] + e1[2] * e1[2] + e1[3] * e1[3]) * (1.0f / C);
       const float rstd = rsqrtf(var + LN_EPS);
-      typedef T T8 __attribute__((ext_vector_type(8)));
-      T8 y;
+      float y[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        y[i] = (T)(e0[i] * rstd * lw[i] + lb[i]);
-        y[4 + i] = (T)(e1[i] * rstd * lw2[i] + lb2[i]);
+        y[i] = e0[i] * rstd * lw[i] + lb[i];
+        y[4 + i] = e1[i] * rstd * lw2[i] + lb2[i];
       }
-      *reinterpret_cast<T8*>(xn + p * XNP + 16 * (lane & 31)) = y;
+      *reinterpret_cast<frag*>(xn + p * XNP + 8 * ESZ * (lane & 31)) = MP<T>::pack8(y);
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
@@ -229,6 +270,16 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[m][n] += g4[m] * b4[m];
+    // fp8: gamma * W2 was packed times the power of two S2, so the residual rides through the chunk loop times S2
+    // (exact) and comes back times 1/S2 behind the block's last fc2
+    const float s1 = F8 ? bk.scales[0] : 1.0f, is1 = F8 ? bk.scales[1] : 1.0f;
+    if (F8) {
+      const float s2 = bk.scales[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] *= s2;
+    }
 
     // One step = fc1 of chunk ch, then GELU of chunk ch BETWEEN the fc2 products of chunk ch - 1 (software pipeline
     // inside the wave: the two waves of a SIMD meet at the same barrier every chunk, so they are in the same phase
@@ -249,19 +300,20 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]
       f32x4 hacc[NB];
       {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + ch * CHUNK + 16 * wave + 4 * kg);
+        f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + ch * CHUNK + 16 * wave + 4 * kg);
+        if (F8) bv *= s1;   // (the filter was packed times S1: the sum leaves times 1/S1 in front of the GELU)
 #pragma unroll
         for (int n = 0; n < NB; ++n) hacc[n] = bv;
       }
       frag xb[2][NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) xb[0][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (8 * kg) * 2);
+      for (int n = 0; n < NB; ++n) xb[0][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (8 * kg) * ESZ);
 #pragma unroll
       for (int s = 0; s < KS1; ++s) {
         if (s + 1 < KS1) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            xb[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * 2);
+            xb[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * ESZ);
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[p][s], xb[s & 1][n], hacc[n]);
@@ -270,12 +322,12 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       }
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
       // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
-      unsigned char* hcur = hb + p * (NCOL * HP);
-      const unsigned char* hprev = hb + (1 - p) * (NCOL * HP);
+      unsigned char* hcur = hb + p * (NCOL * HP2);
+      const unsigned char* hprev = hb + (1 - p) * (NCOL * HP2);
       frag hbf[2][NB];
       if (!first) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * 2);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
       }
       static_assert(NB <= KS2, "one GELU column block per fc2 k-step");
 #pragma unroll
@@ -284,7 +336,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
           if (s + 1 < KS2) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
+              hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
           }
 #pragma unroll
           for (int m = 0; m < 2; ++m)
@@ -294,10 +346,10 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
           a2[1 - p][1][s] = src2[((size_t)(HID / 32) + s) * 64];
         }
         if (s < NB) {
-          T4 hv;
+          float hv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (T)gelu_for<T>(hacc[s][r]);
-          *reinterpret_cast<T4*>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * 2) = hv;
+          for (int r = 0; r < 4; ++r) hv[r] = gelu_for<typename GeluOf2<T>::type>(F8 ? hacc[s][r] * is1 : hacc[s][r]);
+          *reinterpret_cast<quad*>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ) = MP<T>::pack4(hv);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -308,16 +360,16 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     auto fc2_tail = [&]() {
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + 1 * KS2) * 64 + lane;
-      const unsigned char* hprev = hb + 1 * (NCOL * HP);   // chunk NCHUNK - 1 is odd: image 1, fragments in set 1
+      const unsigned char* hprev = hb + 1 * (NCOL * HP2);   // chunk NCHUNK - 1 is odd: image 1, fragments in set 1
       frag hbf[2][NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * 2);
+      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         if (s + 1 < KS2) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
+            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -339,6 +391,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       if (ch == 2) S2P_STAMP(6 + 8 * j);
     }
     fc2_tail();
+    if (F8) {
+      const float is2 = bk.scales[3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] *= is2;
+    }
     S2P_STAMP(7 + 8 * j);
   }
 
@@ -356,6 +415,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
   }
   __syncthreads();
+  // (the downsample keeps 16-bit operands in the fp8 mode too: it is 5 % of the stage's FLOPs and its LN'd input in
+  //  fp8 tripled the mode's score error with trained-like layer scales)
+  using TD = typename std::conditional<F8, bf16_t, T>::type;
+  using fragd = typename MP<TD>::frag;
+  constexpr int XND = C * MP<TD>::ESZ + 16;
   {
     const f32x4 lw = *reinterpret_cast<const f32x4*>(a.ds_lnw + 4 * lane);
     const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ds_lnb + 4 * lane);
@@ -365,10 +429,10 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const f32x4 e = d - mean;
       const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]) * (1.0f / C);
       const float rstd = rsqrtf(var + LN_EPS);
-      T4 y;
+      float y[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = (T)(e[i] * rstd * lw[i] + lb[i]);
-      *reinterpret_cast<T4*>(xn + p * XNP + 8 * lane) = y;
+      for (int i = 0; i < 4; ++i) y[i] = e[i] * rstd * lw[i] + lb[i];
+      *reinterpret_cast<typename MP<TD>::quad*>(xn + p * XND + 4 * MP<TD>::ESZ * lane) = MP<TD>::pack4(y);
     }
   }
   __syncthreads();
@@ -378,9 +442,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // Column = alert (4 live of 16); wave w: output tiles 4 w .. 4 w + 3 (16 channels each), 32 k-steps.
     const int al = col < G ? col : 0;
     // this wave's 4 tiles x 32 k-steps = 128 fragments, contiguous in memory (tile-major): a ring of 16 in flight
-    const frag* src = reinterpret_cast<const frag*>(a.ds_wp) + (size_t)(4 * wave) * KSD * 64 + lane;
+    const fragd* src = reinterpret_cast<const fragd*>(a.ds_wp) + (size_t)(4 * wave) * KSD * 64 + lane;
     constexpr int RING = 16, NSTEP = 4 * KSD;
-    frag wq[RING];
+    fragd wq[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) wq[i] = src[i * 64];
     f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (4 * wave) + 4 * kg);
@@ -390,8 +454,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       for (int i = 0; i < RING; ++i) {
         const int st = g * RING + i, s = st & (KSD - 1), tile = 4 * wave + (st >> 5);
         const int q = s >> 3, pq = 3 * (q >> 1) + (q & 1);
-        const frag bf = *reinterpret_cast<const frag*>(xn + (9 * al + pq) * XNP + (32 * (s & 7) + 8 * kg) * 2);
-        o = MP<T>::run(wq[i], bf, o);
+        const fragd bf = *reinterpret_cast<const fragd*>(xn + (9 * al + pq) * XND + (32 * (s & 7) + 8 * kg) * MP<TD>::ESZ);
+        o = MP<TD>::run(wq[i], bf, o);
         if (st + RING < NSTEP) wq[i] = src[(size_t)(st + RING) * 64];
         if (s == KSD - 1) {   // tile finished (every 32 steps = two ring rounds)
           if (col < G && alert0 + col < a.B)
@@ -430,6 +494,27 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, const float* __res
   out[i] = (T)v;
 }
 
+__global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
+                                     const float* __restrict__ scale, unsigned char* __restrict__ out, int rows, int K,
+                                     int reorder_down, int cin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 32;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  const int row = 16 * tile + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+  float v;
+  if (reorder_down) {
+    const int q = k / cin, c = k - q * cin;
+    v = w[((long)row * cin + c) * 4 + q];
+  } else {
+    v = w[(long)row * K + k];
+  }
+  if (rowscale != nullptr) v *= rowscale[row];
+  out[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
+}
+
 template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
   auto kern = stage2p_kernel<T>;
   static bool attr_set = false;
@@ -446,12 +531,12 @@ template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st)
 }  // namespace
 
 bool stage2p_supported(int prec, int c2, int c3, int depth) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c2 == C && c3 == CO && depth >= 1 && depth <= S2P_MAX_DEPTH;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8) && c2 == C && c3 == CO && depth >= 1 && depth <= S2P_MAX_DEPTH;
 }
 
 // src [rows][K] fp32 (row-major; reorder_down: a [Cout][Cin][2][2] downsample filter) -> MFMA A fragments
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
-                    int cin, hipStream_t st) {
+                    int cin, float* scale, hipStream_t st) {
   const long total = (long)rows * K;
   const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
   if (prec == BTSBOT_BF16)
@@ -460,8 +545,18 @@ int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst
   else if (prec == BTSBOT_F16)
     hipLaunchKernelGGL(pack_frag_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
                        reorder_down, cin);
-  else {
-    btsbot_set_error("pack_s2p: precision %d is not a 16-bit mode", prec);
+  else if (prec == BTSBOT_FP8) {
+    if (scale == nullptr) {
+      btsbot_set_error("pack_s2p: the fp8 mode needs a scale slot");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    // (the downsample filter [Cout][Cin][2][2] is scanned in its own order: the maximum does not care)
+    const int rc = launch_fp8_scale(src, rowscale, total, K, scale, st);
+    if (rc != BTSBOT_OK) return rc;
+    hipLaunchKernelGGL(pack_frag_fp8_kernel, grid, blk, 0, st, src, rowscale, scale, reinterpret_cast<unsigned char*>(dst),
+                       rows, K, reorder_down, cin);
+  } else {
+    btsbot_set_error("pack_s2p: precision %d is not a packed-fragment mode", prec);
     return BTSBOT_ERR_INVALID_ARG;
   }
   LAUNCH_CHECK();
@@ -472,6 +567,7 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage2p_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage2p_t<f16_t>(a, st);
+  if (prec == BTSBOT_FP8) return launch_stage2p_t<fp8_t>(a, st);
   btsbot_set_error("stage2p: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
 }

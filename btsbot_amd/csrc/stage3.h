@@ -13,6 +13,7 @@ struct Stage3Blk {
   const void* w2p;       // gamma * fc2 filter as A fragments: [channel tile][k-step][lane 64][8]
   const float* b2;       // [C]
   const float* gamma;    // [C]
+  const float* scales;   // fp8 mode: {S1, 1/S1, S2, 1/S2} (device), powers of two the two filters were packed with; else nullptr
 };
 
 struct Stage3Args {
@@ -29,5 +30,9 @@ size_t stage3_hfrag_bytes(int prec, int c3, int B);
 // phase 0: centre tap + LN + fc1 + GELU of block `block` (x -> hfrag); phase 1: fc2 + layer scale + residual (in place)
 int launch_stage3(int prec, int c3, const Stage3Args& a, int block, int phase, hipStream_t st);
 // fp32 [rows][K] (x rowscale[row]) -> A fragments of 32 rows x 16 k; swap23: tile row r holds source row swap23(r)
+// fp8: `scale` (device, 2 floats) receives {S, 1/S}, S = the power of two that puts max |w| just below 240
 int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int swap23,
-                   hipStream_t st);
+                   float* scale, hipStream_t st);
+// fp8 packing helper shared with stage2p.hip: scale[0..1] <- {S, 1/S}, S = the power of two that puts
+// max |src[i] * rowscale[i / K]| just below 240 (OCP e4m3's largest finite value is 448)
+int launch_fp8_scale(const float* src, const float* rowscale, long n, int K, float* scale, hipStream_t st);

@@ -19,24 +19,65 @@
 //  same-address device-scope atomics, or cooperative_groups' grid.sync() -- against ~3 us for a kernel boundary.)
 #include "common.h"
 #include "stage3.h"
+#include <type_traits>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// operand traits: fragment type (8 elements per lane), element size, MFMA, and the conversions from fp32
 template <typename T> struct S3M;
-template <> struct S3M<bf16_t> {
-  using frag = bf16x8;
+template <typename T> struct S3M16 {
+  static constexpr int ESZ = 2;
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  typedef T frag __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ pair_t pack2(float a, float b) {
+    pair_t o;
+    o[0] = (T)a;
+    o[1] = (T)b;
+    return o;
+  }
+  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
+    frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
+    return o;
+  }
+};
+template <> struct S3M<bf16_t> : S3M16<bf16_t> {
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
-template <> struct S3M<f16_t> {
-  using frag = f16x8;
+template <> struct S3M<f16_t> : S3M16<f16_t> {
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
+// fp8 (OCP e4m3 on gfx950): 8 elements = one 64-bit register pair.  Activations are clamped to the format's range
+// before the conversion (its largest finite value is 448; what lies beyond would become NaN).
+template <> struct S3M<fp8_t> {
+  static constexpr int ESZ = 1;
+  typedef unsigned short pair_t;
+  typedef long frag;
+  static __device__ __forceinline__ float clamp8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+  static __device__ __forceinline__ pair_t pack2(float a, float b) {
+    return (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(a), clamp8(b), 0, false);
+  }
+  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[0]), clamp8(v[1]), 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[2]), clamp8(v[3]), lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[4]), clamp8(v[5]), 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[6]), clamp8(v[7]), hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+  }
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+  }
+};
+// GELU of the operand mode: fp8 rides on the bf16 schedule (degree-3 polynomial form)
+template <typename T> struct GeluOf { using type = T; };
+template <> struct GeluOf<fp8_t> { using type = bf16_t; };
 
 #define S3_STAMP(i)                                                                       \
   do {                                                                                    \
@@ -54,7 +95,8 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   using frag = typename S3M<T>::frag;
   constexpr int HID = 4 * C, KS = C / 16, NV = C / 128, RING = KS > 32 ? KS / 2 : KS;
   static_assert(RING % 4 == 0, "ring quarters");
-  constexpr int PITCH = C * 2 + 16;     // bytes per LDS row: C 16-bit values + 16 (8 rows cover the 32 banks)
+  constexpr int ESZ = S3M<T>::ESZ;
+  constexpr int PITCH = C * ESZ + 16;   // bytes per LDS row: C operand values + 16 (8 rows cover the 32 banks)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int ht = nt * (N1 / 32) + wave;                 // this wave's tile of 32 hidden units
   // ---- the 32 rows first (4 per wave; lane = channels 128 i + 2 lane + {0, 1}), then the per-channel constants
@@ -101,37 +143,38 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
       q = fmaf(v[u][i].x, v[u][i].x, fmaf(v[u][i].y, v[u][i].y, q));
     }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
-    unsigned char* row = smem + (4 * wave + u) * PITCH + 4 * lane;
+    unsigned char* row = smem + (4 * wave + u) * PITCH + 2 * ESZ * lane;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      typedef T __attribute__((ext_vector_type(2))) T2;
-      T2 o;
-      o[0] = (T)fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x);
-      o[1] = (T)fmaf(v[u][i].y * rstd, lw[i].y, lb[i].y);
-      *reinterpret_cast<T2*>(row + 256 * i) = o;
+      *reinterpret_cast<typename S3M<T>::pair_t*>(row + 128 * ESZ * i) =
+          S3M<T>::pack2(fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x), fmaf(v[u][i].y * rstd, lw[i].y, lb[i].y));
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   S3_STAMP(10);
-  // ---- fc1 bias into the accumulator: register r of a lane = hidden unit 32 ht + (r & 7) + 8 h + 16 (r >> 3)
+  // ---- fc1 bias into the accumulator: register r of a lane = hidden unit 32 ht + (r & 7) + 8 h + 16 (r >> 3).
+  //      (fp8: the filter is packed times a power of two S1 -- bk.scales = {S1, 1/S1, S2, 1/S2} -- so the bias goes in
+  //      times S1 and the sum comes out times 1/S1; the 16-bit modes have no scales)
+  constexpr bool F8 = std::is_same<T, fp8_t>::value;
+  const float s1 = F8 ? bk.scales[0] : 1.0f, is1 = F8 ? bk.scales[1] : 1.0f;
   f32x16 acc;
   {
     const float* bp = bk.b1 + 32 * ht + 8 * h;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * (qd & 1) + 16 * (qd >> 1));
-      acc[4 * qd + 0] = bv.x;
-      acc[4 * qd + 1] = bv.y;
-      acc[4 * qd + 2] = bv.z;
-      acc[4 * qd + 3] = bv.w;
+      acc[4 * qd + 0] = bv.x * s1;
+      acc[4 * qd + 1] = bv.y * s1;
+      acc[4 * qd + 2] = bv.z * s1;
+      acc[4 * qd + 3] = bv.w * s1;
     }
   }
   __syncthreads();
   S3_STAMP(11);
-  const unsigned char* bp = smem + lr * PITCH + h * 16;
+  const unsigned char* bp = smem + lr * PITCH + h * 8 * ESZ;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const frag bf = *reinterpret_cast<const frag*>(bp + ks * 32);
+    const frag bf = *reinterpret_cast<const frag*>(bp + ks * 16 * ESZ);
     acc = S3M<T>::run(wq[ks % RING], bf, acc);
     if (ks + RING < KS) wq[ks % RING] = wsrc[(ks + RING) * 64];
   }
@@ -140,9 +183,10 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   frag* hout = reinterpret_cast<frag*>(a.hfrag);
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
-    frag o;
+    float g[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (T)gelu_for<T>(acc[8 * hh + j]);
+    for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[8 * hh + j] * is1);
+    const frag o = S3M<T>::pack8(g);
     hout[((size_t)ab * (HID / 16) + 2 * ht + hh) * 64 + lane] = o;
   }
   __syncthreads();   // the rows in LDS are read out: the next tile may overwrite them
@@ -201,6 +245,13 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
       s.z += p.z;
       s.w += p.w;
     }
+    if (std::is_same<T, fp8_t>::value) {   // fp8: gamma * W2 was packed times S2
+      const float is2 = bk.scales[3];
+      s.x *= is2;
+      s.y *= is2;
+      s.z *= is2;
+      s.w *= is2;
+    }
     if (al < a.B) {
       float* xp = a.x + (size_t)al * C + c;
       const float4 xv = *reinterpret_cast<const float4*>(xp);
@@ -250,8 +301,40 @@ __global__ void pack_s3_kernel(const float* __restrict__ w, const float* __restr
   out[i] = (T)v;
 }
 
+// ---- fp8: max |w| -> power-of-two scale -> packed bytes
+__global__ void absmax_kernel(const float* __restrict__ w, const float* __restrict__ rowscale, unsigned* __restrict__ bits,
+                              long n, int K) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i] * (rowscale != nullptr ? rowscale[i / K] : 1.0f)));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));   // (non-negative floats order like their bits)
+}
+__global__ void scale_from_max_kernel(float* scale) {
+  const float m = __uint_as_float(*reinterpret_cast<const unsigned*>(scale));
+  const float s = m > 0.f ? exp2f(floorf(log2f(240.0f / m))) : 1.0f;
+  scale[0] = s;
+  scale[1] = 1.0f / s;
+}
+__global__ void pack_s3_fp8_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
+                                   const float* __restrict__ scale, unsigned char* __restrict__ out, int rows, int K,
+                                   int swap23) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 16;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  int r = l & 31;
+  if (swap23) r = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const int row = 32 * tile + r, k = 16 * s + 8 * (l >> 5) + j;
+  float v = w[(long)row * K + k] * scale[0];
+  if (rowscale != nullptr) v *= rowscale[row];
+  out[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+
 template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
-  constexpr int LDS1 = M1 * (C * 2 + 16);
+  constexpr int LDS1 = M1 * (C * S3M<T>::ESZ + 16);
   if (phase == 0) {
     hipLaunchKernelGGL((s3_fc1_kernel<T, C>), dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
   } else {
@@ -270,7 +353,7 @@ template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase,
 }  // namespace
 
 bool stage3_supported(int prec, int c3, int depth) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (c3 == 512 || c3 == 640) && depth >= 1 && depth <= S3_MAX_DEPTH;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8) && (c3 == 512 || c3 == 640) && depth >= 1 && depth <= S3_MAX_DEPTH;
 }
 
 size_t stage3_hfrag_bytes(int prec, int c3, int B) {
@@ -283,12 +366,22 @@ int launch_stage3(int prec, int c3, const Stage3Args& a, int block, int phase, h
   if (prec == BTSBOT_F16 && c3 == 512) return launch_t<f16_t, 512>(a, block, phase, st);
   if (prec == BTSBOT_BF16 && c3 == 640) return launch_t<bf16_t, 640>(a, block, phase, st);
   if (prec == BTSBOT_F16 && c3 == 640) return launch_t<f16_t, 640>(a, block, phase, st);
+  if (prec == BTSBOT_FP8 && c3 == 512) return launch_t<fp8_t, 512>(a, block, phase, st);
+  if (prec == BTSBOT_FP8 && c3 == 640) return launch_t<fp8_t, 640>(a, block, phase, st);
   btsbot_set_error("stage3: precision %d / width %d not supported", prec, c3);
   return BTSBOT_ERR_INVALID_ARG;
 }
 
+int launch_fp8_scale(const float* src, const float* rowscale, long n, int K, float* scale, hipStream_t st) {
+  HIP_TRY(hipMemsetAsync(scale, 0, 8, st));
+  hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, src, rowscale, reinterpret_cast<unsigned*>(scale), n, K);
+  hipLaunchKernelGGL(scale_from_max_kernel, dim3(1), dim3(1), 0, st, scale);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int swap23,
-                   hipStream_t st) {
+                   float* scale, hipStream_t st) {
   const long total = (long)rows * K;
   const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
   if (prec == BTSBOT_BF16)
@@ -297,8 +390,17 @@ int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst,
   else if (prec == BTSBOT_F16)
     hipLaunchKernelGGL(pack_s3_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
                        swap23);
-  else {
-    btsbot_set_error("pack_s3: precision %d is not a 16-bit mode", prec);
+  else if (prec == BTSBOT_FP8) {
+    if (scale == nullptr) {
+      btsbot_set_error("pack_s3: the fp8 mode needs a scale slot");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    const int rc = launch_fp8_scale(src, rowscale, total, K, scale, st);
+    if (rc != BTSBOT_OK) return rc;
+    hipLaunchKernelGGL(pack_s3_fp8_kernel, grid, blk, 0, st, src, rowscale, scale, reinterpret_cast<unsigned char*>(dst),
+                       rows, K, swap23);
+  } else {
+    btsbot_set_error("pack_s3: precision %d is not a packed-fragment mode", prec);
     return BTSBOT_ERR_INVALID_ARG;
   }
   LAUNCH_CHECK();

@@ -66,7 +66,10 @@ enum btsbot_wiring {
 enum btsbot_precision {
   BTSBOT_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 fma chains -- the parity mode          */
   BTSBOT_BF16 = 1, /* v_mfma_f32_16x16x32_bf16                                                   */
-  BTSBOT_F16 = 2   /* v_mfma_f32_16x16x32_f16 (same rate as bf16, 3 more mantissa bits)          */
+  BTSBOT_F16 = 2,  /* v_mfma_f32_16x16x32_f16 (same rate as bf16, 3 more mantissa bits)          */
+  BTSBOT_FP8 = 3   /* inference only: the bf16 schedule with the pointwise convolutions of stages 2-3
+                      (55 % of the FLOPs, the filter-streaming-bound part) on v_mfma_*_fp8_fp8, OCP e4m3,
+                      one power-of-two scale per filter; training entry points behave as BTSBOT_BF16 */
 };
 
 typedef struct btsbot_config {
