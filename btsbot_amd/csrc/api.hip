@@ -304,8 +304,7 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   h->use_stage1 = !(n1 != nullptr && n1[0] == '1');
   const char* n2 = getenv("BTSBOT_AMD_NO_STAGE2");
   h->use_s2 = !(n2 != nullptr && n2[0] == '1');
-  const char* n2p = getenv("BTSBOT_AMD_NO_S2P");
-  h->use_s2p = h->use_s2 && !(n2p != nullptr && n2p[0] == '1');
+  h->use_s2p = h->use_s2;
   {
     const char* nh = getenv("BTSBOT_AMD_NO_HEAD16");
     h->use_head16 = !(nh != nullptr && nh[0] == '1');
@@ -810,20 +809,6 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         continue;
       }
       for (const BlockPk& b : h->blocks[i]) {
-        if (h->use_s2 && c.precision != BTSBOT_F32 && hw == 3 && ch == 256) {
-          // depthwise + LN + fc1 + GELU in one launch (stage2.hip), then the fc2 GEMM
-          TRY(timed(h, CAT_S2FC1, st, [&] {
-            return launch_s2_fc1(c.precision, x, reinterpret_cast<const float*>(h->extra + b.p_dw),
-                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_fc1,
-                                 m + b.fc1_b, hb, nb,
-                                 h->stamps ? h->stamps + 32 + 16384 : nullptr, st);
-          }));
-          TRY(timed(h, CAT_FC2, st, [&] {
-            return launch_gemm(c.precision, EPI_RESID, hb, h->extra + b.p_fc2, m + b.fc2_b,
-                               m + b.gamma, x, x, rows, ch, 4 * ch, st);
-          }));
-          continue;
-        }
         TRY(timed(h, CAT_DWLN, st, [&] {
           return launch_dwconv_ln(c.precision, x,
                                   reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,

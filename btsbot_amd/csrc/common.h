@@ -256,9 +256,6 @@ size_t s0par_bytes();
 int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
                       const float* b1, const float* b2, const float* gamma, void* out,
                       hipStream_t st);
-int launch_s2_fc1(int prec, const float* x, const float* dw_w, const float* dw_b, const float* ln_w,
-                  const float* ln_b, const void* w1, const float* b1, void* h, int B,
-                  unsigned long long* stamps, hipStream_t st);   // stage2.hip: dw7x7+LN+fc1+GELU on 3x3x256 maps, 16-bit modes
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
                    int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0);   // wgrad.hip: 16-bit modes, colsum optional
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...

@@ -32,13 +32,13 @@ struct DownPk {
 
 constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
-enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_S2FC1, CAT_STAGE2, CAT_S3FC1, CAT_S3FC2, CAT_HEAD16,
+enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_STAGE2, CAT_S3FC1, CAT_S3FC2, CAT_HEAD16,
        CAT_MV_STEM, CAT_MV_G_STEM, CAT_MV_G_CONV1, CAT_MV_G_CONV3, CAT_MV_G_SC, CAT_MV_G_QKV, CAT_MV_G_PROJ, CAT_MV_G_FC1,
        CAT_MV_G_FC2, CAT_MV_FUSED, CAT_MV_FRONT, CAT_MV_ABLK, CAT_MV_ELT, CAT_MV_DW, CAT_MV_SE, CAT_MV_LN, CAT_MV_ATTN, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
                                      "head_kernel", "fused_mlp_kernel", "stage0b_kernel", "stage1b_kernel",
-                                     "s2_fc1_kernel", "stage2p_kernel", "s3_fc1_kernel", "s3_fc2_kernel", "head16_kernel",
+                                     "stage2p_kernel", "s3_fc1_kernel", "s3_fc2_kernel", "head16_kernel",
                                      "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
                                      "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
                                      "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
@@ -90,8 +90,8 @@ struct btsbot_ctx {
   std::vector<int> prof_cat;
   size_t prof_used = 0;
 
-  bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1 keeps dwconv_ln + fc1 GEMM launches for stage 2
-  bool use_s2p = true;     // BTSBOT_AMD_NO_S2P=1: per-block launches (stage2.hip + fc2 GEMM) instead of stage2p.hip
+  bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1: the per-op launches (dwconv_ln + fc1 / fc2 GEMMs) for stage 2
+  bool use_s2p = true;     // (= use_s2: stage2p.hip is the stage-2 kernel)
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
   bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
   int prec_tail() const { return fp8 ? BTSBOT_FP8 : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip

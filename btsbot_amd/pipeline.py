@@ -19,7 +19,7 @@ Synchronisation is kept off the GPU's queues: a result is handed out once its ba
 the batch's stream; with `depth` batches queued the GPU never runs dry), so it is valid on any stream without a
 stream-side wait -- cross-stream waits cost ~10 us of barrier packets each on this stack, four of them per batch
 ate the whole gain (0.32 -> 0.39 ms per batch), and a host-side wait right behind the batch just queued (lag =
-depth) cost half of it; map() therefore keeps the host four batches ahead.  For the same reason the side stream waits for the caller's stream
+depth) cost half of it; map() therefore keeps the host `lag` batches (default 16) ahead.  For the same reason the side stream waits for the caller's stream
 only when the inputs may still be in flight there (`inputs_ready=False`, the default); a loader that hands over
 finished tensors (synchronous copies, pinned-memory prefetch with its own sync) passes `inputs_ready=True`.
 """
@@ -84,10 +84,12 @@ class ScoreStream:
         done.synchronize()
         return out
 
-    def map(self, batches: Iterable[Tuple[torch.Tensor, ...]], lag: int = 4) -> Iterator[torch.Tensor]:
+    def map(self, batches: Iterable[Tuple[torch.Tensor, ...]], lag: int = 16) -> Iterator[torch.Tensor]:
         """Score an iterable of input tuples, results in order.  The host stays `lag` batches ahead of the oldest
         unfinished one: every batch is followed by a completion event, and a result is handed out (after a host-side
-        wait on its event) once `lag` newer batches are queued."""
+        wait on its event) once `lag` newer batches are queued.  A short lag makes the loop sensitive to host jitter (with 4
+        batches = 1.3 ms of queued work one descheduling of the host thread empties the queues); the price of a long one
+        is `lag` output tensors and input tuples kept alive."""
         lag = max(lag, len(self.models))
         pending = collections.deque()
         for inputs in batches:

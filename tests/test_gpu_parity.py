@@ -275,8 +275,8 @@ def test_adamw_kernel(cuda):
         assert np.allclose(p.cpu().numpy(), g["traj"][s], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("env", ["BTSBOT_AMD_NO_STAGE2", "BTSBOT_AMD_NO_STAGE0", "BTSBOT_AMD_NO_STAGE1", "BTSBOT_AMD_NO_S2P",
-                                 "BTSBOT_AMD_NO_S3", "BTSBOT_AMD_NO_HEAD16"])
+@pytest.mark.parametrize("env", ["BTSBOT_AMD_NO_STAGE2", "BTSBOT_AMD_NO_STAGE0", "BTSBOT_AMD_NO_STAGE1", "BTSBOT_AMD_NO_S3",
+                                 "BTSBOT_AMD_NO_HEAD16"])
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_alternative_schedules_match_oracle(cuda, monkeypatch, env, prec):
     """The library's schedule switches (read at model creation) fall back from a stage's fused kernel to
