@@ -35,9 +35,10 @@ __all__ = ["ScoreStream"]
 
 def _replica(model):
     cfg = getattr(model, "_init_config", None)
-    if cfg is None or getattr(model, "_wiring", "") == "frozen_fusion":
+    if cfg is None:
         raise NotImplementedError(f"ScoreStream(depth > 1) cannot replicate a {type(model).__name__}")
-    twin = type(model)(dict(cfg, pretrained=False), precision=model.precision)
+    # (frozen_fusion reads its branches' checkpoints when constructed: the replica takes them from the state dict)
+    twin = type(model)(dict(cfg, pretrained=False, skip_load_state=True), precision=model.precision)
     twin.load_state_dict(model.state_dict())
     dev = next(model.parameters()).device
     return twin.to(dev).eval()

@@ -37,7 +37,9 @@ def parse_args():
     p.add_argument("--pretrain", type=str, default="galaxyzoo", choices=["imagenet", "galaxyzoo", "randinit"])
     p.add_argument("--multi_modal", action="store_true")
     p.add_argument("--data-dir", type=str, default="example_data")
-    p.add_argument("--precision", type=str, default=None, choices=[None, "f32", "bf16", "f16"])
+    p.add_argument("--precision", type=str, default=None, choices=[None, "f32", "bf16", "f16", "fp8"])
+    p.add_argument("--all-batches", action="store_true",
+                   help="score the whole file, not just its first batch, through btsbot.ScoreStream (two batches in flight)")
     p.add_argument("--random-weights", action="store_true",
                    help="no checkpoint: seeded random weights of the chosen architecture")
     return p.parse_args()
@@ -73,6 +75,21 @@ def run_inference(model, multi_modal: bool, data_dir: str, device="cuda"):
     return raw_preds, labels_batch.cpu().numpy()
 
 
+def run_all_batches(model, multi_modal: bool, data_dir: str, device="cuda"):
+    """The scoring loop over every batch of the file: what val.py:103-157 does with one model(...) call per batch, here
+    with consecutive batches on alternating HIP streams (btsbot.ScoreStream)."""
+    cand = pd.read_csv(os.path.join(data_dir, "usage_candidates.csv"), index_col=None)
+    triplets = np.load(os.path.join(data_dir, "usage_triplets.npy"), mmap_mode="r")
+    images, metadata, labels = prepare_inputs(cand, triplets, multi_modal)
+    ds = DeviceDataset(images, metadata, labels, batch_size=64, device=device, shuffle=False,
+                       drop_last=False, augment=False, check_nan=False)
+    scorer = btsbot.ScoreStream(model.to(device).eval(), depth=2)
+    scores = [torch.sigmoid(z).squeeze(1) for z in scorer.map(batch[:-1] for batch in ds)]
+    scores = torch.cat(scores).cpu().numpy()
+    print(f"{len(scores)} alerts scored, {int((scores >= 0.5).sum())} above 0.5")
+    return scores
+
+
 def random_model(architecture: str, multi_modal: bool, precision):
     cfg = dict(pretrained=False, train_data_version="v11", metadata_cols=METADATA_COLS,
                meta_fc1_neurons=128, meta_fc2_neurons=128, meta_dropout=0.25, comb_fc1_neurons=128,
@@ -94,4 +111,7 @@ if __name__ == "__main__":
         model = btsbot.load_HF_model(args.architecture, args.multi_modal, args.pretrain)
         if args.precision:
             model.set_precision(args.precision)
-    run_inference(model, args.multi_modal, args.data_dir)
+    if args.all_batches:
+        run_all_batches(model, args.multi_modal, args.data_dir)
+    else:
+        run_inference(model, args.multi_modal, args.data_dir)

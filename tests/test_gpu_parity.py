@@ -402,3 +402,11 @@ def test_score_stream_matches_plain_calls(cuda):
             assert o.shape == r.shape and torch.equal(o, r)
     with pytest.raises(RuntimeError):
         btsbot_amd.ScoreStream(m.train(), depth=2)
+    # a frozen_fusion replica takes its branches from the state dict, not from the checkpoint files
+    kind, cfg = CONFIGS["frozen_fusion"]
+    f = build_model(kind, cfg, seeded_state(kind, cfg, seed=4), cuda, "f16")
+    with torch.no_grad():
+        want = f(image_input=batches[1][0], metadata_input=batches[1][1]).clone()
+    got = list(btsbot_amd.ScoreStream(f, depth=2).map([batches[1], batches[1], batches[1]]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, want) for g in got)
