@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
       *reinterpret_cast<float4*>(part + wave * 256 + slot) = make_float4(s1[0], s1[1], s1[2], s1[3]);
       *reinterpret_cast<float4*>(part + 1024 + wave * 256 + slot) = make_float4(s2[0], s2[1], s2[2], s2[3]);
     }
+    if (j == 0) SB_STAMP(14);
     __syncthreads();   // partial sums complete; nobody reads the planar image any more
+    if (j == 0) SB_STAMP(15);
     {
       const float t1 = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid];
       const float t2 = part[1024 + tid] + part[1280 + tid] + part[1536 + tid] + part[1792 + tid];

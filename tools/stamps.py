@@ -26,6 +26,7 @@ for base, tag in ((0, "stage0"), (16, "stage1")):
     for i in range(1, 14):
         print(f"   {names[i]:22s} +{t[base + i] - t[base + i - 1]:8d}")
 
+print("   stage0 b0 LN detail: reductions", t[14] - t[4], " barrier", t[15] - t[14], " combine + normalise + write", t[5] - t[15])
 import numpy as np
 for off, tag, n in ((32, "stage0", B), (32 + 8192, "stage1", (B + 1) // 2)):
     w = np.array(t[off:off + 2 * n]).reshape(n, 2)
