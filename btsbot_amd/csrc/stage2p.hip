@@ -123,6 +123,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   // operand images: bytes per pixel row (the regions keep their 16-bit sizes)
   constexpr int XNP = C * ESZ + 16, HP = CHUNK * ESZ + 16;
+  // fc1's B operand (the block's LN image, the same for all 8 chunks): k-steps kept in registers for the whole block;
+  // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
+  constexpr int XRES = F8 ? KS1 : 4;   // (16-bit: 5 or 6 spill in the block prologue and lose more than they save)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
   unsigned char* xn = smem + OFF_XN;
@@ -153,34 +156,22 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   __syncthreads();   // zero fill done before the first map is written
 
   // this wave's fragment streams: fc1 tile (8 ch + wave) of a chunk: 8 KiB contiguous; fc2 tiles 2 wave, 2 wave + 1:
-  // 2 x 4 KiB.  Two register sets: a chunk's fragments are requested one whole chunk ahead (the loads of all 256
-  // CUs hit the same L2 lines at about the same time: ~1.1k cycles of transfer per 64 KB burst per CU on top of
-  // the L2 latency -- a half-chunk of lookahead measured 20 us per block, the transfer time of the filters is 8.4).
-  frag a1[2][KS1], a2[2][2][KS2];
-  auto load_chunk = [&](auto P, const Stage2pBlk& bk, int ch) {
-    constexpr int p = decltype(P)::value;
-    const frag* src1 = reinterpret_cast<const frag*>(bk.w1p) + ((size_t)(ch * NW + wave) * KS1) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) a1[p][s] = src1[s * 64];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const frag* src2 = reinterpret_cast<const frag*>(bk.w2p) +
-                         ((size_t)(2 * wave + m) * (HID / 32) + ch * KS2) * 64 + lane;
-#pragma unroll
-      for (int s = 0; s < KS2; ++s) a2[p][m][s] = src2[s * 64];
-    }
-  };
+  // 2 x 4 KiB.  ONE register set, refilled in place: the slot a product has just read is requested again at once with
+  // the same k-step of the next chunk, which arrives a whole chunk (~3k cycles) before it is needed (the loads of all
+  // 256 CUs hit the same L2 lines at about the same time: ~1.1k cycles of transfer per 64 KB burst per CU on top of
+  // the L2 latency).  The registers a second set would take hold the fc1 B operand instead (below).
+  frag a1[KS1], a2[2][KS2];
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  if (a.depth > 0) {
-    load_chunk(P0{}, a.blk[0], 0);
-    // (a step multiplies the PREVIOUS chunk's fc2 fragments and refills their slots with the chunk after this one:
-    //  chunk 1's go in ahead, every later one is fetched two steps before its use)
+  if (a.depth > 0) {   // chunk 0 of both filters (fc2 runs one step behind fc1: its chunk 0 is first used in step 1)
+    const frag* src1 = reinterpret_cast<const frag*>(a.blk[0].w1p) + ((size_t)wave * KS1) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) a1[s] = src1[s * 64];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const frag* src2 = reinterpret_cast<const frag*>(a.blk[0].w2p) + ((size_t)(2 * wave + m) * (HID / 32) + 1 * KS2) * 64 + lane;
+      const frag* src2 = reinterpret_cast<const frag*>(a.blk[0].w2p) + ((size_t)(2 * wave + m) * (HID / 32)) * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) a2[1][m][s] = src2[s * 64];
+      for (int s = 0; s < KS2; ++s) a2[m][s] = src2[s * 64];
     }
   }
 
@@ -265,6 +256,12 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
+    frag xr[XRES][NB];
+#pragma unroll
+    for (int s = 0; s < XRES; ++s)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        xr[s][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
     // residual + gamma * b2 (the bias of the folded fc2)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -285,19 +282,21 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // inside the wave: the two waves of a SIMD meet at the same barrier every chunk, so they are in the same phase
     // all the time and nothing overlaps unless a wave overlaps its own VALU and MFMA work; with fc1 -> GELU -> barrier
     // -> fc2 in line a chunk took 3.35k cycles against 1.5k of MFMA work and a 2.3k filter-streaming floor).
-    // P = register set of chunk ch's fc1 fragments; chunk ch - 1's fc2 fragments sit in the OTHER set's a2 slots.
+    // P = which of the two hidden images this chunk writes (the other one holds chunk ch - 1's).
     // The next chunk's 16 fragment loads are spread over the k-steps: issued in one burst they hold every wave at the
     // CU's one vector-memory port for ~2k cycles before its first product.
     auto step = [&](auto P, auto FIRST, int ch) {
       constexpr int p = decltype(P)::value;
       constexpr bool first = decltype(FIRST)::value;
-      // (after the stage's last chunk the loads below re-read this block's first chunks: an unconditional load
+      // (after the stage's last chunk the fc1 loads below re-read this block's first chunk: an unconditional load
       //  keeps the k-step loops free of branches -- hipcc waits vmcnt(0) behind every conditional load)
       const Stage2pBlk& nb = ch + 1 < NCHUNK ? bk : a.blk[j + 1 < a.depth ? j + 1 : j];
       const int nch = ch + 1 < NCHUNK ? ch + 1 : 0;
       const frag* src1 = reinterpret_cast<const frag*>(nb.w1p) + ((size_t)(nch * NW + wave) * KS1) * 64 + lane;
-      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + nch * KS2) * 64 + lane;
-      // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]
+      // fc2 runs one step behind: its slots are refilled with THIS chunk's fragments (used in the next step)
+      const frag* src2 = reinterpret_cast<const frag*>(bk.w2p) + ((size_t)(2 * wave) * (HID / 32) + ch * KS2) * 64 + lane;
+      // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]: k-steps
+      // 0 .. XRES-1 from the registers filled after the LayerNorm, the rest from LDS
       f32x4 hacc[NB];
       {
         f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + ch * CHUNK + 16 * wave + 4 * kg);
@@ -306,18 +305,21 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         for (int n = 0; n < NB; ++n) hacc[n] = bv;
       }
       frag xb[2][NB];
+      if (XRES < KS1) {
 #pragma unroll
-      for (int n = 0; n < NB; ++n) xb[0][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (8 * kg) * ESZ);
+        for (int n = 0; n < NB; ++n)
+          xb[XRES & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * XRES + 8 * kg) * ESZ);
+      }
 #pragma unroll
       for (int s = 0; s < KS1; ++s) {
-        if (s + 1 < KS1) {
+        if (s >= XRES && s + 1 < KS1) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
             xb[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * ESZ);
         }
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[p][s], xb[s & 1][n], hacc[n]);
-        a1[1 - p][s] = src1[s * 64];
+        for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[s], s < XRES ? xr[s < XRES ? s : 0][n] : xb[s & 1][n], hacc[n]);
+        a1[s] = src1[s * 64];
         __builtin_amdgcn_sched_barrier(0);
       }
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[1 - p][m][s], hbf[s & 1][n], acc[m][n]);
-          a2[1 - p][0][s] = src2[s * 64];
-          a2[1 - p][1][s] = src2[((size_t)(HID / 32) + s) * 64];
+            for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & 1][n], acc[m][n]);
+          a2[0][s] = src2[s * 64];
+          a2[1][s] = src2[((size_t)(HID / 32) + s) * 64];
         }
         if (s < NB) {
           float hv[4];
@@ -356,11 +358,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       __syncthreads();   // image hb[p] complete; hb[1 - p] is read out
     };
     // the fc2 half of a step of its own: the block's last chunk (the residual must be complete before the next
-    // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 1
+    // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 0
     auto fc2_tail = [&]() {
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
-      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32) + 1 * KS2) * 64 + lane;
-      const unsigned char* hprev = hb + 1 * (NCOL * HP2);   // chunk NCHUNK - 1 is odd: image 1, fragments in set 1
+      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32)) * 64 + lane;
+      const unsigned char* hprev = hb + 1 * (NCOL * HP2);   // chunk NCHUNK - 1 is odd: image 1
       frag hbf[2][NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
@@ -374,13 +376,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[1][m][s], hbf[s & 1][n], acc[m][n]);
-        a2[1][0][s] = src2[s * 64];
-        a2[1][1][s] = src2[((size_t)(HID / 32) + s) * 64];
+          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & 1][n], acc[m][n]);
+        a2[0][s] = src2[s * 64];
+        a2[1][s] = src2[((size_t)(HID / 32) + s) * 64];
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    static_assert(NCHUNK % 2 == 0, "the last chunk runs in register set 1");
+    static_assert(NCHUNK % 2 == 0, "the last chunk writes hidden image 1");
     step(P0{}, std::true_type{}, 0);
     step(P1{}, std::false_type{}, 1);
     S2P_STAMP(5 + 8 * j);
