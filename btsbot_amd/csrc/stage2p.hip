@@ -386,11 +386,12 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     step(P0{}, std::true_type{}, 0);
     step(P1{}, std::false_type{}, 1);
     S2P_STAMP(5 + 8 * j);
+    // (no stamp inside this loop: its store sits under a branch on the thread id, and behind divergent control flow
+    //  hipcc turned the loop's counted vmcnt waits into vmcnt(0))
 #pragma unroll 1
     for (int ch = 2; ch < NCHUNK; ch += 2) {
       step(P0{}, std::false_type{}, ch);
       step(P1{}, std::false_type{}, ch + 1);
-      if (ch == 2) S2P_STAMP(6 + 8 * j);
     }
     fc2_tail();
     if (F8) {

@@ -49,7 +49,7 @@ for j in range(6):
     b = 1 + 8 * j
     nxt = s2[1 + 8 * (j + 1)] if j < 5 else s2[56]
     print(f"   block {j}: map->LDS +{s2[b+1]-s2[b]:6d}  depthwise +{s2[b+2]-s2[b+1]:6d}  LN +{s2[b+3]-s2[b+2]:6d}  "
-          f"chunks 0-1 +{s2[b+4]-s2[b+3]:6d}  2-3 +{s2[b+5]-s2[b+4]:6d}  4-7 +{s2[b+6]-s2[b+5]:6d}  (block {nxt - s2[b]:7d})")
+          f"chunks 0-1 +{s2[b+4]-s2[b+3]:6d}  2-7 +{s2[b+6]-s2[b+4]:6d}  (block {nxt - s2[b]:7d})")
 print(f"   downsample: LN +{s2[57]-s2[56]:6d}  conv +{s2[58]-s2[57]:6d}")
 
 s3 = t[32 + 16384 + 64:32 + 16384 + 64 + 16]
