@@ -94,8 +94,14 @@ constexpr int KS1 = C / 32;                           // 8 k-steps of fc1
 constexpr int KS2 = CHUNK / 32;                       // 4 k-steps of fc2 per chunk
 constexpr int CO = 512, KD = 4 * C, KSD = KD / 32;    // downsample: 512 outputs, K = 1024
 constexpr int XLP = C;                                // fp32 map: floats per pixel row
-constexpr int XNP2 = C * 2 + 16;                      // 16-bit LN image: bytes per pixel row (528)
-constexpr int HP2 = CHUNK * 2 + 16;                   // hidden image: bytes per pixel row (272)
+// Operand images [pixel][k]: a ds_read_b128 is served in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,
+// 28-31} and the same + 32 -- each of which must cover the 16 slots of a 256-byte bank row.  A group holds every
+// pixel column once, at two neighbouring k-groups; with rows 32 bytes (mod 256) apart the slot is 2 col + kg: a
+// bijection.  (Rows 16 bytes apart, the classic padding, made every group 2-way on one slot: half of the kernel's LDS
+// cycles were conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50.)  fp8 reads 8 bytes per lane in two groups
+// of 32 lanes: 16 bytes apart is the bijection there.
+constexpr int XNP2 = C * 2 + 32;                      // 16-bit LN image: bytes per pixel row (544)
+constexpr int HP2 = CHUNK * 2 + 32;                   // hidden image: bytes per pixel row (288)
 constexpr int OFF_XL = 0;                             // [48][256] f32 (rows >= 36 stay zero)
 constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;       // 49152
 constexpr int OFF_H = OFF_XN + NCOL * XNP2;           // + 25344
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr int ESZ = MP<T>::ESZ;
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   // operand images: bytes per pixel row (the regions keep their 16-bit sizes)
-  constexpr int XNP = C * ESZ + 16, HP = CHUNK * ESZ + 16;
+  constexpr int XNP = C * ESZ + 16 * ESZ, HP = CHUNK * ESZ + 16 * ESZ;
   // fc1's B operand (the block's LN image, the same for all 8 chunks): k-steps kept in registers for the whole block;
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   constexpr int XRES = F8 ? KS1 : 4;   // (16-bit: 5 or 6 spill in the block prologue and lose more than they save)
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   //  fp8 tripled the mode's score error with trained-like layer scales)
   using TD = typename std::conditional<F8, bf16_t, T>::type;
   using fragd = typename MP<TD>::frag;
-  constexpr int XND = C * MP<TD>::ESZ + 16;
+  constexpr int XND = C * MP<TD>::ESZ + 16 * MP<TD>::ESZ;
   {
     const f32x4 lw = *reinterpret_cast<const f32x4*>(a.ds_lnw + 4 * lane);
     const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ds_lnb + 4 * lane);
