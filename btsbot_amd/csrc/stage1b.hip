@@ -314,6 +314,13 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
                                          (lptr_t)(dst + i * 1024), 16, 0, 0);
     };
+    // one of the four pieces (the chunk loop spreads them over its MFMAs: four LDS-DMAs back to back held the wave
+    // for 230-420 cycles at the vector-memory port, a fifth of a step)
+    auto issue_piece = [&](int k, int i) {
+      unsigned char* dst = (w1wave ? w1slot(k % NSLOT) : w2slot(k % NSLOT)) + (wave & 1) * 4096;
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
+                                       (lptr_t)(dst + i * 1024), 16, 0, 0);
+    };
     SC_STAMP(3 + 5 * j);
 
     // ---- depthwise 7x7 on the matrix pipe.  Per channel (= block) and output tile (rows 4 yb + j, columns 4 xb + i):
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
         LS(3);
-        issue(ch + (w1wave ? 4 : 2));   // (indices past the last chunk wrap: harmless reloads into dead slots)
+        const int kdma = ch + (w1wave ? 4 : 2);   // (indices past the last chunk wrap: harmless reloads into dead slots)
         __builtin_amdgcn_sched_barrier(0);
         LS(4);
         float g[16];
@@ -536,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         for (int r = 0; r < 8; ++r) {
           if (!LAST) hn = SCM<T>::run(a1[r], xf[r], hn);
           g[r] = gelu_for<T>(hc[r]);
+          if (r & 1) issue_piece(kdma, r >> 1);
           __builtin_amdgcn_sched_barrier(0);
         }
         LS(5);
