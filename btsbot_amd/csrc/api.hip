@@ -312,6 +312,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   {
     const char* n3 = getenv("BTSBOT_AMD_NO_S3");
     h->use_s3 = !(n3 != nullptr && n3[0] == '1');
+    const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
+    h->use_side = !(nss != nullptr && nss[0] == '1');
   }
   *out = h;
   return BTSBOT_OK;
@@ -332,6 +334,8 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->bucket_ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->side_ev) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return BTSBOT_OK;
 }
@@ -1095,6 +1099,8 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
   for (int i = 0; i < h->n_buckets; ++i)
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
+  if (need_img && h->use_side && h->side == nullptr)
+    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   float* dfeat = nullptr;
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));

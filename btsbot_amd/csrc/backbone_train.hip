@@ -21,6 +21,10 @@ struct BlkBuf {
   void* xn;
   void* a;
   void* h;
+  // backward only: the gradients the filter-gradient GEMMs read, one pair per block so that those GEMMs can trail
+  // the input-gradient chain on a second stream without a block overwriting what the previous one still reads
+  void* dyT;     // d(loss)/d(block output), operand type [rows][C]
+  void* da;      // d(loss)/d(fc1 pre-activation), operand type [rows][4C]
 };
 
 constexpr size_t WPART_FLOATS = (size_t)16 << 20;   // 64 MB: every shape of the pico / nano schedule fits (else atomics)
@@ -31,7 +35,8 @@ struct BBCache {
   std::vector<std::vector<BlkBuf>> blk;
   // backward scratch
   float *dyA, *dyB, *dC;    // fp32 [max rows*C]
-  void *dyT, *da;           // operand type [max rows*C], [max rows*4C]
+  void* dyT_down[4];        // operand type [rows_i][C_i]: d(loss)/d(downsample i output) (i >= 1)
+  void* dyT_stem;           // operand type [B*225][C0]: gradient behind the stem LayerNorm
   float *G, *S;             // fp32 [max C*4C], [max 4C]
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
@@ -54,7 +59,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
     cur += al(bytes);
     return p;
   };
-  size_t maxrc = 0, maxr4c = 0, maxc4c = 0, maxpat = 0;
+  size_t maxrc = 0, maxc4c = 0, maxpat = 0;
   k.blk.resize(4);
   for (int i = 0; i < 4; ++i) {
     const size_t rows = (size_t)B * STAGE_HW[i] * STAGE_HW[i], ch = c.dims[i];
@@ -68,18 +73,19 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.xn = take(rows * ch * esz);
       b.a = take(rows * 4 * ch * esz);
       b.h = take(rows * 4 * ch * esz);
+      b.dyT = take(rows * ch * esz);
+      b.da = take(rows * 4 * ch * esz);
       k.blk[i].push_back(b);
     }
+    k.dyT_down[i] = i > 0 ? take(rows * ch * esz) : nullptr;
     if (rows * ch > maxrc) maxrc = rows * ch;
-    if (rows * 4 * ch > maxr4c) maxr4c = rows * 4 * ch;
     if (4 * ch * ch > maxc4c) maxc4c = 4 * ch * ch;
     if (i > 0 && 4 * ch * c.dims[i - 1] > maxc4c) maxc4c = 4 * ch * c.dims[i - 1];
   }
   k.dyA = reinterpret_cast<float*>(take(maxrc * 4));
   k.dyB = reinterpret_cast<float*>(take(maxrc * 4));
   k.dC = reinterpret_cast<float*>(take(maxrc * 4));
-  k.dyT = take(maxrc * esz);
-  k.da = take(maxr4c * esz);
+  k.dyT_stem = take((size_t)B * 225 * c.dims[0] * esz);
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
@@ -157,14 +163,58 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   const btsbot_config& c = h->cfg;
   const float* m = h->mirror;
   const int prec = c.precision;
-  const size_t esz = h->esz();
   BBCache k = carve_bb(h, h->bbcache, B);
   float* dy = k.dyA;
   float* dxn = k.dyB;
   HIP_TRY(hipMemcpyAsync(dy, dfeat, (size_t)B * c.dims[3] * 4, hipMemcpyDeviceToDevice, st));
-  // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type and
-  // clears the next filter-gradient accumulators -- the cast launch in front of the next block is then skipped
+  // Two streams.  `st` carries the chain every block waits on (dy -> da -> dxn -> LayerNorm -> depthwise -> dy of the
+  // block before); the filter-gradient GEMMs, their slice reductions and the layer-scale / bias gradients hang off
+  // that chain (nothing downstream reads them before the optimiser), so they trail it on `h->side`: in stages 2-3
+  // neither the chain's kernels (9216 / 1024 rows) nor these fill the chip on their own.  fork() = the side stream
+  // sees everything queued on `st` so far, join() = `st` waits for the side stream (bucket boundaries and the end).
+  // G / S / wpart are touched on the side stream only.  BTSBOT_AMD_NO_SIDE_STREAM=1: everything on `st` (A/B).
+  const bool two = h->use_side && h->side != nullptr;
+  hipStream_t sd = two ? h->side : st;
+  size_t nev = 0;
+  auto next_event = [&](hipEvent_t* e) -> int {
+    if (nev == h->side_ev.size()) {
+      hipEvent_t fresh;
+      HIP_TRY(hipEventCreateWithFlags(&fresh, hipEventDisableTiming));
+      h->side_ev.push_back(fresh);
+    }
+    *e = h->side_ev[nev++];
+    return BTSBOT_OK;
+  };
+  auto fork = [&]() -> int {
+    if (!two) return BTSBOT_OK;
+    hipEvent_t e;
+    TRYB(next_event(&e));
+    HIP_TRY(hipEventRecord(e, st));
+    HIP_TRY(hipStreamWaitEvent(sd, e, 0));
+    return BTSBOT_OK;
+  };
+  auto join = [&]() -> int {
+    if (!two) return BTSBOT_OK;
+    hipEvent_t e;
+    TRYB(next_event(&e));
+    HIP_TRY(hipEventRecord(e, sd));
+    HIP_TRY(hipStreamWaitEvent(st, e, 0));
+    return BTSBOT_OK;
+  };
+  // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type (the cast
+  // launch in front of the next block is then skipped) and, with one stream, clears the next G / S accumulators
   const bool fold_cast = prec != BTSBOT_F32;
+  const bool fold_clear = fold_cast && !two;
+  auto clear_gs = [&](size_t g_floats) -> int {   // S sits directly in front of G
+    if (fold_clear) return BTSBOT_OK;
+    HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + g_floats) - k.S) * sizeof(float), sd));
+    return BTSBOT_OK;
+  };
+  // operand-type buffer the consumer after block (i, j) reads its dy from: the block before, else the downsample
+  auto next_dyT = [&](int i, int j) -> void* {
+    if (j > 0) return k.blk[i][j - 1].dyT;
+    return i > 0 ? k.dyT_down[i] : nullptr;
+  };
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
@@ -172,40 +222,49 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const BlockPk& b = h->blocks[i][j];
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
-      // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
       if (!dyT_ready)
-        TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.S,
-                               (long)((k.G + (size_t)ch * H) - k.S)));
+        TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st, fold_clear ? k.S : nullptr,
+                               fold_clear ? (long)((k.G + (size_t)ch * H) - k.S) : 0));
       dyT_ready = false;
-      TRYB(wgrad_cs(prec, k.dyT, s.h, k.G, k.S, rows, ch, H, H, st, k.wpart));
-      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
-                            grads + b.fc2_b, grads + b.gamma, ch, H, st));
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
-      TRYB(launch_gemm(prec, EPI_DGELU, k.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
-                       reinterpret_cast<const float*>(s.a), k.da, rows, H, ch, st));
+      TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
+                       reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
+      TRYB(fork());
+      // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
+      TRYB(clear_gs((size_t)ch * H));
+      TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart));
+      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
+                            grads + b.fc2_b, grads + b.gamma, ch, H, sd));
       // ---- fc1:  dW1 += da^T xn,  db1 += colsum(da),  dxn = da W1
-      TRYB(wgrad_cs(prec, k.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, st, k.wpart));
-      TRYB(launch_gemm(prec, EPI_PLAIN, k.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
+      TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart));
+      TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
       // ---- LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
       // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
       TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
-      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, fold_cast ? k.dyT : nullptr, prec,
-                           fold_cast ? k.S : nullptr, fold_cast ? (long)((k.G + (size_t)ch * H) - k.S) : 0));
-      dyT_ready = fold_cast;
+      void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
+      // the accumulators the next consumer clears: G of the block before, or of the downsample
+      const size_t nclear = j > 0 ? (size_t)ch * H : (i > 0 ? (size_t)ch * 4 * c.dims[i - 1] : 0);
+      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec,
+                           fold_clear && nxt ? k.S : nullptr,
+                           fold_clear && nxt ? (long)((k.G + nclear) - k.S) : 0));
+      dyT_ready = nxt != nullptr;
     }
     if (i > 0) {
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
       const int cin = c.dims[i - 1], hwp = STAGE_HW[i - 1];
       const long prow = (long)B * hwp * hwp;
+      void* dyT = k.dyT_down[i];
       if (!dyT_ready)
-        TRYB(launch_scale_cast(prec, dy, nullptr, k.dyT, (long)rows * ch, ch, st, k.G, (long)ch * 4 * cin));
+        TRYB(launch_scale_cast(prec, dy, nullptr, dyT, (long)rows * ch, ch, st, fold_clear ? k.S : nullptr,
+                               fold_clear ? (long)((k.G + (size_t)ch * 4 * cin) - k.S) : 0));
       dyT_ready = false;
-      TRYB(wgrad_cs(prec, k.dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin,
-                    st, k.wpart));
-      TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, st));
-      TRYB(launch_gemm(prec, EPI_PLAIN, k.dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
+      TRYB(fork());
+      TRYB(clear_gs((size_t)ch * 4 * cin));
+      TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));
+      TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, sd));
+      TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
       TRYB(launch_unpatch(k.dpat, dxn, B, hwp, cin, st));
       // LN backward per input pixel (x_prev = stage i-1 output); result is the new dy
@@ -213,7 +272,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                          grads + h->down[i].ln_b, prow, cin, st));
     }
     // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete here
-    if (i >= 2 && h->n_buckets == 3) HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], st));
+    if (i >= 2 && h->n_buckets == 3) {
+      TRYB(join());
+      HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], st));
+    }
   }
   // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]
   {
@@ -225,11 +287,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                      k.stem_pre, rows, c0, 48, st));
     TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
                        grads + h->stem_lnb, rows, c0, st));
-    TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT, (long)rows * c0, c0, st));
-    TRYB(wgrad_cs(prec, k.dyT, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
-                  st, k.wpart));
+    TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT_stem, (long)rows * c0, c0, st));
+    TRYB(fork());
+    TRYB(wgrad_cs(prec, k.dyT_stem, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
+                  sd, k.wpart));
   }
+  TRYB(join());
   if (h->n_buckets == 3) HIP_TRY(hipEventRecord(h->bucket_ev[2], st));
-  (void)esz;
   return BTSBOT_OK;
 }

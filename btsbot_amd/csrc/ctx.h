@@ -119,6 +119,10 @@ struct btsbot_ctx {
   int64_t bucket_lo[3] = {0, 0, 0}, bucket_hi[3] = {0, 0, 0};
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
+  // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> side_ev;
+  bool use_side = true;    // BTSBOT_AMD_NO_SIDE_STREAM=1: the whole backward on the caller's stream (A/B timing)
 
   unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1
   bool debug = false;

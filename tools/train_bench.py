@@ -18,11 +18,11 @@ m = m.to(dev).train()
 img, meta, lab = synthetic_batch(B, seed=3)
 img, meta, lab = img.to(dev), meta.to(dev), lab.to(dev)
 tr = Trainer(m, lr=1e-4, betas=(0.99, 0.99), epochs=8, warmup_epochs=2)
-for _ in range(2):
+for _ in range(5):
     tr.step(img, meta, lab)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 5
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 for _ in range(n):
     loss = tr.step(img, meta, lab)
 torch.cuda.synchronize()
