@@ -312,6 +312,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   {
     const char* n3 = getenv("BTSBOT_AMD_NO_S3");
     h->use_s3 = !(n3 != nullptr && n3[0] == '1');
+    const char* ndl = getenv("BTSBOT_AMD_NO_DWLN");
+    h->use_dwln = !(ndl != nullptr && ndl[0] == '1');
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
   }
@@ -1099,17 +1101,48 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
   for (int i = 0; i < h->n_buckets; ++i)
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
-  if (need_img && h->use_side && h->side == nullptr)
-    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  if (h->use_side && h->side == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  h->side_used = 0;
   float* dfeat = nullptr;
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));
   if (need_img) {
     TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));   // records the bucket events
   } else {
+    TRY(side_join(h, st));
     for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));
   }
   h->bucket_recorded = true;
+  return BTSBOT_OK;
+}
+
+static int side_event(btsbot_ctx* h, hipEvent_t* e) {
+  if (h->side_used == h->side_ev.size()) {
+    hipEvent_t fresh;
+    HIP_TRY(hipEventCreateWithFlags(&fresh, hipEventDisableTiming));
+    h->side_ev.push_back(fresh);
+  }
+  *e = h->side_ev[h->side_used++];
+  return BTSBOT_OK;
+}
+
+int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd) {
+  *sd = st;
+  if (!h->use_side || h->side == nullptr) return BTSBOT_OK;
+  hipEvent_t e;
+  TRY(side_event(h, &e));
+  HIP_TRY(hipEventRecord(e, st));
+  HIP_TRY(hipStreamWaitEvent(h->side, e, 0));
+  *sd = h->side;
+  return BTSBOT_OK;
+}
+
+int side_join(btsbot_ctx* h, hipStream_t st) {
+  if (!h->use_side || h->side == nullptr) return BTSBOT_OK;
+  hipEvent_t e;
+  TRY(side_event(h, &e));
+  HIP_TRY(hipEventRecord(e, h->side));
+  HIP_TRY(hipStreamWaitEvent(st, e, 0));
   return BTSBOT_OK;
 }
 

@@ -40,6 +40,7 @@ struct BBCache {
   float *G, *S;             // fp32 [max C*4C], [max 4C]
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
+  size_t dwpart_floats;
   float* wpart;             // fp32 WPART_FLOATS: slice partials of the filter-gradient GEMMs (wgrad.hip)
   void* stem_patches;       // [B*225][48] operand type
   float* stem_pre;          // [B*225][C0] fp32
@@ -89,7 +90,8 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
-  k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
+  k.dwpart_floats = (size_t)256 * 50 * c.dims[3];
+  k.dwpart = reinterpret_cast<float*>(take(k.dwpart_floats * 4));
   k.wpart = reinterpret_cast<float*>(take(WPART_FLOATS * 4));
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
   k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
@@ -174,33 +176,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // sees everything queued on `st` so far, join() = `st` waits for the side stream (bucket boundaries and the end).
   // G / S / wpart are touched on the side stream only.  BTSBOT_AMD_NO_SIDE_STREAM=1: everything on `st` (A/B).
   const bool two = h->use_side && h->side != nullptr;
-  hipStream_t sd = two ? h->side : st;
-  size_t nev = 0;
-  auto next_event = [&](hipEvent_t* e) -> int {
-    if (nev == h->side_ev.size()) {
-      hipEvent_t fresh;
-      HIP_TRY(hipEventCreateWithFlags(&fresh, hipEventDisableTiming));
-      h->side_ev.push_back(fresh);
-    }
-    *e = h->side_ev[nev++];
-    return BTSBOT_OK;
-  };
-  auto fork = [&]() -> int {
-    if (!two) return BTSBOT_OK;
-    hipEvent_t e;
-    TRYB(next_event(&e));
-    HIP_TRY(hipEventRecord(e, st));
-    HIP_TRY(hipStreamWaitEvent(sd, e, 0));
-    return BTSBOT_OK;
-  };
-  auto join = [&]() -> int {
-    if (!two) return BTSBOT_OK;
-    hipEvent_t e;
-    TRYB(next_event(&e));
-    HIP_TRY(hipEventRecord(e, sd));
-    HIP_TRY(hipStreamWaitEvent(st, e, 0));
-    return BTSBOT_OK;
-  };
+  hipStream_t sd = st;
+  auto fork = [&]() -> int { return side_fork(h, st, &sd); };
+  auto join = [&]() -> int { return side_join(h, st); };
   // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type (the cast
   // launch in front of the next block is then skipped) and, with one stream, clears the next G / S accumulators
   const bool fold_cast = prec != BTSBOT_F32;
@@ -214,6 +192,15 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   auto next_dyT = [&](int i, int j) -> void* {
     if (j > 0) return k.blk[i][j - 1].dyT;
     return i > 0 ? k.dyT_down[i] : nullptr;
+  };
+  // G floats of the consumer after block (i, j) (the block before: C x 4C; the downsample: C x 4 C_in)
+  auto next_g_floats = [&](int i, int j) -> size_t {
+    const size_t ch = c.dims[i];
+    return j > 0 ? ch * 4 * ch : (i > 0 ? ch * 4 * c.dims[i - 1] : 0);
+  };
+  auto clear_next = [&](int i, int j) -> int {   // one stream: S / G of the next consumer (dw_plain_kernel folds this in)
+    HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + next_g_floats(i, j)) - k.S) * sizeof(float), st));
+    return BTSBOT_OK;
   };
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
@@ -229,26 +216,33 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
+      // ---- side: fc2 / layer-scale (S = colsum(dy), G = dy^T h), fc1 (dW1 += da^T xn, db1 += colsum(da))
       TRYB(fork());
-      // ---- fc2 / layer-scale:  S = colsum(dy), G = dy^T h
       TRYB(clear_gs((size_t)ch * H));
       TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
-      // ---- fc1:  dW1 += da^T xn,  db1 += colsum(da),  dxn = da W1
       TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart));
+      // ---- dxn = da W1, then the LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
-      // ---- LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
-      TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
-      // ---- depthwise: filter gradient, then dx = dy + conv_flipped(dd)
-      TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
       void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
-      // the accumulators the next consumer clears: G of the block before, or of the downsample
-      const size_t nclear = j > 0 ? (size_t)ch * H : (i > 0 ? (size_t)ch * 4 * c.dims[i - 1] : 0);
-      TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec,
-                           fold_clear && nxt ? k.S : nullptr,
-                           fold_clear && nxt ? (long)((k.G + nclear) - k.S) : 0));
+      if (h->use_dwln && dwln_bwd_supported(hw, ch)) {
+        // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
+        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, grads + b.ln_w, grads + b.ln_b,
+                             grads + b.dw_w, grads + b.dw_b, k.dwpart, k.dwpart_floats, B, hw, ch, st));
+        if (fold_clear && nxt) TRYB(clear_next(i, j));
+      } else {
+        TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
+        // ---- depthwise filter gradient.  Stays in the chain: behind a fork of its own (per-block dd buffers) the
+        //      step was 0.02-0.06 ms slower, as was a single fork placed here instead of behind da
+        TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
+        // ---- depthwise input gradient: dx = dy + conv_flipped(dd)
+        // the accumulators the next consumer clears: G of the block before, or of the downsample
+        TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec,
+                             fold_clear && nxt ? k.S : nullptr,
+                             fold_clear && nxt ? (long)((k.G + next_g_floats(i, j)) - k.S) : 0));
+      }
       dyT_ready = nxt != nullptr;
     }
     if (i > 0) {

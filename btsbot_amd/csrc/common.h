@@ -274,6 +274,12 @@ int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
 // (out16: also the result in the 16-bit operand type prec16 -- the next block's GEMM operand; zero: accumulators to clear)
 int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, float* partials,
                     int B, int HW, int C, hipStream_t st);   // partials: >= 256 * 50 * C floats
+// dwln_bwd.hip: the three launches above (LayerNorm backward, depthwise filter gradient, depthwise input gradient)
+// as one kernel, dd never leaving LDS; dy is updated in place (dy += conv(dd, flipped taps))
+bool dwln_bwd_supported(int HW, int C);
+int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                    void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, float* partials,
+                    size_t part_floats, int B, int HW, int C, hipStream_t st);
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]

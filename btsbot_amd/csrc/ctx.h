@@ -121,7 +121,9 @@ struct btsbot_ctx {
   bool bucket_recorded = false;
   // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
   hipStream_t side = nullptr;
-  std::vector<hipEvent_t> side_ev;
+  std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()
+  size_t side_used = 0;
+  bool use_dwln = true;    // BTSBOT_AMD_NO_DWLN=1: LayerNorm / depthwise backward as three launches (A/B timing)
   bool use_side = true;    // BTSBOT_AMD_NO_SIDE_STREAM=1: the whole backward on the caller's stream (A/B timing)
 
   unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1
@@ -132,3 +134,7 @@ struct btsbot_ctx {
   int esz() const { return cfg.precision == BTSBOT_F32 ? 4 : 2; }
 };
 
+// Fork / join of the backward's second stream.  side_fork: work queued on *sd afterwards sees everything queued on
+// `st` so far (*sd = st when the second stream is off); side_join: `st` waits for everything queued on the side.
+int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
+int side_join(btsbot_ctx* h, hipStream_t st);

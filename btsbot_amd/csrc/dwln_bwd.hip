@@ -1,0 +1,241 @@
+// Backward of a ConvNeXt block's front half -- LayerNorm and the 7x7 depthwise convolution -- as ONE kernel
+// (training step; replaces what autograd does for timm's ConvNeXtBlock.norm / .conv_dw between
+// /root/reference/btsbot/train.py:510 and :526):
+//
+//     dd  = LN'(d) . dxn                       d = dwconv(x_in) + bias, kept by the forward;  dxn = d(loss)/d(LN out)
+//     dg += dxn * xhat,  dbeta += dxn          (LayerNorm weight / bias gradients, per channel)
+//     dW[c][t] += sum_p dd[p][c] x_in[p + delta_t][c],   db[c] += sum_p dd[p][c]      (depthwise filter / bias)
+//     dy  = dy + conv(dd, flipped taps)        (gradient w.r.t. the block input, joins the residual path)
+//
+// Unfused (ln_bwd_kernel -> dw_wgrad_kernel -> dw_plain_kernel, backward.hip) dd makes a round trip through HBM and is
+// read twice, and stages 2-3 pay three launch latencies for 9 MB tensors.  Here dd exists only in LDS:
+// a workgroup takes `ga` alerts one after the other; per alert it stages x_in, runs the LayerNorm backward over the
+// map's pixels (C/4 lanes per pixel, float4 pieces, result straight into LDS), then every thread = (channel, row group)
+// runs both convolutions off the two LDS maps.  Filter-gradient taps stay in registers across the workgroup's alerts
+// and leave as one partial row per row group (column-summed by the caller, as dw_wgrad_kernel's), the LayerNorm
+// parameter gradients as one atomic per channel per workgroup.  fp32 throughout (every precision mode).
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-6f;
+
+template <int HW, int C, int NT>
+__global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ d, const float* __restrict__ dxn,
+                                                      const float* __restrict__ g, const float* __restrict__ xin,
+                                                      const float* __restrict__ w, float* dy,
+                                                      void* __restrict__ out16, int prec16, float* dg, float* dbeta,
+                                                      float* __restrict__ partials, int B, int ga) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [P][C] | ds [P][C] | flipped taps [49][C]
+  constexpr int P = HW * HW;
+  constexpr int LPR = C / 4, R = 64 / LPR, NW = NT / 64;   // lanes per pixel row, rows per wave pass, waves
+  constexpr int G = NT / C;                                // row groups of the convolution phase
+  static_assert(LPR <= 64 && NT % C == 0 && 2 * NW * R * C <= 2 * P * C, "geometry");
+  float* xs = sm;
+  float* ds = sm + P * C;
+  float* ws = ds + P * C;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int c = tid % C, rg = tid / C;
+  for (int i = tid; i < 49 * C; i += NT) {
+    const int t = i / C, cc = i - t * C;
+    ws[i] = w[(48 - t) * C + cc];
+  }
+  const float4 gl = *reinterpret_cast<const float4*>(g + 4 * l);
+  const float ga4[4] = {gl.x, gl.y, gl.z, gl.w};
+  float adg[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[49], ab = 0.f;
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+  auto gsum = [](float v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  };
+  const int a0 = blockIdx.x * ga, a1 = min(B, a0 + ga);
+  for (int a = a0; a < a1; ++a) {
+    const size_t base = (size_t)a * P * C;
+    __syncthreads();   // the previous alert's convolutions have read both maps (first trip: the taps are staged)
+    {
+      // x_in -> LDS: eight 16-byte pieces in flight per thread before the first LDS store
+      const float4* src = reinterpret_cast<const float4*>(xin + base);
+      float4* dst = reinterpret_cast<float4*>(xs);
+      constexpr int n4 = P * C / 4, NB = 8;
+      for (int i0 = tid; i0 < n4; i0 += NT * NB) {
+        float4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = src[min(i0 + k * NT, n4 - 1)];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+          if (i0 + k * NT < n4) dst[i0 + k * NT] = v[k];
+      }
+    }
+    // LayerNorm backward, two row groups per wave pass (4 x 16-byte loads in flight per lane)
+    for (int r0 = wv * R * 2; r0 < P; r0 += NW * R * 2) {
+      float4 v[2], dx[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * R + sub;
+        ok[u] = r < P;
+        const int rr = ok[u] ? r : 0;
+        v[u] = *reinterpret_cast<const float4*>(d + base + (size_t)rr * C + 4 * l);
+        dx[u] = *reinterpret_cast<const float4*>(dxn + base + (size_t)rr * C + 4 * l);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * R + sub;
+        float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const float dxa[4] = {dx[u].x, dx[u].y, dx[u].z, dx[u].w};
+        const float mean = gsum((x[0] + x[1]) + (x[2] + x[3])) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] -= mean;
+          q += x[i] * x[i];
+        }
+        const float rstd = rsqrtf(gsum(q) * (1.f / C) + LN_EPS);
+        float t[4], st = 0.f, stx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] *= rstd;
+          t[i] = dxa[i] * ga4[i];
+          st += t[i];
+          stx += t[i] * x[i];
+          if (ok[u]) {
+            adg[i] += dxa[i] * x[i];
+            adb[i] += dxa[i];
+          }
+        }
+        st = gsum(st) * (1.f / C);
+        stx = gsum(stx) * (1.f / C);
+        if (ok[u])
+          *reinterpret_cast<float4*>(ds + r * C + 4 * l) =
+              make_float4(rstd * (t[0] - st - x[0] * stx), rstd * (t[1] - st - x[1] * stx),
+                          rstd * (t[2] - st - x[2] * stx), rstd * (t[3] - st - x[3] * stx));
+      }
+    }
+    __syncthreads();
+    // both convolutions, thread = (channel, row group)
+    for (int y = rg; y < HW; y += G) {
+      float gy[HW], ax[HW];
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) ax[xx] = dy[base + (size_t)(y * HW + xx) * C + c];   // requested first
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) {
+        gy[xx] = ds[(y * HW + xx) * C + c];
+        ab += gy[xx];
+      }
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int iy = y + ky - 3;
+        if (iy < 0 || iy >= HW) continue;
+        float in[HW];
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) {
+            const int ix = xx + kx - 3;
+            if (ix >= 0 && ix < HW) acc[ky * 7 + kx] = fmaf(gy[xx], in[ix], acc[ky * 7 + kx]);
+          }
+        float wk[7];
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) in[xx] = ds[(iy * HW + xx) * C + c];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) wk[kx] = ws[(ky * 7 + kx) * C + c];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) {
+            const int ix = xx + kx - 3;
+            if (ix >= 0 && ix < HW) ax[xx] = fmaf(in[ix], wk[kx], ax[xx]);
+          }
+      }
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) {
+        const size_t o = base + (size_t)(y * HW + xx) * C + c;
+        dy[o] = ax[xx];
+        if (out16 != nullptr) {   // the same values as the next 16-bit GEMM's operand
+          if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[o] = (bf16_t)ax[xx];
+          else reinterpret_cast<f16_t*>(out16)[o] = (f16_t)ax[xx];
+        }
+      }
+    }
+  }
+  {   // this row group's partial row: [C][49] filter taps, then [C] biases
+    float* row = partials + ((size_t)blockIdx.x * G + rg) * 50 * C;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) row[(size_t)c * 49 + t] = acc[t];
+    row[(size_t)49 * C + c] = ab;
+  }
+  // LayerNorm parameter gradients: the wave's row groups and the waves meet in LDS, one atomic per channel
+  __syncthreads();
+  float* sh = sm;   // [2][NW * R][C]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sh[(wv * R + sub) * C + 4 * l + i] = adg[i];
+    sh[(NW * R + wv * R + sub) * C + 4 * l + i] = adb[i];
+  }
+  __syncthreads();
+  for (int cc = tid; cc < C; cc += NT) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int j = 0; j < NW * R; ++j) {
+      sa += sh[j * C + cc];
+      sb += sh[(NW * R + j) * C + cc];
+    }
+    atomicAdd(dg + cc, sa);
+    atomicAdd(dbeta + cc, sb);
+  }
+}
+
+template <int HW, int C, int NT>
+int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                void* out16, int prec16, float* dg, float* dbeta, float* dw, float* partials, size_t part_floats,
+                int B, hipStream_t st) {
+  constexpr size_t lds = ((size_t)2 * HW * HW + 49) * C * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  int ga = (B + 255) / 256;   // <= 256 workgroups: <= 256 same-address atomics per channel, <= 256 G partial rows
+  if (ga < 1) ga = 1;
+  const int grid = (B + ga - 1) / ga;
+  constexpr int G = NT / C;
+  if ((size_t)grid * G * 50 * C > part_floats) {
+    btsbot_set_error("dwln_bwd: partial rows (%d x %d floats) exceed the scratch lent", grid * G, 50 * C);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT>), dim3(grid), dim3(NT), lds, st, d, dxn, g, xin, w, dy, out16,
+                     prec16, dg, dbeta, partials, B, ga);
+  LAUNCH_CHECK();
+  return launch_colsum(BTSBOT_F32, partials, dw, grid * G, 50 * C, st);
+}
+
+}  // namespace
+
+// the (map, width) pairs of convnext_pico's stages 0-2; everything else keeps the three-kernel form
+bool dwln_bwd_supported(int HW, int C) { return (HW == 15 && C == 64) || (HW == 7 && C == 128) || (HW == 3 && C == 256); }
+
+// dw: filter gradient [C][49] with the bias gradient [C] directly behind it (master-arena layout); w: taps [49][C]
+int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                    void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, float* partials,
+                    size_t part_floats, int B, int HW, int C, hipStream_t st) {
+  if (B <= 0) return BTSBOT_OK;
+  if (dbias != dw + (size_t)49 * C) {
+    btsbot_set_error("dwln_bwd: filter and bias gradients must be adjacent in the arena");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (HW == 15 && C == 64)
+    return dwln_launch<15, 64, 256>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
+  if (HW == 7 && C == 128)
+    return dwln_launch<7, 128, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
+  if (HW == 3 && C == 256)
+    return dwln_launch<3, 256, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
+  btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
+  return BTSBOT_ERR_INVALID_ARG;
+}

@@ -1,3 +1,4 @@
+#include <stdlib.h>
 // Training-mode heads (fp32): forward with BatchNorm1d batch statistics + dropout, and the backward
 // pass of the fusion head and the metadata branch.
 //
@@ -273,12 +274,12 @@ size_t train_cache_floats(const btsbot_ctx* h, int M) {
   if (h->has_meta) n += (size_t)M * (2 * c.n_meta + 2 * c.meta_fc1 + c.meta_fc2) + c.n_meta;
   n += (size_t)M * h->comb_dims[0];                     // z
   for (int i = 0; i < h->n_comb; ++i) n += 2 * (size_t)M * h->comb_dims[i + 1];   // pre + act
-  n += 3 * (size_t)M * train_dwidth(h);                 // backward scratch (d-buffers)
+  n += 5 * (size_t)M * train_dwidth(h);                 // backward scratch (d-buffers)
   return n + 1024;
 }
 
 struct TrainPtrs {
-  float *feat, *xhat, *x1, *bn_rstd, *a1, *h1, *a2, *z, *pre[3], *actv[3], *d0, *d1, *dm;
+  float *feat, *xhat, *x1, *bn_rstd, *a1, *h1, *a2, *z, *pre[3], *actv[3], *dbuf[5];
 };
 
 static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
@@ -308,9 +309,7 @@ static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
     p.actv[i] = take((size_t)M * h->comb_dims[i + 1]);
   }
   const size_t dw = train_dwidth(h);
-  p.d0 = take((size_t)M * dw);
-  p.d1 = take((size_t)M * dw);
-  p.dm = take((size_t)M * dw);
+  for (int i = 0; i < 5; ++i) p.dbuf[i] = take((size_t)M * dw);
   return p;
 }
 
@@ -368,7 +367,9 @@ int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* lo
 }
 
 // Backward of the heads.  Writes d(loss)/d(param) for the fusion head (always) and the metadata
-// branch (need_meta) into `grads` (master-arena layout).
+// branch (need_meta) into `grads` (master-arena layout).  The chain the image branch waits on (d(z) through the
+// fusion layers, the head LayerNorm) runs on `st`; the fusion head's weight gradients and the whole metadata-branch
+// backward read what that chain leaves behind (one gradient buffer per layer) and run on `sd` behind side_fork().
 int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
                         int need_meta, int need_image, float** dfeat_out,
                         const uint8_t* meta_mask, const uint8_t* comb_mask, hipStream_t st) {
@@ -378,19 +379,16 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
   const int F = h->has_image ? c.dims[3] : 0;
   const int zd = h->comb_dims[0];
   const float ksc = c.comb_dropout < 1.f ? 1.f / (1.f - c.comb_dropout) : 0.f;
-  // fusion head, last layer first; dcur = gradient w.r.t. the layer's (pre-activation) output
-  const float* dcur = dlogits;
-  float* bufs[2] = {p.d0, p.d1};
+  // fusion head, last layer first; dout[i] = gradient w.r.t. layer i's (pre-activation) output
+  const float* dout[3] = {nullptr, nullptr, nullptr};
+  const float* dz = nullptr;      // d(loss)/d(z), z = [image feature | metadata feature]
+  dout[h->n_comb - 1] = dlogits;
+  const bool want_dz = (need_meta && h->has_meta) || need_image;
   for (int i = h->n_comb - 1; i >= 0; --i) {
     const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
-    const float* in = i == 0 ? p.z : p.actv[i - 1];
-    const int ldi = i == 0 ? zd : K;
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, st, dcur, in, ldi,
-                       grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
-    LAUNCH_CHECK();
-    if (i == 0 && !(need_meta && h->has_meta) && !need_image) break;   // nobody needs d(z)
-    float* din = bufs[i & 1];
-    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dcur, m + h->comb_w[i],
+    if (i == 0 && !want_dz) break;
+    float* din = p.dbuf[i];
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dout[i], m + h->comb_w[i],
                        din, K, M, N, K);
     LAUNCH_CHECK();
     if (i > 0) {   // through dropout + activation of layer i-1
@@ -398,48 +396,61 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
       hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * K), dim3(256), 0, st, din, K, p.pre[i - 1],
                          din, M, K, h->act, drop ? comb_mask : nullptr, ksc);
       LAUNCH_CHECK();
+      dout[i - 1] = din;
+    } else {
+      dz = din;
     }
-    dcur = din;
   }
-  if (need_image && h->has_image) {
-    // d(z)[:, 0:F] is the gradient of the (head-normalised) image feature; pull it out of the
-    // concat layout before the metadata backward recycles that buffer, then undo the head LN
-    float* dfeat = p.d1 == dcur ? p.d0 : p.d1;
-    HIP_TRY(hipMemcpy2DAsync(dfeat, (size_t)F * 4, dcur, (size_t)zd * 4, (size_t)F * 4, M,
+  float* dfeat = p.dbuf[3];
+  if (need_image && h->has_image)
+    // d(z)[:, 0:F] is the gradient of the (head-normalised) image feature; pulled out of the concat layout
+    // (the metadata backward below recycles d(z))
+    HIP_TRY(hipMemcpy2DAsync(dfeat, (size_t)F * 4, dz, (size_t)zd * 4, (size_t)F * 4, M,
                              hipMemcpyDeviceToDevice, st));
-    if (h->hn_w >= 0)
+  hipStream_t sd = st;
+  TRY_RET(side_fork(h, st, &sd));
+  if (need_image && h->has_image) {
+    if (h->hn_w >= 0)   // undo the head LayerNorm
       TRY_RET(launch_ln_bwd(p.feat, dfeat, m + h->hn_w, dfeat, grads + h->hn_w, grads + h->hn_b, M,
                             F, st));
     *dfeat_out = dfeat;
   }
+  for (int i = h->n_comb - 1; i >= 0; --i) {
+    const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
+    const float* in = i == 0 ? p.z : p.actv[i - 1];
+    const int ldi = i == 0 ? zd : K;
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, sd, dout[i], in, ldi,
+                       grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
+    LAUNCH_CHECK();
+  }
   if (need_meta && h->has_meta) {
-    // dcur = d(z) [M][zd]; the metadata features are its columns F .. F+f2
+    // the metadata features are columns F .. F+f2 of d(z) [M][zd]
     const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
-    float* da2 = p.dm;                         // scratch holding neither d(z) nor d(feat)
-    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, dcur + F, zd,
+    float* da2 = p.dbuf[4];
+    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, sd, dz + F, zd,
                        p.a2, da2, M, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE, nullptr,
                        1.f);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc2 * (c.meta_fc1 + 1) + 15) / 16), dim3(256), 0, st,
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc2 * (c.meta_fc1 + 1) + 15) / 16), dim3(256), 0, sd,
                        da2, p.h1, c.meta_fc1, grads + h->m2_w, grads + h->m2_b, M, c.meta_fc2,
                        c.meta_fc1);
     LAUNCH_CHECK();
-    float* dh1 = const_cast<float*>(dcur);     // d(z) is dead once da2 exists
-    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, da2,
+    float* dh1 = const_cast<float*>(dz);     // d(z) is dead once da2 exists
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, sd, da2,
                        m + h->m2_w, dh1, c.meta_fc1, M, c.meta_fc2, c.meta_fc1);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, dh1, c.meta_fc1,
+    hipLaunchKernelGGL(act_bwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, sd, dh1, c.meta_fc1,
                        p.a1, dh1, M, c.meta_fc1, h->act, c.meta_dropout > 0.f ? meta_mask : nullptr,
                        ks1);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc1 * (c.n_meta + 1) + 15) / 16), dim3(256), 0, st,
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc1 * (c.n_meta + 1) + 15) / 16), dim3(256), 0, sd,
                        dh1, p.x1, c.n_meta, grads + h->m1_w, grads + h->m1_b, M, c.meta_fc1,
                        c.n_meta);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.n_meta), dim3(256), 0, st, dh1,
+    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.n_meta), dim3(256), 0, sd, dh1,
                        m + h->m1_w, da2, c.n_meta, M, c.meta_fc1, c.n_meta);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.n_meta), dim3(256), 0, st, da2, M, c.n_meta,
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.n_meta), dim3(256), 0, sd, da2, M, c.n_meta,
                        m + h->bn_w, p.xhat, p.bn_rstd, grads + h->bn_w, grads + h->bn_b);
     LAUNCH_CHECK();
   }
