@@ -12,7 +12,7 @@
 // a workgroup takes `ga` alerts one after the other; per alert it stages x_in, runs the LayerNorm backward over the
 // map's pixels (C/4 lanes per pixel, float4 pieces, result straight into LDS), then every thread = (channel, row group)
 // runs both convolutions off the two LDS maps.  Filter-gradient taps stay in registers across the workgroup's alerts
-// and leave as one partial row per row group (column-summed by the caller, as dw_wgrad_kernel's), the LayerNorm
+// and leave as one partial row per workgroup (column-summed by the caller, as dw_wgrad_kernel's), the LayerNorm
 // parameter gradients as one atomic per channel per workgroup.  fp32 throughout (every precision mode).
 #include "common.h"
 
@@ -164,8 +164,28 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
       }
     }
   }
-  {   // this row group's partial row: [C][49] filter taps, then [C] biases
-    float* row = partials + ((size_t)blockIdx.x * G + rg) * 50 * C;
+  // the row groups' filter-gradient taps meet in LDS (the maps are dead) by halving: the upper half of the groups
+  // parks its taps ([G/2][50][C] floats at most: fits the maps' footprint), the lower half adds them; the workgroup
+  // leaves ONE partial row: [C][49] filter taps, then [C] biases
+#pragma unroll
+  for (int half = G / 2; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (rg >= half && rg < 2 * half) {
+      float* red = sm + (size_t)(rg - half) * 50 * C;
+#pragma unroll
+      for (int t = 0; t < 49; ++t) red[t * C + c] = acc[t];
+      red[49 * C + c] = ab;
+    }
+    __syncthreads();
+    if (rg < half) {
+      const float* red = sm + (size_t)rg * 50 * C;
+#pragma unroll
+      for (int t = 0; t < 49; ++t) acc[t] += red[t * C + c];
+      ab += red[49 * C + c];
+    }
+  }
+  if (rg == 0) {
+    float* row = partials + (size_t)blockIdx.x * 50 * C;
 #pragma unroll
     for (int t = 0; t < 49; ++t) row[(size_t)c * 49 + t] = acc[t];
     row[(size_t)49 * C + c] = ab;
@@ -195,25 +215,29 @@ template <int HW, int C, int NT>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                 void* out16, int prec16, float* dg, float* dbeta, float* dw, float* partials, size_t part_floats,
                 int B, hipStream_t st) {
+  constexpr int G = NT / C;
   constexpr size_t lds = ((size_t)2 * HW * HW + 49) * C * sizeof(float);
+  static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= lds, "closing reduction fits the maps' footprint");
   static bool attr = false;
   if (!attr) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  int ga = (B + 255) / 256;   // <= 256 workgroups: <= 256 same-address atomics per channel, <= 256 G partial rows
+  // one workgroup per CU where the maps take 128 KB (15x15x64), two where they take <= 80 KB:
+  // <= 512 same-address atomics per channel, <= 512 partial rows
+  constexpr int WGS = lds > 80 * 1024 ? 256 : 512;
+  int ga = (B + WGS - 1) / WGS;
   if (ga < 1) ga = 1;
   const int grid = (B + ga - 1) / ga;
-  constexpr int G = NT / C;
-  if ((size_t)grid * G * 50 * C > part_floats) {
-    btsbot_set_error("dwln_bwd: partial rows (%d x %d floats) exceed the scratch lent", grid * G, 50 * C);
+  if ((size_t)grid * 50 * C > part_floats) {
+    btsbot_set_error("dwln_bwd: partial rows (%d x %d floats) exceed the scratch lent", grid, 50 * C);
     return BTSBOT_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT>), dim3(grid), dim3(NT), lds, st, d, dxn, g, xin, w, dy, out16,
                      prec16, dg, dbeta, partials, B, ga);
   LAUNCH_CHECK();
-  return launch_colsum(BTSBOT_F32, partials, dw, grid * G, 50 * C, st);
+  return launch_colsum(BTSBOT_F32, partials, dw, grid, 50 * C, st);
 }
 
 }  // namespace
@@ -231,7 +255,7 @@ int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const floa
     return BTSBOT_ERR_INVALID_ARG;
   }
   if (HW == 15 && C == 64)
-    return dwln_launch<15, 64, 256>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
+    return dwln_launch<15, 64, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
   if (HW == 7 && C == 128)
     return dwln_launch<7, 128, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
   if (HW == 3 && C == 256)

@@ -126,6 +126,49 @@ def test_head_gradients_with_a_wide_fused_input(cuda):
 
 @pytest.mark.parametrize("name", ["mm_pico", "convnext", "mm_nano_ls"])
 def test_full_backward_matches_autograd(cuda, name):
+    _full_backward(cuda, name)
+
+
+@pytest.mark.parametrize("env", ["BTSBOT_AMD_NO_SIDE_STREAM", "BTSBOT_AMD_NO_DWLN"])
+def test_full_backward_alternative_schedules(cuda, monkeypatch, env):
+    """The same gradients with the whole backward on one stream, and with the LayerNorm / depthwise backward as three
+    launches instead of dwln_bwd_kernel (the switches are read when the handle is created)."""
+    monkeypatch.setenv(env, "1")
+    _full_backward(cuda, "mm_pico")
+
+
+def test_fused_layernorm_depthwise_backward_with_several_alerts_per_workgroup(cuda, monkeypatch):
+    """dwln_bwd_kernel walks ceil(B / 256) (stage 0) or ceil(B / 512) alerts per workgroup; B = 6 above is one each.
+    At B = 600 (3 / 2 per workgroup, the last workgroups short) its gradients must agree with the three-launch form
+    checked against the oracle above (fp32 mode, same weights and batch; bound: atomics / summation order)."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    B = 600
+    img, meta, labels = synthetic_batch(B, seed=4)
+    masks = {k: v.to(torch.uint8) for k, v in _masks(kind, cfg, B, seed=9).items()}
+
+    def grads():
+        m = build_model(kind, cfg, sd, cuda, "f32").train()
+        m._forced_masks = masks
+        logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+        loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+            logits, labels.to(cuda).float().unsqueeze(1))
+        loss.backward()
+        return {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
+
+    fused = grads()
+    monkeypatch.setenv("BTSBOT_AMD_NO_DWLN", "1")
+    plain = grads()
+    worst = 0.0
+    for k, b in plain.items():
+        scale = max(b.abs().max().item(), 1e-7)
+        err = (fused[k] - b).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err <= 2e-4, f"grad {k}: rel err {err:.3e} (scale {scale:.3e})"
+    print(f"fused vs three-launch backward at B={B}: worst relative difference {worst:.2e}")
+
+
+def _full_backward(cuda, name):
     """Every parameter trainable (train.py:233-236): gradients of the whole model -- stem, every
     ConvNeXt block (layer-scale, depthwise, LayerNorm, fc1, fc2), downsamples, head LayerNorm,
     metadata branch, fusion head -- against torch autograd through the fp32 CPU oracle.
