@@ -217,7 +217,7 @@ int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bd
 int launch_ln_patch(int prec, const float* x, const float* lnw, const float* lnb, void* patches,
                     int B, int HW, int Cin, hipStream_t st);
 
-// fused fc1 -> GELU -> fc2 -> layer-scale -> residual (fused_mlp.hip); 16-bit modes, C in {64,128}
+// fused fc1 -> GELU -> fc2 -> layer-scale -> residual (fused_mlp.hip); 16-bit modes, C in {64,128} and nano's {80,160}
 bool fused_mlp_supported(int prec, int C);
 size_t fused_mlp_packed_bytes(int C);
 int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, void* dst,

@@ -42,12 +42,14 @@ template <> struct M32<f16_t> {
 };
 
 template <int C> struct FusedGeom {
+  static constexpr int CP = (C + 31) / 32 * 32;         // GEMM2's output rows: C rounded up to whole 32-row tiles
+                                                        // (convnext_nano's 80 -> 96: the packed W2 carries zero rows)
   static constexpr int NSUB = 4 * C / 32;               // 32-hidden-unit sub-chunks per block
   static constexpr int SUBS = C <= 64 ? 4 : 2;          // sub-chunks per ring slot
   static constexpr int NCHUNK = NSUB / SUBS;
   static constexpr int W1ROW = 2 * C + 16;              // bytes per staged W1 row (padded)
   static constexpr int W2ROW = 80;                      // bytes per staged W2 row (32 x 2 B + 16)
-  static constexpr int SUBBYTES = 32 * W1ROW + C * W2ROW;
+  static constexpr int SUBBYTES = 32 * W1ROW + CP * W2ROW;
   static constexpr int CHUNKBYTES = SUBS * SUBBYTES;
   static constexpr bool RESIDENT = NCHUNK <= 2;
 };
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
   using G = FusedGeom<C>;
   using frag = typename M32<T>::frag;
   constexpr int KS1 = C / 16;   // k-steps of GEMM1
-  constexpr int CT = C / 32;    // 32-channel output tiles of GEMM2
+  constexpr int CT = G::CP / 32;   // 32-channel output tiles of GEMM2 (the last one ragged when C % 32 != 0)
+  static_assert(C % 16 == 0 && (4 * C) % 32 == 0 && G::NSUB % G::SUBS == 0, "geometry");
   constexpr int PIECES = G::CHUNKBYTES / 16;      // 16-byte pieces per chunk
   constexpr int CPT = (PIECES + 511) / 512;       // ... per thread (last round ragged)
   static_assert(G::CHUNKBYTES % 16 == 0, "chunk must be a whole number of 16-byte pieces");
@@ -120,16 +123,18 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m = tile * 256 + wave * 32 + lr;          // this lane's pixel row
     const int mc = m < M ? m : M - 1;
-    // (C = 64 runs four waves per SIMD on 128 VGPRs: no room to hold the residual rows across the tile)
-    constexpr bool PRE_R = C > 64;
+    // (C = 64 runs four waves per SIMD on 128 VGPRs, C = 160 holds 2 x 10 input fragments and 5 output tiles:
+    //  no room to hold the residual rows across the tile)
+    constexpr bool PRE_R = C > 64 && C <= 128;
     float4 rres[PRE_R ? CT : 1][4];                      // x[m][c .. c+3] for the epilogue
     if (PRE_R) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rres[PRE_R ? ct : 0][q] =
-              *reinterpret_cast<const float4*>(x + (size_t)mc * C + ct * 32 + 8 * q + 4 * h);
+          if (ct * 32 + 8 * q < C)
+            rres[PRE_R ? ct : 0][q] =
+                *reinterpret_cast<const float4*>(x + (size_t)mc * C + ct * 32 + 8 * q + 4 * h);
     }
     {
       const int tn = tile + (int)gridDim.x;
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
       for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (ct * 32 + 8 * q >= C) continue;   // rows C .. CP-1 of the ragged last tile
           const int c = ct * 32 + 8 * q + 4 * h;
           const float4 bv = *reinterpret_cast<const float4*>(b2 + c);
           const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
       // ---- optional second output for the next consumer of x (MaxViT schedule): post_mode 1 =
       // LayerNorm_C(x) * pw + pb (eps 1e-6), post_mode 2 = x * pw + pb (an eval-mode BatchNorm), in the operand
       // type.  A pixel's channels live on lanes lr and lr + 32: one cross-lane step per reduction.
-      if (post_mode != 0) {
+      if (G::CP == C && post_mode != 0) {   // (whole tiles only: the MaxViT widths)
         float mean = 0.f, rstd = 1.f;
         if (post_mode == 1) {
           float s = 0.f;
@@ -284,7 +290,7 @@ __global__ void pack_fused_kernel(const float* __restrict__ w1, const float* __r
     } else {
       const int o2 = o - 32 * W1EL;
       const int c = o2 / W2EL, pos = o2 - c * W2EL;
-      if (pos < 32) {
+      if (pos < 32 && c < C) {
         const int s = pos >> 4, hh = (pos >> 3) & 1, e = pos & 7;
         const int hid = sub * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
         v = w2[(size_t)c * 4 * C + hid];
@@ -330,12 +336,14 @@ int launch_pack_cfg(const float* w1, const float* w2, void* dst, hipStream_t st)
 }  // namespace
 
 bool fused_mlp_supported(int prec, int C) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128);
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128 || C == 80 || C == 160);
 }
 
 size_t fused_mlp_packed_bytes(int C) {
   if (C == 64) return (size_t)FusedGeom<64>::NSUB * FusedGeom<64>::SUBBYTES;
   if (C == 128) return (size_t)FusedGeom<128>::NSUB * FusedGeom<128>::SUBBYTES;
+  if (C == 80) return (size_t)FusedGeom<80>::NSUB * FusedGeom<80>::SUBBYTES;
+  if (C == 160) return (size_t)FusedGeom<160>::NSUB * FusedGeom<160>::SUBBYTES;
   return 0;
 }
 
@@ -345,6 +353,10 @@ int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, voi
   if (prec == BTSBOT_BF16 && C == 128) return launch_pack_cfg<bf16_t, 128>(w1, w2, dst, st);
   if (prec == BTSBOT_F16 && C == 64) return launch_pack_cfg<f16_t, 64>(w1, w2, dst, st);
   if (prec == BTSBOT_F16 && C == 128) return launch_pack_cfg<f16_t, 128>(w1, w2, dst, st);
+  if (prec == BTSBOT_BF16 && C == 80) return launch_pack_cfg<bf16_t, 80>(w1, w2, dst, st);
+  if (prec == BTSBOT_BF16 && C == 160) return launch_pack_cfg<bf16_t, 160>(w1, w2, dst, st);
+  if (prec == BTSBOT_F16 && C == 80) return launch_pack_cfg<f16_t, 80>(w1, w2, dst, st);
+  if (prec == BTSBOT_F16 && C == 160) return launch_pack_cfg<f16_t, 160>(w1, w2, dst, st);
   btsbot_set_error("pack_fused_mlp: unsupported (prec %d, C %d)", prec, C);
   return BTSBOT_ERR_INVALID_ARG;
 }
@@ -361,6 +373,15 @@ int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const flo
     return launch_fused_cfg<f16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
   if (prec == BTSBOT_F16 && C == 128)
     return launch_fused_cfg<f16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
+  // convnext_nano's stages 0-1 (no second output: post_mode is a MaxViT feature)
+  if (post_out == nullptr && prec == BTSBOT_BF16 && C == 80)
+    return launch_fused_cfg<bf16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+  if (post_out == nullptr && prec == BTSBOT_BF16 && C == 160)
+    return launch_fused_cfg<bf16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+  if (post_out == nullptr && prec == BTSBOT_F16 && C == 80)
+    return launch_fused_cfg<f16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+  if (post_out == nullptr && prec == BTSBOT_F16 && C == 160)
+    return launch_fused_cfg<f16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
   btsbot_set_error("fused_mlp: unsupported (prec %d, C %d)", prec, C);
   return BTSBOT_ERR_INVALID_ARG;
 }
