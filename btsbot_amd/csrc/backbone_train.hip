@@ -38,6 +38,7 @@ struct BBCache {
   void* dyT_down[4];        // operand type [rows_i][C_i]: d(loss)/d(downsample i output) (i >= 1)
   void* dyT_stem;           // operand type [B*225][C0]: gradient behind the stem LayerNorm
   float *G, *S;             // fp32 [max C*4C], [max 4C]
+  size_t g_floats;
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
   size_t dwpart_floats;
@@ -89,6 +90,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.dyT_stem = take((size_t)B * 225 * c.dims[0] * esz);
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
+  k.g_floats = maxc4c;
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
   k.dwpart_floats = (size_t)256 * 50 * c.dims[3];
   k.dwpart = reinterpret_cast<float*>(take(k.dwpart_floats * 4));
@@ -175,32 +177,19 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // neither the chain's kernels (9216 / 1024 rows) nor these fill the chip on their own.  fork() = the side stream
   // sees everything queued on `st` so far, join() = `st` waits for the side stream (bucket boundaries and the end).
   // G / S / wpart are touched on the side stream only.  BTSBOT_AMD_NO_SIDE_STREAM=1: everything on `st` (A/B).
-  const bool two = h->use_side && h->side != nullptr;
   hipStream_t sd = st;
   auto fork = [&]() -> int { return side_fork(h, st, &sd); };
   auto join = [&]() -> int { return side_join(h, st); };
   // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type (the cast
-  // launch in front of the next block is then skipped) and, with one stream, clears the next G / S accumulators
+  // launch in front of the next block is then skipped)
   const bool fold_cast = prec != BTSBOT_F32;
-  const bool fold_clear = fold_cast && !two;
-  auto clear_gs = [&](size_t g_floats) -> int {   // S sits directly in front of G
-    if (fold_clear) return BTSBOT_OK;
-    HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + g_floats) - k.S) * sizeof(float), sd));
-    return BTSBOT_OK;
-  };
+  // G / S (S directly in front of G) are the accumulators of the fc2 / downsample filter-gradient GEMMs: cleared once
+  // here, afterwards every consumer (fc2_grads_kernel, unpack_down_grad_kernel) leaves what it read zero
+  HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + k.g_floats) - k.S) * sizeof(float), st));
   // operand-type buffer the consumer after block (i, j) reads its dy from: the block before, else the downsample
   auto next_dyT = [&](int i, int j) -> void* {
     if (j > 0) return k.blk[i][j - 1].dyT;
     return i > 0 ? k.dyT_down[i] : nullptr;
-  };
-  // G floats of the consumer after block (i, j) (the block before: C x 4C; the downsample: C x 4 C_in)
-  auto next_g_floats = [&](int i, int j) -> size_t {
-    const size_t ch = c.dims[i];
-    return j > 0 ? ch * 4 * ch : (i > 0 ? ch * 4 * c.dims[i - 1] : 0);
-  };
-  auto clear_next = [&](int i, int j) -> int {   // one stream: S / G of the next consumer (dw_plain_kernel folds this in)
-    HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + next_g_floats(i, j)) - k.S) * sizeof(float), st));
-    return BTSBOT_OK;
   };
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
@@ -210,15 +199,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
       if (!dyT_ready)
-        TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st, fold_clear ? k.S : nullptr,
-                               fold_clear ? (long)((k.G + (size_t)ch * H) - k.S) : 0));
+        TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
       // ---- side: fc2 / layer-scale (S = colsum(dy), G = dy^T h), fc1 (dW1 += da^T xn, db1 += colsum(da))
       TRYB(fork());
-      TRYB(clear_gs((size_t)ch * H));
       TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
@@ -231,17 +218,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
         TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, grads + b.ln_w, grads + b.ln_b,
                              grads + b.dw_w, grads + b.dw_b, k.dwpart, k.dwpart_floats, B, hw, ch, st));
-        if (fold_clear && nxt) TRYB(clear_next(i, j));
       } else {
         TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
         // ---- depthwise filter gradient.  Stays in the chain: behind a fork of its own (per-block dd buffers) the
         //      step was 0.02-0.06 ms slower, as was a single fork placed here instead of behind da
         TRYB(launch_dw_wgrad(s.xin, dxn, grads + b.dw_w, grads + b.dw_b, k.dwpart, B, hw, ch, st));
         // ---- depthwise input gradient: dx = dy + conv_flipped(dd)
-        // the accumulators the next consumer clears: G of the block before, or of the downsample
-        TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec,
-                             fold_clear && nxt ? k.S : nullptr,
-                             fold_clear && nxt ? (long)((k.G + next_g_floats(i, j)) - k.S) : 0));
+        TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec));
       }
       dyT_ready = nxt != nullptr;
     }
@@ -251,11 +234,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const long prow = (long)B * hwp * hwp;
       void* dyT = k.dyT_down[i];
       if (!dyT_ready)
-        TRYB(launch_scale_cast(prec, dy, nullptr, dyT, (long)rows * ch, ch, st, fold_clear ? k.S : nullptr,
-                               fold_clear ? (long)((k.G + (size_t)ch * 4 * cin) - k.S) : 0));
+        TRYB(launch_scale_cast(prec, dy, nullptr, dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
       TRYB(fork());
-      TRYB(clear_gs((size_t)ch * 4 * cin));
       TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, sd));
       TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,

@@ -157,8 +157,10 @@ __global__ __launch_bounds__(256) void rowscale_cast_kernel(const float* __restr
 
 // fc2 weight/scale gradients from G = dy^T h:  dW2[c][k] = gamma[c] G[c][k];
 // dgamma[c] = sum_k W2[c][k] G[c][k] + b2[c] S[c];  db2[c] = gamma[c] S[c]    (S = colsum(dy))
-__global__ __launch_bounds__(256) void fc2_grads_kernel(const float* __restrict__ G,
-                                                        const float* __restrict__ S,
+// G and S are accumulators of the filter-gradient GEMM in front: every element is read exactly once here and left
+// zero for the next block's GEMM (was: a memset launch per block)
+__global__ __launch_bounds__(256) void fc2_grads_kernel(float* __restrict__ G,
+                                                        float* __restrict__ S,
                                                         const float* __restrict__ w2,
                                                         const float* __restrict__ b2,
                                                         const float* __restrict__ gamma,
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void fc2_grads_kernel(const float* __restrict_
   float part = 0.f;
   for (int k = threadIdx.x; k < H; k += 256) {
     const float gv = G[(size_t)c * H + k];
+    G[(size_t)c * H + k] = 0.f;
     dW2[(size_t)c * H + k] = g * gv;
     part += w2[(size_t)c * H + k] * gv;
   }
@@ -177,8 +180,10 @@ __global__ __launch_bounds__(256) void fc2_grads_kernel(const float* __restrict_
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
   __syncthreads();
   if (threadIdx.x == 0) {
-    dgamma[c] = sh[0] + sh[1] + sh[2] + sh[3] + b2[c] * S[c];
-    db2[c] = g * S[c];
+    const float sc = S[c];
+    S[c] = 0.f;
+    dgamma[c] = sh[0] + sh[1] + sh[2] + sh[3] + b2[c] * sc;
+    db2[c] = g * sc;
   }
 }
 
@@ -592,7 +597,7 @@ int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void*
   return BTSBOT_OK;
 }
 
-int launch_fc2_grads(const float* G, const float* S, const float* w2, const float* b2,
+int launch_fc2_grads(float* G, float* S, const float* w2, const float* b2,
                      const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
                      hipStream_t st) {
   hipLaunchKernelGGL(fc2_grads_kernel, dim3(C), dim3(256), 0, st, G, S, w2, b2, gamma, dW2, db2,

@@ -263,7 +263,7 @@ int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void*
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
                       hipStream_t st, float* zero = nullptr, long zero_n = 0);   // also zero[0..zero_n) = 0
-int launch_fc2_grads(const float* G, const float* S, const float* w2, const float* b2,
+int launch_fc2_grads(float* G, float* S, const float* w2, const float* b2,
                      const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
                      hipStream_t st);
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
@@ -287,7 +287,7 @@ int launch_transpose_cast(int prec, const float* src, const float* rowscale, voi
                           hipStream_t st);
 int launch_pack_down_t(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st);
 // Gd [Cout][4][Cin] (q-major patches order) accumulated into dst [Cout][Cin][4] (master layout)
-int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st);
+int launch_unpack_down_grad(float* Gd, float* dst, int Cout, int Cin, hipStream_t st);   // leaves Gd zero
 
 bool stage1_supported(int prec, int c1, int c2);   // stage1b.hip
 

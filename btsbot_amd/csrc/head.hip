@@ -240,7 +240,8 @@ __global__ void pack_down_t_kernel(const float* __restrict__ s, T* __restrict__ 
   }
 }
 
-__global__ void unpack_down_grad_kernel(const float* __restrict__ g, float* __restrict__ d, int Cout,
+// (g is the accumulator of the filter-gradient GEMM in front: read exactly once here and left zero for its next user)
+__global__ void unpack_down_grad_kernel(float* __restrict__ g, float* __restrict__ d, int Cout,
                                         int Cin) {
   const int64_t n = (int64_t)Cout * Cin * 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -248,7 +249,9 @@ __global__ void unpack_down_grad_kernel(const float* __restrict__ g, float* __re
     const int q = (int)(i & 3);
     const int ci = (int)((i >> 2) % Cin);
     const int co = (int)(i / (4 * (int64_t)Cin));
-    d[i] = g[((int64_t)co * 4 + q) * Cin + ci];      // d[co][ci][q] = g[co][q][ci]
+    const int64_t j = ((int64_t)co * 4 + q) * Cin + ci;
+    d[i] = g[j];                                     // d[co][ci][q] = g[co][q][ci]
+    g[j] = 0.f;
   }
 }
 
@@ -462,7 +465,7 @@ int launch_transpose_cast(int prec, const float* src, const float* rowscale, voi
   return BTSBOT_OK;
 }
 
-int launch_unpack_down_grad(const float* Gd, float* dst, int Cout, int Cin, hipStream_t st) {
+int launch_unpack_down_grad(float* Gd, float* dst, int Cout, int Cin, hipStream_t st) {
   hipLaunchKernelGGL(unpack_down_grad_kernel, dim3(nblocks((int64_t)Cout * Cin * 4)), dim3(256), 0,
                      st, Gd, dst, Cout, Cin);
   LAUNCH_CHECK();
