@@ -25,6 +25,8 @@ struct BlkBuf {
   // the input-gradient chain on a second stream without a block overwriting what the previous one still reads
   void* dyT;     // d(loss)/d(block output), operand type [rows][C]
   void* da;      // d(loss)/d(fc1 pre-activation), operand type [rows][4C]
+  float* dwpart; // dwln_bwd_kernel's partial rows [dwrows][52 C] (nullptr: the block runs the three-launch form)
+  int dwrows;
 };
 
 constexpr size_t WPART_FLOATS = (size_t)16 << 20;   // 64 MB: every shape of the pico / nano schedule fits (else atomics)
@@ -41,7 +43,6 @@ struct BBCache {
   size_t g_floats;
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
-  size_t dwpart_floats;
   float* wpart;             // fp32 WPART_FLOATS: slice partials of the filter-gradient GEMMs (wgrad.hip)
   void* stem_patches;       // [B*225][48] operand type
   float* stem_pre;          // [B*225][C0] fp32
@@ -77,6 +78,8 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.h = take(rows * 4 * ch * esz);
       b.dyT = take(rows * ch * esz);
       b.da = take(rows * 4 * ch * esz);
+      b.dwrows = h->use_dwln && dwln_bwd_supported(STAGE_HW[i], (int)ch) ? dwln_bwd_rows(STAGE_HW[i], (int)ch, B) : 0;
+      b.dwpart = b.dwrows ? reinterpret_cast<float*>(take((size_t)b.dwrows * 52 * ch * 4)) : nullptr;
       k.blk[i].push_back(b);
     }
     k.dyT_down[i] = i > 0 ? take(rows * ch * esz) : nullptr;
@@ -92,8 +95,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.g_floats = maxc4c;
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
-  k.dwpart_floats = (size_t)256 * 50 * c.dims[3];
-  k.dwpart = reinterpret_cast<float*>(take(k.dwpart_floats * 4));
+  k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
   k.wpart = reinterpret_cast<float*>(take(WPART_FLOATS * 4));
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
   k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
@@ -178,8 +180,19 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // sees everything queued on `st` so far, join() = `st` waits for the side stream (bucket boundaries and the end).
   // G / S / wpart are touched on the side stream only.  BTSBOT_AMD_NO_SIDE_STREAM=1: everything on `st` (A/B).
   hipStream_t sd = st;
-  auto fork = [&]() -> int { return side_fork(h, st, &sd); };
-  auto join = [&]() -> int { return side_join(h, st); };
+  // dwln_bwd_kernel leaves one partial row per workgroup; the column sum that folds them into the arena is queued on
+  // the side stream at the next fork (it then sees the kernel's rows) instead of behind the kernel in the chain
+  struct { const float* part; float* dst; int rows, cols; } pend = {nullptr, nullptr, 0, 0};
+  auto fork = [&]() -> int {
+    TRYB(side_fork(h, st, &sd));
+    if (pend.rows > 0) TRYB(launch_colsum(BTSBOT_F32, pend.part, pend.dst, pend.rows, pend.cols, sd));
+    pend.rows = 0;
+    return BTSBOT_OK;
+  };
+  auto join = [&]() -> int {
+    if (pend.rows > 0) TRYB(fork());
+    return side_join(h, st);
+  };
   // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type (the cast
   // launch in front of the next block is then skipped)
   const bool fold_cast = prec != BTSBOT_F32;
@@ -214,10 +227,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
       void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
-      if (h->use_dwln && dwln_bwd_supported(hw, ch)) {
+      // (the partial rows follow the arena's layout of conv_dw.weight | conv_dw.bias | norm.weight | norm.bias)
+      const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
+      if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
-        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, grads + b.ln_w, grads + b.ln_b,
-                             grads + b.dw_w, grads + b.dw_b, k.dwpart, k.dwpart_floats, B, hw, ch, st));
+        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st));
+        pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
       } else {
         TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
         // ---- depthwise filter gradient.  Stays in the chain: behind a fork of its own (per-block dd buffers) the

@@ -277,9 +277,9 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, fl
 // dwln_bwd.hip: the three launches above (LayerNorm backward, depthwise filter gradient, depthwise input gradient)
 // as one kernel, dd never leaving LDS; dy is updated in place (dy += conv(dd, flipped taps))
 bool dwln_bwd_supported(int HW, int C);
+int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) one launch writes
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                    void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, float* partials,
-                    size_t part_floats, int B, int HW, int C, hipStream_t st);
+                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st);
 int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]

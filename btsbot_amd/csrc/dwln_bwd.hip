@@ -12,8 +12,8 @@
 // a workgroup takes `ga` alerts one after the other; per alert it stages x_in, runs the LayerNorm backward over the
 // map's pixels (C/4 lanes per pixel, float4 pieces, result straight into LDS), then every thread = (channel, row group)
 // runs both convolutions off the two LDS maps.  Filter-gradient taps stay in registers across the workgroup's alerts
-// and leave as one partial row per workgroup (column-summed by the caller, as dw_wgrad_kernel's), the LayerNorm
-// parameter gradients as one atomic per channel per workgroup.  fp32 throughout (every precision mode).
+// and leave, with the LayerNorm parameter gradients, as one partial row per workgroup which the caller column-sums
+// into the arena (<= 64 atomics per column there instead of one per workgroup here).  fp32 throughout (every mode).
 #include "common.h"
 
 namespace {
@@ -24,7 +24,7 @@ template <int HW, int C, int NT>
 __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ d, const float* __restrict__ dxn,
                                                       const float* __restrict__ g, const float* __restrict__ xin,
                                                       const float* __restrict__ w, float* dy,
-                                                      void* __restrict__ out16, int prec16, float* dg, float* dbeta,
+                                                      void* __restrict__ out16, int prec16,
                                                       float* __restrict__ partials, int B, int ga) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [P][C] | ds [P][C] | flipped taps [49][C]
   constexpr int P = HW * HW;
@@ -184,13 +184,14 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
       ab += red[49 * C + c];
     }
   }
+  float* row = partials + (size_t)blockIdx.x * 52 * C;
   if (rg == 0) {
-    float* row = partials + (size_t)blockIdx.x * 50 * C;
 #pragma unroll
     for (int t = 0; t < 49; ++t) row[(size_t)c * 49 + t] = acc[t];
     row[(size_t)49 * C + c] = ab;
   }
-  // LayerNorm parameter gradients: the wave's row groups and the waves meet in LDS, one atomic per channel
+  // LayerNorm parameter gradients: the wave's row groups and the waves meet in LDS, then join the partial row
+  // (no same-address atomics here: 512 workgroups x 2 C of them cost ~8 us per launch in ln_bwd_kernel)
   __syncthreads();
   float* sh = sm;   // [2][NW * R][C]
 #pragma unroll
@@ -206,38 +207,35 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
       sa += sh[j * C + cc];
       sb += sh[(NW * R + j) * C + cc];
     }
-    atomicAdd(dg + cc, sa);
-    atomicAdd(dbeta + cc, sb);
+    row[(size_t)50 * C + cc] = sa;
+    row[(size_t)51 * C + cc] = sb;
   }
 }
 
+template <int HW, int C, int NT> struct DwlnCfg {
+  static constexpr size_t lds = ((size_t)2 * HW * HW + 49) * C * sizeof(float);
+  // one workgroup per CU where the maps take 128 KB (15x15x64), two where they take <= 80 KB
+  static constexpr int WGS = lds > 80 * 1024 ? 256 : 512;
+  static int ga(int B) { return B < WGS ? 1 : (B + WGS - 1) / WGS; }
+  static int grid(int B) { return (B + ga(B) - 1) / ga(B); }
+};
+
 template <int HW, int C, int NT>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                void* out16, int prec16, float* dg, float* dbeta, float* dw, float* partials, size_t part_floats,
-                int B, hipStream_t st) {
+                void* out16, int prec16, float* partials, int B, hipStream_t st) {
+  using K = DwlnCfg<HW, C, NT>;
   constexpr int G = NT / C;
-  constexpr size_t lds = ((size_t)2 * HW * HW + 49) * C * sizeof(float);
-  static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= lds, "closing reduction fits the maps' footprint");
+  static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
   static bool attr = false;
   if (!attr) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::lds));
     attr = true;
   }
-  // one workgroup per CU where the maps take 128 KB (15x15x64), two where they take <= 80 KB:
-  // <= 512 same-address atomics per channel, <= 512 partial rows
-  constexpr int WGS = lds > 80 * 1024 ? 256 : 512;
-  int ga = (B + WGS - 1) / WGS;
-  if (ga < 1) ga = 1;
-  const int grid = (B + ga - 1) / ga;
-  if ((size_t)grid * 50 * C > part_floats) {
-    btsbot_set_error("dwln_bwd: partial rows (%d x %d floats) exceed the scratch lent", grid, 50 * C);
-    return BTSBOT_ERR_INVALID_ARG;
-  }
-  hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT>), dim3(grid), dim3(NT), lds, st, d, dxn, g, xin, w, dy, out16,
-                     prec16, dg, dbeta, partials, B, ga);
+  hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
+                     out16, prec16, partials, B, K::ga(B));
   LAUNCH_CHECK();
-  return launch_colsum(BTSBOT_F32, partials, dw, grid, 50 * C, st);
+  return BTSBOT_OK;
 }
 
 }  // namespace
@@ -245,21 +243,24 @@ int dwln_launch(const float* d, const float* dxn, const float* g, const float* x
 // the (map, width) pairs of convnext_pico's stages 0-2; everything else keeps the three-kernel form
 bool dwln_bwd_supported(int HW, int C) { return (HW == 15 && C == 64) || (HW == 7 && C == 128) || (HW == 3 && C == 256); }
 
-// dw: filter gradient [C][49] with the bias gradient [C] directly behind it (master-arena layout); w: taps [49][C]
+// partial rows one launch writes for a batch of B alerts (each 52 * C floats)
+int dwln_bwd_rows(int HW, int C, int B) {
+  if (B <= 0) return 0;
+  if (HW == 15 && C == 64) return DwlnCfg<15, 64, 512>::grid(B);
+  if (HW == 7 && C == 128) return DwlnCfg<7, 128, 512>::grid(B);
+  if (HW == 3 && C == 256) return DwlnCfg<3, 256, 512>::grid(B);
+  return 0;
+}
+
+// w: taps [49][C].  partials: dwln_bwd_rows() x 52 * C floats; row = [C][49] depthwise filter | [C] depthwise bias |
+// [C] LayerNorm weight | [C] LayerNorm bias gradients of one workgroup -- the master arena's layout of those four
+// tensors, so the caller finishes with ONE column sum of the rows into the arena (launch_colsum, any stream).
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                    void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, float* partials,
-                    size_t part_floats, int B, int HW, int C, hipStream_t st) {
+                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
-  if (dbias != dw + (size_t)49 * C) {
-    btsbot_set_error("dwln_bwd: filter and bias gradients must be adjacent in the arena");
-    return BTSBOT_ERR_INVALID_ARG;
-  }
-  if (HW == 15 && C == 64)
-    return dwln_launch<15, 64, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
-  if (HW == 7 && C == 128)
-    return dwln_launch<7, 128, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
-  if (HW == 3 && C == 256)
-    return dwln_launch<3, 256, 512>(d, dxn, g, xin, w, dy, out16, prec16, dg, dbeta, dw, partials, part_floats, B, st);
+  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
 }
