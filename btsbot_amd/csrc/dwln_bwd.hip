@@ -9,7 +9,7 @@
 //
 // Unfused (ln_bwd_kernel -> dw_wgrad_kernel -> dw_plain_kernel, backward.hip) dd makes a round trip through HBM and is
 // read twice, and stages 2-3 pay three launch latencies for 9 MB tensors.  Here dd exists only in LDS:
-// a workgroup takes `ga` alerts one after the other; per alert it stages x_in, runs the LayerNorm backward over the
+// a workgroup takes `ga` alerts one after the other (3x3 maps: four per pass); per alert it stages x_in, runs the LayerNorm backward over the
 // map's pixels (C/4 lanes per pixel, float4 pieces, result straight into LDS), then every thread = (channel, row group)
 // runs both convolutions off the two LDS maps.  Filter-gradient taps stay in registers across the workgroup's alerts
 // and leave, with the LayerNorm parameter gradients, as one partial row per workgroup which the caller column-sums
@@ -20,20 +20,20 @@ namespace {
 
 constexpr float LN_EPS = 1e-6f;
 
-template <int HW, int C, int NT>
+template <int HW, int C, int NT, int NA>
 __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ d, const float* __restrict__ dxn,
                                                       const float* __restrict__ g, const float* __restrict__ xin,
                                                       const float* __restrict__ w, float* dy,
                                                       void* __restrict__ out16, int prec16,
                                                       float* __restrict__ partials, int B, int ga) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [P][C] | ds [P][C] | flipped taps [49][C]
-  constexpr int P = HW * HW;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [NA P][C] | ds [NA P][C] | flipped taps [49][C]
+  constexpr int P = HW * HW, PA = NA * P;   // NA alerts share a pass (3x3 maps: their latencies are paid once)
   constexpr int LPR = C / 4, R = 64 / LPR, NW = NT / 64;   // lanes per pixel row, rows per wave pass, waves
   constexpr int G = NT / C;                                // row groups of the convolution phase
-  static_assert(LPR <= 64 && NT % C == 0 && 2 * NW * R * C <= 2 * P * C, "geometry");
+  static_assert(LPR <= 64 && NT % C == 0 && 2 * NW * R * C <= 2 * PA * C, "geometry");
   float* xs = sm;
-  float* ds = sm + P * C;
-  float* ws = ds + P * C;
+  float* ds = sm + PA * C;
+  float* ws = ds + PA * C;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = lane / LPR, l = lane % LPR;
   const int c = tid % C, rg = tid / C;
@@ -53,14 +53,17 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
     return v;
   };
   const int a0 = blockIdx.x * ga, a1 = min(B, a0 + ga);
-  for (int a = a0; a < a1; ++a) {
+  for (int a = a0; a < a1; a += NA) {
+    const int na = min(NA, a1 - a);          // alerts of this pass (consecutive alerts = consecutive rows)
+    const int pa = na * P;
     const size_t base = (size_t)a * P * C;
     __syncthreads();   // the previous alert's convolutions have read both maps (first trip: the taps are staged)
     {
       // x_in -> LDS: eight 16-byte pieces in flight per thread before the first LDS store
       const float4* src = reinterpret_cast<const float4*>(xin + base);
       float4* dst = reinterpret_cast<float4*>(xs);
-      constexpr int n4 = P * C / 4, NB = 8;
+      constexpr int NB = PA * C / 4 >= 8 * NT ? 8 : (PA * C / 4 + NT - 1) / NT;
+      const int n4 = pa * C / 4;
       for (int i0 = tid; i0 < n4; i0 += NT * NB) {
         float4 v[NB];
 #pragma unroll
@@ -71,13 +74,13 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
       }
     }
     // LayerNorm backward, two row groups per wave pass (4 x 16-byte loads in flight per lane)
-    for (int r0 = wv * R * 2; r0 < P; r0 += NW * R * 2) {
+    for (int r0 = wv * R * 2; r0 < pa; r0 += NW * R * 2) {
       float4 v[2], dx[2];
       bool ok[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int r = r0 + u * R + sub;
-        ok[u] = r < P;
+        ok[u] = r < pa;
         const int rr = ok[u] ? r : 0;
         v[u] = *reinterpret_cast<const float4*>(d + base + (size_t)rr * C + 4 * l);
         dx[u] = *reinterpret_cast<const float4*>(dxn + base + (size_t)rr * C + 4 * l);
@@ -117,13 +120,17 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // both convolutions, thread = (channel, row group)
-    for (int y = rg; y < HW; y += G) {
+    for (int q = rg; q < na * HW; q += G) {
+      const int al = q / HW, y = q - al * HW;       // (alert of the pass, map row)
+      const float* xsa = xs + al * P * C;
+      const float* dsa = ds + al * P * C;
+      const size_t abase = base + (size_t)al * P * C;
       float gy[HW], ax[HW];
 #pragma unroll
-      for (int xx = 0; xx < HW; ++xx) ax[xx] = dy[base + (size_t)(y * HW + xx) * C + c];   // requested first
+      for (int xx = 0; xx < HW; ++xx) ax[xx] = dy[abase + (size_t)(y * HW + xx) * C + c];   // requested first
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) {
-        gy[xx] = ds[(y * HW + xx) * C + c];
+        gy[xx] = dsa[(y * HW + xx) * C + c];
         ab += gy[xx];
       }
 #pragma unroll
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
         if (iy < 0 || iy >= HW) continue;
         float in[HW];
 #pragma unroll
-        for (int xx = 0; xx < HW; ++xx) in[xx] = xs[(iy * HW + xx) * C + c];
+        for (int xx = 0; xx < HW; ++xx) in[xx] = xsa[(iy * HW + xx) * C + c];
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
           }
         float wk[7];
 #pragma unroll
-        for (int xx = 0; xx < HW; ++xx) in[xx] = ds[(iy * HW + xx) * C + c];
+        for (int xx = 0; xx < HW; ++xx) in[xx] = dsa[(iy * HW + xx) * C + c];
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) wk[kx] = ws[(ky * 7 + kx) * C + c];
 #pragma unroll
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
       }
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) {
-        const size_t o = base + (size_t)(y * HW + xx) * C + c;
+        const size_t o = abase + (size_t)(y * HW + xx) * C + c;
         dy[o] = ax[xx];
         if (out16 != nullptr) {   // the same values as the next 16-bit GEMM's operand
           if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[o] = (bf16_t)ax[xx];
@@ -212,27 +219,27 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int HW, int C, int NT> struct DwlnCfg {
-  static constexpr size_t lds = ((size_t)2 * HW * HW + 49) * C * sizeof(float);
+template <int HW, int C, int NT, int NA> struct DwlnCfg {
+  static constexpr size_t lds = ((size_t)2 * NA * HW * HW + 49) * C * sizeof(float);
   // one workgroup per CU where the maps take 128 KB (15x15x64), two where they take <= 80 KB
   static constexpr int WGS = lds > 80 * 1024 ? 256 : 512;
   static int ga(int B) { return B < WGS ? 1 : (B + WGS - 1) / WGS; }
   static int grid(int B) { return (B + ga(B) - 1) / ga(B); }
 };
 
-template <int HW, int C, int NT>
+template <int HW, int C, int NT, int NA>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                 void* out16, int prec16, float* partials, int B, hipStream_t st) {
-  using K = DwlnCfg<HW, C, NT>;
+  using K = DwlnCfg<HW, C, NT, NA>;
   constexpr int G = NT / C;
   static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
   static bool attr = false;
   if (!attr) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT, NA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::lds));
     attr = true;
   }
-  hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
+  hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT, NA>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
                      out16, prec16, partials, B, K::ga(B));
   LAUNCH_CHECK();
   return BTSBOT_OK;
@@ -246,9 +253,9 @@ bool dwln_bwd_supported(int HW, int C) { return (HW == 15 && C == 64) || (HW == 
 // partial rows one launch writes for a batch of B alerts (each 52 * C floats)
 int dwln_bwd_rows(int HW, int C, int B) {
   if (B <= 0) return 0;
-  if (HW == 15 && C == 64) return DwlnCfg<15, 64, 512>::grid(B);
-  if (HW == 7 && C == 128) return DwlnCfg<7, 128, 512>::grid(B);
-  if (HW == 3 && C == 256) return DwlnCfg<3, 256, 512>::grid(B);
+  if (HW == 15 && C == 64) return DwlnCfg<15, 64, 512, 1>::grid(B);
+  if (HW == 7 && C == 128) return DwlnCfg<7, 128, 512, 1>::grid(B);
+  if (HW == 3 && C == 256) return DwlnCfg<3, 256, 512, 4>::grid(B);
   return 0;
 }
 
@@ -258,9 +265,9 @@ int dwln_bwd_rows(int HW, int C, int B) {
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
-  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
-  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
-  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
 }
