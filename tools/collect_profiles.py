@@ -51,6 +51,9 @@ try:   # training-step kernel stats and the MFMA-utilisation pass (tools/round_e
                    check=True, stdout=subprocess.DEVNULL)
 except ValueError:
     print("no train_trace / mfma pass under gpurun_out/final (older round_end.sh)")
+for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt")):   # tools/nano_bench.py; train step default vs
+    if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
+        shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")
 open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])
 for k, v in sorted(out["kernels"].items(), key=lambda x: -x[1]["traffic_bytes"] * x[1]["launches"])[:10]:
     print(f'{v["family"]:24s} launches {v["launches"]:4d}  fetch {v["fetch_bytes"]/1e6:8.2f} MB  write {v["write_bytes"]/1e6:8.2f} MB')
