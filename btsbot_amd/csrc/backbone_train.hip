@@ -257,9 +257,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
       TRYB(launch_unpatch(k.dpat, dxn, B, hwp, cin, st));
-      // LN backward per input pixel (x_prev = stage i-1 output); result is the new dy
+      // LN backward per input pixel (x_prev = stage i-1 output); result is the new dy, in the 16-bit modes also as
+      // the operand of stage i-1's last block (was a cast launch)
+      void* nxt16 = fold_cast && !h->blocks[i - 1].empty() ? k.blk[i - 1].back().dyT : nullptr;
       TRYB(launch_ln_bwd(k.xs[i - 1], dxn, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
-                         grads + h->down[i].ln_b, prow, cin, st));
+                         grads + h->down[i].ln_b, prow, cin, st, nxt16, prec));
+      dyT_ready = nxt16 != nullptr;
     }
     // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete here
     if (i >= 2 && h->n_buckets == 3) {
@@ -276,8 +279,8 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
     TRYB(launch_gemm(prec, EPI_BIAS, k.stem_patches, ws16, m + h->stem_b, nullptr, nullptr,
                      k.stem_pre, rows, c0, 48, st));
     TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
-                       grads + h->stem_lnb, rows, c0, st));
-    TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT_stem, (long)rows * c0, c0, st));
+                       grads + h->stem_lnb, rows, c0, st, fold_cast ? k.dyT_stem : nullptr, prec));
+    if (!fold_cast) TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT_stem, (long)rows * c0, c0, st));
     TRYB(fork());
     TRYB(wgrad_cs(prec, k.dyT_stem, k.stem_patches, grads + h->stem_w, grads + h->stem_b, rows, c0, 48, 48,
                   sd, k.wpart));

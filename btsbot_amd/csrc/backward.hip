@@ -138,12 +138,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
 template <typename T>
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ in,
                                                          const float* __restrict__ scale,
-                                                         T* __restrict__ out, long n, int C,
-                                                         float* __restrict__ zero, long zero_n) {
+                                                         T* __restrict__ out, long n, int C) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     out[i] = (T)(in[i] * (scale != nullptr ? scale[i % C] : 1.f));
-  // (the accumulators of the filter-gradient GEMM that consumes `out`: cleared here instead of by a memset launch)
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = 0.f;
 }
 
 // out[r][c] = (T)(in[r][c] * rowscale[r])
@@ -194,7 +191,8 @@ template <int CPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d,
                                                      const float* __restrict__ dxn,
                                                      const float* __restrict__ g, float* dd,
-                                                     float* dg, float* dbeta, long rows, int C) {
+                                                     float* dg, float* dbeta, long rows, int C,
+                                                     void* __restrict__ out16, int prec16) {
   const int lane = threadIdx.x & 63;
   const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
   float gl[CPT], adg[CPT], adb[CPT];
@@ -251,7 +249,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = lane + 64 * i;
-      if (c < C) dd[r * C + c] = rstd * (t[i] - st - v[i] * stx);
+      if (c < C) {
+        const float o = rstd * (t[i] - st - v[i] * stx);
+        dd[r * C + c] = o;
+        if (out16 != nullptr) {   // the same values as the next 16-bit GEMM's operand (was a cast launch)
+          if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[r * C + c] = (bf16_t)o;
+          else reinterpret_cast<f16_t*>(out16)[r * C + c] = (f16_t)o;
+        }
+      }
     }
   }
   // the block's 4 waves meet in LDS: one atomic per channel per block
@@ -277,11 +282,8 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const float* __restrict__
                                                        const float* __restrict__ w, int flip,
                                                        const float* __restrict__ bias,
                                                        const float* addend, float* out, int C,
-                                                       void* __restrict__ out16, int prec16,
-                                                       float* __restrict__ zero, long zero_n) {
+                                                       void* __restrict__ out16, int prec16) {
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [HW*HW][C] map | [49][C] taps
-  // (the next filter-gradient GEMM's accumulators: cleared here, the launch that precedes it in the backward)
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = 0.f;
   constexpr int P = HW * HW;
   float* ws = xs + P * C;
   const size_t base = (size_t)blockIdx.x * P * C;
@@ -549,20 +551,20 @@ int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_
 }
 
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
-                      hipStream_t st, float* zero, long zero_n) {
+                      hipStream_t st) {
   if (n <= 0) return BTSBOT_OK;
   switch (prec) {
     case BTSBOT_F32:
       hipLaunchKernelGGL(scale_cast_kernel<float>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<float*>(out), n, C, zero, zero_n);
+                         reinterpret_cast<float*>(out), n, C);
       break;
     case BTSBOT_BF16:
       hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<bf16_t*>(out), n, C, zero, zero_n);
+                         reinterpret_cast<bf16_t*>(out), n, C);
       break;
     case BTSBOT_F16:
       hipLaunchKernelGGL(scale_cast_kernel<f16_t>, dim3(gridn(n)), dim3(256), 0, st, in, scale,
-                         reinterpret_cast<f16_t*>(out), n, C, zero, zero_n);
+                         reinterpret_cast<f16_t*>(out), n, C);
       break;
     default:
       btsbot_set_error("scale_cast: bad precision %d", prec);
@@ -613,7 +615,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restrict__ d,
                                                             const float* __restrict__ dxn,
                                                             const float* __restrict__ g, float* dd,
-                                                            float* dg, float* dbeta, long rows) {
+                                                            float* dg, float* dbeta, long rows,
+                                                            void* __restrict__ out16, int prec16) {
   constexpr int C = 4 * LPR, R = 64 / LPR;       // rows per wave pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -676,10 +679,22 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
       }
       st = gsum(st) * (1.f / C);
       stx = gsum(stx) * (1.f / C);
-      if (ok[u])
-        *reinterpret_cast<float4*>(dd + r * C + 4 * l) =
-            make_float4(rstd * (t[0] - st - x[0] * stx), rstd * (t[1] - st - x[1] * stx),
-                        rstd * (t[2] - st - x[2] * stx), rstd * (t[3] - st - x[3] * stx));
+      if (ok[u]) {
+        const float4 o = make_float4(rstd * (t[0] - st - x[0] * stx), rstd * (t[1] - st - x[1] * stx),
+                                     rstd * (t[2] - st - x[2] * stx), rstd * (t[3] - st - x[3] * stx));
+        *reinterpret_cast<float4*>(dd + r * C + 4 * l) = o;
+        if (out16 != nullptr) {   // the same values as the next 16-bit GEMM's operand (was a cast launch)
+          if (prec16 == BTSBOT_BF16) {
+            typedef bf16_t __attribute__((ext_vector_type(4))) b4;
+            *reinterpret_cast<b4*>(reinterpret_cast<bf16_t*>(out16) + r * C + 4 * l) =
+                b4{(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+          } else {
+            typedef f16_t __attribute__((ext_vector_type(4))) h4;
+            *reinterpret_cast<h4*>(reinterpret_cast<f16_t*>(out16) + r * C + 4 * l) =
+                h4{(f16_t)o.x, (f16_t)o.y, (f16_t)o.z, (f16_t)o.w};
+          }
+        }
+      }
     }
   }
   // row groups of the wave and the 4 waves meet in LDS: one atomic per channel per block
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
 }
 
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
-                  float* dbeta, long rows, int C, hipStream_t st) {
+                  float* dbeta, long rows, int C, hipStream_t st, void* out16, int prec16) {
   if (rows <= 0) return BTSBOT_OK;
   static const long cap = [] {
     const char* e = getenv("BTSBOT_AMD_LNBWD_BLOCKS");   // tuning knob: workgroups (= same-address atomics per channel;
@@ -718,17 +733,17 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
     if (nb > cap) nb = cap;
     if (C == 64)
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<16>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows);
+                         dd, dg, dbeta, rows, out16, prec16);
     else
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<32>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows);
+                         dd, dg, dbeta, rows, out16, prec16);
     LAUNCH_CHECK();
     return BTSBOT_OK;
   }
   const int cpt = (C + 63) / 64;
 #define LNB(CPT)                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
-                     dd, dg, dbeta, rows, C)
+                     dd, dg, dbeta, rows, C, out16, prec16)
   if (cpt <= 1) LNB(1);
   else if (cpt <= 2) LNB(2);
   else if (cpt <= 4) LNB(4);
@@ -746,7 +761,7 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
 
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
                     const float* addend, float* out, int B, int HW, int C, hipStream_t st,
-                    void* out16, int prec16, float* zero, long zero_n) {
+                    void* out16, int prec16) {
   if (B <= 0) return BTSBOT_OK;
   const size_t lds = ((size_t)HW * HW + 49) * C * sizeof(float);
 #define DWP(H)                                                                                 \
@@ -758,7 +773,7 @@ int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
       attr = lds;                                                                              \
     }                                                                                          \
     hipLaunchKernelGGL((dw_plain_kernel<H>), dim3(B), dim3(256), lds, st, x, w, flip, bias,    \
-                       addend, out, C, out16, prec16, zero, zero_n);                           \
+                       addend, out, C, out16, prec16);                                         \
   }
   if (HW == 15) DWP(15)
   else if (HW == 7) DWP(7)

@@ -262,16 +262,17 @@ int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
-                      hipStream_t st, float* zero = nullptr, long zero_n = 0);   // also zero[0..zero_n) = 0
+                      hipStream_t st);
 int launch_fc2_grads(float* G, float* S, const float* w2, const float* b2,
                      const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
                      hipStream_t st);
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
-                  float* dbeta, long rows, int C, hipStream_t st);
+                  float* dbeta, long rows, int C, hipStream_t st, void* out16 = nullptr, int prec16 = 0);
+// (out16: also dd in the 16-bit operand type prec16 -- the operand of the GEMM that consumes it)
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
                     const float* addend, float* out, int B, int HW, int C, hipStream_t st,
-                    void* out16 = nullptr, int prec16 = 0, float* zero = nullptr, long zero_n = 0);
-// (out16: also the result in the 16-bit operand type prec16 -- the next block's GEMM operand; zero: accumulators to clear)
+                    void* out16 = nullptr, int prec16 = 0);
+// (out16: also the result in the 16-bit operand type prec16 -- the next block's GEMM operand)
 int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, float* partials,
                     int B, int HW, int C, hipStream_t st);   // partials: >= 256 * 50 * C floats
 // dwln_bwd.hip: the three launches above (LayerNorm backward, depthwise filter gradient, depthwise input gradient)
