@@ -43,7 +43,7 @@ struct BBCache {
   size_t g_floats;
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
-  float* wpart;             // fp32 WPART_FLOATS: slice partials of the filter-gradient GEMMs (wgrad.hip)
+  float* wpart;             // fp32 2 x WPART_FLOATS: slice partials of the filter-gradient GEMMs (wgrad.hip)
   void* stem_patches;       // [B*225][48] operand type
   float* stem_pre;          // [B*225][C0] fp32
   size_t total;
@@ -96,7 +96,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.g_floats = maxc4c;
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
   k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
-  k.wpart = reinterpret_cast<float*>(take(WPART_FLOATS * 4));
+  k.wpart = reinterpret_cast<float*>(take(2 * WPART_FLOATS * 4));   // two GEMMs' partial tiles at a time
   k.stem_patches = take((size_t)B * 225 * 48 * esz);
   k.stem_pre = reinterpret_cast<float*>(take((size_t)B * 225 * c.dims[0] * 4));
   k.total = cur;
@@ -158,8 +158,9 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
 // range first.
 // out[n][k] += sum_m D[m][n] A[m][k] and cs[n] += sum_m D[m][n]; D and A in the mode's operand type
 static int wgrad_cs(int prec, const void* D, const void* A, float* out, float* cs, int M, int N,
-                    int K, int ldo, hipStream_t st, float* part = nullptr) {
-  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS);
+                    int K, int ldo, hipStream_t st, float* part = nullptr, WgradReduceJob* defer = nullptr) {
+  if (defer != nullptr) defer->nsl = 0;
+  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS, defer);
   const int rc = launch_wgrad(prec, D, A, out, M, N, K, ldo, st);
   return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
 }
@@ -219,10 +220,14 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
       // ---- side: fc2 / layer-scale (S = colsum(dy), G = dy^T h), fc1 (dW1 += da^T xn, db1 += colsum(da))
       TRYB(fork());
-      TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart));
+      //      (the two GEMMs' slice reductions share one launch: separate halves of the partial-tile scratch)
+      WgradReduceJob red[2];
+      TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart, &red[0]));
+      TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart + WPART_FLOATS,
+                    &red[1]));
+      TRYB(launch_wgrad_reduce(red, 2, sd));
       TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
-      TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart));
       // ---- dxn = da W1, then the LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));

@@ -256,8 +256,16 @@ size_t s0par_bytes();
 int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
                       const float* b1, const float* b2, const float* gamma, void* out,
                       hipStream_t st);
+// slice reduction of a filter-gradient GEMM (wgrad.hip), described so that two of them can share a launch
+struct WgradReduceJob {
+  const float* part;   // partial tiles [nsl][gy][gx][TN][TK]
+  float* out;          // out[n][k] += sum over the slices
+  int N, K, ldo, gx, gy, nsl, TN, TK;   // nsl == 0: nothing to reduce
+};
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
-                   int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0);   // wgrad.hip: 16-bit modes, colsum optional
+                   int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0,
+                   WgradReduceJob* defer = nullptr);   // wgrad.hip: 16-bit modes, colsum optional
+int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st);
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]

@@ -199,32 +199,38 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
   }
 }
 
-// out[n][k] += sum over slices of the partial tiles (fixed order: bit-reproducible)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
-                                                           float* __restrict__ out, int N, int K, int ldo,
-                                                           int gx, int gy, int nsl, int TN, int TK) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= N * K) return;
-  const int n = idx / K, k = idx - n * K;
-  const int tx = n / TN, ty = k / TK;
-  const float* p = part + ((size_t)ty * gx + tx) * (TN * TK) + (n - tx * TN) * TK + (k - ty * TK);
-  const size_t sstride = (size_t)gx * gy * TN * TK;
+// out[n][k] += sum over slices of the partial tiles (fixed order: bit-reproducible).  One launch serves up to two
+// GEMMs (a block's fc2 and fc1 filter gradients): workgroups [0, nblk0) belong to job 0, the rest to job 1.
+struct ReduceJobs {
+  WgradReduceJob j[2];
+  int nblk0;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceJobs a) {
+  const bool second = (int)blockIdx.x >= a.nblk0;
+  const WgradReduceJob& J = a.j[second ? 1 : 0];
+  const int idx = ((int)blockIdx.x - (second ? a.nblk0 : 0)) * 256 + threadIdx.x;
+  if (idx >= J.N * J.K) return;
+  const int n = idx / J.K, k = idx - n * J.K;
+  const int tx = n / J.TN, ty = k / J.TK;
+  const float* p = J.part + ((size_t)ty * J.gx + tx) * (J.TN * J.TK) + (n - tx * J.TN) * J.TK + (k - ty * J.TK);
+  const size_t sstride = (size_t)J.gx * J.gy * J.TN * J.TK;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int s = 0;
 #pragma unroll 2
-  for (; s + 3 < nsl; s += 4) {
+  for (; s + 3 < J.nsl; s += 4) {
     s0 += p[(size_t)s * sstride];
     s1 += p[(size_t)(s + 1) * sstride];
     s2 += p[(size_t)(s + 2) * sstride];
     s3 += p[(size_t)(s + 3) * sstride];
   }
-  for (; s < nsl; ++s) s0 += p[(size_t)s * sstride];
-  out[(size_t)n * ldo + k] += (s0 + s1) + (s2 + s3);
+  for (; s < J.nsl; ++s) s0 += p[(size_t)s * sstride];
+  J.out[(size_t)n * J.ldo + k] += (s0 + s1) + (s2 + s3);
 }
 
 template <typename T, int TN, int TK>
 int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M, int N, int K,
-                  int ldo, hipStream_t st, float* part, size_t part_floats) {
+                  int ldo, hipStream_t st, float* part, size_t part_floats, WgradReduceJob* defer) {
   const int gx = (N + TN - 1) / TN, gy = (K + TK - 1) / TK;
   // slices of the reduction.  Two-pass form (partial tiles + wgrad_reduce_kernel, when the caller lends scratch):
   // ~512 workgroups, at least 256 rows each; atomic form (every slice ends in TN x TK fp32 atomics: fewer, longer
@@ -261,37 +267,57 @@ int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M
                      reinterpret_cast<const T*>(D), reinterpret_cast<const T*>(A), out, colsum, M,
                      N, K, ldo, mslice, two_pass ? part : nullptr);
   LAUNCH_CHECK();
-  if (two_pass) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part, out, N, K, ldo,
-                       gx, gy, nsl, TN, TK);
-    LAUNCH_CHECK();
+  WgradReduceJob job = {part, out, N, K, ldo, gx, gy, two_pass ? nsl : 0, TN, TK};
+  if (defer != nullptr) {
+    *defer = job;   // (nsl == 0: the slices met through atomics, nothing left to add)
+    return BTSBOT_OK;
   }
-  return BTSBOT_OK;
+  return launch_wgrad_reduce(&job, 1, st);
 }
 
 template <typename T>
 int wgrad2_t(const void* D, const void* A, float* out, float* colsum, int M, int N, int K, int ldo,
-             hipStream_t st, float* part, size_t pf) {
-  if (N > 64 && K > 64) return wgrad2_launch<T, 128, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
-  if (N > 64) return wgrad2_launch<T, 128, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
-  if (K > 64) return wgrad2_launch<T, 64, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
-  return wgrad2_launch<T, 64, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf);
+             hipStream_t st, float* part, size_t pf, WgradReduceJob* defer) {
+  if (N > 64 && K > 64) return wgrad2_launch<T, 128, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf, defer);
+  if (N > 64) return wgrad2_launch<T, 128, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf, defer);
+  if (K > 64) return wgrad2_launch<T, 64, 128>(D, A, out, colsum, M, N, K, ldo, st, part, pf, defer);
+  return wgrad2_launch<T, 64, 64>(D, A, out, colsum, M, N, K, ldo, st, part, pf, defer);
 }
 
 }  // namespace
 
+// the slice reduction of up to two filter-gradient GEMMs (jobs with nsl == 0 are skipped) as one launch
+int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st) {
+  ReduceJobs a;
+  int n = 0, nblk[2] = {0, 0};
+  for (int i = 0; i < njobs && n < 2; ++i)
+    if (jobs[i].nsl > 0) {
+      a.j[n] = jobs[i];
+      nblk[n] = (jobs[i].N * jobs[i].K + 255) / 256;
+      ++n;
+    }
+  if (n == 0) return BTSBOT_OK;
+  if (n == 1) a.j[1] = a.j[0];
+  a.nblk0 = nblk[0];
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk[0] + nblk[1]), dim3(256), 0, st, a);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 // 16-bit modes only; N and K must be multiples of 8 and the operands 16-byte aligned.
 // part (optional): scratch for the slices' partial tiles -> two-pass reduction instead of atomics into `out`
+// defer (optional): the reduction is not launched here; *defer describes it for launch_wgrad_reduce()
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
-                   int K, int ldo, hipStream_t st, float* part, size_t part_floats) {
+                   int K, int ldo, hipStream_t st, float* part, size_t part_floats, WgradReduceJob* defer) {
+  if (defer != nullptr) defer->nsl = 0;
   if (M <= 0) return BTSBOT_OK;
   if ((N & 7) || (K & 7) || ((uintptr_t)D & 15) || ((uintptr_t)A & 15)) {
     btsbot_set_error("wgrad16: N=%d K=%d / operand alignment not supported", N, K);
     return BTSBOT_ERR_INVALID_ARG;
   }
   switch (prec) {
-    case BTSBOT_BF16: return wgrad2_t<bf16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats);
-    case BTSBOT_F16: return wgrad2_t<f16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats);
+    case BTSBOT_BF16: return wgrad2_t<bf16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats, defer);
+    case BTSBOT_F16: return wgrad2_t<f16_t>(D, A, out, colsum, M, N, K, ldo, st, part, part_floats, defer);
     default:
       btsbot_set_error("wgrad16: precision %d is not a 16-bit mode", prec);
       return BTSBOT_ERR_INVALID_ARG;
