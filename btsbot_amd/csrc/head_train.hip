@@ -142,6 +142,68 @@ __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict_
   }
 }
 
+// The same for K % 4 == 0 (every layer but the first metadata one): a lane owns FOUR consecutive k of one n (one
+// 16-byte load of `in` per row instead of four dwords, the dpre value shared by all four products), workgroup =
+// 64 consecutive k of one n x 16 interleaved slices of m, which meet in LDS in a fixed order as above.
+__global__ __launch_bounds__(256) void lin_bwd_w4_kernel(const float* __restrict__ dpre,
+                                                         const float* __restrict__ in, int ldi,
+                                                         float* __restrict__ dw,
+                                                         float* __restrict__ db, int M, int N, int K) {
+  __shared__ float4 sh[16][17];
+  __shared__ float shb[16];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int kb = (K + 63) / 64;
+  const int n = blockIdx.x / kb, k0 = (blockIdx.x - n * kb) * 64 + 4 * o;
+  const bool live = k0 < K;
+  const bool bias = blockIdx.x - n * kb == 0 && o == 0;   // this lane also sums dpre[:, n]
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  float b0 = 0.f;
+  const float* dp = dpre + n;
+  const float* ip = in + (live ? k0 : 0);
+  int m = g;
+  for (; m + 16 < M; m += 32) {
+    const float d0 = dp[(size_t)m * N], d1 = dp[(size_t)(m + 16) * N];
+    const float4 v0 = *reinterpret_cast<const float4*>(ip + (size_t)m * ldi);
+    const float4 v1 = *reinterpret_cast<const float4*>(ip + (size_t)(m + 16) * ldi);
+    a0.x = fmaf(d0, v0.x, a0.x); a0.y = fmaf(d0, v0.y, a0.y); a0.z = fmaf(d0, v0.z, a0.z); a0.w = fmaf(d0, v0.w, a0.w);
+    a1.x = fmaf(d1, v1.x, a1.x); a1.y = fmaf(d1, v1.y, a1.y); a1.z = fmaf(d1, v1.z, a1.z); a1.w = fmaf(d1, v1.w, a1.w);
+    b0 += d0 + d1;
+  }
+  for (; m < M; m += 16) {
+    const float d0 = dp[(size_t)m * N];
+    const float4 v0 = *reinterpret_cast<const float4*>(ip + (size_t)m * ldi);
+    a0.x = fmaf(d0, v0.x, a0.x); a0.y = fmaf(d0, v0.y, a0.y); a0.z = fmaf(d0, v0.z, a0.z); a0.w = fmaf(d0, v0.w, a0.w);
+    b0 += d0;
+  }
+  sh[g][o] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  if (o == 0) shb[g] = b0;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sb = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) {
+      const float4 v = sh[gg][o];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      sb += shb[gg];
+    }
+    if (live) *reinterpret_cast<float4*>(dw + (size_t)n * K + k0) = s;
+    if (bias) db[n] = sb;
+  }
+}
+
+static int launch_lin_bwd_w(const float* dpre, const float* in, int ldi, float* dw, float* db, int M, int N, int K,
+                            hipStream_t st) {
+  const bool vec = K % 4 == 0 && ldi % 4 == 0 && (((uintptr_t)in | (uintptr_t)dw) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(lin_bwd_w4_kernel, dim3(N * ((K + 63) / 64)), dim3(256), 0, st, dpre, in, ldi, dw, db, M, N, K);
+  else
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, st, dpre, in, ldi, dw, db,
+                       M, N, K);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 // BatchNorm1d, training: one workgroup per feature j.  Biased variance normalises, unbiased
 // variance goes into running_var (torch semantics), momentum 0.1.
 __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ x, int M,
@@ -419,9 +481,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
     const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
     const float* in = i == 0 ? p.z : p.actv[i - 1];
     const int ldi = i == 0 ? zd : K;
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, sd, dout[i], in, ldi,
-                       grads + h->comb_w[i], grads + h->comb_b[i], M, N, K);
-    LAUNCH_CHECK();
+    TRY_RET(launch_lin_bwd_w(dout[i], in, ldi, grads + h->comb_w[i], grads + h->comb_b[i], M, N, K, sd));
   }
   if (need_meta && h->has_meta) {
     // the metadata features are columns F .. F+f2 of d(z) [M][zd]
@@ -431,10 +491,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
                        p.a2, da2, M, c.meta_fc2, h->meta_trailing_act ? h->act : ACT_NONE, nullptr,
                        1.f);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc2 * (c.meta_fc1 + 1) + 15) / 16), dim3(256), 0, sd,
-                       da2, p.h1, c.meta_fc1, grads + h->m2_w, grads + h->m2_b, M, c.meta_fc2,
-                       c.meta_fc1);
-    LAUNCH_CHECK();
+    TRY_RET(launch_lin_bwd_w(da2, p.h1, c.meta_fc1, grads + h->m2_w, grads + h->m2_b, M, c.meta_fc2, c.meta_fc1, sd));
     float* dh1 = const_cast<float*>(dz);     // d(z) is dead once da2 exists
     hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, sd, da2,
                        m + h->m2_w, dh1, c.meta_fc1, M, c.meta_fc2, c.meta_fc1);
@@ -443,10 +500,7 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
                        p.a1, dh1, M, c.meta_fc1, h->act, c.meta_dropout > 0.f ? meta_mask : nullptr,
                        ks1);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)c.meta_fc1 * (c.n_meta + 1) + 15) / 16), dim3(256), 0, sd,
-                       dh1, p.x1, c.n_meta, grads + h->m1_w, grads + h->m1_b, M, c.meta_fc1,
-                       c.n_meta);
-    LAUNCH_CHECK();
+    TRY_RET(launch_lin_bwd_w(dh1, p.x1, c.n_meta, grads + h->m1_w, grads + h->m1_b, M, c.meta_fc1, c.n_meta, sd));
     hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * c.n_meta), dim3(256), 0, sd, dh1,
                        m + h->m1_w, da2, c.n_meta, M, c.meta_fc1, c.n_meta);
     LAUNCH_CHECK();
