@@ -218,16 +218,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
-      // ---- side: fc2 / layer-scale (S = colsum(dy), G = dy^T h), fc1 (dW1 += da^T xn, db1 += colsum(da))
-      TRYB(fork());
-      //      (the two GEMMs' slice reductions share one launch: separate halves of the partial-tile scratch)
-      WgradReduceJob red[2];
-      TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart, &red[0]));
-      TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart + WPART_FLOATS,
-                    &red[1]));
-      TRYB(launch_wgrad_reduce(red, 2, sd));
-      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
-                            grads + b.fc2_b, grads + b.gamma, ch, H, sd));
+      TRYB(fork());   // the side stream may start once da exists; its work is queued below, behind the chain's
       // ---- dxn = da W1, then the LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
@@ -246,6 +237,17 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         // ---- depthwise input gradient: dx = dy + conv_flipped(dd)
         TRYB(launch_dw_plain(dxn, wdw, 1, nullptr, dy, dy, B, hw, ch, st, nxt, prec));
       }
+      // ---- side: fc2 / layer-scale (S = colsum(dy), G = dy^T h), fc1 (dW1 += da^T xn, db1 += colsum(da)).  Queued
+      //      after the chain's launches above (the fork itself sits behind da), so the host's five launches here never
+      //      stand between the chain and its next kernel (measured: no difference, the host runs ahead either way)
+      //      (the two GEMMs' slice reductions share one launch: separate halves of the partial-tile scratch)
+      WgradReduceJob red[2];
+      TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart, &red[0]));
+      TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart + WPART_FLOATS,
+                    &red[1]));
+      TRYB(launch_wgrad_reduce(red, 2, sd));
+      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
+                            grads + b.fc2_b, grads + b.gamma, ch, H, sd));
       dyT_ready = nxt != nullptr;
     }
     if (i > 0) {
@@ -257,8 +259,6 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(launch_scale_cast(prec, dy, nullptr, dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
       TRYB(fork());
-      TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));
-      TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, sd));
       TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
       TRYB(launch_unpatch(k.dpat, dxn, B, hwp, cin, st));
@@ -268,6 +268,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_ln_bwd(k.xs[i - 1], dxn, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
                          grads + h->down[i].ln_b, prow, cin, st, nxt16, prec));
       dyT_ready = nxt16 != nullptr;
+      // (side work queued behind the chain's launches, as in the blocks)
+      TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));
+      TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, sd));
     }
     // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete here
     if (i >= 2 && h->n_buckets == 3) {
