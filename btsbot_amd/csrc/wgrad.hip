@@ -11,7 +11,9 @@
 //
 // Workgroup = TN x TK output tile x one slice of M, 4 waves in 2 x 2, v_mfma_f32_32x32x16.
 // Global loads of tile t+1 are in flight while tile t is multiplied (register-staged double
-// buffer, one barrier per 32-row tile).  Slices meet in the output through fp32 atomics.
+// buffer, one barrier per 64-row tile: with 32-row tiles a tile's 8 MFMAs per wave hid a quarter of the load
+// latency, 64 rows took the isolated backward from 3.68 to 3.58 ms).  Slices leave as dense partial tiles which
+// wgrad_reduce_kernel adds in a fixed order (or, without scratch, meet in the output through fp32 atomics).
 // Replaces (with backward.hip) what autograd does for nn.Linear / 1x1 Conv2d weight gradients at
 // /root/reference/btsbot/train.py:526.
 #include <stdlib.h>
@@ -57,7 +59,7 @@ __device__ __forceinline__ s16x8 tr_frag(const unsigned char* tile, int pitchb, 
   return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-constexpr int TM = 32;   // reduction rows per LDS tile
+constexpr int TM = 64;   // reduction rows per LDS tile
 
 template <typename T, int TN, int TK>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
   constexpr int PN = TN * 2 + 64, PK = TK * 2 + 64;          // row pitch in bytes
   constexpr int DB = TM * PN, AB = TM * PK;                   // bytes per tile
   constexpr int FN = TN / 64, FK = TK / 64;                   // 32x32 fragments per wave
-  constexpr int LN = TN / 64, LK = TK / 64;                   // 16-byte chunks per thread per tile
+  constexpr int LN = TN * TM / 2048, LK = TK * TM / 2048;     // 16-byte chunks per thread per tile
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * (DB + AB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
@@ -233,7 +235,8 @@ int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M
                   int ldo, hipStream_t st, float* part, size_t part_floats, WgradReduceJob* defer) {
   const int gx = (N + TN - 1) / TN, gy = (K + TK - 1) / TK;
   // slices of the reduction.  Two-pass form (partial tiles + wgrad_reduce_kernel, when the caller lends scratch):
-  // ~512 workgroups, at least 256 rows each; atomic form (every slice ends in TN x TK fp32 atomics: fewer, longer
+  // ~384 workgroups, at least 256 rows each (re-swept with 64-row LDS tiles and the second stream: 256-512 workgroups
+  // x 256-512 rows all land within 1.5 % of each other); atomic form (every slice ends in TN x TK fp32 atomics: fewer, longer
   // slices win): ~384 workgroups, at least 512 rows.  Measured per 1024-alert step: 4.59 ms vs 4.67 ms.
   static const int env_rows = [] {
     const char* e = getenv("BTSBOT_AMD_WGRAD_MIN_ROWS");   // tuning knob (overrides both defaults)
@@ -259,7 +262,7 @@ int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M
   };
   bool two_pass = !atomic_only && part != nullptr;
   if (two_pass) {
-    slices(env_rows ? env_rows : 256, env_wg ? env_wg : 512);
+    slices(env_rows ? env_rows : 256, env_wg ? env_wg : 384);
     two_pass = nsl > 1 && (size_t)nsl * gx * gy * TN * TK <= part_floats;
   }
   if (!two_pass) slices(env_rows ? env_rows : 512, env_wg ? env_wg : 384);
