@@ -6,7 +6,7 @@ set -u
 O=gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
 PROF="--pipeline-depth 1 --no-extra-legs"   # profiled runs: one stream, so a kernel's duration is its own
-timeout -k 10 420 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1 &&
+timeout -k 10 600 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1 &&
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 &&
 ( time timeout -k 10 400 python bench.py ) > $O/bench_default.log 2>&1 &&
 timeout -k 10 120 python tools/nano_bench.py 1024 bf16 > $O/nano.log 2>&1 &&
