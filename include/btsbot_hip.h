@@ -168,8 +168,12 @@ int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const floa
  * metadata branch (need_meta_grads): writes d(loss)/d(param) into grad_arena, which has the master
  * arena's layout (other entries are left untouched).  dlogits = d(loss)/d(logits) [batch], e.g. from
  * btsbot_bce_fwd_bwd.  need_image_grads != 0 also differentiates the ConvNeXt image branch (stem,
- * every block, downsamples, head LayerNorm); those gradients are reduced over the batch with fp32
- * atomics, so their last bits vary from run to run. */
+ * every block, downsamples, head LayerNorm); some of those gradients are reduced over the batch with fp32
+ * atomics, so their last bits vary from run to run.
+ * Stream semantics are the caller's: everything is ordered after the work already queued on `stream`, and
+ * work queued on `stream` afterwards sees every gradient.  Inside, the weight-gradient kernels run on a second
+ * stream the handle owns (forked from and joined back into `stream` with events; BTSBOT_AMD_NO_SIDE_STREAM=1
+ * keeps every launch on `stream`). */
 int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, int need_meta_grads,
                     int need_image_grads, void* stream);
 
