@@ -261,12 +261,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(fork());
       TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
-      TRYB(launch_unpatch(k.dpat, dxn, B, hwp, cin, st));
-      // LN backward per input pixel (x_prev = stage i-1 output); result is the new dy, in the 16-bit modes also as
-      // the operand of stage i-1's last block (was a cast launch)
+      // LN backward per input pixel (x_prev = stage i-1 output), its incoming gradient gathered from the patch matrix
+      // (was an unpatch launch); result is the new dy, in the 16-bit modes also as the operand of stage i-1's last
+      // block (was a cast launch)
       void* nxt16 = fold_cast && !h->blocks[i - 1].empty() ? k.blk[i - 1].back().dyT : nullptr;
-      TRYB(launch_ln_bwd(k.xs[i - 1], dxn, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
-                         grads + h->down[i].ln_b, prow, cin, st, nxt16, prec));
+      TRYB(launch_ln_bwd(k.xs[i - 1], k.dpat, m + h->down[i].ln_w, dy, grads + h->down[i].ln_w,
+                         grads + h->down[i].ln_b, prow, cin, st, nxt16, prec, hwp));
       dyT_ready = nxt16 != nullptr;
       // (side work queued behind the chain's launches, as in the blocks)
       TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));

@@ -184,6 +184,23 @@ __global__ __launch_bounds__(256) void fc2_grads_kernel(float* __restrict__ G,
   }
 }
 
+// Source row of the LayerNorm backward's incoming gradient.  Dense: dxn + r * C.  After a 2x2 / stride-2 downsample
+// (patch_hw = side of the downsample's INPUT map): the gradient arrives as patches [B * HO * HO][4 C] (k = q * C + c,
+// q = 2 (y & 1) + (x & 1)); input pixel r = (b, y, x) reads its slice of the patch that covers it, pixels outside
+// every patch (the odd last row / column) get zero.  (Was: unpatch_kernel scattering into a dense map first.)
+__device__ __forceinline__ const float* ln_bwd_src(const float* dxn, long r, int C, int patch_hw, bool* zero) {
+  *zero = false;
+  if (patch_hw == 0) return dxn + r * C;
+  const int P = patch_hw * patch_hw, HO = patch_hw / 2;
+  const long b = r / P;
+  const int p = (int)(r - b * P), iy = p / patch_hw, ix = p - iy * patch_hw;
+  if (iy >= 2 * HO || ix >= 2 * HO) {
+    *zero = true;
+    return dxn;
+  }
+  return dxn + ((b * HO + (iy >> 1)) * HO + (ix >> 1)) * 4 * (long)C + ((iy & 1) * 2 + (ix & 1)) * C;
+}
+
 // LayerNorm backward over the C channels of each row.  One wave per row (grid-stride).
 //   xhat = (d - mean) * rstd;  t = dxn * g;  dd = rstd * (t - mean(t) - xhat * mean(t * xhat))
 //   dg += dxn * xhat;  dbeta += dxn
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ dxn,
                                                      const float* __restrict__ g, float* dd,
                                                      float* dg, float* dbeta, long rows, int C,
-                                                     void* __restrict__ out16, int prec16) {
+                                                     void* __restrict__ out16, int prec16, int patch_hw) {
   const int lane = threadIdx.x & 63;
   const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
   float gl[CPT], adg[CPT], adb[CPT];
@@ -206,11 +223,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   // explicitly before this row's stores (they arrive under the four wave reductions)
   float nv[CPT], ndx[CPT];
   auto fetch = [&](long r) {
+    bool zero;
+    const float* src = ln_bwd_src(dxn, r, C, patch_hw, &zero);
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = lane + 64 * i;
       nv[i] = c < C ? d[r * C + c] : 0.f;
-      ndx[i] = c < C ? dxn[r * C + c] : 0.f;
+      const float g = c < C ? src[c] : 0.f;
+      ndx[i] = zero ? 0.f : g;
     }
   };
   if (w0 < rows) fetch(w0);
@@ -451,30 +471,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   }
 }
 
-// downsample backward glue: for every INPUT pixel of [B][HW][HW][Cin]: if it lies in a 2x2/s2
-// patch, gather its slice of dpatches ([B*HO*HO][4*Cin], k = q*Cin + c) into dxn, else dxn = 0.
-__global__ __launch_bounds__(256) void unpatch_kernel(const float* __restrict__ dpatches,
-                                                      float* __restrict__ dxn, int B, int HW,
-                                                      int Cin) {
-  const int HO = HW / 2;
-  const long n = (long)B * HW * HW * Cin;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % Cin);
-    long r = i / Cin;
-    const int ix = (int)(r % HW);
-    r /= HW;
-    const int iy = (int)(r % HW);
-    const int b = (int)(r / HW);
-    float v = 0.f;
-    if (iy < 2 * HO && ix < 2 * HO) {
-      const int oy = iy >> 1, ox = ix >> 1, q = (iy & 1) * 2 + (ix & 1);
-      v = dpatches[(((size_t)b * HO + oy) * HO + ox) * 4 * Cin + q * Cin + c];
-    }
-    dxn[i] = v;
-  }
-}
-
-// im2col of the stem: img [B][3][63][63] f32 -> patches [B*225][48] (T), k = ci*16 + ky*4 + kx
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img,
                                                           T* __restrict__ patches, int B) {
@@ -616,7 +612,7 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
                                                             const float* __restrict__ dxn,
                                                             const float* __restrict__ g, float* dd,
                                                             float* dg, float* dbeta, long rows,
-                                                            void* __restrict__ out16, int prec16) {
+                                                            void* __restrict__ out16, int prec16, int patch_hw) {
   constexpr int C = 4 * LPR, R = 64 / LPR;       // rows per wave pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -636,7 +632,10 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
       const long r = r0 + u * R + sub;
       const long rr = r < rows ? r : 0;
       nv[u] = *reinterpret_cast<const float4*>(d + rr * C + 4 * l);
-      ndx[u] = *reinterpret_cast<const float4*>(dxn + rr * C + 4 * l);
+      bool zero;
+      const float* src = ln_bwd_src(dxn, rr, C, patch_hw, &zero);
+      const float4 g4 = *reinterpret_cast<const float4*>(src + 4 * l);
+      ndx[u] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : g4;
     }
   };
   const long rfirst = ((long)blockIdx.x * 4 + wv) * R * 2;
@@ -718,7 +717,7 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
 }
 
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
-                  float* dbeta, long rows, int C, hipStream_t st, void* out16, int prec16) {
+                  float* dbeta, long rows, int C, hipStream_t st, void* out16, int prec16, int patch_hw) {
   if (rows <= 0) return BTSBOT_OK;
   static const long cap = [] {
     const char* e = getenv("BTSBOT_AMD_LNBWD_BLOCKS");   // tuning knob: workgroups (= same-address atomics per channel;
@@ -733,17 +732,17 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
     if (nb > cap) nb = cap;
     if (C == 64)
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<16>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows, out16, prec16);
+                         dd, dg, dbeta, rows, out16, prec16, patch_hw);
     else
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<32>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows, out16, prec16);
+                         dd, dg, dbeta, rows, out16, prec16, patch_hw);
     LAUNCH_CHECK();
     return BTSBOT_OK;
   }
   const int cpt = (C + 63) / 64;
 #define LNB(CPT)                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
-                     dd, dg, dbeta, rows, C, out16, prec16)
+                     dd, dg, dbeta, rows, C, out16, prec16, patch_hw)
   if (cpt <= 1) LNB(1);
   else if (cpt <= 2) LNB(2);
   else if (cpt <= 4) LNB(4);
@@ -821,14 +820,6 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, fl
 #undef DWW
   LAUNCH_CHECK();
   return colsum_t<float>(partials, dw, grid * (C < 256 ? 256 / C : 1), 50 * C, st);
-}
-
-int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st) {
-  const long n = (long)B * HW * HW * Cin;
-  if (n <= 0) return BTSBOT_OK;
-  hipLaunchKernelGGL(unpatch_kernel, dim3(gridn(n)), dim3(256), 0, st, dpatches, dxn, B, HW, Cin);
-  LAUNCH_CHECK();
-  return BTSBOT_OK;
 }
 
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st) {

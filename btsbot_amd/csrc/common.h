@@ -275,8 +275,11 @@ int launch_fc2_grads(float* G, float* S, const float* w2, const float* b2,
                      const float* gamma, float* dW2, float* db2, float* dgamma, int C, int H,
                      hipStream_t st);
 int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, float* dg,
-                  float* dbeta, long rows, int C, hipStream_t st, void* out16 = nullptr, int prec16 = 0);
-// (out16: also dd in the 16-bit operand type prec16 -- the operand of the GEMM that consumes it)
+                  float* dbeta, long rows, int C, hipStream_t st, void* out16 = nullptr, int prec16 = 0,
+                  int patch_hw = 0);
+// (out16: also dd in the 16-bit operand type prec16 -- the operand of the GEMM that consumes it;
+//  patch_hw != 0: dxn holds the gradient of a 2x2 / stride-2 downsample's patch matrix [B (hw/2)^2][4 C] for input
+//  maps of side patch_hw, gathered per input pixel -- the rows count input pixels)
 int launch_dw_plain(const float* x, const float* w, int flip, const float* bias,
                     const float* addend, float* out, int B, int HW, int C, hipStream_t st,
                     void* out16 = nullptr, int prec16 = 0);
@@ -289,7 +292,6 @@ bool dwln_bwd_supported(int HW, int C);
 int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) one launch writes
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st);
-int launch_unpatch(const float* dpatches, float* dxn, int B, int HW, int Cin, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
 int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,
