@@ -8,7 +8,8 @@
 //     kept per block : x_in (fp32), d = dwconv(x_in) (fp32), xn = LN(d) (operand type),
 //                      a = fc1 pre-activation, h = gelu(a)
 //     kept per stage : the stage output (input of the next downsample), the 2x2 patch matrix
-// Everything else (LN statistics, stem conv output) is recomputed in the backward.
+//     kept once      : the stem convolution's output before its LayerNorm (fp32)
+// Everything else (LN statistics) is recomputed in the backward.
 #include <string.h>
 
 #include "ctx.h"
@@ -124,7 +125,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   // fc2 (+ residual) into block j+1's xin, the stage's last block into xs[i].
   auto stage_in = [&](int i) { return h->blocks[i].empty() ? k.xs[i] : k.blk[i][0].xin; };
   TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
-                   B, c.dims[0], st));
+                   B, c.dims[0], st, k.stem_pre));   // (the pre-LayerNorm output is kept for the backward)
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
     if (i > 0) {
@@ -281,11 +282,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]
   {
     const int c0 = c.dims[0], rows = B * 225;
-    const void* ws16 = prec == BTSBOT_F32 ? static_cast<const void*>(m + h->stem_w)
-                                          : static_cast<const void*>(h->extra + h->p_stem16);
-    TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, st));
-    TRYB(launch_gemm(prec, EPI_BIAS, k.stem_patches, ws16, m + h->stem_b, nullptr, nullptr,
-                     k.stem_pre, rows, c0, 48, st));
+    TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, st));   // the filter gradient's operand
     TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
                        grads + h->stem_lnb, rows, c0, st, fold_cast ? k.dyT_stem : nullptr, prec));
     if (!fold_cast) TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT_stem, (long)rows * c0, c0, st));

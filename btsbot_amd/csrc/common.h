@@ -202,8 +202,9 @@ int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const flo
                                const float* ln_b = nullptr, void* ln_out = nullptr);
 
 // stem: conv 4x4 s4 (+bias) + LayerNorm over C0.  img [B,3,63,63] fp32 -> out [B,225,C0] fp32.
+// (pre_out, optional: the convolution's output before the LayerNorm, [B,225,C0] fp32 -- what the training backward needs)
 int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
-                const float* lnb, float* out, int B, int C0, hipStream_t st);
+                const float* lnb, float* out, int B, int C0, hipStream_t st, float* pre_out = nullptr);
 
 // depthwise 7x7 p3 (+bias) + LayerNorm over C.  x [B,HW*HW,C] fp32 -> xn [B,HW*HW,C] prec-typed.
 // wdw is tap-major [49][C] fp32.

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
                                                    const float* __restrict__ bias,
                                                    const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb,
-                                                   float* __restrict__ out, int B) {
+                                                   float* __restrict__ out, int B,
+                                                   float* __restrict__ pre_out) {
   constexpr int LDW = C0 + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [225][C0+1]
   const int a = blockIdx.x;
@@ -388,6 +389,19 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   for (int i = threadIdx.x; i < 225 * C0; i += 256) {
     const int pp = i / C0, c = i - pp * C0;
     dst[i] = smem[pp * LDW + c];
+  }
+  if (pre_out != nullptr) {   // training: the convolution's output before the LayerNorm, kept for its backward
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < C0; ++c) smem[p * LDW + c] = o[c];
+    }
+    __syncthreads();
+    float* dp = pre_out + (size_t)a * 225 * C0;
+    for (int i = threadIdx.x; i < 225 * C0; i += 256) {
+      const int pp = i / C0, c = i - pp * C0;
+      dp[i] = smem[pp * LDW + c];
+    }
   }
 }
 
@@ -496,12 +510,12 @@ int launch_ln_patch(int prec, const float* x, const float* lnw, const float* lnb
 }
 
 int launch_stem(const float* img, const float* w, const float* bias, const float* lnw,
-                const float* lnb, float* out, int B, int C0, hipStream_t st) {
+                const float* lnb, float* out, int B, int C0, hipStream_t st, float* pre_out) {
   if (B <= 0) return BTSBOT_OK;
   const size_t lds = (size_t)225 * (C0 + 1) * sizeof(float);
   if (C0 == 64) {
     hipLaunchKernelGGL((stem_kernel<64>), dim3(B), dim3(256), lds, st, img, w, bias, lnw, lnb, out,
-                       B);
+                       B, pre_out);
   } else if (C0 == 80) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -510,7 +524,7 @@ int launch_stem(const float* img, const float* w, const float* bias, const float
       attr_set = true;
     }
     hipLaunchKernelGGL((stem_kernel<80>), dim3(B), dim3(256), lds, st, img, w, bias, lnw, lnb, out,
-                       B);
+                       B, pre_out);
   } else {
     btsbot_set_error("stem: no kernel for C0=%d", C0);
     return BTSBOT_ERR_INVALID_ARG;

@@ -102,16 +102,19 @@ __global__ __launch_bounds__(256) void lin_bwd_in_kernel(const float* __restrict
 }
 
 // dw[n][k] = sum_m dpre[m][n] * in[m*ldi + k];  db[n] = sum_m dpre[m][n]
-// Workgroup = 16 consecutive outputs x 16 interleaved slices of m; the slices meet in LDS in a fixed
-// order, so the result is deterministic (no atomics).
+// Workgroup = OUTS consecutive outputs x SL interleaved slices of m (OUTS * SL = 256); the slices meet in LDS in a
+// fixed order, so the result is deterministic (no atomics).  16 x 16 for wide layers; 4 x 64 for the first metadata
+// layer (128 x 26 outputs: with 16 slices its 208 workgroups walked 64 rows each behind exposed load latencies).
+template <int OUTS, int SL>
 __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dpre,
                                                         const float* __restrict__ in, int ldi,
                                                         float* __restrict__ dw,
                                                         float* __restrict__ db, int M, int N,
                                                         int K) {
-  __shared__ float sh[16][17];
-  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + o;
+  static_assert(OUTS * SL == 256, "one thread per (output, slice)");
+  __shared__ float sh[SL][OUTS + 1];
+  const int o = threadIdx.x % OUTS, g = threadIdx.x / OUTS;
+  const int idx = blockIdx.x * OUTS + o;
   const bool live = idx < N * (K + 1);
   const int n = live ? idx / (K + 1) : 0, k = live ? idx - n * (K + 1) : 0;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -120,23 +123,23 @@ __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict_
     if (k < K) {
       const float* ip = in + k;
       int m = g;
-      for (; m + 48 < M; m += 64) {
+      for (; m + 3 * SL < M; m += 4 * SL) {
         a0 = fmaf(dp[(size_t)m * N], ip[(size_t)m * ldi], a0);
-        a1 = fmaf(dp[(size_t)(m + 16) * N], ip[(size_t)(m + 16) * ldi], a1);
-        a2 = fmaf(dp[(size_t)(m + 32) * N], ip[(size_t)(m + 32) * ldi], a2);
-        a3 = fmaf(dp[(size_t)(m + 48) * N], ip[(size_t)(m + 48) * ldi], a3);
+        a1 = fmaf(dp[(size_t)(m + SL) * N], ip[(size_t)(m + SL) * ldi], a1);
+        a2 = fmaf(dp[(size_t)(m + 2 * SL) * N], ip[(size_t)(m + 2 * SL) * ldi], a2);
+        a3 = fmaf(dp[(size_t)(m + 3 * SL) * N], ip[(size_t)(m + 3 * SL) * ldi], a3);
       }
-      for (; m < M; m += 16) a0 = fmaf(dp[(size_t)m * N], ip[(size_t)m * ldi], a0);
+      for (; m < M; m += SL) a0 = fmaf(dp[(size_t)m * N], ip[(size_t)m * ldi], a0);
     } else {
-      for (int m = g; m < M; m += 16) a0 += dp[(size_t)m * N];
+      for (int m = g; m < M; m += SL) a0 += dp[(size_t)m * N];
     }
   }
   sh[g][o] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (threadIdx.x < 16 && live) {
+  if (threadIdx.x < OUTS && live) {
     float s = 0.f;
 #pragma unroll
-    for (int gg = 0; gg < 16; ++gg) s += sh[gg][o];
+    for (int gg = 0; gg < SL; ++gg) s += sh[gg][o];
     if (k < K) dw[(size_t)n * K + k] = s;
     else db[n] = s;
   }
@@ -197,9 +200,12 @@ static int launch_lin_bwd_w(const float* dpre, const float* in, int ldi, float* 
   const bool vec = K % 4 == 0 && ldi % 4 == 0 && (((uintptr_t)in | (uintptr_t)dw) & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(lin_bwd_w4_kernel, dim3(N * ((K + 63) / 64)), dim3(256), 0, st, dpre, in, ldi, dw, db, M, N, K);
+  else if ((long)N * (K + 1) <= 8192)
+    hipLaunchKernelGGL((lin_bwd_w_kernel<4, 64>), dim3(((long)N * (K + 1) + 3) / 4), dim3(256), 0, st, dpre, in, ldi,
+                       dw, db, M, N, K);
   else
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, st, dpre, in, ldi, dw, db,
-                       M, N, K);
+    hipLaunchKernelGGL((lin_bwd_w_kernel<16, 16>), dim3(((long)N * (K + 1) + 15) / 16), dim3(256), 0, st, dpre, in,
+                       ldi, dw, db, M, N, K);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
