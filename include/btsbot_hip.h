@@ -155,7 +155,8 @@ int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* met
  * kept in a cache sized by btsbot_reserve_train(max_batch, with_image_grads) (whole batch, no
  * chunking, because of the batch statistics).  keep_image_activations != 0 runs the image branch
  * through the per-op training schedule that keeps, per block, x_in / LN output / fc1 pre-activation /
- * hidden activation (about 1.2 MB per alert) for a later btsbot_backward(need_image_grads=1);
+ * hidden activation (about 1.2 MB per alert; 2.8 MB with the backward's own per-block buffers) for a later
+ * btsbot_backward(need_image_grads=1);
  * otherwise the image branch runs the fused inference kernels.  The MaxViT wirings take only that second form:
  * their BatchNorm2d layers use the running statistics (a frozen, eval-mode branch under trainable heads). */
 int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_image_grads);
