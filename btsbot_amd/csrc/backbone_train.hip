@@ -273,10 +273,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(wgrad_cs(prec, dyT, k.patches[i], k.G, grads + h->down[i].b, rows, ch, 4 * cin, 4 * cin, sd, k.wpart));
       TRYB(launch_unpack_down_grad(k.G, grads + h->down[i].w, ch, cin, sd));
     }
-    // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete here
+    // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete once the
+    // side stream has drained what it holds AND seen the chain up to here -- so the event is recorded on the side
+    // stream behind a fork, and the chain itself does not wait (a join here stalled it ~17 us twice per step)
     if (i >= 2 && h->n_buckets == 3) {
-      TRYB(join());
-      HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], st));
+      TRYB(fork());
+      HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], sd));
     }
   }
   // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]

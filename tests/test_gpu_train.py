@@ -168,6 +168,36 @@ def test_fused_layernorm_depthwise_backward_with_several_alerts_per_workgroup(cu
     print(f"fused vs three-launch backward at B={B}: worst relative difference {worst:.2e}")
 
 
+def test_gradient_buckets_are_complete_when_their_events_fire(cuda):
+    """btsbot_wait_grad_bucket: a stream that waits on bucket i (recorded on the backward's side stream for the first
+    two buckets) must see that bucket's final gradients -- the snapshot a second stream takes behind each event equals
+    the arena after a full synchronisation.  (What the bucketed all-reduce of train.py relies on at N > 1.)"""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    B = 512
+    img, meta, _ = synthetic_batch(B, seed=4)
+    m = build_model(kind, cfg, sd, cuda, "bf16").train()
+    img, meta = img.to(cuda), meta.to(cuda)
+    buckets = m._grad_buckets()
+    assert len(buckets) == 3
+    side = torch.cuda.Stream(device=cuda)
+    for rep in range(3):
+        with torch.no_grad():
+            masks = m._dropout_masks(B, cuda, None)
+            logits = m._forward_train_raw(img, meta, masks, True).reshape(-1)
+            dl = torch.full_like(logits, 1e-3 * (rep + 1))
+            grads = m._backward_raw(dl, True, True)
+            snaps = []
+            for b, (lo, hi) in enumerate(buckets):
+                m._wait_grad_bucket(b, side.cuda_stream)
+                with torch.cuda.stream(side):
+                    snaps.append(grads[lo:hi].clone())
+            torch.cuda.synchronize()
+            for b, ((lo, hi), snap) in enumerate(zip(buckets, snaps)):
+                assert torch.equal(snap, grads[lo:hi]), f"bucket {b} changed after its event (repetition {rep})"
+                assert snap.abs().max().item() > 0, b
+
+
 def _full_backward(cuda, name):
     """Every parameter trainable (train.py:233-236): gradients of the whole model -- stem, every
     ConvNeXt block (layer-scale, depthwise, LayerNorm, fc1, fc2), downsamples, head LayerNorm,
