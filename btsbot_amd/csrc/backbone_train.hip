@@ -206,6 +206,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
     if (j > 0) return k.blk[i][j - 1].dyT;
     return i > 0 ? k.dyT_down[i] : nullptr;
   };
+  // the stem filter gradient's operand depends on the triplets only: built on the side stream while it is still idle
+  // (at the end of the chain it was 36 us of the step's tail)
+  TRYB(fork());
+  TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, sd));
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
@@ -284,7 +288,6 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // ---- stem: y = LN(patches(img) Ws^T + bs);  dy is d(loss)/d(stem output) [B*225][C0]
   {
     const int c0 = c.dims[0], rows = B * 225;
-    TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, st));   // the filter gradient's operand
     TRYB(launch_ln_bwd(k.stem_pre, dy, m + h->stem_lnw, dxn, grads + h->stem_lnw,
                        grads + h->stem_lnb, rows, c0, st, fold_cast ? k.dyT_stem : nullptr, prec));
     if (!fold_cast) TRYB(launch_scale_cast(prec, dxn, nullptr, k.dyT_stem, (long)rows * c0, c0, st));

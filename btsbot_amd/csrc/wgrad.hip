@@ -208,26 +208,44 @@ struct ReduceJobs {
   int nblk0;
 };
 
+// SG = slice groups per output: 1 = a thread walks all slices of its output; 4 = small outputs with many slices (the
+// stem's 64 x 48 filter over ~400 slices: 12 workgroups walked 400 dependent-latency loads each) -- a workgroup is
+// 64 outputs x 4 interleaved slice groups which meet in LDS in a fixed order
+template <int SG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceJobs a) {
+  constexpr int OPB = 256 / SG;   // outputs per workgroup
   const bool second = (int)blockIdx.x >= a.nblk0;
   const WgradReduceJob& J = a.j[second ? 1 : 0];
-  const int idx = ((int)blockIdx.x - (second ? a.nblk0 : 0)) * 256 + threadIdx.x;
-  if (idx >= J.N * J.K) return;
-  const int n = idx / J.K, k = idx - n * J.K;
+  const int o = threadIdx.x % OPB, sg = threadIdx.x / OPB;
+  const int idx = ((int)blockIdx.x - (second ? a.nblk0 : 0)) * OPB + o;
+  const bool live = idx < J.N * J.K;
+  const int n = live ? idx / J.K : 0, k = live ? idx - n * J.K : 0;
   const int tx = n / J.TN, ty = k / J.TK;
   const float* p = J.part + ((size_t)ty * J.gx + tx) * (J.TN * J.TK) + (n - tx * J.TN) * J.TK + (k - ty * J.TK);
   const size_t sstride = (size_t)J.gx * J.gy * J.TN * J.TK;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
+  if (live) {
+    int s = sg;
 #pragma unroll 2
-  for (; s + 3 < J.nsl; s += 4) {
-    s0 += p[(size_t)s * sstride];
-    s1 += p[(size_t)(s + 1) * sstride];
-    s2 += p[(size_t)(s + 2) * sstride];
-    s3 += p[(size_t)(s + 3) * sstride];
+    for (; s + 3 * SG < J.nsl; s += 4 * SG) {
+      s0 += p[(size_t)s * sstride];
+      s1 += p[(size_t)(s + SG) * sstride];
+      s2 += p[(size_t)(s + 2 * SG) * sstride];
+      s3 += p[(size_t)(s + 3 * SG) * sstride];
+    }
+    for (; s < J.nsl; s += SG) s0 += p[(size_t)s * sstride];
   }
-  for (; s < J.nsl; ++s) s0 += p[(size_t)s * sstride];
-  J.out[(size_t)n * J.ldo + k] += (s0 + s1) + (s2 + s3);
+  float tot = (s0 + s1) + (s2 + s3);
+  if (SG > 1) {
+    __shared__ float sh[SG][OPB];
+    sh[sg][o] = tot;
+    __syncthreads();
+    if (sg != 0) return;
+    tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < SG; ++g) tot += sh[g][o];
+  }
+  if (live) J.out[(size_t)n * J.ldo + k] += tot;
 }
 
 template <typename T, int TN, int TK>
@@ -301,8 +319,14 @@ int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st) {
     }
   if (n == 0) return BTSBOT_OK;
   if (n == 1) a.j[1] = a.j[0];
-  a.nblk0 = nblk[0];
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk[0] + nblk[1]), dim3(256), 0, st, a);
+  // one small output with many slices: four slice groups per output
+  if (n == 1 && a.j[0].N * a.j[0].K <= 16384 && a.j[0].nsl >= 64) {
+    a.nblk0 = (a.j[0].N * a.j[0].K + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(a.nblk0), dim3(256), 0, st, a);
+  } else {
+    a.nblk0 = nblk[0];
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nblk[0] + nblk[1]), dim3(256), 0, st, a);
+  }
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
