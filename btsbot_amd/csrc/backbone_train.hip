@@ -1,5 +1,5 @@
 // Training-mode schedule of the ConvNeXt image branch: a forward that keeps what the backward
-// needs, and the backward itself (kernels in backward.hip / gemm.hip / convnext.hip).
+// needs, and the backward itself (kernels in backward.hip / dwln_bwd.hip / wgrad.hip / gemm2.hip / convnext.hip).
 //
 // Replaces, for the timm backbone reached at /root/reference/btsbot/architectures.py:108,132, what
 // torch autograd does between model(...) (train.py:510) and loss.backward() (train.py:526).
