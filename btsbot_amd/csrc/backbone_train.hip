@@ -234,6 +234,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
         TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st));
         pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
+      } else if (hw == 1 && h->use_dwln && ch <= 640) {
+        // ---- 1x1 maps: the same three steps per (alert, channel) in one launch
+        TRYB(launch_ln_dw1_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, grads + b.ln_w, grads + b.ln_b,
+                               grads + b.dw_w, grads + b.dw_b, rows, ch, st));
       } else {
         TRYB(launch_ln_bwd(s.d, dxn, m + b.ln_w, dxn, grads + b.ln_w, grads + b.ln_b, rows, ch, st));
         // ---- depthwise filter gradient.  Stays in the chain: behind a fork of its own (per-block dd buffers) the

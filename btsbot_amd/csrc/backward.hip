@@ -8,6 +8,8 @@
 // LayerNorm backward on the recomputed depthwise output; depthwise dgrad = the same depthwise
 // kernel with the 7x7 filter flipped; depthwise wgrad = per-tap correlation reduced over pixels
 // and alerts.  Reductions over the batch use fp32 atomics into the (pre-zeroed) gradient arena.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -291,6 +293,94 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
     atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+  }
+}
+
+// 1x1 maps (stage 3): the block's LayerNorm backward, depthwise filter gradient and depthwise input gradient in one
+// launch.  On a 1x1 map the 7x7 depthwise convolution is its centre tap, so everything is per (alert, channel):
+//   dd = LN'(d) . dxn;   dy += dd * w[24][c];   dW[c][24] += dd * x_in;   db[c] += dd;   dg, dbeta as ln_bwd_kernel
+// One wave per alert (grid-stride); the workgroup's four waves meet in LDS, one atomic per channel per workgroup and
+// gradient.  (Was ln_bwd_kernel + dw_wgrad_kernel<1> + its column sum + dw_plain_kernel<1>: 48 us per block.)
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_dw1_bwd_kernel(const float* __restrict__ d, const float* __restrict__ dxn,
+                                                         const float* __restrict__ g, const float* __restrict__ xin,
+                                                         const float* __restrict__ wc, float* dy,
+                                                         void* __restrict__ out16, int prec16, float* dg, float* dbeta,
+                                                         float* dw, float* dbias, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+  float gl[CPT], wl[CPT], adg[CPT], adb[CPT], adw[CPT], adc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = lane + 64 * i;
+    gl[i] = c < C ? g[c] : 0.f;
+    wl[i] = c < C ? wc[c] : 0.f;
+    adg[i] = adb[i] = adw[i] = adc[i] = 0.f;
+  }
+  for (long r = w0; r < rows; r += nw) {
+    float v[CPT], t[CPT], dxr[CPT], xr[CPT], yr[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? d[r * C + c] : 0.f;
+      dxr[i] = c < C ? dxn[r * C + c] : 0.f;
+      xr[i] = c < C ? xin[r * C + c] : 0.f;
+      yr[i] = c < C ? dy[r * C + c] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? v[i] - mean : 0.f;
+      q += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + LN_EPS);
+    float st = 0.f, stx = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      v[i] *= rstd;                     // xhat
+      t[i] = dxr[i] * gl[i];
+      st += t[i];
+      stx += t[i] * v[i];
+      adg[i] += dxr[i] * v[i];
+      adb[i] += dxr[i];
+    }
+    st = wave_sum(st) / C;
+    stx = wave_sum(stx) / C;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float dd = rstd * (t[i] - st - v[i] * stx);
+        adw[i] += dd * xr[i];
+        adc[i] += dd;
+        const float o = yr[i] + dd * wl[i];
+        dy[r * C + c] = o;
+        if (out16 != nullptr) {
+          if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[r * C + c] = (bf16_t)o;
+          else reinterpret_cast<f16_t*>(out16)[r * C + c] = (f16_t)o;
+        }
+      }
+    }
+  }
+  __shared__ float sh[4][4][CPT * 64];
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    sh[0][wv][lane + 64 * i] = adg[i];
+    sh[1][wv][lane + 64 * i] = adb[i];
+    sh[2][wv][lane + 64 * i] = adw[i];
+    sh[3][wv][lane + 64 * i] = adc[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
+    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+    atomicAdd(dw + (size_t)c * 49 + 24, sh[2][0][c] + sh[2][1][c] + sh[2][2][c] + sh[2][3][c]);
+    atomicAdd(dbias + c, sh[3][0][c] + sh[3][1][c] + sh[3][2][c] + sh[3][3][c]);
   }
 }
 
@@ -754,6 +844,29 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
     return BTSBOT_ERR_INVALID_ARG;
   }
 #undef LNB
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// w: taps [49][C] (the centre row is read); dw: filter gradient [C][49], dbias [C] (master-arena layout)
+int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                      void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, long rows, int C,
+                      hipStream_t st) {
+  if (rows <= 0) return BTSBOT_OK;
+  long blocks = (rows + 3) / 4;
+  if (blocks > 32) blocks = 32;   // 4 x <= 32 same-address atomics per channel: with 256 workgroups the step was 0.04 ms slower
+  const float* wc = w + (size_t)24 * C;
+  const int cpt = (C + 63) / 64;
+#define LD1(CPT)                                                                                       \
+  hipLaunchKernelGGL((ln_dw1_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, xin, wc, dy, \
+                     out16, prec16, dg, dbeta, dw, dbias, rows, C)
+  if (cpt <= 8) LD1(8);
+  else if (cpt <= 10) LD1(10);
+  else {
+    btsbot_set_error("ln_dw1_bwd: C=%d too wide", C);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+#undef LD1
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

@@ -289,6 +289,10 @@ int launch_dw_wgrad(const float* x, const float* dd, float* dw, float* dbias, fl
                     int B, int HW, int C, hipStream_t st);   // partials: >= 256 * 50 * C floats
 // dwln_bwd.hip: the three launches above (LayerNorm backward, depthwise filter gradient, depthwise input gradient)
 // as one kernel, dd never leaving LDS; dy is updated in place (dy += conv(dd, flipped taps))
+// 1x1 maps: the same three steps (plus the filter gradient's column sum) as one per-(alert, channel) kernel, backward.hip
+int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                      void* out16, int prec16, float* dg, float* dbeta, float* dw, float* dbias, long rows, int C,
+                      hipStream_t st);
 bool dwln_bwd_supported(int HW, int C);
 int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) one launch writes
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
