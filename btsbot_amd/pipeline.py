@@ -58,15 +58,27 @@ class ScoreStream:
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self.inputs_ready = inputs_ready
         self._next = 0
+        self._order_after_caller()
+
+    def _order_after_caller(self):
+        # the replicas' parameters were written on the caller's stream (load_state_dict, .to(device)); their first
+        # btsbot_pack_params runs on a side stream: order the two whatever `inputs_ready` says
+        cur = torch.cuda.current_stream(self.device)
+        for side in self.streams:
+            side.wait_stream(cur)
 
     def refresh(self):
         """Copy the first model's parameters into the replicas (after they changed)."""
         sd = self.models[0].state_dict()
         for twin in self.models[1:]:
             twin.load_state_dict(sd)
+        self._order_after_caller()
 
     def submit(self, *inputs: torch.Tensor):
-        """Enqueue one batch; returns a ticket for result().  The inputs must stay alive (and unmodified) until then."""
+        """Enqueue one batch; returns a ticket for result().  The ticket keeps the input tensors alive until result()
+        has seen the batch finish (they were allocated on the caller's stream and are read on a side stream: dropped
+        earlier, the caching allocator could hand their memory to the caller's next batch while this one is still
+        queued); the caller must not MODIFY them until then."""
         k = self._next
         self._next = (k + 1) % len(self.models)
         side = self.streams[k]
@@ -76,13 +88,16 @@ class ScoreStream:
             out = self.models[k](*inputs)
             done = torch.cuda.Event()
             done.record(side)
-        return out, done
+        return out, done, inputs
 
     def result(self, ticket) -> torch.Tensor:
         """The batch's logits; returns once the batch has finished on the GPU (host-side wait), so the tensor is valid
         on every stream."""
-        out, done = ticket
+        out, done, _inputs = ticket
         done.synchronize()
+        # `out` was allocated while a side stream was current: tell the allocator that the caller's stream uses it too,
+        # or the block could be handed to a later forward on that side stream while a caller-stream kernel still reads it
+        out.record_stream(torch.cuda.current_stream(self.device))
         return out
 
     def map(self, batches: Iterable[Tuple[torch.Tensor, ...]], lag: int = 16) -> Iterator[torch.Tensor]:

@@ -88,10 +88,12 @@ class Trainer:
         """train.py:332 -- once per epoch."""
         self.epoch += 1
 
-    def step(self, images: Optional[torch.Tensor], meta: Optional[torch.Tensor],
-             labels: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
-        """One optimisation step on this rank's shard; returns sum_i loss_i / global_batch as a
-        device scalar (the rank's contribution to the global mean loss)."""
+    def gradients(self, images: Optional[torch.Tensor], meta: Optional[torch.Tensor], labels: torch.Tensor,
+                  global_batch: Optional[int] = None, exchange: bool = True):
+        """Forward + BCE + backward (+ the exchange step when `exchange` and more than one rank) on this rank's shard,
+        without the optimiser update: returns (sum_i loss_i / global_batch as a device scalar, the flat gradient arena
+        -- a buffer the library reuses on the next call).  `step` is this followed by AdamW; the multi-GPU tests call it
+        to compare sharded + exchanged gradients with a single-process pass over the whole batch."""
         m = self.model
         if not m.training:
             raise RuntimeError("Trainer.step: put the model in train mode first (model.train())")
@@ -121,13 +123,26 @@ class Trainer:
                                                 C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()),
                                                 st), "btsbot_bce_fwd_bwd")
             grads = m._backward_raw(dl, self.need_meta, self.need_image)
+            if world > 1 and exchange:
+                # the one exchange of the step (local gradients are already scaled by 1 / n_global)
+                self.exchange.exchange(grads, m._wait_grad_bucket)
+            self.last_logits = logits
+        return loss[0] / n_global, grads
+
+    def step(self, images: Optional[torch.Tensor], meta: Optional[torch.Tensor],
+             labels: torch.Tensor, global_batch: Optional[int] = None, exchange: bool = True) -> torch.Tensor:
+        """One optimisation step on this rank's shard; returns sum_i loss_i / global_batch as a
+        device scalar (the rank's contribution to the global mean loss).  (`exchange=False` leaves the all-reduce
+        out: bench.py times the step both ways to report what the collective costs in wall time.)"""
+        m = self.model
+        loss, grads = self.gradients(images, meta, labels, global_batch, exchange)
+        dev = grads.device
+        with torch.no_grad():
             if self.exp_avg is None:
                 self.exp_avg = torch.zeros_like(m._arena)
                 self.exp_avg_sq = torch.zeros_like(m._arena)
-            if world > 1:
-                # the one exchange of the step (local gradients are already scaled by 1 / n_global)
-                self.exchange.exchange(grads, m._wait_grad_bucket)
             self.t += 1
+            L = _lib.lib()
             with torch.cuda.device(dev):
                 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 for lo, hi in self.ranges:
@@ -138,8 +153,7 @@ class Trainer:
                         self.betas[0], self.betas[1], self.eps, self.wd, self.t, st),
                         "btsbot_adamw_step")
             m.mark_weights_dirty()
-            self.last_logits = logits
-        return loss[0] / n_global
+        return loss
 
 
 def train_epoch(trainer: Trainer, dataset, epoch_metrics: bool = True):

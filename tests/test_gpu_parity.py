@@ -410,3 +410,34 @@ def test_score_stream_matches_plain_calls(cuda):
     got = list(btsbot_amd.ScoreStream(f, depth=2).map([batches[1], batches[1], batches[1]]))
     torch.cuda.synchronize()
     assert all(torch.equal(g, want) for g in got)
+
+
+def test_score_stream_keeps_generator_inputs_alive(cuda):
+    """ADVICE r2 (pipeline.py): map() fed from a GENERATOR of freshly allocated batches (what DeviceDataset.__iter__
+    and any loader doing .to(device) hand over), with the host `lag` batches ahead of the oldest unfinished one: every
+    batch's inputs are dropped by the generator as soon as the next one is pulled, so only the ticket keeps them alive
+    while their forward is still queued on a side stream.  Scores must equal plain model(...) calls."""
+    import btsbot_amd
+    kind, cfg = CONFIGS["mm_pico"]
+    m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "bf16")
+    img, meta, _ = synthetic_batch(256, seed=31)
+    img, meta = img.to(cuda), meta.to(cuda)
+    nb = 24
+    with torch.no_grad():
+        ref = [m(image_input=torch.roll(img, k, 0), metadata_input=torch.roll(meta, k, 0)).clone() for k in range(nb)]
+
+    def gen():
+        for k in range(nb):
+            a, b = torch.roll(img, k, 0), torch.roll(meta, k, 0)    # new allocations on the caller's stream
+            yield a, b
+            del a, b
+            # what a loader does next: allocate and fill more memory on the caller's stream
+            torch.empty_like(img).fill_(float("nan"))
+
+    scorer = btsbot_amd.ScoreStream(m, depth=2)
+    outs = []
+    for o in scorer.map(gen(), lag=nb + 4):
+        outs.append(torch.sigmoid(o))          # a caller-stream consumer of a side-stream allocation
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert torch.equal(o, torch.sigmoid(r))
