@@ -24,6 +24,8 @@ import torch.distributed as dist                # noqa: E402
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("BTSBOT_TEST_WATCHDOG", "240")), exit=True)   # a hung collective
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("BTSBOT_TEST_BACKEND", "nccl")
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
@@ -38,6 +40,9 @@ def main():
     from btsbot_amd.synthetic import synthetic_batch
     from helpers import CONFIGS, seeded_state
     res = {"backend": backend, "world": world}
+    # a one-rank group per rank (every rank takes part in every new_group call): the single-process reference pass on
+    # rank 0 must not enter the world's collectives
+    solo = [dist.new_group([r]) for r in range(world)][rank]
 
     # ---- 1 + 2: gradients of a sharded step against the whole batch in one process ---------------------------
     per_rank = 64
@@ -68,7 +73,7 @@ def main():
     torch.cuda.synchronize(dev)
     if rank == 0:
         ref_m = build(3)
-        ref_tr = Trainer(ref_m, lr=1e-4)
+        ref_tr = Trainer(ref_m, lr=1e-4, group=solo)
         rloss, rg = ref_tr.gradients(img, None, lab, global_batch=per_rank * world, exchange=False)
         torch.cuda.synchronize(dev)
         scale = rg.abs().max().item()

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, backend, tmp_path, timeout=600):
+def _run(world, backend, tmp_path, timeout=300):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
