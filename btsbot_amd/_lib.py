@@ -15,7 +15,7 @@ OK = 0
 WIRING = {"mm_ConvNeXt": 0, "ConvNeXt": 1, "frozen_fusion": 2, "um_nn": 3, "mm_MaxViT": 4,
           "MaxViT": 5, "frozen_fusion_MaxViT": 6}
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2,
-             "float16": 2, "fp8": 3}
+             "float16": 2, "fp8": 3, "f16x2": 4}
 
 # every symbol include/btsbot_hip.h declares (tests/test_abi.py checks the export list)
 SYMBOLS = [

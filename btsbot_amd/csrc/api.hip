@@ -74,8 +74,8 @@ int build_tables(btsbot_ctx* h) {
     h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
     h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
     h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
-    h->stage2p = stage2p_supported(c.precision, c.dims[2], c.dims[3], c.depths[2]);
-    h->stage3 = stage3_supported(c.precision, c.dims[3], c.depths[3]);
+    h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
+    h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
@@ -201,7 +201,7 @@ void ws_layout(const btsbot_ctx* h, int chunk, size_t* ox, size_t* ox2, size_t* 
     *oxn = bump(cur, xn_el * chunk * h->esz());
     size_t h_bytes = h_el * chunk * h->esz();
     if (h->stage3) {   // stage3.hip keeps GELU(fc1) in fragment order, alerts rounded up to its 64-row tiles
-      const size_t s3 = stage3_hfrag_bytes(c.precision, c.dims[3], chunk);
+      const size_t s3 = stage3_hfrag_bytes(h->prec_tail(), c.dims[3], chunk);
       h_bytes = s3 > h_bytes ? s3 : h_bytes;
     }
     *oh = bump(cur, h_bytes);
@@ -221,7 +221,7 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
                      BTSBOT_ABI_VERSION);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_FP8 ||
+  if (cfg->precision < BTSBOT_F32 || cfg->precision > BTSBOT_F16X2 ||
       cfg->wiring < BTSBOT_MM_CONVNEXT || cfg->wiring > BTSBOT_FROZEN_FUSION_MAXVIT) {
     btsbot_set_error("create: bad precision %d or wiring %d", cfg->precision, cfg->wiring);
     return BTSBOT_ERR_INVALID_ARG;
@@ -231,6 +231,10 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   if (cfg->precision == BTSBOT_FP8) {   // everything but the fragment-streaming stages reads the bf16 schedule
     h->fp8 = true;
     h->cfg.precision = BTSBOT_BF16;
+  }
+  if (cfg->precision == BTSBOT_F16X2) {   // kernels without a split-operand form run the fp32 schedule
+    h->x2 = true;
+    h->cfg.precision = BTSBOT_F32;
   }
   const int w = cfg->wiring;
   h->has_image = (w != BTSBOT_UM_NN);
@@ -500,7 +504,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   if (convnext && h->stage1 && !train_only)
     TRY(launch_pack_frag32(c.precision, m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
   if (convnext && h->stage2p && !train_only)
-    TRY(launch_pack_s2p(c.precision, m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
+    TRY(launch_pack_s2p(h->prec_down3(), m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], nullptr, st));
   if (h->head16 && !train_only) {
     if (h->has_meta) {

@@ -9,9 +9,44 @@
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
 struct fp8_t { unsigned char v; };   // tag of the fp8 (OCP e4m3) operand mode of stage2p.hip / stage3.hip
+struct f16x2_t { _Float16 v; };      // tag of the split-operand mode (BTSBOT_F16X2): x = hi + lo, both f16
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+// split operands: 8 / 4 / 2 values as f16 head + f16 remainder (the remainder of a value below ~2^-13 is an f16
+// subnormal: the matrix pipe takes subnormal f16 operands as they are, kernels are built with the default
+// denormal mode)
+struct h2x8 { f16x8 hi, lo; };
+struct h2x4 { f16x4v hi, lo; };
+struct h2x2 { f16x2v hi, lo; };
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ h2x8 split8(const float (&v)[8]) {
+  h2x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 a, b;
+    split_f16(v[j], a, b);
+    o.hi[j] = a;
+    o.lo[j] = b;
+  }
+  return o;
+}
+__device__ __forceinline__ h2x4 split4(const float (&v)[4]) {
+  h2x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 a, b;
+    split_f16(v[j], a, b);
+    o.hi[j] = a;
+    o.lo[j] = b;
+  }
+  return o;
+}
 
 // ---------------------------------------------------------------------------------------
 // error plumbing (no exception crosses the ABI)

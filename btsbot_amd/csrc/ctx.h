@@ -94,7 +94,10 @@ struct btsbot_ctx {
   bool use_s2p = true;     // (= use_s2: stage2p.hip is the stage-2 kernel)
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
   bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
-  int prec_tail() const { return fp8 ? BTSBOT_FP8 : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip
+  bool x2 = false;         // created with BTSBOT_F16X2: cfg.precision reads BTSBOT_F32 (the schedule of every kernel without
+                           // a split-operand form), the kernels that have one run it
+  int prec_tail() const { return fp8 ? BTSBOT_FP8 : x2 ? BTSBOT_F16X2 : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip
+  int prec_down3() const { return x2 ? BTSBOT_F16X2 : cfg.precision; }   // ... of the last downsample inside stage2p.hip
   bool stage3 = false;     // stage3.hip: the 1x1 stage as two fragment-streaming launches per block
   bool use_s3 = true;      // BTSBOT_AMD_NO_S3=1: dwconv_ln + the generic GEMMs instead
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)

@@ -38,10 +38,26 @@ namespace {
 
 // operand traits: fragment (8 elements per lane), element size, MFMA, conversions from fp32
 template <typename T> struct MP;
+// Besides the arithmetic a trait says where a fragment lies: gld = fragment number f of a packed array in HBM (64 lanes
+// x 8 values); ld8 / st8 / st4 = 8 / 8 / 4 consecutive values of an operand image in LDS at byte address p of its
+// first (for the split mode: only) plane.  PLANE = byte distance of the split mode's remainder plane.
 template <typename T> struct MP16 {
   static constexpr int ESZ = 2;
+  static constexpr bool SPLIT = false;
   typedef T frag __attribute__((ext_vector_type(8)));
   typedef T quad __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ frag gld(const void* base, size_t f, int lane) {
+    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
+  }
+  template <int PLANE> static __device__ __forceinline__ frag ld8(const unsigned char* p) {
+    return *reinterpret_cast<const frag*>(p);
+  }
+  template <int PLANE> static __device__ __forceinline__ void st8(unsigned char* p, const float (&v)[8]) {
+    *reinterpret_cast<frag*>(p) = pack8(v);
+  }
+  template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
+    *reinterpret_cast<quad*>(p) = pack4(v);
+  }
   static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
     frag o;
 #pragma unroll
@@ -67,10 +83,60 @@ template <> struct MP<f16_t> : MP16<f16_t> {
 };
 // fp8 (OCP e4m3): 8 elements = one 64-bit register pair; activations clamped to +-448 before the conversion (beyond
 // its largest finite value the format has only NaN).  Filters carry one power-of-two scale each (stage3.hip).
+// split operands (BTSBOT_F16X2): value = f16 head + f16 remainder, product = lo*hi + hi*lo + hi*hi on the f16 MFMA.
+// LDS images keep the 16-bit geometry for the heads and a second plane of the same geometry for the remainders (so
+// the bank mapping of every read is the 16-bit one); a packed fragment in HBM is 2 KiB: heads, then remainders.
+template <> struct MP<f16x2_t> {
+  static constexpr int ESZ = 2;
+  static constexpr bool SPLIT = true;
+  typedef h2x8 frag;
+  typedef h2x4 quad;
+  static __device__ __forceinline__ frag gld(const void* base, size_t f, int lane) {
+    const f16x8* p = reinterpret_cast<const f16x8*>(base) + f * 128 + lane;
+    frag o;
+    o.hi = p[0];
+    o.lo = p[64];
+    return o;
+  }
+  template <int PLANE> static __device__ __forceinline__ frag ld8(const unsigned char* p) {
+    frag o;
+    o.hi = *reinterpret_cast<const f16x8*>(p);
+    o.lo = *reinterpret_cast<const f16x8*>(p + PLANE);
+    return o;
+  }
+  template <int PLANE> static __device__ __forceinline__ void st8(unsigned char* p, const float (&v)[8]) {
+    const frag o = split8(v);
+    *reinterpret_cast<f16x8*>(p) = o.hi;
+    *reinterpret_cast<f16x8*>(p + PLANE) = o.lo;
+  }
+  template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
+    const quad o = split4(v);
+    *reinterpret_cast<f16x4v*>(p) = o.hi;
+    *reinterpret_cast<f16x4v*>(p + PLANE) = o.lo;
+  }
+  static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+  }
+};
 template <> struct MP<fp8_t> {
   static constexpr int ESZ = 1;
+  static constexpr bool SPLIT = false;
   typedef long frag;
   typedef unsigned quad;
+  static __device__ __forceinline__ frag gld(const void* base, size_t f, int lane) {
+    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
+  }
+  template <int PLANE> static __device__ __forceinline__ frag ld8(const unsigned char* p) {
+    return *reinterpret_cast<const frag*>(p);
+  }
+  template <int PLANE> static __device__ __forceinline__ void st8(unsigned char* p, const float (&v)[8]) {
+    *reinterpret_cast<frag*>(p) = pack8(v);
+  }
+  template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
+    *reinterpret_cast<quad*>(p) = pack4(v);
+  }
   static __device__ __forceinline__ float c8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
   static __device__ __forceinline__ quad pack4(const float (&v)[4]) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(c8(v[0]), c8(v[1]), 0, false);
@@ -104,9 +170,15 @@ constexpr int XNP2 = C * 2 + 32;                      // 16-bit LN image: bytes 
 constexpr int HP2 = CHUNK * 2 + 32;                   // hidden image: bytes per pixel row (288)
 constexpr int OFF_XL = 0;                             // [48][256] f32 (rows >= 36 stay zero)
 constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;       // 49152
-constexpr int OFF_H = OFF_XN + NCOL * XNP2;           // + 25344
-constexpr int OFF_B1 = OFF_H + 2 * NCOL * HP2;        // + 26112: fc1 bias [1024] f32
-constexpr int LDS_BYTES = OFF_B1 + HID * 4;           // 104704
+constexpr int XN_PLANE = NCOL * XNP2, H_PLANE = NCOL * HP2;   // 26112, 13824 (the split mode has two planes of each)
+template <typename T> struct Lds {
+  static constexpr int NPL = MP<T>::SPLIT ? 2 : 1;
+  static constexpr int H_IMG = NPL * H_PLANE;                 // one hidden image (two of them)
+  static constexpr int OFF_H = OFF_XN + NPL * XN_PLANE;
+  static constexpr int OFF_B1 = OFF_H + 2 * H_IMG;            // fc1 bias [1024] f32
+  static constexpr int BYTES = OFF_B1 + HID * 4;              // 104704 (split: 160768)
+};
+static_assert(Lds<f16x2_t>::BYTES <= 160 * 1024, "the split mode's images fit one CU");
 constexpr float LN_EPS = 1e-6f;
 #define S2P_STAMP(i)                                                                      \
   do {                                                                                    \
@@ -124,19 +196,20 @@ __device__ __forceinline__ float half_sum(float v) {
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   using frag = typename MP<T>::frag;
-  using quad = typename MP<T>::quad;
   constexpr int ESZ = MP<T>::ESZ;
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   // operand images: bytes per pixel row (the regions keep their 16-bit sizes)
   constexpr int XNP = C * ESZ + 16 * ESZ, HP = CHUNK * ESZ + 16 * ESZ;
   // fc1's B operand (the block's LN image, the same for all 8 chunks): k-steps kept in registers for the whole block;
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
-  constexpr int XRES = F8 ? KS1 : 4;   // (16-bit: 5 or 6 spill in the block prologue and lose more than they save)
+  // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
+  constexpr int XRES = F8 ? KS1 : MP<T>::SPLIT ? 0 : 4;   // (16-bit: 5 or 6 spill in the block prologue and lose more than they save)
+  constexpr int H_IMG = Lds<T>::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
   unsigned char* xn = smem + OFF_XN;
-  unsigned char* hb = smem + OFF_H;   // two hidden images, NCOL * HP2 bytes apart
-  float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
+  unsigned char* hb = smem + Lds<T>::OFF_H;   // two hidden images, H_IMG bytes apart
+  float* b1s = reinterpret_cast<float*>(smem + Lds<T>::OFF_B1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
@@ -145,7 +218,10 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 
   S2P_STAMP(0);
   // pad rows of the operand images: zero once (they are never written again)
-  for (int i = tid; i < (NCOL - NPX) * XNP / 4; i += NT) reinterpret_cast<unsigned*>(xn + NPX * XNP)[i] = 0u;
+  for (int i = tid; i < (NCOL - NPX) * XNP / 4; i += NT) {
+    reinterpret_cast<unsigned*>(xn + NPX * XNP)[i] = 0u;
+    if (MP<T>::SPLIT) reinterpret_cast<unsigned*>(xn + XN_PLANE + NPX * XNP)[i] = 0u;
+  }
   for (int i = tid; i < NCOL * XLP; i += NT) xl[i] = 0.f;
 
   // ---- residual stream: this wave's 32 channels x 48 pixels, acc[m][n][r] = x[16 n + col][32 wave + 16 m + 4 kg + r]
@@ -169,15 +245,16 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   frag a1[KS1], a2[2][KS2];
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  if (a.depth > 0) {   // chunk 0 of both filters (fc2 runs one step behind fc1: its chunk 0 is first used in step 1)
-    const frag* src1 = reinterpret_cast<const frag*>(a.blk[0].w1p) + ((size_t)wave * KS1) * 64 + lane;
+  // (split: the two streams are 128 registers; they are NOT carried through the depthwise / LayerNorm phases -- every
+  //  block requests its chunk 0 at the start of its chunk loop instead, one exposed L2 round trip per block)
+  constexpr bool CARRY = !MP<T>::SPLIT;
+  if (a.depth > 0 && CARRY) {   // chunk 0 of both filters (fc2 runs one step behind fc1: its chunk 0 is first used in step 1)
 #pragma unroll
-    for (int s = 0; s < KS1; ++s) a1[s] = src1[s * 64];
+    for (int s = 0; s < KS1; ++s) a1[s] = MP<T>::gld(a.blk[0].w1p, (size_t)wave * KS1 + s, lane);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const frag* src2 = reinterpret_cast<const frag*>(a.blk[0].w2p) + ((size_t)(2 * wave + m) * (HID / 32)) * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) a2[m][s] = src2[s * 64];
+      for (int s = 0; s < KS2; ++s) a2[m][s] = MP<T>::gld(a.blk[0].w2p, (size_t)(2 * wave + m) * (HID / 32) + s, lane);
     }
   }
 
@@ -258,16 +335,16 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         y[i] = e0[i] * rstd * lw[i] + lb[i];
         y[4 + i] = e1[i] * rstd * lw2[i] + lb2[i];
       }
-      *reinterpret_cast<frag*>(xn + p * XNP + 8 * ESZ * (lane & 31)) = MP<T>::pack8(y);
+      MP<T>::template st8<XN_PLANE>(xn + p * XNP + 8 * ESZ * (lane & 31), y);
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
-    frag xr[XRES][NB];
+    frag xr[XRES > 0 ? XRES : 1][NB];
 #pragma unroll
     for (int s = 0; s < XRES; ++s)
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        xr[s][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
+        xr[s][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
     // residual + gamma * b2 (the bias of the folded fc2)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -298,9 +375,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       //  keeps the k-step loops free of branches -- hipcc waits vmcnt(0) behind every conditional load)
       const Stage2pBlk& nb = ch + 1 < NCHUNK ? bk : a.blk[j + 1 < a.depth ? j + 1 : j];
       const int nch = ch + 1 < NCHUNK ? ch + 1 : 0;
-      const frag* src1 = reinterpret_cast<const frag*>(nb.w1p) + ((size_t)(nch * NW + wave) * KS1) * 64 + lane;
+      const void* src1 = nb.w1p;
+      const size_t f1 = (size_t)(nch * NW + wave) * KS1;
       // fc2 runs one step behind: its slots are refilled with THIS chunk's fragments (used in the next step)
-      const frag* src2 = reinterpret_cast<const frag*>(bk.w2p) + ((size_t)(2 * wave) * (HID / 32) + ch * KS2) * 64 + lane;
+      const void* src2 = bk.w2p;
+      const size_t f2 = (size_t)(2 * wave) * (HID / 32) + ch * KS2;
       // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]: k-steps
       // 0 .. XRES-1 from the registers filled after the LayerNorm, the rest from LDS
       f32x4 hacc[NB];
@@ -310,54 +389,70 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) hacc[n] = bv;
       }
-      frag xb[2][NB];
-      if (XRES < KS1) {
+      // (split: B fragments are 8 registers each and the filter streams hold 128: ONE buffer, read at the start of its
+      //  k-step -- nine products per k-step and the SIMD's other wave cover the LDS latency)
+      constexpr int DB = MP<T>::SPLIT ? 1 : 2;
+      frag xb[DB][NB];
+      if (XRES < KS1 && DB == 2) {
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          xb[XRES & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * XRES + 8 * kg) * ESZ);
+          xb[XRES & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * XRES + 8 * kg) * ESZ);
       }
 #pragma unroll
       for (int s = 0; s < KS1; ++s) {
-        if (s >= XRES && s + 1 < KS1) {
+        if (DB == 2 && s >= XRES && s + 1 < KS1) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            xb[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * ESZ);
+            xb[(s + 1) & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * ESZ);
+        }
+        if (DB == 1 && s >= XRES) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            xb[0][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
         }
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[s], s < XRES ? xr[s < XRES ? s : 0][n] : xb[s & 1][n], hacc[n]);
-        a1[s] = src1[s * 64];
+        for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[s], s < XRES ? xr[s < XRES ? s : 0][n] : xb[s & (DB - 1)][n], hacc[n]);
+        a1[s] = MP<T>::gld(src1, f1 + s, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
       // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
-      unsigned char* hcur = hb + p * (NCOL * HP2);
-      const unsigned char* hprev = hb + (1 - p) * (NCOL * HP2);
-      frag hbf[2][NB];
-      if (!first) {
+      unsigned char* hcur = hb + p * H_IMG;
+      const unsigned char* hprev = hb + (1 - p) * H_IMG;
+      frag hbf[DB][NB];
+      if (!first && DB == 2) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
       }
       static_assert(NB <= KS2, "one GELU column block per fc2 k-step");
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         if (!first) {
-          if (s + 1 < KS2) {
+          if (DB == 2 && s + 1 < KS2) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+              hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+          }
+          if (DB == 1) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * s + 8 * kg) * ESZ);
           }
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & 1][n], acc[m][n]);
-          a2[0][s] = src2[s * 64];
-          a2[1][s] = src2[((size_t)(HID / 32) + s) * 64];
+            for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
+          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
+        } else if (!CARRY) {   // (first step of a block: this chunk's fc2 fragments, used in the next step)
+          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
         }
         if (s < NB) {
           float hv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) hv[r] = gelu_for<typename GeluOf2<T>::type>(F8 ? hacc[s][r] * is1 : hacc[s][r]);
-          *reinterpret_cast<quad*>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ) = MP<T>::pack4(hv);
+          MP<T>::template st4<H_PLANE>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ, hv);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -367,28 +462,43 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 0
     auto fc2_tail = [&]() {
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
-      const frag* src2 = reinterpret_cast<const frag*>(nb.w2p) + ((size_t)(2 * wave) * (HID / 32)) * 64 + lane;
-      const unsigned char* hprev = hb + 1 * (NCOL * HP2);   // chunk NCHUNK - 1 is odd: image 1
-      frag hbf[2][NB];
+      const void* src2 = nb.w2p;
+      const size_t f2 = (size_t)(2 * wave) * (HID / 32);
+      const unsigned char* hprev = hb + 1 * H_IMG;   // chunk NCHUNK - 1 is odd: image 1
+      constexpr int DB = MP<T>::SPLIT ? 1 : 2;
+      frag hbf[DB][NB];
+      if (DB == 2) {
 #pragma unroll
-      for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
+      }
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
-        if (s + 1 < KS2) {
+        if (DB == 2 && s + 1 < KS2) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+            hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+        }
+        if (DB == 1) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * s + 8 * kg) * ESZ);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & 1][n], acc[m][n]);
-        a2[0][s] = src2[s * 64];
-        a2[1][s] = src2[((size_t)(HID / 32) + s) * 64];
+          for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
+        if (CARRY) {
+          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     static_assert(NCHUNK % 2 == 0, "the last chunk writes hidden image 1");
+    if (!CARRY) {
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) a1[s] = MP<T>::gld(bk.w1p, (size_t)wave * KS1 + s, lane);
+    }
     step(P0{}, std::true_type{}, 0);
     step(P1{}, std::false_type{}, 1);
     S2P_STAMP(5 + 8 * j);
@@ -441,7 +551,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       float y[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = e[i] * rstd * lw[i] + lb[i];
-      *reinterpret_cast<typename MP<TD>::quad*>(xn + p * XND + 4 * MP<TD>::ESZ * lane) = MP<TD>::pack4(y);
+      MP<TD>::template st4<XN_PLANE>(xn + p * XND + 4 * MP<TD>::ESZ * lane, y);
     }
   }
   __syncthreads();
@@ -451,11 +561,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // Column = alert (4 live of 16); wave w: output tiles 4 w .. 4 w + 3 (16 channels each), 32 k-steps.
     const int al = col < G ? col : 0;
     // this wave's 4 tiles x 32 k-steps = 128 fragments, contiguous in memory (tile-major): a ring of 16 in flight
-    const fragd* src = reinterpret_cast<const fragd*>(a.ds_wp) + (size_t)(4 * wave) * KSD * 64 + lane;
-    constexpr int RING = 16, NSTEP = 4 * KSD;
+    const size_t fd0 = (size_t)(4 * wave) * KSD;
+    constexpr int RING = MP<TD>::SPLIT ? 8 : 16, NSTEP = 4 * KSD;
     fragd wq[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) wq[i] = src[i * 64];
+    for (int i = 0; i < RING; ++i) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + i, lane);
     f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (4 * wave) + 4 * kg);
 #pragma unroll 1
     for (int g = 0; g < NSTEP / RING; ++g) {
@@ -463,9 +573,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       for (int i = 0; i < RING; ++i) {
         const int st = g * RING + i, s = st & (KSD - 1), tile = 4 * wave + (st >> 5);
         const int q = s >> 3, pq = 3 * (q >> 1) + (q & 1);
-        const fragd bf = *reinterpret_cast<const fragd*>(xn + (9 * al + pq) * XND + (32 * (s & 7) + 8 * kg) * MP<TD>::ESZ);
+        const fragd bf = MP<TD>::template ld8<XN_PLANE>(xn + (9 * al + pq) * XND + (32 * (s & 7) + 8 * kg) * MP<TD>::ESZ);
         o = MP<TD>::run(wq[i], bf, o);
-        if (st + RING < NSTEP) wq[i] = src[(size_t)(st + RING) * 64];
+        if (st + RING < NSTEP) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + st + RING, lane);
         if (s == KSD - 1) {   // tile finished (every 32 steps = two ring rounds)
           if (col < G && alert0 + col < a.B)
             *reinterpret_cast<f32x4*>(a.out + (size_t)(alert0 + col) * CO + 16 * tile + 4 * kg) = o;
@@ -503,6 +613,30 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, const float* __res
   out[i] = (T)v;
 }
 
+// split mode: 2 KiB per fragment, [lane][8] heads then [lane][8] remainders
+__global__ void pack_frag_split_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
+                                       _Float16* __restrict__ out, int rows, int K, int reorder_down, int cin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 32;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  const int row = 16 * tile + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+  float v;
+  if (reorder_down) {
+    const int q = k / cin, c = k - q * cin;
+    v = w[((long)row * cin + c) * 4 + q];
+  } else {
+    v = w[(long)row * K + k];
+  }
+  if (rowscale != nullptr) v *= rowscale[row];
+  _Float16 hi, lo;
+  split_f16(v, hi, lo);
+  out[fs * 1024 + l * 8 + j] = hi;
+  out[fs * 1024 + 512 + l * 8 + j] = lo;
+}
+
 __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
                                      const float* __restrict__ scale, unsigned char* __restrict__ out, int rows, int K,
                                      int reorder_down, int cin) {
@@ -529,10 +663,10 @@ template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st)
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)LDS_BYTES));
+                                (int)Lds<T>::BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), Lds<T>::BYTES, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -540,7 +674,8 @@ template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st)
 }  // namespace
 
 bool stage2p_supported(int prec, int c2, int c3, int depth) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8) && c2 == C && c3 == CO && depth >= 1 && depth <= S2P_MAX_DEPTH;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8 || prec == BTSBOT_F16X2) && c2 == C && c3 == CO &&
+         depth >= 1 && depth <= S2P_MAX_DEPTH;
 }
 
 // src [rows][K] fp32 (row-major; reorder_down: a [Cout][Cin][2][2] downsample filter) -> MFMA A fragments
@@ -553,6 +688,9 @@ int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst
                        reorder_down, cin);
   else if (prec == BTSBOT_F16)
     hipLaunchKernelGGL(pack_frag_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
+                       reorder_down, cin);
+  else if (prec == BTSBOT_F16X2)
+    hipLaunchKernelGGL(pack_frag_split_kernel, grid, blk, 0, st, src, rowscale, reinterpret_cast<_Float16*>(dst), rows, K,
                        reorder_down, cin);
   else if (prec == BTSBOT_FP8) {
     if (scale == nullptr) {
@@ -577,6 +715,7 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (prec == BTSBOT_BF16) return launch_stage2p_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage2p_t<f16_t>(a, st);
   if (prec == BTSBOT_FP8) return launch_stage2p_t<fp8_t>(a, st);
+  if (prec == BTSBOT_F16X2) return launch_stage2p_t<f16x2_t>(a, st);
   btsbot_set_error("stage2p: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
 }

@@ -27,10 +27,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // operand traits: fragment type (8 elements per lane), element size, MFMA, and the conversions from fp32
 template <typename T> struct S3M;
+// Every trait also says how a fragment lies in memory: ldg / stg = fragment number f of a packed fragment array in HBM
+// (64 lanes x 8 values), lds_ld8 / lds_st2 = values c .. c + 7 / c, c + 1 of an operand row in LDS (`plane` = the
+// row's width in values; only the split mode, which keeps a row's remainders `plane` values behind its heads, uses it).
 template <typename T> struct S3M16 {
   static constexpr int ESZ = 2;
+  static constexpr int MAXRING = 32;      // fragments a wave keeps in flight per operand stream
   typedef T pair_t __attribute__((ext_vector_type(2)));
   typedef T frag __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
+    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
+  }
+  static __device__ __forceinline__ void stg(void* base, size_t f, int lane, frag v) {
+    reinterpret_cast<frag*>(base)[f * 64 + lane] = v;
+  }
+  static __device__ __forceinline__ frag lds_ld8(const unsigned char* row, int c, int plane) {
+    return *reinterpret_cast<const frag*>(row + c * 2);
+  }
+  static __device__ __forceinline__ void lds_st2(unsigned char* row, int c, int plane, float a, float b) {
+    *reinterpret_cast<pair_t*>(row + c * 2) = pack2(a, b);
+  }
   static __device__ __forceinline__ pair_t pack2(float a, float b) {
     pair_t o;
     o[0] = (T)a;
@@ -58,8 +74,21 @@ template <> struct S3M<f16_t> : S3M16<f16_t> {
 // before the conversion (its largest finite value is 448; what lies beyond would become NaN).
 template <> struct S3M<fp8_t> {
   static constexpr int ESZ = 1;
+  static constexpr int MAXRING = 32;
   typedef unsigned short pair_t;
   typedef long frag;
+  static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
+    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
+  }
+  static __device__ __forceinline__ void stg(void* base, size_t f, int lane, frag v) {
+    reinterpret_cast<frag*>(base)[f * 64 + lane] = v;
+  }
+  static __device__ __forceinline__ frag lds_ld8(const unsigned char* row, int c, int plane) {
+    return *reinterpret_cast<const frag*>(row + c);
+  }
+  static __device__ __forceinline__ void lds_st2(unsigned char* row, int c, int plane, float a, float b) {
+    *reinterpret_cast<pair_t*>(row + c) = pack2(a, b);
+  }
   static __device__ __forceinline__ float clamp8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
   static __device__ __forceinline__ pair_t pack2(float a, float b) {
     return (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(a), clamp8(b), 0, false);
@@ -73,6 +102,46 @@ template <> struct S3M<fp8_t> {
   }
   static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+  }
+};
+// split operands (BTSBOT_F16X2): value = f16 head + f16 remainder; a product is hi*hi + hi*lo + lo*hi on the f16 MFMA
+// (the lo*lo term is below 2^-22 of the product).  A packed fragment is 2 KiB: the heads' 1 KiB, then the remainders'.
+template <> struct S3M<f16x2_t> {
+  static constexpr int ESZ = 4;
+  static constexpr int MAXRING = 8;       // 8 registers per fragment
+  typedef h2x8 frag;
+  static __device__ __forceinline__ frag pack8(const float (&v)[8]) { return split8(v); }
+  static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
+    const f16x8* p = reinterpret_cast<const f16x8*>(base) + f * 128 + lane;
+    frag o;
+    o.hi = p[0];
+    o.lo = p[64];
+    return o;
+  }
+  static __device__ __forceinline__ void stg(void* base, size_t f, int lane, frag v) {
+    f16x8* p = reinterpret_cast<f16x8*>(base) + f * 128 + lane;
+    p[0] = v.hi;
+    p[64] = v.lo;
+  }
+  static __device__ __forceinline__ frag lds_ld8(const unsigned char* row, int c, int plane) {
+    frag o;
+    o.hi = *reinterpret_cast<const f16x8*>(row + c * 2);
+    o.lo = *reinterpret_cast<const f16x8*>(row + (plane + c) * 2);
+    return o;
+  }
+  static __device__ __forceinline__ void lds_st2(unsigned char* row, int c, int plane, float a, float b) {
+    f16x2v hi, lo;
+    _Float16 h0, l0, h1, l1;
+    split_f16(a, h0, l0);
+    split_f16(b, h1, l1);
+    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+    *reinterpret_cast<f16x2v*>(row + c * 2) = hi;
+    *reinterpret_cast<f16x2v*>(row + (plane + c) * 2) = lo;
+  }
+  static __device__ __forceinline__ f32x16 run(const frag& a, const frag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
   }
 };
 // GELU of the operand mode: fp8 rides on the bf16 schedule (degree-3 polynomial form)
@@ -93,7 +162,8 @@ constexpr int RED_BYTES = 8 * 2 * 4 * 64 * 16;   // fc2: 8 K slices x 2 alert bl
 template <typename T, int C>
 __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& bk, int ab, int nt, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
-  constexpr int HID = 4 * C, KS = C / 16, NV = C / 128, RING = KS > 32 ? KS / 2 : KS;
+  constexpr int HID = 4 * C, KS = C / 16, NV = C / 128;
+  constexpr int RING0 = KS > 32 ? KS / 2 : KS, RING = RING0 < S3M<T>::MAXRING ? RING0 : S3M<T>::MAXRING;
   static_assert(RING % 4 == 0, "ring quarters");
   constexpr int ESZ = S3M<T>::ESZ;
   constexpr int PITCH = C * ESZ + 16;   // bytes per LDS row: C operand values + 16 (8 rows cover the 32 banks)
@@ -119,13 +189,13 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   }
   // ---- the wave's filter fragments, a quarter in front of each row's LayerNorm: the requests queue at the TA port
   //      (a wave cannot run ahead of its own unissued loads) while the VALU works on the row before
-  const frag* wsrc = reinterpret_cast<const frag*>(bk.w1p) + (size_t)ht * KS * 64 + lane;
+  const size_t wf0 = (size_t)ht * KS;      // this wave's first filter fragment
   frag wq[RING];
   S3_STAMP(9);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
 #pragma unroll
-    for (int i = u * (RING / 4); i < (u + 1) * (RING / 4); ++i) wq[i] = wsrc[i * 64];
+    for (int i = u * (RING / 4); i < (u + 1) * (RING / 4); ++i) wq[i] = S3M<T>::ldg(bk.w1p, wf0 + i, lane);
     __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
@@ -143,12 +213,11 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
       q = fmaf(v[u][i].x, v[u][i].x, fmaf(v[u][i].y, v[u][i].y, q));
     }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
-    unsigned char* row = smem + (4 * wave + u) * PITCH + 2 * ESZ * lane;
+    unsigned char* row = smem + (4 * wave + u) * PITCH;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      *reinterpret_cast<typename S3M<T>::pair_t*>(row + 128 * ESZ * i) =
-          S3M<T>::pack2(fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x), fmaf(v[u][i].y * rstd, lw[i].y, lb[i].y));
-    }
+    for (int i = 0; i < NV; ++i)
+      S3M<T>::lds_st2(row, 128 * i + 2 * lane, C, fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x),
+                      fmaf(v[u][i].y * rstd, lw[i].y, lb[i].y));
     __builtin_amdgcn_sched_barrier(0);
   }
   S3_STAMP(10);
@@ -171,23 +240,21 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   }
   __syncthreads();
   S3_STAMP(11);
-  const unsigned char* bp = smem + lr * PITCH + h * 8 * ESZ;
+  const unsigned char* bp = smem + lr * PITCH;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const frag bf = *reinterpret_cast<const frag*>(bp + ks * 16 * ESZ);
+    const frag bf = S3M<T>::lds_ld8(bp, ks * 16 + h * 8, C);
     acc = S3M<T>::run(wq[ks % RING], bf, acc);
-    if (ks + RING < KS) wq[ks % RING] = wsrc[(ks + RING) * 64];
+    if (ks + RING < KS) wq[ks % RING] = S3M<T>::ldg(bk.w1p, wf0 + ks + RING, lane);
   }
   S3_STAMP(12);
   // ---- GELU, out as fc2's B fragments: lane (alert lr, half h) holds k = 16 ks2 + 8 h + 0..7 of k-step ks2 = 2 ht + hh
-  frag* hout = reinterpret_cast<frag*>(a.hfrag);
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[8 * hh + j] * is1);
-    const frag o = S3M<T>::pack8(g);
-    hout[((size_t)ab * (HID / 16) + 2 * ht + hh) * 64 + lane] = o;
+    S3M<T>::stg(a.hfrag, (size_t)ab * (HID / 16) + 2 * ht + hh, lane, S3M<T>::pack8(g));
   }
   __syncthreads();   // the rows in LDS are read out: the next tile may overwrite them
 }
@@ -195,20 +262,19 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
 template <typename T, int C>
 __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
-  constexpr int HID = 4 * C, KSA = HID / 16, KSW = KSA / 8, RING = KSW <= 16 ? KSW : KSW / 2;
+  constexpr int HID = 4 * C, KSA = HID / 16, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
+  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : 4;   // (split: 3 streams x 4 fragments x 8 registers)
   static_assert(KSW % RING == 0, "k-steps per wave");
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = mt * M2;
-  const frag* wsrc = reinterpret_cast<const frag*>(bk.w2p) + ((size_t)ct * KSA + wave * KSW) * 64 + lane;
-  const frag* h0 = reinterpret_cast<const frag*>(a.hfrag) + ((size_t)(m0 / 32) * KSA + wave * KSW) * 64 + lane;
-  const frag* h1 = h0 + (size_t)KSA * 64;
+  const size_t wf0 = (size_t)ct * KSA + wave * KSW, hf0 = (size_t)(m0 / 32) * KSA + wave * KSW, hf1 = hf0 + KSA;
   frag wa[RING], ha[RING], hb[RING];
 #pragma unroll
   for (int i = 0; i < RING; ++i) {
-    wa[i] = wsrc[i * 64];
-    ha[i] = h0[i * 64];
-    hb[i] = h1[i * 64];
+    wa[i] = S3M<T>::ldg(bk.w2p, wf0 + i, lane);
+    ha[i] = S3M<T>::ldg(a.hfrag, hf0 + i, lane);
+    hb[i] = S3M<T>::ldg(a.hfrag, hf1 + i, lane);
   }
   __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc sinks the loads to their MFMAs: ~10 in flight instead of 48)
   f32x16 acc[2];
@@ -219,9 +285,9 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
     acc[0] = S3M<T>::run(wa[ks % RING], ha[ks % RING], acc[0]);
     acc[1] = S3M<T>::run(wa[ks % RING], hb[ks % RING], acc[1]);
     if (ks + RING < KSW) {
-      wa[ks % RING] = wsrc[(ks + RING) * 64];
-      ha[ks % RING] = h0[(ks + RING) * 64];
-      hb[ks % RING] = h1[(ks + RING) * 64];
+      wa[ks % RING] = S3M<T>::ldg(bk.w2p, wf0 + ks + RING, lane);
+      ha[ks % RING] = S3M<T>::ldg(a.hfrag, hf0 + ks + RING, lane);
+      hb[ks % RING] = S3M<T>::ldg(a.hfrag, hf1 + ks + RING, lane);
     }
   }
   S3_STAMP(13);
@@ -301,6 +367,26 @@ __global__ void pack_s3_kernel(const float* __restrict__ w, const float* __restr
   out[i] = (T)v;
 }
 
+// split mode: the same fragments, 2 KiB each: [lane][8] heads, then [lane][8] remainders
+__global__ void pack_s3_split_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
+                                     _Float16* __restrict__ out, int rows, int K, int swap23) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * K) return;
+  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const long fs = i >> 9;
+  const int ksteps = K / 16;
+  const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+  int r = l & 31;
+  if (swap23) r = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const int row = 32 * tile + r, k = 16 * s + 8 * (l >> 5) + j;
+  float v = w[(long)row * K + k];
+  if (rowscale != nullptr) v *= rowscale[row];
+  _Float16 hi, lo;
+  split_f16(v, hi, lo);
+  out[fs * 1024 + l * 8 + j] = hi;
+  out[fs * 1024 + 512 + l * 8 + j] = lo;
+}
+
 // ---- fp8: max |w| -> power-of-two scale -> packed bytes
 __global__ void absmax_kernel(const float* __restrict__ w, const float* __restrict__ rowscale, unsigned* __restrict__ bits,
                               long n, int K) {
@@ -336,7 +422,15 @@ __global__ void pack_s3_fp8_kernel(const float* __restrict__ w, const float* __r
 template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
   constexpr int LDS1 = M1 * (C * S3M<T>::ESZ + 16);
   if (phase == 0) {
-    hipLaunchKernelGGL((s3_fc1_kernel<T, C>), dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
+    auto kern1 = s3_fc1_kernel<T, C>;
+    if (LDS1 > 65536) {
+      static bool attr1_set = false;
+      if (!attr1_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+        attr1_set = true;
+      }
+    }
+    hipLaunchKernelGGL(kern1, dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
   } else {
     auto kern = s3_fc2_kernel<T, C>;
     static bool attr_set = false;
@@ -353,11 +447,12 @@ template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase,
 }  // namespace
 
 bool stage3_supported(int prec, int c3, int depth) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8) && (c3 == 512 || c3 == 640) && depth >= 1 && depth <= S3_MAX_DEPTH;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8 || prec == BTSBOT_F16X2) && (c3 == 512 || c3 == 640) &&
+         depth >= 1 && depth <= S3_MAX_DEPTH;
 }
 
 size_t stage3_hfrag_bytes(int prec, int c3, int B) {
-  return (size_t)((B + M2 - 1) / M2) * M2 * 4 * c3 * (prec == BTSBOT_F32 ? 4 : 2);
+  return (size_t)((B + M2 - 1) / M2) * M2 * 4 * c3 * (prec == BTSBOT_F32 || prec == BTSBOT_F16X2 ? 4 : 2);
 }
 
 int launch_stage3(int prec, int c3, const Stage3Args& a, int block, int phase, hipStream_t st) {
@@ -368,6 +463,8 @@ int launch_stage3(int prec, int c3, const Stage3Args& a, int block, int phase, h
   if (prec == BTSBOT_F16 && c3 == 640) return launch_t<f16_t, 640>(a, block, phase, st);
   if (prec == BTSBOT_FP8 && c3 == 512) return launch_t<fp8_t, 512>(a, block, phase, st);
   if (prec == BTSBOT_FP8 && c3 == 640) return launch_t<fp8_t, 640>(a, block, phase, st);
+  if (prec == BTSBOT_F16X2 && c3 == 512) return launch_t<f16x2_t, 512>(a, block, phase, st);
+  if (prec == BTSBOT_F16X2 && c3 == 640) return launch_t<f16x2_t, 640>(a, block, phase, st);
   btsbot_set_error("stage3: precision %d / width %d not supported", prec, c3);
   return BTSBOT_ERR_INVALID_ARG;
 }
@@ -389,6 +486,9 @@ int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst,
                        swap23);
   else if (prec == BTSBOT_F16)
     hipLaunchKernelGGL(pack_s3_kernel<f16_t>, grid, blk, 0, st, src, rowscale, reinterpret_cast<f16_t*>(dst), rows, K,
+                       swap23);
+  else if (prec == BTSBOT_F16X2)
+    hipLaunchKernelGGL(pack_s3_split_kernel, grid, blk, 0, st, src, rowscale, reinterpret_cast<_Float16*>(dst), rows, K,
                        swap23);
   else if (prec == BTSBOT_FP8) {
     if (scale == nullptr) {

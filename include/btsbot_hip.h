@@ -67,9 +67,14 @@ enum btsbot_precision {
   BTSBOT_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 fma chains -- the parity mode          */
   BTSBOT_BF16 = 1, /* v_mfma_f32_16x16x32_bf16                                                   */
   BTSBOT_F16 = 2,  /* v_mfma_f32_16x16x32_f16 (same rate as bf16, 3 more mantissa bits)          */
-  BTSBOT_FP8 = 3   /* inference only: the bf16 schedule with the pointwise convolutions of stages 2-3
+  BTSBOT_FP8 = 3,  /* inference only: the bf16 schedule with the pointwise convolutions of stages 2-3
                       (55 % of the FLOPs, the filter-streaming-bound part) on v_mfma_*_fp8_fp8, OCP e4m3,
                       one power-of-two scale per filter; training entry points behave as BTSBOT_BF16 */
+  BTSBOT_F16X2 = 4 /* split operands: every MFMA operand of the pointwise / downsample convolutions is an f16
+                      head plus an f16 remainder (x = hi + lo, 22 significant bits), a product is three
+                      v_mfma_f32_*_f16 (hi*hi + hi*lo + lo*hi) -- scores within 1e-4 of the fp32 reference at
+                      the 16-bit matrix rate; kernels without a split form run the fp32 schedule.  Inference
+                      only: the training entry points behave as BTSBOT_F32 */
 };
 
 typedef struct btsbot_config {
