@@ -71,9 +71,10 @@ int build_tables(btsbot_ctx* h) {
     h->stem_b = add_param(h, "stem.0.bias", {c0});
     h->stem_lnw = add_param(h, "stem.1.weight", {c0});
     h->stem_lnb = add_param(h, "stem.1.bias", {c0});
-    h->stage0 = stage0_supported(c.precision, c0) && c.depths[0] == 2;
+    h->stage0 = stage0_supported(h->prec_s01(), c0) && c.depths[0] == 2;
     h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
-    h->stage1 = stage1_supported(c.precision, c.dims[1], c.dims[2]) && c.depths[1] == 2;
+    if (h->x2 && h->stage0) h->p_x2_stem = bump(cur, (size_t)c0 * 48 * 2);
+    h->stage1 = stage1_supported(h->prec_s01(), c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
     h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
     h->blocks.resize(4);
@@ -92,6 +93,10 @@ int build_tables(btsbot_ctx* h) {
         if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) {
           h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
           h->down[i].p_scale = bump(cur, 64);
+        }
+        if (i == 1 && h->x2 && h->stage0) {
+          h->down[i].p_x2_w = bump(cur, (size_t)ch * cin * 4 * 2);
+          h->down[i].p_x2_wlo = bump(cur, (size_t)ch * cin * 4 * 2);
         }
       }
       for (int j = 0; j < c.depths[i]; ++j) {
@@ -112,7 +117,11 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc2 = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
-                    : (i == 1 && ch == 128 && c.precision != BTSBOT_F32) ? bump(cur, s1par_bytes()) : 0;
+                    : (i == 1 && ch == 128 && (c.precision != BTSBOT_F32 || h->x2)) ? bump(cur, s1par_bytes()) : 0;
+        if (h->x2 && ((i == 0 && h->stage0) || (i == 1 && h->stage1))) {
+          b.p_x2_w1 = bump(cur, (size_t)4 * ch * ch * 2);
+          b.p_x2_w2g = bump(cur, (size_t)4 * ch * ch * 2);
+        }
         if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
@@ -152,7 +161,7 @@ int build_tables(btsbot_ctx* h) {
     h->comb_b[i] = add_param(h, p + "bias", {h->comb_dims[i + 1]});
     h->p_comb[i] = bump(cur, (size_t)h->comb_dims[i + 1] * h->comb_dims[i] * 4);
   }
-  h->head16 = head16_supported(c.precision, h->has_image ? c.dims[3] : 0, h->has_meta ? c.n_meta : 0, c.meta_fc1, c.meta_fc2,
+  h->head16 = head16_supported(h->prec_head(), h->has_image ? c.dims[3] : 0, h->has_meta ? c.n_meta : 0, c.meta_fc1, c.meta_fc2,
                                h->n_comb, h->comb_dims);
   if (h->head16) {
     if (h->has_meta) {
@@ -488,31 +497,40 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s3(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 1, sc, st));
           TRY(launch_pack_s3(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, sc + 2, st));
         }
-        if (i == 1 && ch == 128 && c.precision != BTSBOT_F32 && !train_only)
-          TRY(launch_pack_s1par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw),
+        if (i == 1 && ch == 128 && (c.precision != BTSBOT_F32 || (h->x2 && h->stage1)) && !train_only)
+          TRY(launch_pack_s1par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
-        if (i == 0 && ch == 64 && c.precision != BTSBOT_F32 && !train_only)   // (after the tap-major transpose above: same stream)
-          TRY(launch_pack_s0par(c.precision, reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
+        if (i == 0 && ch == 64 && (c.precision != BTSBOT_F32 || (h->x2 && h->stage0)) && !train_only)   // (after the tap-major transpose above: same stream)
+          TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
+        if (b.p_x2_w1 != 0 && !train_only) {   // split mode, stages 0-1: the pointwise filters stay plain f16
+          TRY(launch_cast(BTSBOT_F16, m + b.fc1_w, h->extra + b.p_x2_w1, (int64_t)4 * ch * ch, st));
+          TRY(launch_rowscale_cast(BTSBOT_F16, m + b.fc2_w, m + b.gamma, h->extra + b.p_x2_w2g, ch, 4 * ch, st));
+        }
         if (b.fused && !train_only)
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
                                     h->extra + b.p_fused, st));
       }
     }
   }
+  if (convnext && h->x2 && h->stage0 && !train_only) {
+    TRY(launch_cast(BTSBOT_F16, m + h->stem_w, h->extra + h->p_x2_stem, (int64_t)c.dims[0] * 48, st));
+    TRY(launch_pack_down_split(m + h->down[1].w, h->extra + h->down[1].p_x2_w, h->extra + h->down[1].p_x2_wlo, c.dims[1],
+                               c.dims[0], st));
+  }
   if (convnext && h->stage1 && !train_only)
-    TRY(launch_pack_frag32(c.precision, m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
+    TRY(launch_pack_frag32(h->prec_s01(), m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
   if (convnext && h->stage2p && !train_only)
     TRY(launch_pack_s2p(h->prec_down3(), m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], nullptr, st));
   if (h->head16 && !train_only) {
     if (h->has_meta) {
-      TRY(launch_pack_h16(c.precision, m + h->m1_w, h->extra + h->p_m1h, c.meta_fc1, c.n_meta, st));
-      TRY(launch_pack_h16(c.precision, m + h->m2_w, h->extra + h->p_m2h, c.meta_fc2, c.meta_fc1, st));
+      TRY(launch_pack_h16(h->prec_head(), m + h->m1_w, h->extra + h->p_m1h, c.meta_fc1, c.n_meta, st));
+      TRY(launch_pack_h16(h->prec_head(), m + h->m2_w, h->extra + h->p_m2h, c.meta_fc2, c.meta_fc1, st));
     }
     for (int i = 0; i < h->n_comb; ++i)
-      TRY(launch_pack_h16(c.precision, m + h->comb_w[i], h->extra + h->p_combh[i], h->comb_dims[i + 1], h->comb_dims[i], st));
+      TRY(launch_pack_h16(h->prec_head(), m + h->comb_w[i], h->extra + h->p_combh[i], h->comb_dims[i + 1], h->comb_dims[i], st));
   }
   if (h->has_meta) {
     TRY(launch_bn_fold(m + h->bn_w, m + h->bn_b, m + h->bn_rm, m + h->bn_rv,
@@ -648,7 +666,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       Stage0Args a;
       memset(&a, 0, sizeof(a));
       a.img = img;
-      a.stem_w = h->extra + h->p_stem16;
+      a.stem_w = h->extra + (h->x2 ? h->p_x2_stem : h->p_stem16);
       a.stem_b = m + h->stem_b;
       a.stem_lnw = m + h->stem_lnw;
       a.stem_lnb = m + h->stem_lnb;
@@ -661,13 +679,14 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.blk[j].b1 = m + b.fc1_b;
         a.blk[j].b2 = m + b.fc2_b;
         a.blk[j].gamma = m + b.gamma;
-        a.blk[j].w1 = h->extra + b.p_fc1;
-        a.blk[j].w2g = h->extra + b.p_fc2g;
+        a.blk[j].w1 = h->extra + (h->x2 ? b.p_x2_w1 : b.p_fc1);
+        a.blk[j].w2g = h->extra + (h->x2 ? b.p_x2_w2g : b.p_fc2g);
         a.blk[j].par = h->extra + b.p_s0par;
       }
       a.ds_lnw = m + h->down[1].ln_w;
       a.ds_lnb = m + h->down[1].ln_b;
-      a.ds_w = h->extra + h->down[1].p_w;
+      a.ds_w = h->extra + (h->x2 ? h->down[1].p_x2_w : h->down[1].p_w);
+      a.ds_w_lo = h->x2 ? h->extra + h->down[1].p_x2_wlo : nullptr;
       a.ds_b = m + h->down[1].b;
       a.out = x;
       a.tap_stem = h->debug ? h->taps[0] : nullptr;
@@ -680,7 +699,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       a.stamps = h->stamps;
       a.wgt = h->stamps ? h->stamps + 32 : nullptr;
       TRY(timed(h, CAT_STAGE0, st, [&] {
-        return launch_stage0b(c.precision, a, st);
+        return launch_stage0b(h->prec_s01(), a, st);
       }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
@@ -723,8 +742,8 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
             a.blk[j].b1 = m + b.fc1_b;
           a.blk[j].b2 = m + b.fc2_b;
           a.blk[j].gamma = m + b.gamma;
-          a.blk[j].w1 = h->extra + b.p_fc1;
-          a.blk[j].w2g = h->extra + b.p_fc2g;
+          a.blk[j].w1 = h->extra + (h->x2 ? b.p_x2_w1 : b.p_fc1);
+          a.blk[j].w2g = h->extra + (h->x2 ? b.p_x2_w2g : b.p_fc2g);
           a.blk[j].par = h->extra + b.p_s0par;
         }
         a.ds_lnw = m + h->down[2].ln_w;
@@ -742,7 +761,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.stamps = h->stamps ? h->stamps + 16 : nullptr;
         a.wgt = h->stamps ? h->stamps + 32 + 2 * 4096 : nullptr;
         TRY(timed(h, CAT_STAGE1, st, [&] {
-          return launch_stage1b(c.precision, a, st);
+          return launch_stage1b(h->prec_s01(), a, st);
         }));
         float* t = x;
         x = x2;
@@ -878,7 +897,7 @@ static int forward_chunk(btsbot_ctx* h, const float* img, const float* meta, flo
     g.scores = scores;
     g.B = nb;
     g.stamps = h->stamps ? h->stamps + 32 + 16384 + 64 + 1500 : nullptr;
-    TRY(timed(h, CAT_HEAD16, st, [&] { return launch_head16(c.precision, g, st); }));
+    TRY(timed(h, CAT_HEAD16, st, [&] { return launch_head16(h->prec_head(), g, st); }));
     h->last_chunk = nb;
     return BTSBOT_OK;
   }

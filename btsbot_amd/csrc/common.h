@@ -391,6 +391,8 @@ int launch_pack_jobs(int prec, const PackJob* dev_jobs, int njobs, int total_blo
 int launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
 // downsample filter [Cout][Cin][2][2] fp32 -> [Cout][(ky*2+kx)*Cin + cin] prec-typed
 int launch_pack_down(int prec, const float* src, void* dst, int Cout, int Cin, hipStream_t st);
+// split mode (BTSBOT_F16X2): the same element order, f16 heads into `hi`, f16 remainders into `lo`
+int launch_pack_down_split(const float* src, void* hi, void* lo, int Cout, int Cin, hipStream_t st);
 // BatchNorm1d eval fold: scale = w / sqrt(rv + eps), shift = b - rm * scale
 int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                    float* shift, int n, hipStream_t st);

@@ -216,6 +216,22 @@ __global__ void pack_down_kernel(const float* __restrict__ s, T* __restrict__ d,
   }
 }
 
+// split mode: the same order as pack_down_kernel, f16 heads in dh and f16 remainders in dl
+__global__ void pack_down_split_kernel(const float* __restrict__ s, f16_t* __restrict__ dh, f16_t* __restrict__ dl,
+                                       int Cout, int Cin) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int q = (int)((i / Cin) & 3);
+    const int co = (int)(i / (4 * (int64_t)Cin));
+    f16_t hi, lo;
+    split_f16(s[((int64_t)co * Cin + ci) * 4 + q], hi, lo);
+    dh[i] = hi;
+    dl[i] = lo;
+  }
+}
+
 template <typename T>
 __global__ void transpose_cast_kernel(const float* __restrict__ s, const float* __restrict__ rowscale,
                                       T* __restrict__ d, int R, int Cc) {
@@ -428,6 +444,14 @@ int launch_pack_down(int prec, const float* src, void* dst, int Cout, int Cin, h
       btsbot_set_error("pack_down: bad precision %d", prec);
       return BTSBOT_ERR_INVALID_ARG;
   }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int launch_pack_down_split(const float* src, void* hi, void* lo, int Cout, int Cin, hipStream_t st) {
+  const int64_t n = (int64_t)Cout * Cin * 4;
+  hipLaunchKernelGGL(pack_down_split_kernel, dim3(nblocks(n)), dim3(256), 0, st, src, reinterpret_cast<f16_t*>(hi),
+                     reinterpret_cast<f16_t*>(lo), Cout, Cin);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }

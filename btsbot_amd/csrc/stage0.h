@@ -23,6 +23,7 @@ struct Stage0Args {
   const float* ds_lnw;
   const float* ds_lnb;
   const void* ds_w;       // [128][256] 16-bit, k = (ky*2+kx)*64 + c
+  const void* ds_w_lo;    // split mode (BTSBOT_F16X2): the f16 remainders of ds_w, same layout; else unused
   const float* ds_b;
   float* out;             // [B][49][128] f32
   float* tap_stem;        // optional [B][225][64] f32 copies (validation)
@@ -41,7 +42,8 @@ struct Stage1Args {
   Stage0Blk blk[2];       // dw_w is [49][128]
   const float* ds_lnw;
   const float* ds_lnb;
-  const void* ds_w;       // 32x32x16 A fragments of the [256][512] filter, k = (ky*2+kx)*128 + c (launch_pack_frag32)
+  const void* ds_w;       // 32x32x16 A fragments of the [256][512] filter, k = (ky*2+kx)*128 + c (launch_pack_frag32);
+                          // split mode (BTSBOT_F16X2): 2 KiB per fragment, heads then remainders
   const float* ds_b;
   float* out;             // [B][9][256] f32
   float* scratch;         // [B][49][128] f32: the residual stream between the two blocks (stage1b.hip)

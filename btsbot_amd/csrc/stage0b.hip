@@ -75,6 +75,8 @@ constexpr int TW_R = 21, TW_BYTES = TW_R * C * 4 * 4 * 2;   // 43008
 constexpr int PF_DWB = 0, PF_LNW = C, PF_LNB = 2 * C, PF_B1 = 3 * C, PF_B2 = PF_B1 + HID, PF_FLOATS = 512;
 static_assert(PF_B2 + C == PF_FLOATS, "parameter image layout");
 constexpr int PARB = TW_BYTES + PF_FLOATS * 4;    // 45056
+// split mode (BTSBOT_F16X2): the taps' f16 remainders follow their heads, the fp32 part comes last
+constexpr int PARB_X2 = 2 * TW_BYTES + PF_FLOATS * 4;
 constexpr int OFF_RING = PLB;
 constexpr int OFF_B1 = OFF_RING + RINGB;          // 256 + 64 floats: this block's fc1 bias, gamma*b2
 constexpr int OFF_ST = OFF_B1 + (HID + C) * 4;    // LayerNorm (rstd, -mean * rstd) per padded pixel slot: 2 x 256 floats
@@ -142,19 +144,22 @@ __device__ __forceinline__ void ln_regs(const f32x16 (&x)[CT], const float* __re
     }
 }
 
-template <typename T>
+// LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind (split mode)
+template <typename T, int LOPLANE = 0>
 __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char* map, int p, int h) {
   typedef T T4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      T4 v;
-      v[0] = (T)x[ct][4 * qd + 0];
-      v[1] = (T)x[ct][4 * qd + 1];
-      v[2] = (T)x[ct][4 * qd + 2];
-      v[3] = (T)x[ct][4 * qd + 3];
+      T4 v, w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (T)x[ct][4 * qd + e];
+        if (LOPLANE > 0) w[e] = (T)(x[ct][4 * qd + e] - (float)v[e]);
+      }
       *reinterpret_cast<T4*>(map + p * PITCH + (ct * 32 + 8 * qd + 4 * h) * 2) = v;
+      if (LOPLANE > 0) *reinterpret_cast<T4*>(map + LOPLANE + p * PITCH + (ct * 32 + 8 * qd + 4 * h) * 2) = w;
     }
 }
 
@@ -208,8 +213,15 @@ template <bool SQ> __device__ __forceinline__ void block_reduce64(const float (&
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
+// X2 (BTSBOT_F16X2, T = f16): the LayerNorm outputs and the hidden activations go to the matrix pipe as f16 head +
+// f16 remainder (two products per k-step against the f16 filters), the depthwise taps likewise (two 4x4x4 products per
+// tap fragment against the f16 map), the downsample with both operands split (three products).  What stays plain f16
+// -- the stem's operands, the map the depthwise phase reads, the pointwise filters -- is budgeted in DESIGN.md
+// (tools/error_budget2.py): 1.4e-5 rms of the 1e-4 score tolerance for the whole network.
+// WPS = waves per SIMD the register allocation leaves room for (2: two workgroups per CU, 256 registers; 1: one
+// workgroup per CU with 512 registers -- the split mode's doubled fragments spill at 256)
+template <typename T, bool X2, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   using frag = typename SBM<T>::frag;
   using frag4 = typename SBM<T>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -239,14 +251,18 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
   SB_STAMP(0);
   // a block's Toeplitz taps (16 channels x 4 rows x 21 fragments per wave, lane-linear 8-byte loads) and its
   // per-lane scalars: requested one phase ahead of the depthwise convolution that needs them
-  frag4 tw[TW_R];
+  frag4 tw[TW_R], twl[X2 ? TW_R : 1];
   float dwbias, lng, lnb2, b1v, b2v;
   auto load_block_params = [&](int j) {
     const Stage0Blk& bk = a.blk[j];
     const uint2* src = reinterpret_cast<const uint2*>(bk.par) + wave * 64 + lane;
 #pragma unroll
     for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, src[r * 256]);
-    const float* pf = reinterpret_cast<const float*>(bk.par + TW_BYTES);
+    if (X2) {
+#pragma unroll
+      for (int r = 0; r < TW_R; ++r) twl[r] = __builtin_bit_cast(frag4, src[TW_BYTES / 8 + r * 256]);
+    }
+    const float* pf = reinterpret_cast<const float*>(bk.par + (X2 ? 2 : 1) * TW_BYTES);
     dwbias = pf[PF_DWB + dch];
     lng = pf[PF_LNW + dch];
     lnb2 = pf[PF_LNB + dch];
@@ -382,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
               const int q = xb + rbi - 1;
               if (q < 0 || q > 3) continue;
               acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+              if (X2) acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
             }
         }
       }
@@ -415,7 +432,9 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
       st[256 + tid] = -mean * rstd;
     }
     __syncthreads();
-    {
+    // the LayerNorm output into the [pixel][channel] image: its f16 values, or (split mode, second pass through the same
+    // bytes) their f16 remainders
+    auto write_ln = [&](bool lo_pass) {
       T* mo = reinterpret_cast<T*>(map) + dch;
 #pragma unroll
       for (int yb = 0; yb < 4; ++yb)
@@ -430,22 +449,34 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
             for (int i = 0; i < 4; ++i) {
               if (xb == 3 && i == 3) continue;   // column 15 is padding
               const float y = fmaf(fmaf(v[yb * 16 + xb * 4 + i], rr[i], mm[i]), lng, lnb2);
-              mo[((4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = (T)y;
+              const T yh = (T)y;
+              mo[((4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = lo_pass ? (T)(y - (float)yh) : yh;
             }
           }
         }
-    }
+    };
+    write_ln(false);
     SB_STAMP(5 + 5 * j);
     __syncthreads();   // LN image complete
 
     // ---- fc1 -> GELU -> fc2 over 8 chunks; fc2 accumulates into x (gamma is in the filter)
     {
-      frag xf[2][4];
+      frag xf[2][4], xfl[X2 ? 2 : 1][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           xf[t][ks] = *reinterpret_cast<const frag*>(map + pix[t] * PITCH + ks * 32 + h * 16);
+      if (X2) {   // the remainders through the same image bytes
+        __syncthreads();
+        write_ln(true);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            xfl[t][ks] = *reinterpret_cast<const frag*>(map + pix[t] * PITCH + ks * 32 + h * 16);
+      }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -505,7 +536,10 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) hacc[t][4 * qd + e] = bq[qd][e];
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
+          for (int ks = 0; ks < 4; ++ks) {
+            hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
+            if (X2) hacc[t] = SBM<T>::run(a1[ks], xfl[t][ks], hacc[t]);
+          }
         }
         // (issued here, not at the barrier: an LDS-DMA holds the issuing wave ~90 cycles per
         //  instruction, which now passes while the fc1 MFMAs drain)
@@ -515,11 +549,18 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
           // GELU in two halves, each followed by the fc2 MFMAs that consume it
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
-            frag hf;
+            frag hf, hfl;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) hf[r] = (T)gelu_for<T>(hacc[t][8 * s2 + r]);
+            for (int r = 0; r < 8; ++r) {
+              const float gv = gelu_for<T>(hacc[t][8 * s2 + r]);
+              hf[r] = (T)gv;
+              if (X2) hfl[r] = (T)(gv - (float)hf[r]);
+            }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) x[t][ct] = SBM<T>::run(a2[ct][s2], hf, x[t][ct]);
+            for (int ct = 0; ct < CT; ++ct) {
+              x[t][ct] = SBM<T>::run(a2[ct][s2], hf, x[t][ct]);
+              if (X2) x[t][ct] = SBM<T>::run(a2[ct][s2], hfl, x[t][ct]);
+            }
           }
         }
       }
@@ -544,15 +585,23 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
     // wave -> 32 output channels (cot = wave) x the 49 output pixels (2 column blocks); K = 4 x 64
     // (filter fragments requested first: their L2 latency passes under the LayerNorm below)
     const T* dw = reinterpret_cast<const T*>(a.ds_w) + (size_t)(wave * 32 + lr) * 256 + h * 8;
-    frag af[16];
+    frag af[16], afl[X2 ? 16 : 1];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const frag*>(dw + ks * 16);
     // (every wave loaded its xf from the last block's LN image before that MLP's second barrier)
+    constexpr int MAPB = 256 * PITCH;   // split mode: the remainder image follows (into the filter ring's bytes)
+    static_assert(2 * MAPB <= OFF_B1, "two [pixel][channel] images in front of the bias words");
+    if (X2) __syncthreads();            // ... which every wave must have read out
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x16 xn[CT];
       ln_regs(x[t], a.ds_lnw, a.ds_lnb, h, xn);
-      regs_to_map<T>(xn, map, pix[t], h);
+      regs_to_map<T, X2 ? MAPB : 0>(xn, map, pix[t], h);
+    }
+    if (X2) {
+      const T* dwl = reinterpret_cast<const T*>(a.ds_w_lo) + (size_t)(wave * 32 + lr) * 256 + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) afl[ks] = *reinterpret_cast<const frag*>(dwl + ks * 16);
     }
     __syncthreads();
     SB_STAMP(12);
@@ -576,6 +625,11 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
         const int q = ks >> 2;
         const int pin = (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
         const frag bf = *reinterpret_cast<const frag*>(map + pin * PITCH + (ks & 3) * 32 + h * 16);
+        if (X2) {
+          const frag bfl = *reinterpret_cast<const frag*>(map + MAPB + pin * PITCH + (ks & 3) * 32 + h * 16);
+          acc = SBM<T>::run(afl[ks], bf, acc);
+          acc = SBM<T>::run(af[ks], bfl, acc);
+        }
         acc = SBM<T>::run(af[ks], bf, acc);
       }
       if (olive) {
@@ -591,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void stage0b_kernel(Stage0Args a) {
 }
 
 // one block's parameter image (layout at TW_R / PF_* above); taps tap-major [49][64] fp32
-template <typename T>
+template <typename T, bool X2>
 __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                   const float* __restrict__ b1, const float* __restrict__ b2,
@@ -602,7 +656,9 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
     const int k = idx & 3, i = (idx >> 2) & 3, c = (idx >> 4) & (C - 1), r = idx >> 10;
     const int ky = r / 3, rb = r % 3 - 1, kx = 4 * rb + k - i + 3;
     const float w = (kx >= 0 && kx < 7) ? taps[(ky * 7 + kx) * C + c] : 0.f;
-    reinterpret_cast<T*>(out)[idx] = (T)w;
+    const T wh = (T)w;
+    reinterpret_cast<T*>(out)[idx] = wh;
+    if (X2) reinterpret_cast<T*>(out)[NTW + idx] = (T)(w - (float)wh);
     return;
   }
   const int f = idx - NTW;
@@ -613,11 +669,11 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
   else if (f < PF_B1) v = ln_b[f - PF_LNB];
   else if (f < PF_B2) v = b1[f - PF_B1];
   else v = gamma[f - PF_B2] * b2[f - PF_B2];
-  reinterpret_cast<float*>(out + TW_BYTES)[f] = v;
+  reinterpret_cast<float*>(out + (X2 ? 2 : 1) * TW_BYTES)[f] = v;
 }
 
-template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
-  auto kern = stage0b_kernel<T>;
+template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
+  auto kern = stage0b_kernel<T, X2, WPS>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -631,7 +687,32 @@ template <typename T> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) 
 
 }  // namespace
 
-size_t s0par_bytes() { return PARB; }
+#ifdef STAGE0B_X2_TU
+// ---- this translation unit (stage0x.hip) holds only the split-operand instantiation: co-compiled instantiations of
+//      one kernel template share the register allocator's context and move each other's spills
+int launch_stage0b_x2(const Stage0Args& a, hipStream_t st) {
+  // one workgroup per CU with 512 registers (WPS 1) or two with 256 and spills (WPS 2): measured on MI355X at B = 1024,
+  // stage0b 246 / 229 us, stage1b 165 / 183 us -- each kernel defaults to its faster form; BTSBOT_AMD_X2_WPS=1|2 forces one
+  static const int wps = [] {
+    const char* e = getenv("BTSBOT_AMD_X2_WPS");
+    return e != nullptr && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 2;
+  }();
+  return wps == 2 ? launch_stage0b_t<f16_t, true, 2>(a, st) : launch_stage0b_t<f16_t, true, 1>(a, st);
+}
+int launch_pack_s0par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, const float* b1,
+                         const float* b2, const float* gamma, void* out, hipStream_t st) {
+  const dim3 grid((TW_R * C * 16 + PF_FLOATS + 255) / 256), blk(256);
+  hipLaunchKernelGGL((pack_s0par_kernel<f16_t, true>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma,
+                     reinterpret_cast<unsigned char*>(out));
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+#else
+int launch_stage0b_x2(const Stage0Args& a, hipStream_t st);
+int launch_pack_s0par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, const float* b1,
+                         const float* b2, const float* gamma, void* out, hipStream_t st);
+
+size_t s0par_bytes() { return PARB_X2; }   // (the split mode's image is the larger one)
 
 // taps: the block's depthwise filter tap-major [49][64] fp32; the others the master parameters
 int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const float* ln_w, const float* ln_b,
@@ -639,9 +720,11 @@ int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const floa
   const dim3 grid((TW_R * C * 16 + PF_FLOATS + 255) / 256), blk(256);
   unsigned char* o = reinterpret_cast<unsigned char*>(out);
   if (prec == BTSBOT_BF16)
-    hipLaunchKernelGGL(pack_s0par_kernel<bf16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
+    hipLaunchKernelGGL((pack_s0par_kernel<bf16_t, false>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
   else if (prec == BTSBOT_F16)
-    hipLaunchKernelGGL(pack_s0par_kernel<f16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
+    hipLaunchKernelGGL((pack_s0par_kernel<f16_t, false>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b, b1, b2, gamma, o);
+  else if (prec == BTSBOT_F16X2)
+    return launch_pack_s0par_x2(taps, dw_b, ln_w, ln_b, b1, b2, gamma, out, st);
   else {
     btsbot_set_error("pack_s0par: precision %d is not a 16-bit mode", prec);
     return BTSBOT_ERR_INVALID_ARG;
@@ -651,7 +734,7 @@ int launch_pack_s0par(int prec, const float* taps, const float* dw_b, const floa
 }
 
 bool stage0_supported(int prec, int c0) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c0 == 64;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_F16X2) && c0 == 64;
 }
 
 // Needs Stage0Blk::par, ::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.
@@ -659,6 +742,14 @@ int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage0b_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage0b_t<f16_t>(a, st);
+  if (prec == BTSBOT_F16X2) {
+    if (a.ds_w_lo == nullptr) {
+      btsbot_set_error("stage0b: the split mode needs the downsample filter's remainders (ds_w_lo)");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    return launch_stage0b_x2(a, st);
+  }
   btsbot_set_error("stage0b: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
 }
+#endif

@@ -77,6 +77,8 @@ constexpr float LN_EPS = 1e-6f;
 // then fp32: dw bias [128] | LN weight [128] | LN bias [128]
 constexpr int TW_R = 21, TW_BYTES = TW_R * C * 4 * 4 * 2;   // 86016
 constexpr int PARB = TW_BYTES + 3 * C * 4;        // 87552
+// split mode (BTSBOT_F16X2): the taps' f16 remainders follow their heads, the fp32 part comes last
+constexpr int PARB_X2 = 2 * TW_BYTES + 3 * C * 4;
 
 #define SC_STAMP(i)                                                                \
   do {                                                                             \
@@ -157,19 +159,22 @@ __device__ __forceinline__ void ln_regs(const f32x16 (&x)[CT], const float* __re
     }
 }
 
-template <typename T>
+// LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind (split mode)
+template <typename T, int LOPLANE = 0>
 __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char* map, int p, int h) {
   typedef T __attribute__((ext_vector_type(4))) T4;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      T4 v;
-      v[0] = (T)x[ct][4 * qd + 0];
-      v[1] = (T)x[ct][4 * qd + 1];
-      v[2] = (T)x[ct][4 * qd + 2];
-      v[3] = (T)x[ct][4 * qd + 3];
+      T4 v, w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (T)x[ct][4 * qd + e];
+        if (LOPLANE > 0) w[e] = (T)(x[ct][4 * qd + e] - (float)v[e]);
+      }
       *reinterpret_cast<T4*>(map + p * PITCH + (ct * 32 + 8 * qd + 4 * h) * 2) = v;
+      if (LOPLANE > 0) *reinterpret_cast<T4*>(map + LOPLANE + p * PITCH + (ct * 32 + 8 * qd + 4 * h) * 2) = w;
     }
 }
 
@@ -187,8 +192,12 @@ __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned c
       *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = (T)x[ct][r];
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
+// X2 (BTSBOT_F16X2, T = f16): as in stage0b.hip -- LayerNorm outputs and hidden activations as f16 head + remainder
+// (two products per k-step against the f16 filters), the depthwise taps likewise, the downsample with both operands split.
+// WPS = waves per SIMD the register allocation leaves room for (2: two workgroups per CU, 256 registers; 1: one
+// workgroup per CU with 512 registers -- the split mode's doubled fragments spill at 256)
+template <typename T, bool X2, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   using frag = typename SCM<T>::frag;
   using frag4 = typename SCM<T>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -266,10 +275,14 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     const float b1v0 = bk.b1[tid], b1v1 = bk.b1[256 + tid];
     const float b2v = bk.gamma[tid & (C - 1)] * bk.b2[tid & (C - 1)];
     const uint2* twsrc = reinterpret_cast<const uint2*>(bk.par) + (2 * wave) * 64 + ln;
-    frag4 tw[TW_R];
+    frag4 tw[TW_R], twl[X2 ? TW_R : 1];
 #pragma unroll
     for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, twsrc[r * 512]);
-    const float* pf = reinterpret_cast<const float*>(bk.par + TW_BYTES);
+    if (X2) {
+#pragma unroll
+      for (int r = 0; r < TW_R; ++r) twl[r] = __builtin_bit_cast(frag4, twsrc[TW_BYTES / 8 + r * 512]);
+    }
+    const float* pf = reinterpret_cast<const float*>(bk.par + (X2 ? 2 : 1) * TW_BYTES);
     float dwbias[2], lng[2], lnb2[2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
@@ -339,6 +352,10 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
       if (gi == 1) {   // the second group's taps into the same registers (their last use is behind us)
 #pragma unroll
         for (int r = 0; r < TW_R; ++r) tw[r] = __builtin_bit_cast(frag4, twsrc[r * 512 + 64]);
+        if (X2) {
+#pragma unroll
+          for (int r = 0; r < TW_R; ++r) twl[r] = __builtin_bit_cast(frag4, twsrc[TW_BYTES / 8 + r * 512 + 64]);
+        }
       }
 #pragma unroll
       for (int al = 0; al < G; ++al) {
@@ -365,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
                 const int q = xb + rbi - 1;
                 if (q < 0 || q > 1) continue;
                 acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+                if (X2) acc[yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
               }
           }
         }
@@ -412,7 +430,9 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
       st[128 + tid] = -mean * rstd;
     }
     __syncthreads();
-    {
+    // the LayerNorm output into the [pixel][channel] image: its f16 values, or (split mode, second pass through the same
+    // bytes) their f16 remainders
+    auto write_ln = [&](bool lo_pass) {
 #pragma unroll
       for (int gi = 0; gi < 2; ++gi) {
         T* mo = reinterpret_cast<T*>(stg) + 16 * (2 * wave + gi) + db;
@@ -431,12 +451,14 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
                 for (int i = 0; i < 4; ++i) {
                   if (xb == 1 && i == 3) continue;   // column 7 is padding
                   const float y = fmaf(fmaf(v[gi][al][yb * 8 + xb * 4 + i], rr[i], mm[i]), lng[gi], lnb2[gi]);
-                  mo[(al * PA + (4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = (T)y;
+                  const T yh = (T)y;
+                  mo[(al * PA + (4 * yb + dj) * HW + 4 * xb + i) * (PITCH / 2)] = lo_pass ? (T)(y - (float)yh) : yh;
                 }
               }
             }
       }
-    }
+    };
+    write_ln(false);
     __syncthreads();   // LN image complete
     issue(0);          // chunk 0 lives in slot 2 = the (dead) planar image's first 16 KB
     SC_STAMP(5 + 5 * j);
@@ -450,10 +472,18 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     //      (gamma is in the filter).
     load_x(j == 0 ? xsrc : xscr, x);
     {
-      frag xf[KS1];
+      frag xf[KS1], xfl[X2 ? KS1 : 1];
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks)
         xf[ks] = *reinterpret_cast<const frag*>(stg + pm * PITCH + ks * 32 + h * 16);
+      if (X2) {   // the remainders through the same image bytes
+        __syncthreads();
+        write_ln(true);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+          xfl[ks] = *reinterpret_cast<const frag*>(stg + pm * PITCH + ks * 32 + h * 16);
+      }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -505,7 +535,10 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         bias_acc(0, hacc[0]);
         read_a1(0, a1);
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) hacc[0] = SCM<T>::run(a1[ks], xf[ks], hacc[0]);
+        for (int ks = 0; ks < KS1; ++ks) {
+          hacc[0] = SCM<T>::run(a1[ks], xf[ks], hacc[0]);
+          if (X2) hacc[0] = SCM<T>::run(a1[ks], xfl[ks], hacc[0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         wait_vm<0>();   // W1(1), W1(2) / W2(1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -541,29 +574,42 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         float g[16];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          if (!LAST) hn = SCM<T>::run(a1[r], xf[r], hn);
+          if (!LAST) {
+            hn = SCM<T>::run(a1[r], xf[r], hn);
+            if (X2) hn = SCM<T>::run(a1[r], xfl[r], hn);
+          }
           g[r] = gelu_for<T>(hc[r]);
           if (r & 1) issue_piece(kdma, r >> 1);
           __builtin_amdgcn_sched_barrier(0);
         }
         LS(5);
         if (!LAST) read_a1(ch + 2, a1);
-        frag hf;
+        frag hf, hfl;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) hf[r] = (T)g[r];
+        for (int r = 0; r < 8; ++r) {
+          hf[r] = (T)g[r];
+          if (X2) hfl[r] = (T)(g[r] - (float)hf[r]);
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           x[ct] = SCM<T>::run(a2[ct][0], hf, x[ct]);
+          if (X2) x[ct] = SCM<T>::run(a2[ct][0], hfl, x[ct]);
           g[8 + 2 * ct] = gelu_for<T>(hc[8 + 2 * ct]);
           g[9 + 2 * ct] = gelu_for<T>(hc[9 + 2 * ct]);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (!LAST) bias_acc(ch + 2, hc);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) hf[r] = (T)g[8 + r];
+        for (int r = 0; r < 8; ++r) {
+          hf[r] = (T)g[8 + r];
+          if (X2) hfl[r] = (T)(g[8 + r] - (float)hf[r]);
+        }
         LS(6);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) x[ct] = SCM<T>::run(a2[ct][1], hf, x[ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          x[ct] = SCM<T>::run(a2[ct][1], hf, x[ct]);
+          if (X2) x[ct] = SCM<T>::run(a2[ct][1], hfl, x[ct]);
+        }
         LS(7);
       };
 #pragma unroll 1
@@ -611,16 +657,23 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     {
       f32x16 xn[CT];
       ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn);
-      if (inmap) regs_to_map<T>(xn, stg, p, h);
+      if (inmap) regs_to_map<T, X2 ? MAPB : 0>(xn, stg, p, h);   // (split: the remainder image behind it, dead bytes too)
     }
+    static_assert(2 * MAPB <= OFF_B1, "two [pixel][channel] images in front of the bias words");
     // this wave's output tiles wave, wave + 4 (32 channels each) x 32 k-steps: 64 filter fragments packed as
     // MFMA A operands (1 KiB each, launch_pack_frag32), a ring of 16 in flight
-    constexpr int KSD = 4 * C / 16, RING = 16, NSTEP = 2 * KSD;
+    constexpr int KSD = 4 * C / 16, RING = X2 ? 8 : 16, NSTEP = 2 * KSD;
+    // (split: a packed fragment is 2 KiB, the heads' 1 KiB then the remainders')
     const frag* wsrc = reinterpret_cast<const frag*>(a.ds_w) + lane;
-    auto fsrc = [&](int stp) { return wsrc + (size_t)((wave + 4 * (stp >> 5)) * KSD + (stp & (KSD - 1))) * 64; };
-    frag wq[RING];
+    auto fsrc = [&](int stp) {
+      return wsrc + (size_t)((wave + 4 * (stp >> 5)) * KSD + (stp & (KSD - 1))) * (X2 ? 128 : 64);
+    };
+    frag wq[RING], wql[X2 ? RING : 1];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) wq[i] = *fsrc(i);
+    for (int i = 0; i < RING; ++i) {
+      wq[i] = *fsrc(i);
+      if (X2) wql[i] = fsrc(i)[64];
+    }
     __syncthreads();
     SC_STAMP(12);
     const int o = lr;                                // output pixel slot: 18 of 32 used
@@ -629,10 +682,11 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
     const int g = oc / PO, oo = oc - g * PO;
     const int oy = oo / 3, ox = oo - oy * 3;
     f32x16 acc;
+    constexpr int RPT = KSD / RING;   // ring rounds per output tile
 #pragma unroll 1
     for (int rd = 0; rd < NSTEP / RING; ++rd) {
-      const int cot = wave + 4 * (rd >> 1);
-      if ((rd & 1) == 0) {
+      const int cot = wave + 4 * (rd / RPT);
+      if (rd % RPT == 0) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const float4 bv = *reinterpret_cast<const float4*>(a.ds_b + cot * 32 + 8 * qd + 4 * h);
@@ -648,10 +702,18 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
         const int q = ks >> 3;                     // tap (ky*2 + kx): 8 k-steps of 16 channels each
         const int pin = g * PA + (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
         const frag bf = *reinterpret_cast<const frag*>(stg + pin * PITCH + (ks & 7) * 32 + h * 16);
+        if (X2) {
+          const frag bfl = *reinterpret_cast<const frag*>(stg + MAPB + pin * PITCH + (ks & 7) * 32 + h * 16);
+          acc = SCM<T>::run(wql[i], bf, acc);
+          acc = SCM<T>::run(wq[i], bfl, acc);
+        }
         acc = SCM<T>::run(wq[i], bf, acc);
-        if (stp + RING < NSTEP) wq[i] = *fsrc(stp + RING);
+        if (stp + RING < NSTEP) {
+          wq[i] = *fsrc(stp + RING);
+          if (X2) wql[i] = fsrc(stp + RING)[64];
+        }
       }
-      if ((rd & 1) == 1 && olive) {
+      if (rd % RPT == RPT - 1 && olive) {
         float* dst = a.out + ((size_t)a0 * PO + o) * CN + cot * 32 + 4 * h;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
@@ -664,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void stage1b_kernel(Stage1Args a) {
 }
 
 // one block's parameter image (layout at TW_R above); taps: tap-major [49][128] fp32
-template <typename T>
+template <typename T, bool X2>
 __global__ void pack_s1par_kernel(const float* __restrict__ taps, const float* __restrict__ dw_b,
                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                   unsigned char* __restrict__ out) {
@@ -674,7 +736,9 @@ __global__ void pack_s1par_kernel(const float* __restrict__ taps, const float* _
     const int k = idx & 3, i = (idx >> 2) & 3, c = (idx >> 4) & (C - 1), r = idx / (16 * C);
     const int ky = r / 3, rb = r % 3 - 1, kx = 4 * rb + k - i + 3;
     const float w = (kx >= 0 && kx < 7) ? taps[(ky * 7 + kx) * C + c] : 0.f;
-    reinterpret_cast<T*>(out)[idx] = (T)w;
+    const T wh = (T)w;
+    reinterpret_cast<T*>(out)[idx] = wh;
+    if (X2) reinterpret_cast<T*>(out)[NTW + idx] = (T)(w - (float)wh);
     return;
   }
   const int f = idx - NTW;
@@ -683,12 +747,12 @@ __global__ void pack_s1par_kernel(const float* __restrict__ taps, const float* _
   if (f < C) v = dw_b[f];
   else if (f < 2 * C) v = ln_w[f - C];
   else v = ln_b[f - 2 * C];
-  reinterpret_cast<float*>(out + TW_BYTES)[f] = v;
+  reinterpret_cast<float*>(out + (X2 ? 2 : 1) * TW_BYTES)[f] = v;
 }
 
 // fp32 downsample filter [Cout][Cin][2][2] -> 32x32x16 A fragments [row tile][k-step][lane][8], lane l holds row
 // (l & 31), k = 16 s + 8 (l >> 5) + j of its tile, k = (2 ky + kx) * Cin + c
-template <typename T>
+template <typename T, bool X2 = false>
 __global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cin) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int K = 4 * cin;
@@ -699,11 +763,18 @@ __global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ 
   const int sk = (int)(fs % ksteps), tile = (int)(fs / ksteps);
   const int row = 32 * tile + (l & 31), k = 16 * sk + 8 * (l >> 5) + j;
   const int q = k / cin, c = k - q * cin;
-  out[i] = (T)w[((long)row * cin + c) * 4 + q];
+  const float v = w[((long)row * cin + c) * 4 + q];
+  const T vh = (T)v;
+  if (X2) {   // 2 KiB per fragment: [lane][8] heads, then [lane][8] remainders
+    out[fs * 1024 + l * 8 + j] = vh;
+    out[fs * 1024 + 512 + l * 8 + j] = (T)(v - (float)vh);
+  } else {
+    out[i] = vh;
+  }
 }
 
-template <typename T> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
-  auto kern = stage1b_kernel<T>;
+template <typename T, bool X2 = false, int WPS = 2> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
+  auto kern = stage1b_kernel<T, X2, WPS>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -717,16 +788,50 @@ template <typename T> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) 
 
 }  // namespace
 
-size_t s1par_bytes() { return PARB; }
+#ifdef STAGE1B_X2_TU
+// ---- this translation unit (stage1x.hip) holds only the split-operand instantiations (see stage0b.hip)
+int launch_stage1b_x2(const Stage1Args& a, hipStream_t st) {
+  // one workgroup per CU with 512 registers (WPS 1) or two with 256 and spills (WPS 2): measured on MI355X at B = 1024,
+  // stage0b 246 / 229 us, stage1b 165 / 183 us -- each kernel defaults to its faster form; BTSBOT_AMD_X2_WPS=1|2 forces one
+  static const int wps = [] {
+    const char* e = getenv("BTSBOT_AMD_X2_WPS");
+    return e != nullptr && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 1;
+  }();
+  return wps == 2 ? launch_stage1b_t<f16_t, true, 2>(a, st) : launch_stage1b_t<f16_t, true, 1>(a, st);
+}
+int launch_pack_s1par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, void* out,
+                         hipStream_t st) {
+  const dim3 grid((TW_R * C * 16 + 3 * C + 255) / 256), blk(256);
+  hipLaunchKernelGGL((pack_s1par_kernel<f16_t, true>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b,
+                     reinterpret_cast<unsigned char*>(out));
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+int launch_pack_frag32_x2(const float* src, void* dst, int cout, int cin, hipStream_t st) {
+  const long total = (long)cout * 4 * cin;
+  hipLaunchKernelGGL((pack_frag32_kernel<f16_t, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src,
+                     reinterpret_cast<f16_t*>(dst), cout, cin);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+#else
+int launch_stage1b_x2(const Stage1Args& a, hipStream_t st);
+int launch_pack_s1par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, void* out,
+                         hipStream_t st);
+int launch_pack_frag32_x2(const float* src, void* dst, int cout, int cin, hipStream_t st);
+
+size_t s1par_bytes() { return PARB_X2; }   // (the split mode's image is the larger one)
 
 int launch_pack_s1par(int prec, const float* taps, const float* dw_b, const float* ln_w,
                       const float* ln_b, void* out, hipStream_t st) {
   unsigned char* o = reinterpret_cast<unsigned char*>(out);
   const dim3 grid((TW_R * C * 16 + 3 * C + 255) / 256), blk(256);
   if (prec == BTSBOT_BF16)
-    hipLaunchKernelGGL(pack_s1par_kernel<bf16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
+    hipLaunchKernelGGL((pack_s1par_kernel<bf16_t, false>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
   else if (prec == BTSBOT_F16)
-    hipLaunchKernelGGL(pack_s1par_kernel<f16_t>, grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
+    hipLaunchKernelGGL((pack_s1par_kernel<f16_t, false>), grid, blk, 0, st, taps, dw_b, ln_w, ln_b, o);
+  else if (prec == BTSBOT_F16X2)
+    return launch_pack_s1par_x2(taps, dw_b, ln_w, ln_b, out, st);
   else {
     btsbot_set_error("pack_s1par: precision %d is not a 16-bit mode", prec);
     return BTSBOT_ERR_INVALID_ARG;
@@ -743,6 +848,8 @@ int launch_pack_frag32(int prec, const float* src, void* dst, int cout, int cin,
     hipLaunchKernelGGL(pack_frag32_kernel<bf16_t>, grid, blk, 0, st, src, reinterpret_cast<bf16_t*>(dst), cout, cin);
   else if (prec == BTSBOT_F16)
     hipLaunchKernelGGL(pack_frag32_kernel<f16_t>, grid, blk, 0, st, src, reinterpret_cast<f16_t*>(dst), cout, cin);
+  else if (prec == BTSBOT_F16X2)
+    return launch_pack_frag32_x2(src, dst, cout, cin, st);
   else {
     btsbot_set_error("pack_frag32: precision %d is not a 16-bit mode", prec);
     return BTSBOT_ERR_INVALID_ARG;
@@ -752,7 +859,7 @@ int launch_pack_frag32(int prec, const float* src, void* dst, int cout, int cin,
 }
 
 bool stage1_supported(int prec, int c1, int c2) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && c1 == 128 && c2 == 256;
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_F16X2) && c1 == 128 && c2 == 256;
 }
 
 // Needs Stage0Blk::par (launch_pack_s1par), ::w1 (plain [512][128]) and Stage0Blk::w2g (gamma-scaled [128][512]), 16-bit,
@@ -761,6 +868,8 @@ int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16) return launch_stage1b_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage1b_t<f16_t>(a, st);
+  if (prec == BTSBOT_F16X2) return launch_stage1b_x2(a, st);
   btsbot_set_error("stage1b: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
 }
+#endif

@@ -2,9 +2,14 @@
 btsbot_amd modules, against the CPU oracle and the committed reference-wrapper goldens.
 
 Tolerances (the reference's own notion of "same output" is rtol 1e-4 / atol 1e-5 on fp32 logits,
-/root/reference/btsbot/to_onnx.py:135-137; the north star asks for scores within 1e-4).  Every bound is at most
-twice what is measured on these seeds, so a numerical regression fails the suite:
-  f32  mode: |dlogit| <= 1e-4 * max(1, max|logit|)  and  |dscore| <= 1e-5   (measured 7e-6 / 2e-6)
+/root/reference/btsbot/to_onnx.py:135-137; the north star asks for scores within 1e-4).  The two modes that claim the
+north star are held to ITS constant, |dscore| <= 1e-4 (f16x2) and 1e-5 (f32); the plain 16-bit modes do not meet it
+with these stress weights and are held to at most twice what is measured on these seeds, so a numerical regression
+fails the suite:
+  f32   mode: |dlogit| <= 1e-4 * max(1, max|logit|)  and  |dscore| <= 1e-5   (measured 7e-6 / 2e-6)
+  f16x2 mode: |dscore| <= 1e-4, the north-star tolerance itself (split operands: f16 head + f16 remainder; measured
+             6.9e-5 at B = 1024 with layer-scale gamma ~ 1, of which the operands left plain f16 -- the depthwise
+             input map and the pointwise filters of stages 0-1, the stem -- own all of it: tools/error_budget2.py)
   f16  mode: |dscore| <= 3e-4   (measured 1.4e-4 at B = 39, 1.7e-4 at B = 1024 with layer-scale gamma ~ 1;
              5e-5 with gamma ~ 0.1, test_f16_meets_1e4_at_trained_like_layer_scale)
   bf16 mode: |dscore| <= 2.5e-3 (measured 1.0e-3 .. 1.3e-3, gamma ~ 1)
@@ -27,7 +32,12 @@ from oracle import convnext_oracle as O   # checker only
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL_SCORE = {"f32": 1e-5, "f16": 3e-4, "bf16": 2.5e-3, "fp8": 3.5e-2}
+NORTH_STAR = 1e-4                       # BASELINE.json: "scores within 1e-4 of the reference"
+TOL_SCORE = {"f32": 1e-5, "f16x2": NORTH_STAR, "f16": 3e-4, "bf16": 2.5e-3, "fp8": 3.5e-2}
+# |dlogit| <= TOL_LOGIT_REL * max(1, max|logit|): the score bound alone is vacuous where the logits are large and the
+# sigmoid saturated (the MaxViT wirings with seeded weights); at most twice what is measured
+# (measured worst over the wirings, tools/logit_tol.py: 1.4e-6 / 2.3e-4 / 9.2e-4 / 5.4e-3 / 5.5e-2)
+TOL_LOGIT_REL = {"f32": 1e-4, "f16x2": 4.5e-4, "f16": 1.8e-3, "bf16": 1.1e-2, "fp8": 0.11}
 
 
 def _oracle(kind, cfg, sd, img, meta):
@@ -41,15 +51,14 @@ def _check(out, ref, prec):
     assert torch.isfinite(out).all()
     ds = (torch.sigmoid(out) - torch.sigmoid(ref)).abs().max().item()
     assert ds <= TOL_SCORE[prec], f"{prec}: max|dscore| {ds}"
-    if prec == "f32":
-        scale = max(1.0, ref.abs().max().item())
-        dl = (out - ref).abs().max().item()
-        assert dl <= 1e-4 * scale, f"f32: max|dlogit| {dl} (scale {scale})"
+    scale = max(1.0, ref.abs().max().item())
+    dl = (out - ref).abs().max().item()
+    assert dl <= TOL_LOGIT_REL[prec] * scale, f"{prec}: max|dlogit| {dl} (scale {scale})"
     return ds
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
-@pytest.mark.parametrize("prec", ["f32", "bf16", "f16", "fp8"])
+@pytest.mark.parametrize("prec", ["f32", "f16x2", "bf16", "f16", "fp8"])
 def test_forward_matches_oracle(cuda, name, prec):
     kind, cfg = CONFIGS[name]
     sd = seeded_state(kind, cfg, seed=3)
@@ -104,6 +113,20 @@ def test_ragged_batches(cuda, batch):
     m = build_model(kind, cfg, sd, cuda, "f32")
     out = run_model(kind, m, img.to(cuda), meta.to(cuda))
     _check(out, ref, "f32")
+
+
+@pytest.mark.parametrize("batch", [1, 3, 7, 9, 2049])
+def test_ragged_batches_split_mode(cuda, batch):
+    """The split-operand kernels' partial workgroups (1 / 2 / 4 alerts per workgroup in stages 0 / 1 / 2, 32- and
+    64-alert tiles in stage 3, 16 per head workgroup) and one alert past the internal 2048-alert chunk."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(min(batch, 64), seed=9)
+    reps = (batch + img.shape[0] - 1) // img.shape[0]
+    img, meta = img.repeat(reps, 1, 1, 1)[:batch], meta.repeat(reps, 1)[:batch]
+    ref = _oracle(kind, cfg, sd, img[:64], meta[:64]).repeat(reps, 1)[:batch]
+    m = build_model(kind, cfg, sd, cuda, "f16x2")
+    _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, "f16x2")
 
 
 def test_empty_batch(cuda):
@@ -161,10 +184,11 @@ def test_large_batch_properties(cuda):
     assert torch.isfinite(full).all()
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["f16x2", "bf16", "f16"])
 def test_full_size_batch_matches_oracle(cuda, prec):
     """BASELINE.json configs[1] at its full size (B = 1024, the batch bench.py times) against the oracle -- every
-    alert, not a self-comparison."""
+    alert, not a self-comparison.  Stress weights (layer scale gamma ~ 1).  f16x2 is asserted against the north star's
+    own 1e-4 (TOL_SCORE)."""
     kind, cfg = CONFIGS["mm_pico"]
     sd = seeded_state(kind, cfg, seed=3)
     img, meta, _ = synthetic_batch(1024, seed=2)
@@ -277,7 +301,7 @@ def test_adamw_kernel(cuda):
 
 @pytest.mark.parametrize("env", ["BTSBOT_AMD_NO_STAGE2", "BTSBOT_AMD_NO_STAGE0", "BTSBOT_AMD_NO_STAGE1", "BTSBOT_AMD_NO_S3",
                                  "BTSBOT_AMD_NO_HEAD16"])
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x2"])
 def test_alternative_schedules_match_oracle(cuda, monkeypatch, env, prec):
     """The library's schedule switches (read at model creation) fall back from a stage's fused kernel to
     the per-op launches the other widths (convnext_nano) run -- they must hold the same parity bound."""
