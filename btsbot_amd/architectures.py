@@ -39,7 +39,11 @@ _CONVNEXT_TABLE = {
     "convnext_nano": ((2, 2, 8, 2), (80, 160, 320, 640)),
 }
 _DEFAULT_KIND = "convnext_nano.d1h_in1k"   # architectures.py:107,128
-MAX_CHUNK = 2048                            # alerts per internal workspace chunk
+# alerts per internal workspace chunk: 28 x 256 -- whole rounds of every stage kernel's grid on 256 CUs (stage0b: one
+# alert per workgroup, 512 resident; stage1b: two per workgroup, 512 resident; stage2p: seven per workgroup, 256
+# resident, which is where a larger chunk pays: its filter stream per workgroup is shared by 7 alerts instead of 4);
+# ~0.3 MB of workspace per alert in the 16-bit modes (2 GB of the 288), 0.4 MB in f32
+MAX_CHUNK = int(os.environ.get("BTSBOT_AMD_CHUNK", "7168"))
 _MAXVIT_TABLE = {"maxvit_tiny_rw_224": ((2, 2, 5, 2), (64, 128, 256, 512))}
 _MAXVIT_DEFAULT_KIND = "maxvit_tiny_rw_224.sw_in1k"   # architectures.py:28,61
 MAXVIT_MAX_CHUNK = int(os.environ.get("BTSBOT_AMD_MV_CHUNK", "1024"))  # ~22 MB of bf16 activations per alert:

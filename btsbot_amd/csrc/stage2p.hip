@@ -153,7 +153,14 @@ template <> struct MP<fp8_t> {
 template <typename T> struct GeluOf2 { using type = T; };
 template <> struct GeluOf2<fp8_t> { using type = bf16_t; };   // fp8 rides on the bf16 schedule's GELU
 
-constexpr int C = 256, HID = 1024, G = S2P_ALERTS, NPX = 9 * G, NCOL = 48, NB = NCOL / 16;   // 36 live of 48 columns
+constexpr int C = 256, HID = 1024;
+// G alerts are resident per workgroup: NPX = 9 G pixel rows in NCOL = 16 NB MFMA columns.  G = 4 (36 of 48 columns,
+// the form for one batch of 1024: one workgroup per CU); G = 7 (63 of 64 columns) for batches large enough that it takes
+// fewer rounds of 256 workgroups: the 1 MB filter stream per block per workgroup, which bounds the kernel, is then
+// shared by 7 alerts instead of 4
+template <int G> struct Geo {
+  static constexpr int NPX = 9 * G, NCOL = (NPX + 15) / 16 * 16, NB = NCOL / 16;
+};
 constexpr int NT = 512, NW = NT / 64;                 // 8 waves: 2 per SIMD
 constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;      // hidden units per fc1 / fc2 step
 constexpr int KS1 = C / 32;                           // 8 k-steps of fc1
@@ -168,17 +175,18 @@ constexpr int XLP = C;                                // fp32 map: floats per pi
 // of 32 lanes: 16 bytes apart is the bijection there.
 constexpr int XNP2 = C * 2 + 32;                      // 16-bit LN image: bytes per pixel row (544)
 constexpr int HP2 = CHUNK * 2 + 32;                   // hidden image: bytes per pixel row (288)
-constexpr int OFF_XL = 0;                             // [48][256] f32 (rows >= 36 stay zero)
-constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;       // 49152
-constexpr int XN_PLANE = NCOL * XNP2, H_PLANE = NCOL * HP2;   // 26112, 13824 (the split mode has two planes of each)
-template <typename T> struct Lds {
+constexpr int OFF_XL = 0;                             // [NCOL][256] f32 (rows >= NPX stay zero)
+template <typename T, int G> struct Lds {
+  static constexpr int NCOL = Geo<G>::NCOL;
+  static constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;      // G = 4: 49152
+  static constexpr int XN_PLANE = NCOL * XNP2, H_PLANE = NCOL * HP2;   // 26112, 13824 (the split mode has two planes of each)
   static constexpr int NPL = MP<T>::SPLIT ? 2 : 1;
   static constexpr int H_IMG = NPL * H_PLANE;                 // one hidden image (two of them)
   static constexpr int OFF_H = OFF_XN + NPL * XN_PLANE;
   static constexpr int OFF_B1 = OFF_H + 2 * H_IMG;            // fc1 bias [1024] f32
-  static constexpr int BYTES = OFF_B1 + HID * 4;              // 104704 (split: 160768)
+  static constexpr int BYTES = OFF_B1 + HID * 4;              // G = 4: 104704 (split: 160768); G = 7: 141312
 };
-static_assert(Lds<f16x2_t>::BYTES <= 160 * 1024, "the split mode's images fit one CU");
+static_assert(Lds<f16x2_t, 4>::BYTES <= 160 * 1024 && Lds<bf16_t, 7>::BYTES <= 160 * 1024, "the images fit one CU");
 constexpr float LN_EPS = 1e-6f;
 #define S2P_STAMP(i)                                                                      \
   do {                                                                                    \
@@ -193,8 +201,10 @@ __device__ __forceinline__ float half_sum(float v) {
   return v + w;
 }
 
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
+  constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
+  constexpr int OFF_XN = Lds<T, G>::OFF_XN, XN_PLANE = Lds<T, G>::XN_PLANE, H_PLANE = Lds<T, G>::H_PLANE;
   using frag = typename MP<T>::frag;
   constexpr int ESZ = MP<T>::ESZ;
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
@@ -203,13 +213,14 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   // fc1's B operand (the block's LN image, the same for all 8 chunks): k-steps kept in registers for the whole block;
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
-  constexpr int XRES = F8 ? KS1 : MP<T>::SPLIT ? 0 : 4;   // (16-bit: 5 or 6 spill in the block prologue and lose more than they save)
-  constexpr int H_IMG = Lds<T>::H_IMG;
+  // (16-bit, 3 column blocks: 5 or 6 spill in the block prologue and lose more than they save; 4 column blocks: 1 -- 2 spill)
+  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? (F8 ? 4 : 1) : F8 ? KS1 : 4;
+  constexpr int H_IMG = Lds<T, G>::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
   unsigned char* xn = smem + OFF_XN;
-  unsigned char* hb = smem + Lds<T>::OFF_H;   // two hidden images, H_IMG bytes apart
-  float* b1s = reinterpret_cast<float*>(smem + Lds<T>::OFF_B1);
+  unsigned char* hb = smem + Lds<T, G>::OFF_H;   // two hidden images, H_IMG bytes apart
+  float* b1s = reinterpret_cast<float*>(smem + Lds<T, G>::OFF_B1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
@@ -295,9 +306,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     S2P_STAMP(2 + 8 * j);
     // ---- depthwise 7x7 on the 3x3 maps, in place: thread = (channel, alert pair)
     {
+      constexpr int AH = (G + 1) / 2;   // alerts per half of the workgroup (odd G: the second half has one fewer)
 #pragma unroll
-      for (int g = 0; g < G / 2; ++g) {
-        float* px = xl + (size_t)((dhalf * (G / 2) + g) * 9) * XLP + dc;
+      for (int g = 0; g < AH; ++g) {
+        if (dhalf * AH + g >= G) continue;
+        float* px = xl + (size_t)((dhalf * AH + g) * 9) * XLP + dc;
         float in[9], o[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) in[i] = px[i * XLP];
@@ -658,15 +671,16 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
   out[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
-template <typename T> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
-  auto kern = stage2p_kernel<T>;
+template <typename T, int G = S2P_ALERTS> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+  auto kern = stage2p_kernel<T, G>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Lds<T>::BYTES));
+                                (int)Lds<T, G>::BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), Lds<T>::BYTES, st, a);
+  constexpr int lds_bytes = Lds<T, G>::BYTES;   // (a comma inside the launch macro's arguments would split them)
+  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), lds_bytes, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -710,11 +724,24 @@ int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst
   return BTSBOT_OK;
 }
 
+// 7 alerts per workgroup when that takes fewer rounds of one workgroup per CU than 4 (256 CUs): the kernel's time per
+// round does not depend on the alerts resident -- the filter stream bounds it
+int stage2p_alerts_per_workgroup(int B) {
+  static const int forced = [] {
+    const char* e = getenv("BTSBOT_AMD_S2P_G");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  if (forced == 4 || forced == 7) return forced;
+  const int r4 = ((B + 3) / 4 + 255) / 256, r7 = ((B + 6) / 7 + 255) / 256;
+  return r7 < r4 ? 7 : 4;
+}
+
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
-  if (prec == BTSBOT_BF16) return launch_stage2p_t<bf16_t>(a, st);
-  if (prec == BTSBOT_F16) return launch_stage2p_t<f16_t>(a, st);
-  if (prec == BTSBOT_FP8) return launch_stage2p_t<fp8_t>(a, st);
+  const bool g7 = stage2p_alerts_per_workgroup(a.B) == 7;
+  if (prec == BTSBOT_BF16) return g7 ? launch_stage2p_t<bf16_t, 7>(a, st) : launch_stage2p_t<bf16_t>(a, st);
+  if (prec == BTSBOT_F16) return g7 ? launch_stage2p_t<f16_t, 7>(a, st) : launch_stage2p_t<f16_t>(a, st);
+  if (prec == BTSBOT_FP8) return g7 ? launch_stage2p_t<fp8_t, 7>(a, st) : launch_stage2p_t<fp8_t>(a, st);
   if (prec == BTSBOT_F16X2) return launch_stage2p_t<f16x2_t>(a, st);
   btsbot_set_error("stage2p: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;

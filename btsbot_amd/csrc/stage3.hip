@@ -108,7 +108,7 @@ template <> struct S3M<fp8_t> {
 // (the lo*lo term is below 2^-22 of the product).  A packed fragment is 2 KiB: the heads' 1 KiB, then the remainders'.
 template <> struct S3M<f16x2_t> {
   static constexpr int ESZ = 4;
-  static constexpr int MAXRING = 8;       // 8 registers per fragment
+  static constexpr int MAXRING = 16;      // 8 registers per fragment
   typedef h2x8 frag;
   static __device__ __forceinline__ frag pack8(const float (&v)[8]) { return split8(v); }
   static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
@@ -263,7 +263,7 @@ template <typename T, int C>
 __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
   constexpr int HID = 4 * C, KSA = HID / 16, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
-  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : 4;   // (split: 3 streams x 4 fragments x 8 registers)
+  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : KSW % 8 == 0 ? 8 : 4;   // (split: 3 streams x 8 fragments x 8 registers)
   static_assert(KSW % RING == 0, "k-steps per wave");
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -111,6 +111,7 @@ def test_ragged_batches(cuda, batch):
     ref = _oracle(kind, cfg, sd, img[:64], meta[:64])
     ref = ref.repeat(reps, 1)[:batch]
     m = build_model(kind, cfg, sd, cuda, "f32")
+    m._max_chunk = 2048                    # (the default chunk is larger: keep the 2049th alert in a chunk of its own)
     out = run_model(kind, m, img.to(cuda), meta.to(cuda))
     _check(out, ref, "f32")
 
@@ -126,6 +127,7 @@ def test_ragged_batches_split_mode(cuda, batch):
     img, meta = img.repeat(reps, 1, 1, 1)[:batch], meta.repeat(reps, 1)[:batch]
     ref = _oracle(kind, cfg, sd, img[:64], meta[:64]).repeat(reps, 1)[:batch]
     m = build_model(kind, cfg, sd, cuda, "f16x2")
+    m._max_chunk = 2048
     _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, "f16x2")
 
 
@@ -196,6 +198,26 @@ def test_full_size_batch_matches_oracle(cuda, prec):
     m = build_model(kind, cfg, sd, cuda, prec)
     ds = _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
     print(f"B=1024 {prec}: max|dscore| {ds:.3e}")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16", "fp8"])
+def test_seven_alerts_per_workgroup_form_of_stage2(cuda, prec):
+    """stage2p.hip keeps 7 alerts (63 of 64 MFMA columns) per workgroup instead of 4 when the batch is large enough
+    that this takes fewer rounds of one workgroup per CU (first at 1793 alerts; bench.py's 8192-alert legs run it).
+    Same oracle bound as the 4-alert form, on a ragged batch (1795 = 256 x 7 + 3: a partial last workgroup), and
+    alert independence against the 4-alert form's logits to the operand-mode's rounding."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(256, seed=13)
+    reps = 8
+    big_img, big_meta = img.repeat(reps, 1, 1, 1)[:1795], meta.repeat(reps, 1)[:1795]
+    ref = _oracle(kind, cfg, sd, img, meta).repeat(reps, 1)[:1795]
+    m = build_model(kind, cfg, sd, cuda, prec)
+    out = run_model(kind, m, big_img.to(cuda), big_meta.to(cuda))
+    _check(out, ref, prec)
+    small = run_model(kind, m, img.to(cuda), meta.to(cuda))          # 256 alerts: the 4-alert form
+    # the two forms add the same products in the same order per alert: identical logits
+    assert torch.equal(out[:256], small)
 
 
 def test_f16_meets_1e4_at_trained_like_layer_scale(cuda):

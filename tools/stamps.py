@@ -9,7 +9,7 @@ from btsbot_amd.synthetic import synthetic_batch
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 kind, cfg = CONFIGS["mm_pico"]
-m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), dev, "bf16")
+m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), dev, os.environ.get("PREC", "bf16"))
 img, meta, _ = synthetic_batch(B, seed=2)
 img, meta = img.to(dev), meta.to(dev)
 for _ in range(3):
