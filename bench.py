@@ -441,8 +441,37 @@ def precision_leg_on(m, img, meta, steps, warmup, fence, dist, world):
         return o
 
     el, _, _ = timed_blocks(run, steps, warmup, fence, dist, dev_of(img), blocks=5, warm_seconds=0.3)
-    return dict(value=round(img.shape[0] * world * steps / el, 1), unit="alerts/s", steps=steps,
-                ms_per_step=round(1e3 * el / steps, 4), api="drop-in model(...) calls, one stream")
+    leg = dict(value=round(img.shape[0] * world * steps / el, 1), unit="alerts/s", steps=steps,
+               ms_per_step=round(1e3 * el / steps, 4), api="drop-in model(...) calls, one stream")
+    leg["roofline"] = family_roofline(m, run, img.shape[0], m.precision, max(steps, 10))
+    return leg
+
+
+def family_roofline(m, run, batch, precision, steps):
+    """The pointwise-conv kernel family's roofline object for `steps` calls of `run(1)` on `batch` alerts per call: HIP
+    events around every launch (btsbot_set_profile), algorithmic FLOP per family from family_work."""
+    m.set_profile(True)
+    run(steps)
+    prof = m.collect_profile()
+    m.set_profile(False)
+    work = family_work(batch, precision)
+    peak = MFMA_PEAK_TFLOPS[precision]
+    per_kernel, fam_flop, fam_ms = {}, 0.0, 0.0
+    for k in POINTWISE:
+        ms, n = prof.get(k, (0.0, 0))
+        if n == 0 or work[k]["flop"] == 0:
+            continue
+        ach = work[k]["flop"] * steps / (ms * 1e-3) / 1e12
+        per_kernel[k] = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_call": n // steps,
+                         "ms_per_call": round(ms / steps, 4)}
+        fam_flop += work[k]["flop"] * steps
+        fam_ms += ms
+    if not per_kernel:
+        return None
+    ach = fam_flop / (fam_ms * 1e-3) / 1e12
+    return {"kernel": "pointwise-conv kernel family, FLOP-weighted: " + " + ".join(per_kernel), "bound": "mfma",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "per_kernel": per_kernel, "alerts_per_call": batch}
 
 
 def dev_of(t):
@@ -632,6 +661,13 @@ def main():
                     value=round(8192 * world * n8 / e8, 1), unit="alerts/s", steps=n8, ms_per_step=round(1e3 * e8 / n8, 4),
                     workload="BASELINE.json configs[4]: mm_ConvNeXt-pico, fp8 MFMA in stages 2-3, 8192 synthetic alerts per "
                              "call, two calls in flight (ScoreStream)")
+
+                def run8_plain(n):
+                    with torch.no_grad():
+                        for _ in range(n):
+                            m8(image_input=big_img, metadata_input=big_meta)
+
+                legs["fp8_batch8192"]["roofline"] = family_roofline(m8, run8_plain, 8192, "fp8", 10)
                 del sc8, m8
             del big_img, big_meta
         except Exception as e:   # noqa: BLE001

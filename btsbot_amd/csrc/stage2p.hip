@@ -43,6 +43,7 @@ template <typename T> struct MP;
 // first (for the split mode: only) plane.  PLANE = byte distance of the split mode's remainder plane.
 template <typename T> struct MP16 {
   static constexpr int ESZ = 2;
+  static constexpr int KSTEP = 32;        // k per MFMA; a lane holds KSTEP / 4 consecutive values of its row / column
   static constexpr bool SPLIT = false;
   typedef T frag __attribute__((ext_vector_type(8)));
   typedef T quad __attribute__((ext_vector_type(4)));
@@ -81,13 +82,12 @@ template <> struct MP<f16_t> : MP16<f16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
 };
-// fp8 (OCP e4m3): 8 elements = one 64-bit register pair; activations clamped to +-448 before the conversion (beyond
-// its largest finite value the format has only NaN).  Filters carry one power-of-two scale each (stage3.hip).
 // split operands (BTSBOT_F16X2): value = f16 head + f16 remainder, product = lo*hi + hi*lo + hi*hi on the f16 MFMA.
 // LDS images keep the 16-bit geometry for the heads and a second plane of the same geometry for the remainders (so
 // the bank mapping of every read is the 16-bit one); a packed fragment in HBM is 2 KiB: heads, then remainders.
 template <> struct MP<f16x2_t> {
   static constexpr int ESZ = 2;
+  static constexpr int KSTEP = 32;
   static constexpr bool SPLIT = true;
   typedef h2x8 frag;
   typedef h2x4 quad;
@@ -120,34 +120,43 @@ template <> struct MP<f16x2_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
   }
 };
+// fp8 (OCP e4m3) on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4: 128 k per instruction at twice the bf16
+// rate per clock (the non-scaled fp8 MFMA of round 2 runs at the bf16 rate).  A lane holds 32 consecutive k of its row /
+// column (lane l: row l & 15, k = 32 (l >> 4) + j; checked with exact integer data, tools/unit/mx_probe.hip).  Both block
+// scales are the constant 2^0 (E8M0 127): the mode keeps ONE power-of-two scale per filter, applied in fp32 around the
+// products (stage3.hip), and unscaled activations clamped to +-448 (beyond its largest finite value the format has only NaN).
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 template <> struct MP<fp8_t> {
   static constexpr int ESZ = 1;
+  static constexpr int KSTEP = 128;
   static constexpr bool SPLIT = false;
-  typedef long frag;
+  typedef v8i32 frag;
   typedef unsigned quad;
+  // a packed fragment in HBM is 2 KiB: [lane][k 0..15 of its 32], then [lane][k 16..31]: two coalesced 1 KiB pieces
   static __device__ __forceinline__ frag gld(const void* base, size_t f, int lane) {
-    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
+    const v4i32* p = reinterpret_cast<const v4i32*>(base) + f * 128 + lane;
+    const v4i32 lo = p[0], hi = p[64];
+    return frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
   template <int PLANE> static __device__ __forceinline__ frag ld8(const unsigned char* p) {
-    return *reinterpret_cast<const frag*>(p);
-  }
-  template <int PLANE> static __device__ __forceinline__ void st8(unsigned char* p, const float (&v)[8]) {
-    *reinterpret_cast<frag*>(p) = pack8(v);
-  }
-  template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
-    *reinterpret_cast<quad*>(p) = pack4(v);
+    const v4i32 lo = *reinterpret_cast<const v4i32*>(p), hi = *reinterpret_cast<const v4i32*>(p + 16);
+    return frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
   static __device__ __forceinline__ float c8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
   static __device__ __forceinline__ quad pack4(const float (&v)[4]) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(c8(v[0]), c8(v[1]), 0, false);
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c8(v[2]), c8(v[3]), w, true);
   }
-  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
+  template <int PLANE> static __device__ __forceinline__ void st8(unsigned char* p, const float (&v)[8]) {
     const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
-    return (long)(((unsigned long)pack4(b) << 32) | pack4(a));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack4(a), pack4(b));
   }
-  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+  template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
+    *reinterpret_cast<quad*>(p) = pack4(v);
+  }
+  static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
   }
 };
 template <typename T> struct GeluOf2 { using type = T; };
@@ -163,8 +172,7 @@ template <int G> struct Geo {
 };
 constexpr int NT = 512, NW = NT / 64;                 // 8 waves: 2 per SIMD
 constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;      // hidden units per fc1 / fc2 step
-constexpr int KS1 = C / 32;                           // 8 k-steps of fc1
-constexpr int KS2 = CHUNK / 32;                       // 4 k-steps of fc2 per chunk
+// (k-steps of fc1 / of fc2 per chunk: C / KSTEP and CHUNK / KSTEP of the operand mode: 8 and 4, fp8: 2 and 1)
 constexpr int CO = 512, KD = 4 * C, KSD = KD / 32;    // downsample: 512 outputs, K = 1024
 constexpr int XLP = C;                                // fp32 map: floats per pixel row
 // Operand images [pixel][k]: a ds_read_b128 is served in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,
@@ -204,6 +212,7 @@ __device__ __forceinline__ float half_sum(float v) {
 template <typename T, int G>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
+  constexpr int KSTEP = MP<T>::KSTEP, VPL = KSTEP / 4, KS1 = C / KSTEP, KS2 = CHUNK / KSTEP, KH = HID / KSTEP;
   constexpr int OFF_XN = Lds<T, G>::OFF_XN, XN_PLANE = Lds<T, G>::XN_PLANE, H_PLANE = Lds<T, G>::H_PLANE;
   using frag = typename MP<T>::frag;
   constexpr int ESZ = MP<T>::ESZ;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
   // (16-bit, 3 column blocks: 5 or 6 spill in the block prologue and lose more than they save; 4 column blocks: 1 -- 2 spill)
-  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? (F8 ? 4 : 1) : F8 ? KS1 : 4;
+  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? 1 : F8 ? KS1 : 4;
   constexpr int H_IMG = Lds<T, G>::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) a2[m][s] = MP<T>::gld(a.blk[0].w2p, (size_t)(2 * wave + m) * (HID / 32) + s, lane);
+      for (int s = 0; s < KS2; ++s) a2[m][s] = MP<T>::gld(a.blk[0].w2p, (size_t)(2 * wave + m) * KH + s, lane);
     }
   }
 
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     for (int s = 0; s < XRES; ++s)
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        xr[s][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
+        xr[s][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (KSTEP * s + VPL * kg) * ESZ);
     // residual + gamma * b2 (the bias of the folded fc2)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const size_t f1 = (size_t)(nch * NW + wave) * KS1;
       // fc2 runs one step behind: its slots are refilled with THIS chunk's fragments (used in the next step)
       const void* src2 = bk.w2p;
-      const size_t f2 = (size_t)(2 * wave) * (HID / 32) + ch * KS2;
+      const size_t f2 = (size_t)(2 * wave) * KH + ch * KS2;
       // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]: k-steps
       // 0 .. XRES-1 from the registers filled after the LayerNorm, the rest from LDS
       f32x4 hacc[NB];
@@ -409,19 +418,19 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       if (XRES < KS1 && DB == 2) {
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          xb[XRES & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * XRES + 8 * kg) * ESZ);
+          xb[XRES & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (KSTEP * XRES + VPL * kg) * ESZ);
       }
 #pragma unroll
       for (int s = 0; s < KS1; ++s) {
         if (DB == 2 && s >= XRES && s + 1 < KS1) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            xb[(s + 1) & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * (s + 1) + 8 * kg) * ESZ);
+            xb[(s + 1) & 1][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (KSTEP * (s + 1) + VPL * kg) * ESZ);
         }
         if (DB == 1 && s >= XRES) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            xb[0][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (32 * s + 8 * kg) * ESZ);
+            xb[0][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (KSTEP * s + VPL * kg) * ESZ);
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) hacc[n] = MP<T>::run(a1[s], s < XRES ? xr[s < XRES ? s : 0][n] : xb[s & (DB - 1)][n], hacc[n]);
@@ -435,31 +444,34 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       frag hbf[DB][NB];
       if (!first && DB == 2) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (VPL * kg) * ESZ);
       }
-      static_assert(NB <= KS2, "one GELU column block per fc2 k-step");
+      // one GELU column block per fc2 k-step; a mode with fewer k-steps than column blocks (fp8: one k-step of 128)
+      // runs the remaining blocks behind the last product
+      constexpr int NS2 = KS2 > NB ? KS2 : NB;
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) {
-        if (!first) {
+      for (int s = 0; s < NS2; ++s) {
+        if (s >= KS2) {
+        } else if (!first) {
           if (DB == 2 && s + 1 < KS2) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+              hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * (s + 1) + VPL * kg) * ESZ);
           }
           if (DB == 1) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * s + 8 * kg) * ESZ);
+              hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * s + VPL * kg) * ESZ);
           }
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
           a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
         } else if (!CARRY) {   // (first step of a block: this chunk's fc2 fragments, used in the next step)
           a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
         }
         if (s < NB) {
           float hv[4];
@@ -476,25 +488,25 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     auto fc2_tail = [&]() {
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const void* src2 = nb.w2p;
-      const size_t f2 = (size_t)(2 * wave) * (HID / 32);
+      const size_t f2 = (size_t)(2 * wave) * KH;
       const unsigned char* hprev = hb + 1 * H_IMG;   // chunk NCHUNK - 1 is odd: image 1
       constexpr int DB = MP<T>::SPLIT ? 1 : 2;
       frag hbf[DB][NB];
       if (DB == 2) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (8 * kg) * ESZ);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (VPL * kg) * ESZ);
       }
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         if (DB == 2 && s + 1 < KS2) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * ESZ);
+            hbf[(s + 1) & 1][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * (s + 1) + VPL * kg) * ESZ);
         }
         if (DB == 1) {
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (32 * s + 8 * kg) * ESZ);
+            hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * s + VPL * kg) * ESZ);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
           for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
         if (CARRY) {
           a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + (HID / 32) + s, lane);
+          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -653,13 +665,15 @@ __global__ void pack_frag_split_kernel(const float* __restrict__ w, const float*
 __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
                                      const float* __restrict__ scale, unsigned char* __restrict__ out, int rows, int K,
                                      int reorder_down, int cin) {
+  // 16x16x128 A fragments, 2 KiB each: lane l holds row (l & 15), k = 128 s + 32 (l >> 4) + j (j < 32); in memory
+  // [lane][j 0..15] then [lane][j 16..31] (MP<fp8_t>::gld)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * K) return;
-  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
-  const long fs = i >> 9;
-  const int ksteps = K / 32;
+  const int j = (int)(i & 31), l = (int)((i >> 5) & 63);
+  const long fs = i >> 11;
+  const int ksteps = K / 128;
   const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
-  const int row = 16 * tile + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+  const int row = 16 * tile + (l & 15), k = 128 * s + 32 * (l >> 4) + j;
   float v;
   if (reorder_down) {
     const int q = k / cin, c = k - q * cin;
@@ -668,7 +682,8 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
     v = w[(long)row * K + k];
   }
   if (rowscale != nullptr) v *= rowscale[row];
-  out[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
+  out[fs * 2048 + (j >> 4) * 1024 + l * 16 + (j & 15)] =
+      (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
 template <typename T, int G = S2P_ALERTS> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {

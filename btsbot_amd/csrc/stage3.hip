@@ -32,6 +32,8 @@ template <typename T> struct S3M;
 // row's width in values; only the split mode, which keeps a row's remainders `plane` values behind its heads, uses it).
 template <typename T> struct S3M16 {
   static constexpr int ESZ = 2;
+  static constexpr int KSTEP = 16;        // k per MFMA; a lane holds KSTEP / 2 consecutive values of its row / column
+  static constexpr bool MX = false;
   static constexpr int MAXRING = 32;      // fragments a wave keeps in flight per operand stream
   typedef T pair_t __attribute__((ext_vector_type(2)));
   typedef T frag __attribute__((ext_vector_type(8)));
@@ -70,44 +72,56 @@ template <> struct S3M<f16_t> : S3M16<f16_t> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
-// fp8 (OCP e4m3 on gfx950): 8 elements = one 64-bit register pair.  Activations are clamped to the format's range
-// before the conversion (its largest finite value is 448; what lies beyond would become NaN).
+// fp8 (OCP e4m3) on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4: 64 k per instruction, twice the bf16 rate
+// per clock (stage2p.hip has the 16x16x128 form and the note on the scales, both the constant 2^0 here too).  A lane
+// holds 32 consecutive k of its row / column: lane l = row l & 31, k = 32 (l >> 5) + j.  Activations are clamped to the
+// format's range before the conversion (its largest finite value is 448; what lies beyond would become NaN).
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 template <> struct S3M<fp8_t> {
   static constexpr int ESZ = 1;
-  static constexpr int MAXRING = 32;
+  static constexpr int KSTEP = 64;
+  static constexpr bool MX = true;
+  static constexpr int MAXRING = 16;      // 8 registers per fragment
   typedef unsigned short pair_t;
-  typedef long frag;
-  static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
-    return reinterpret_cast<const frag*>(base)[f * 64 + lane];
-  }
-  static __device__ __forceinline__ void stg(void* base, size_t f, int lane, frag v) {
-    reinterpret_cast<frag*>(base)[f * 64 + lane] = v;
-  }
-  static __device__ __forceinline__ frag lds_ld8(const unsigned char* row, int c, int plane) {
-    return *reinterpret_cast<const frag*>(row + c);
-  }
-  static __device__ __forceinline__ void lds_st2(unsigned char* row, int c, int plane, float a, float b) {
-    *reinterpret_cast<pair_t*>(row + c) = pack2(a, b);
-  }
+  typedef v8i32 frag;
   static __device__ __forceinline__ float clamp8(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
   static __device__ __forceinline__ pair_t pack2(float a, float b) {
     return (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(a), clamp8(b), 0, false);
   }
-  static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
-    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[0]), clamp8(v[1]), 0, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[2]), clamp8(v[3]), lo, true);
-    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[4]), clamp8(v[5]), 0, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[6]), clamp8(v[7]), hi, true);
-    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+  // a packed fragment in HBM is 2 KiB: [lane][k 0..15 of its 32], then [lane][k 16..31]
+  static __device__ __forceinline__ frag ldg(const void* base, size_t f, int lane) {
+    const v4i32* p = reinterpret_cast<const v4i32*>(base) + f * 128 + lane;
+    const v4i32 lo = p[0], hi = p[64];
+    return frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
-  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+  // 16 values (registers 0..15 of a 32x32 accumulator) as half `half` of fragment f: one coalesced 1 KiB store per wave
+  static __device__ __forceinline__ void stg_half(void* base, size_t f, int half, int lane, const float (&v)[16]) {
+    v4i32 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[4 * q]), clamp8(v[4 * q + 1]), 0, false);
+      o[q] = __builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[4 * q + 2]), clamp8(v[4 * q + 3]), w, true);
+    }
+    reinterpret_cast<v4i32*>(base)[f * 128 + half * 64 + lane] = o;
+  }
+  static __device__ __forceinline__ frag lds_ld8(const unsigned char* row, int c, int plane) {   // 32 values from c on
+    const v4i32 lo = *reinterpret_cast<const v4i32*>(row + c), hi = *reinterpret_cast<const v4i32*>(row + c + 16);
+    return frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  static __device__ __forceinline__ void lds_st2(unsigned char* row, int c, int plane, float a, float b) {
+    *reinterpret_cast<pair_t*>(row + c) = pack2(a, b);
+  }
+  static __device__ __forceinline__ f32x16 run(const frag& a, const frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
   }
 };
 // split operands (BTSBOT_F16X2): value = f16 head + f16 remainder; a product is hi*hi + hi*lo + lo*hi on the f16 MFMA
 // (the lo*lo term is below 2^-22 of the product).  A packed fragment is 2 KiB: the heads' 1 KiB, then the remainders'.
 template <> struct S3M<f16x2_t> {
   static constexpr int ESZ = 4;
+  static constexpr int KSTEP = 16;
+  static constexpr bool MX = false;
   static constexpr int MAXRING = 16;      // 8 registers per fragment
   typedef h2x8 frag;
   static __device__ __forceinline__ frag pack8(const float (&v)[8]) { return split8(v); }
@@ -162,9 +176,11 @@ constexpr int RED_BYTES = 8 * 2 * 4 * 64 * 16;   // fc2: 8 K slices x 2 alert bl
 template <typename T, int C>
 __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& bk, int ab, int nt, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
-  constexpr int HID = 4 * C, KS = C / 16, NV = C / 128;
-  constexpr int RING0 = KS > 32 ? KS / 2 : KS, RING = RING0 < S3M<T>::MAXRING ? RING0 : S3M<T>::MAXRING;
-  static_assert(RING % 4 == 0, "ring quarters");
+  constexpr int KSTEP = S3M<T>::KSTEP, VPL = KSTEP / 2;
+  constexpr int HID = 4 * C, KS = C / KSTEP, NV = C / 128;
+  constexpr int RING0 = KS > 32 ? KS / 2 : KS, RING1 = RING0 < S3M<T>::MAXRING ? RING0 : S3M<T>::MAXRING;
+  constexpr int RING = RING1 / 4 * 4;   // (four quarters, one requested in front of each row's LayerNorm)
+  static_assert(RING >= 4, "ring quarters");
   constexpr int ESZ = S3M<T>::ESZ;
   constexpr int PITCH = C * ESZ + 16;   // bytes per LDS row: C operand values + 16 (8 rows cover the 32 banks)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
@@ -243,18 +259,28 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   const unsigned char* bp = smem + lr * PITCH;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const frag bf = S3M<T>::lds_ld8(bp, ks * 16 + h * 8, C);
+    const frag bf = S3M<T>::lds_ld8(bp, ks * KSTEP + h * VPL, C);
     acc = S3M<T>::run(wq[ks % RING], bf, acc);
     if (ks + RING < KS) wq[ks % RING] = S3M<T>::ldg(bk.w1p, wf0 + ks + RING, lane);
   }
   S3_STAMP(12);
   // ---- GELU, out as fc2's B fragments: lane (alert lr, half h) holds k = 16 ks2 + 8 h + 0..7 of k-step ks2 = 2 ht + hh
+  if constexpr (S3M<T>::MX) {
+    // fc2 sums over all hidden units, so their order inside its k-steps is free: this lane's 16 values are bytes
+    // 16 (ht & 1) .. + 15 of its slot in fragment ht >> 1 -- position (S, half h, j) of fc2's k holds hidden unit
+    // 64 S + 32 (j >> 4) + (j & 7) + 8 h + 16 ((j >> 3) & 1), which is how launch_pack_s3 orders gamma * W2 (kperm)
+    float g[16];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    float g[8];
+    for (int j = 0; j < 16; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[j] * is1);
+    S3M<T>::stg_half(a.hfrag, (size_t)ab * (HID / 64) + (ht >> 1), ht & 1, lane, g);
+  } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[8 * hh + j] * is1);
-    S3M<T>::stg(a.hfrag, (size_t)ab * (HID / 16) + 2 * ht + hh, lane, S3M<T>::pack8(g));
+    for (int hh = 0; hh < 2; ++hh) {
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[8 * hh + j] * is1);
+      S3M<T>::stg(a.hfrag, (size_t)ab * (HID / 16) + 2 * ht + hh, lane, S3M<T>::pack8(g));
+    }
   }
   __syncthreads();   // the rows in LDS are read out: the next tile may overwrite them
 }
@@ -262,8 +288,9 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
 template <typename T, int C>
 __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
-  constexpr int HID = 4 * C, KSA = HID / 16, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
-  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : KSW % 8 == 0 ? 8 : 4;   // (split: 3 streams x 8 fragments x 8 registers)
+  constexpr int HID = 4 * C, KSA = HID / S3M<T>::KSTEP, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
+  // (split / fp8: a fragment is 8 registers, 3 streams x 8 fragments at most)
+  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : KSW % 8 == 0 ? 8 : KSW % 4 == 0 ? 4 : KSW;
   static_assert(KSW % RING == 0, "k-steps per wave");
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,19 +431,26 @@ __global__ void scale_from_max_kernel(float* scale) {
 }
 __global__ void pack_s3_fp8_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
                                    const float* __restrict__ scale, unsigned char* __restrict__ out, int rows, int K,
-                                   int swap23) {
+                                   int swap23, int kperm) {
+  // 32x32x64 A fragments, 2 KiB each: lane l holds tile row (l & 31), 32 values of k-step s; in memory [lane][j 0..15]
+  // then [lane][j 16..31] (S3M<fp8_t>::ldg).  Plain order: k = 64 s + 32 (l >> 5) + j.  kperm (fc2, whose k = the
+  // hidden unit): position (s, h = l >> 5, j) holds k = 64 s + 32 (j >> 4) + (j & 7) + 8 h + 16 ((j >> 3) & 1), the
+  // order in which s3_fc1's accumulators leave as fragments
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * K) return;
-  const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
-  const long fs = i >> 9;
-  const int ksteps = K / 16;
+  const int j = (int)(i & 31), l = (int)((i >> 5) & 63);
+  const long fs = i >> 11;
+  const int ksteps = K / 64;
   const int s = (int)(fs % ksteps), tile = (int)(fs / ksteps);
   int r = l & 31;
   if (swap23) r = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-  const int row = 32 * tile + r, k = 16 * s + 8 * (l >> 5) + j;
+  const int h = l >> 5;
+  const int row = 32 * tile + r;
+  const int k = kperm ? 64 * s + 32 * (j >> 4) + (j & 7) + 8 * h + 16 * ((j >> 3) & 1) : 64 * s + 32 * h + j;
   float v = w[(long)row * K + k] * scale[0];
   if (rowscale != nullptr) v *= rowscale[row];
-  out[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+  out[fs * 2048 + (j >> 4) * 1024 + l * 16 + (j & 15)] =
+      (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
 }
 
 template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
@@ -497,8 +531,9 @@ int launch_pack_s3(int prec, const float* src, const float* rowscale, void* dst,
     }
     const int rc = launch_fp8_scale(src, rowscale, total, K, scale, st);
     if (rc != BTSBOT_OK) return rc;
+    // (fc1's filter: rows in the bit-2/3-swapped order, k as it is; fc2's: rows as they are, k in the fragment order)
     hipLaunchKernelGGL(pack_s3_fp8_kernel, grid, blk, 0, st, src, rowscale, scale, reinterpret_cast<unsigned char*>(dst),
-                       rows, K, swap23);
+                       rows, K, swap23, swap23 ? 0 : 1);
   } else {
     btsbot_set_error("pack_s3: precision %d is not a packed-fragment mode", prec);
     return BTSBOT_ERR_INVALID_ARG;

@@ -487,3 +487,29 @@ def test_score_stream_keeps_generator_inputs_alive(cuda):
     torch.cuda.synchronize()
     for o, r in zip(outs, ref):
         assert torch.equal(o, torch.sigmoid(r))
+
+
+def test_config4_fp8_at_its_full_batch(cuda):
+    """BASELINE.json configs[4] at its own size: the fp8 mode on 8192 alerts in one call (the library works through it
+    in chunks of 7168 + 1024 alerts: the 7-alert and the 4-alert form of stage2p.hip).  The oracle covers a subset --
+    the first 256 alerts, to the fp8 mode's bound -- and size-independent properties cover the rest: the batch is 32
+    repeats of those 256 alerts, and an alert's logit may depend on its position only through stage1b.hip's chunk
+    rotation (a workgroup adds the 16 hidden chunks of fc2 in an order derived from its index, period 256 workgroups =
+    512 alerts): every repeat must reproduce the repeat two before it bit for bit -- across workgroups, chunks and the
+    two forms of stage2p.hip -- and its neighbour to fp32 summation-order differences; every score is finite and
+    inside (0, 1)."""
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(256, seed=2)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, "fp8")
+    big_img, big_meta = img.to(cuda).repeat(32, 1, 1, 1), meta.to(cuda).repeat(32, 1)
+    out = run_model(kind, m, big_img, big_meta)
+    assert out.shape == (8192, 1) and torch.isfinite(out).all()
+    _check(out[:256], ref, "fp8")
+    for r in range(2, 32):
+        assert torch.equal(out[256 * r:256 * (r + 1)], out[256 * (r - 2):256 * (r - 1)]), f"repeat {r} differs from {r - 2}"
+    # (a different summation order of the fp32 accumulators moves an fp8 operand across a rounding boundary now and then)
+    assert (out[256:512] - out[:256]).abs().max().item() <= 2 * TOL_LOGIT_REL["fp8"] * max(1.0, ref.abs().max().item())
+    sc = torch.sigmoid(out)
+    assert bool(((sc > 0) & (sc < 1)).all())
