@@ -537,6 +537,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code path on a one-GPU box (BTSBOT_BENCH_REHEARSAL=1): every rank on cuda:0, collectives
+    # through gloo on device tensors.  Not a measurement -- the ranks share one GPU -- and the line says so.
+    rehearsal = os.environ.get("BTSBOT_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if local_rank >= torch.cuda.device_count():
@@ -549,7 +554,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -781,6 +789,8 @@ def main():
             line["parity"] = parity
         if legs:
             line["precision_legs"] = legs
+        if rehearsal:
+            line["rehearsal"] = "all ranks on ONE GPU, gloo collectives: exercises the N > 1 code path, not a measurement"
         if dist is not None:
             line["collective"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
                                       note="inference: no data-path collective; training leg: bucketed all-reduce")
