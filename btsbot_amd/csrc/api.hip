@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "common.h"
+#include <dlfcn.h>
+
 #include "ctx.h"
 #include "maxvit.h"
 #include "stage0.h"
@@ -347,6 +349,10 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  if (h->xchg != nullptr) {
+    (void)hipStreamDestroy(h->xchg);
+    (void)hipEventDestroy(h->xchg_done);
+  }
   for (hipEvent_t e : h->bucket_ev)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->side_ev) (void)hipEventDestroy(e);
@@ -1191,6 +1197,67 @@ extern "C" int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream
     return BTSBOT_ERR_STATE;
   }
   HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->bucket_ev[bucket], 0));
+  return BTSBOT_OK;
+}
+
+// ---- the exchange step inside the C ABI (btsbot_allreduce_grads) ------------------------
+// RCCL is resolved at the first call with dlopen / dlsym, not linked: a process that never trains across GPUs does
+// not load it, and a host that already has an RCCL (PyTorch ships its own copy) keeps using that one -- the
+// communicator the caller passes in must come from the library this resolves to (by soname: the copy already loaded
+// wins).
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+nccl_allreduce_fn resolve_allreduce() {
+  static nccl_allreduce_fn fn = [] {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib != nullptr) break;
+    }
+    return lib != nullptr ? reinterpret_cast<nccl_allreduce_fn>(dlsym(lib, "ncclAllReduce")) : nullptr;
+  }();
+  return fn;
+}
+}  // namespace
+
+extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
+                                      const int64_t* lo, const int64_t* hi, void* stream) {
+  if (h == nullptr || nccl_comm == nullptr || grads == nullptr || nspans < 0 || (nspans > 0 && (bucket == nullptr || lo == nullptr || hi == nullptr))) {
+    btsbot_set_error("allreduce_grads: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (!h->bucket_recorded) {
+    btsbot_set_error("allreduce_grads: btsbot_backward() has not run on this handle");
+    return BTSBOT_ERR_STATE;
+  }
+  nccl_allreduce_fn allreduce = resolve_allreduce();
+  if (allreduce == nullptr) {
+    btsbot_set_error("allreduce_grads: cannot load RCCL (librccl.so.1: %s)", dlerror());
+    return BTSBOT_ERR_STATE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (h->xchg == nullptr) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->xchg, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->xchg_done, hipEventDisableTiming));
+  }
+  for (int i = 0; i < nspans; ++i) {
+    if (bucket[i] < 0 || bucket[i] >= h->n_buckets || lo[i] < 0 || hi[i] > h->total_floats || lo[i] >= hi[i]) {
+      btsbot_set_error("allreduce_grads: span %d (bucket %d, [%lld, %lld)) is outside the arena", i, bucket[i],
+                       (long long)lo[i], (long long)hi[i]);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    // the collective of a span starts as soon as the backward pass has written its bucket, on the library's exchange
+    // stream: the rest of the backward keeps the caller's stream
+    HIP_TRY(hipStreamWaitEvent(h->xchg, h->bucket_ev[bucket[i]], 0));
+    const int rc = allreduce(grads + lo[i], grads + lo[i], (size_t)(hi[i] - lo[i]), /* ncclFloat32 */ 7, /* ncclSum */ 0,
+                             nccl_comm, h->xchg);
+    if (rc != 0) {
+      btsbot_set_error("allreduce_grads: ncclAllReduce of span %d returned %d", i, rc);
+      return BTSBOT_ERR_HIP;
+    }
+  }
+  HIP_TRY(hipEventRecord(h->xchg_done, h->xchg));
+  HIP_TRY(hipStreamWaitEvent(st, h->xchg_done, 0));   // the optimiser step on `stream` sees the reduced gradients
   return BTSBOT_OK;
 }
 

@@ -127,6 +127,8 @@ struct btsbot_ctx {
   int64_t bucket_lo[3] = {0, 0, 0}, bucket_hi[3] = {0, 0, 0};
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
+  hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
+  hipEvent_t xchg_done = nullptr;
   // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()

@@ -52,7 +52,7 @@ def lr_schedule(lr: float, epochs: int, warmup_epochs: int) -> Sequence[float]:
 class Trainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, pos_weight: float = 1.0, epochs: int = 1,
-                 warmup_epochs: int = 0, group=None, dropout_seed: int = 0):
+                 warmup_epochs: int = 0, group=None, dropout_seed: int = 0, rccl_comm=None):
         self.model = model
         self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pos_weight = float(pos_weight)
@@ -74,6 +74,12 @@ class Trainer:
         self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         self.dropout_seed = int(dropout_seed)
         self._rng = None
+        # the exchange step through the C ABI (btsbot_allreduce_grads) on a raw RCCL communicator (btsbot_amd.rccl.RcclComm)
+        # instead of torch.distributed: what a host that binds only libbtsbot_hip.so does.  The replicas must then be
+        # made equal by the caller (no process group to broadcast over)
+        self.rccl = rccl_comm
+        if rccl_comm is not None:
+            self.rank = rccl_comm.rank
         # replicas start from rank 0's parameters and buffers (what DataParallel's per-step broadcast did
         # implicitly at train.py:238-240); from here on identical gradients keep them identical
         if parallel._world(group) > 1:
@@ -103,7 +109,7 @@ class Trainer:
         if batch < 2 and m._cfg_args["n_meta"] > 0:
             # nn.BatchNorm1d in train mode: "Expected more than 1 value per channel when training"
             raise ValueError("Trainer.step: BatchNorm1d batch statistics need more than one alert per rank")
-        world = parallel._world(self.group)
+        world = self.rccl.world if self.rccl is not None else parallel._world(self.group)
         n_global = int(global_batch) if global_batch is not None else batch * world
         if self._rng is None or self._rng.device != dev:
             # every rank draws its own dropout masks (seed + rank)
@@ -123,7 +129,18 @@ class Trainer:
                                                 C.c_void_p(loss.data_ptr()), C.c_void_p(dl.data_ptr()),
                                                 st), "btsbot_bce_fwd_bwd")
             grads = m._backward_raw(dl, self.need_meta, self.need_image)
-            if world > 1 and exchange:
+            if self.rccl is not None and exchange:
+                plan = self.exchange.plan
+                n = len(plan)
+                bk = (C.c_int32 * n)(*[b for b, _lo, _hi in plan])
+                lo = (C.c_int64 * n)(*[a for _b, a, _hi in plan])
+                hi = (C.c_int64 * n)(*[z for _b, _lo, z in plan])
+                with torch.cuda.device(dev):
+                    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    _lib.check(L.btsbot_allreduce_grads(m._handle.ptr, C.c_void_p(self.rccl.ptr),
+                                                        C.c_void_p(grads.data_ptr()), n, bk, lo, hi, st),
+                               "btsbot_allreduce_grads")
+            elif world > 1 and exchange:
                 # the one exchange of the step (local gradients are already scaled by 1 / n_global)
                 self.exchange.exchange(grads, m._wait_grad_bucket)
             self.last_logits = logits

@@ -195,6 +195,19 @@ int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, in
 int btsbot_grad_buckets(btsbot_handle h, int capacity, int64_t* lo, int64_t* hi);
 int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
 
+/* The exchange step of data-parallel training (replaces torch.nn.parallel.DataParallel's reduce_add_coalesced,
+ * /root/reference/btsbot/train.py:238-240, 526): all-reduce (SUM) over the ranks of `nccl_comm` (an RCCL ncclComm_t) of
+ * `nspans` spans [lo[i], hi[i]) (floats) of the gradient arena `grads`, span i belonging to gradient bucket bucket[i]
+ * of btsbot_grad_buckets().  Every collective runs on a stream of the library's own and starts as soon as the LAST
+ * btsbot_backward() has written its bucket (the rest of the backward pass keeps `stream`: pass the spans in bucket
+ * order); `stream` then waits for all of them, so the btsbot_adamw_step() queued behind this call sees the sums.
+ * Local gradients are already scaled by 1 / n_global (btsbot_bce_fwd_bwd), so SUM is the global-batch mean's
+ * gradient.  No host synchronisation.  RCCL is resolved at the first call (dlopen of librccl.so.1: the copy already
+ * in the process, e.g. PyTorch's, wins) -- the communicator must come from that library; BTSBOT_ERR_STATE if there is
+ * none. */
+int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
+                           const int64_t* lo, const int64_t* hi, void* stream);
+
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and
  * stage outputs (call before btsbot_reserve()). */
 int btsbot_set_debug(btsbot_handle h, int on);

@@ -84,6 +84,19 @@ def main():
         res["bucket_err"] = [(g[a:b] - rg[a:b]).abs().max().item() / scale for a, b in buckets if b > a]
         res["n_buckets"] = len(buckets)
         res["plan"] = [list(p) for p in tr.exchange.plan]
+    # ---- 2b (RCCL only): the same exchange through the C ABI (btsbot_allreduce_grads) on a raw communicator --------
+    if backend == "nccl":
+        from btsbot_amd.rccl import RcclComm
+        box = [RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = RcclComm(rank, world, box[0])
+        tr_c = Trainer(m, lr=1e-4, rccl_comm=comm)
+        _l3, g3 = tr_c.gradients(img[lo:hi].contiguous(), None, lab[lo:hi].contiguous())
+        g3 = g3.clone()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            res["grad_err_c_abi"] = (g3 - rg).abs().max().item() / scale
+        comm.destroy()
     del m, tr
 
     # ---- 3: full training steps with BatchNorm1d and dropout: replicas stay identical ------------------------

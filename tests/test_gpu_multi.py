@@ -56,6 +56,8 @@ def _assert_result(res, world):
     assert res["n_buckets"] == 3 and len(res["plan"]) >= 1
     assert all(e <= 2e-5 for e in res["bucket_err"]), res      # every bucket was complete when its collective ran
     assert res["replicas_identical_after_steps"] and res["loss_finite"], res
+    if res["backend"] == "nccl":
+        assert res["grad_err_c_abi"] <= 2e-5, res              # btsbot_allreduce_grads on a raw RCCL communicator
 
 
 def test_two_gpus_rccl(tmp_path):

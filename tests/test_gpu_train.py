@@ -463,3 +463,52 @@ def test_trainer_steps_over_a_frozen_maxvit_branch_bf16(cuda):
     with torch.no_grad():
         z = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
     assert z.shape == (4, 1) and torch.isfinite(z).all()
+
+
+def test_exchange_step_through_the_c_abi_on_a_one_rank_communicator(cuda):
+    """btsbot_allreduce_grads (include/btsbot_hip.h) with a raw RCCL communicator of ONE rank --
+    what a one-GPU box can run of it: RCCL is resolved, every planned span goes through ncclAllReduce on the library's
+    exchange stream behind its bucket's event, the caller's stream waits for them.  SUM over one rank is the identity:
+    the exchanged arena must equal the local gradients bit for bit, spans and gaps alike; and a full Trainer.step on
+    that path must equal the step without an exchange."""
+    import warnings
+    import btsbot_amd
+    from btsbot_amd.rccl import RcclComm
+    from btsbot_amd.train import Trainer
+    kind, cfg = CONFIGS["mm_pico"]
+    cfg = dict(cfg, meta_dropout=0.0, comb_dropout=0.0)
+    img, meta, lab = synthetic_batch(24, seed=4)
+    img, meta, lab = img.to(cuda), meta.to(cuda), lab.to(cuda)
+
+    def build():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = getattr(btsbot_amd, kind)(cfg, precision="f32")
+        m.load_state_dict(seeded_state(kind, cfg, seed=3))
+        return m.to(cuda).train()
+
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    try:
+        ma, mb = build(), build()
+        for k, p in ma.named_parameters():                      # frozen tensors: gaps inside the planned spans
+            if ".stages.1." in k:
+                p.requires_grad_(False)
+        for k, p in mb.named_parameters():
+            if ".stages.1." in k:
+                p.requires_grad_(False)
+        ta, tb = Trainer(ma, lr=1e-3, rccl_comm=comm), Trainer(mb, lr=1e-3)
+        assert len(ta.exchange.plan) >= 2
+        _la, ga = ta.gradients(img, meta, lab)
+        ga = ga.clone()
+        _lb, gb = tb.gradients(img, meta, lab)
+        torch.cuda.synchronize()
+        scale = gb.abs().max().item()
+        # (the batch reductions use fp32 atomics: two passes agree to the run-to-run band, not bit for bit)
+        assert (ga - gb).abs().max().item() <= 2e-5 * scale
+        for _ in range(2):
+            ta.step(img, meta, lab)
+            tb.step(img, meta, lab)
+        torch.cuda.synchronize()
+        assert (ma._arena - mb._arena).abs().max().item() <= 1e-5
+    finally:
+        comm.destroy()
