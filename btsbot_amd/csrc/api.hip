@@ -342,7 +342,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->extra) (void)hipFree(h->extra);
   for (void* t : h->pack_jobs)
     if (t) (void)hipFree(t);
-  if (h->ws) (void)hipFree(h->ws);
+  if (h->ws && h->ws_owned) (void)hipFree(h->ws);
   if (h->tcache) (void)hipFree(h->tcache);
   if (h->bbcache) (void)hipFree(h->bbcache);
   if (h->mv) maxvit_free(h);
@@ -606,20 +606,30 @@ extern "C" int btsbot_profile_collect(btsbot_handle h, int n_cat, double* ms_sum
   return BTSBOT_OK;
 }
 
-extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
-  if (h == nullptr || max_chunk < 1) {
-    btsbot_set_error("reserve: bad argument");
-    return BTSBOT_ERR_INVALID_ARG;
-  }
+// workspace of the forward path: allocated here (btsbot_reserve) or handed in by the caller (btsbot_use_workspace,
+// the caller-sized form of SURVEY.md section 8b: no allocation inside the library on that path)
+static int install_workspace(btsbot_handle h, int max_chunk, unsigned char* caller_ws, int64_t caller_bytes) {
   size_t total;
   size_t ox, ox2, oxn, oh;
   ws_layout(h, max_chunk, &ox, &ox2, &oxn, &oh, &total);
-  if (h->ws != nullptr && max_chunk <= h->max_chunk && (!h->debug || h->taps[0] != nullptr))
+  if (caller_ws == nullptr && h->ws != nullptr && h->ws_owned && max_chunk <= h->max_chunk &&
+      (!h->debug || h->taps[0] != nullptr))
     return BTSBOT_OK;
+  if (caller_ws != nullptr && (size_t)caller_bytes < total) {
+    btsbot_set_error("use_workspace: %lld bytes for chunks of %d alerts, btsbot_workspace_bytes() says %zu",
+                     (long long)caller_bytes, max_chunk, total);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   HIP_TRY(hipDeviceSynchronize());
-  if (h->ws) (void)hipFree(h->ws);
+  if (h->ws && h->ws_owned) (void)hipFree(h->ws);
   h->ws = nullptr;
-  HIP_TRY(hipMalloc(&h->ws, total));
+  if (caller_ws != nullptr) {
+    h->ws = caller_ws;
+    h->ws_owned = false;
+  } else {
+    HIP_TRY(hipMalloc(&h->ws, total));
+    h->ws_owned = true;
+  }
   h->ws_bytes = total;
   h->max_chunk = max_chunk;
   h->o_x = ox;
@@ -641,6 +651,22 @@ extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
                         (size_t)max_chunk * STAGE_HW[i] * STAGE_HW[i] * h->cfg.dims[i] * 4));
   }
   return BTSBOT_OK;
+}
+
+extern "C" int btsbot_reserve(btsbot_handle h, int max_chunk) {
+  if (h == nullptr || max_chunk < 1) {
+    btsbot_set_error("reserve: bad argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return install_workspace(h, max_chunk, nullptr, 0);
+}
+
+extern "C" int btsbot_use_workspace(btsbot_handle h, int max_chunk, void* workspace, int64_t bytes) {
+  if (h == nullptr || max_chunk < 1 || workspace == nullptr || ((uintptr_t)workspace & 255) != 0) {
+    btsbot_set_error("use_workspace: bad argument (the workspace must be 256-byte aligned device memory)");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return install_workspace(h, max_chunk, reinterpret_cast<unsigned char*>(workspace), bytes);
 }
 
 // run one launch, bracketed by HIP events on `st` when profiling is on

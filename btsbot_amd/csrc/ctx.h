@@ -86,6 +86,7 @@ struct btsbot_ctx {
   bool packed_full = false;   // false after btsbot_pack_params_train(): inference-only operand images are stale
 
   unsigned char* ws = nullptr;
+  bool ws_owned = true;             // false: the caller's memory (btsbot_use_workspace), never freed here
   size_t ws_bytes = 0;
   int max_chunk = 0;
   size_t o_x, o_x2, o_xn, o_h;      // workspace offsets

@@ -140,6 +140,10 @@ int btsbot_pack_params_train(btsbot_handle h, const float* master_arena, void* s
  * `max_chunk` alerts; forward() splits larger batches into chunks internally. */
 int64_t btsbot_workspace_bytes(btsbot_handle h, int max_chunk);
 int btsbot_reserve(btsbot_handle h, int max_chunk);
+/* The caller-sized form (no allocation inside the library): `workspace` = at least
+ * btsbot_workspace_bytes(h, max_chunk) bytes of 256-byte-aligned device memory that stays the caller's -- borrowed
+ * until the next btsbot_reserve() / btsbot_use_workspace() / btsbot_destroy(), never freed here. */
+int btsbot_use_workspace(btsbot_handle h, int max_chunk, void* workspace, int64_t bytes);
 
 /* Replaces: model(image_input=..., metadata_input=...) / model(input_data=...) followed by
  * torch.sigmoid (architectures.py:166-171,121-122,292-293,367-372; inference_example.py:84-91).

@@ -159,6 +159,34 @@ def test_input_validation_and_layout(cuda):
     assert torch.equal(outp, ref[perm.to(cuda)])
 
 
+def test_caller_sized_workspace(cuda):
+    """btsbot_use_workspace (caller-sized workspace, no allocation inside the library): a forward
+    on memory the caller allocated gives the same logits as one on the library's own allocation; a buffer smaller than
+    btsbot_workspace_bytes() is refused."""
+    import ctypes as C
+    kind, cfg = CONFIGS["mm_pico"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(70, seed=2)
+    m = build_model(kind, cfg, sd, cuda, "bf16")
+    twin = build_model(kind, cfg, sd, cuda, "bf16")
+    twin._max_chunk = 32                                   # same chunking on the library's own allocation (an alert's
+    ref = run_model(kind, twin, img.to(cuda), meta.to(cuda)).clone()   # logit depends on its position in the chunk
+    L = _lib.lib()                                         # through stage1b.hip's summation order, nothing else)
+    need = L.btsbot_workspace_bytes(m._handle.ptr, 32)
+    assert need > 0
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=cuda)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    assert L.btsbot_use_workspace(m._handle.ptr, 32, C.c_void_p(base), need - 1) != 0     # one byte short
+    _lib.check(L.btsbot_use_workspace(m._handle.ptr, 32, C.c_void_p(base), need), "btsbot_use_workspace")
+    m._reserved = 32                                       # (the Module's bookkeeping: chunks of 32 are in place)
+    m._max_chunk = 32
+    out = run_model(kind, m, img.to(cuda), meta.to(cuda))  # 70 alerts = chunks of 32 + 32 + 6 in the caller's memory
+    assert torch.equal(out, ref)
+    del m                                                  # the library must not free the caller's buffer
+    torch.cuda.synchronize()
+    ws.fill_(0)
+
+
 def test_weights_repacked_after_update(cuda):
     kind, cfg = CONFIGS["um_nn"]
     sd = seeded_state(kind, cfg, seed=3)
