@@ -28,7 +28,7 @@ SYMBOLS = [
     "btsbot_profile_collect",
     "btsbot_op_gemm", "btsbot_op_dwconv_ln", "btsbot_op_stem", "btsbot_op_ln_patch",
     "btsbot_reserve_train", "btsbot_forward_train", "btsbot_backward", "btsbot_debug_stamps",
-    "btsbot_grad_buckets", "btsbot_wait_grad_bucket", "btsbot_allreduce_grads", "btsbot_use_workspace",
+    "btsbot_grad_buckets", "btsbot_wait_grad_bucket", "btsbot_allreduce_grads", "btsbot_use_workspace", "btsbot_set_option",
     "btsbot_augment", "btsbot_eval_metrics", "btsbot_prep_triplets",
 ]
 
@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
     L.btsbot_grad_buckets.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
     L.btsbot_wait_grad_bucket.restype = i32
     L.btsbot_wait_grad_bucket.argtypes = [vp, i32, vp]
+    L.btsbot_set_option.restype = i32
+    L.btsbot_set_option.argtypes = [vp, C.c_char_p, i32]
     L.btsbot_use_workspace.restype = i32
     L.btsbot_use_workspace.argtypes = [vp, i32, vp, i64]
     L.btsbot_allreduce_grads.restype = i32

@@ -561,6 +561,23 @@ extern "C" int btsbot_debug_stamps(btsbot_handle h, unsigned long long* device_b
   return BTSBOT_OK;
 }
 
+extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
+  if (h == nullptr || key == nullptr) {
+    btsbot_set_error("set_option: NULL argument");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (strcmp(key, "stage2p_alerts") == 0) {
+    if (value != 0 && value != 4 && value != 7) {
+      btsbot_set_error("set_option: stage2p_alerts is 0 (automatic), 4 or 7, got %d", value);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    h->s2p_alerts_hint = value;
+    return BTSBOT_OK;
+  }
+  btsbot_set_error("set_option: unknown option '%s'", key);
+  return BTSBOT_ERR_INVALID_ARG;
+}
+
 extern "C" int btsbot_set_debug(btsbot_handle h, int on) {
   if (h == nullptr) return BTSBOT_ERR_INVALID_ARG;
   h->debug = on != 0;
@@ -827,6 +844,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.out = x2;
         a.tap_stage = h->debug ? h->taps[3] : nullptr;
         a.B = nb;
+        a.alerts_hint = h->s2p_alerts_hint;
         {
           const char* dg = getenv("BTSBOT_AMD_S2P_DIAG");
           a.diag = dg != nullptr ? atoi(dg) : 0;

@@ -29,4 +29,6 @@ struct Stage2pArgs {
   int B;
   unsigned long long* stamps;   // optional: workgroup 0 / thread 0 stores the shader clock per phase (64 entries)
   int diag;              // developer switches (BTSBOT_AMD_S2P_DIAG): 1 barrier at every chunk start, 2 drain loads there
+  int alerts_hint;       // 0: the library picks 4 or 7 alerts per workgroup by rounds; 4 / 7: the caller's choice
+                         // (btsbot_set_option "stage2p_alerts")
 };

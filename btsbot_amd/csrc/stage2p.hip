@@ -741,19 +741,23 @@ int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst
 
 // 7 alerts per workgroup when that takes fewer rounds of one workgroup per CU than 4 (256 CUs): the kernel's time per
 // round does not depend on the alerts resident -- the filter stream bounds it
-int stage2p_alerts_per_workgroup(int B) {
+int stage2p_alerts_per_workgroup(int B, int hint) {
   static const int forced = [] {
     const char* e = getenv("BTSBOT_AMD_S2P_G");
     return e != nullptr ? atoi(e) : 0;
   }();
   if (forced == 4 || forced == 7) return forced;
+  // the caller's hint (btsbot_set_option): a scoring loop that keeps several forwards in flight on different streams
+  // asks for 7 at every batch size -- at 1024 alerts the kernel then occupies 147 CUs instead of 256 for 116 instead of
+  // 105 us, and the other stream's kernels take the rest (measured: +6 % through ScoreStream, -4 % for serial calls)
+  if (hint == 4 || hint == 7) return hint;
   const int r4 = ((B + 3) / 4 + 255) / 256, r7 = ((B + 6) / 7 + 255) / 256;
   return r7 < r4 ? 7 : 4;
 }
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
-  const bool g7 = stage2p_alerts_per_workgroup(a.B) == 7;
+  const bool g7 = stage2p_alerts_per_workgroup(a.B, a.alerts_hint) == 7;
   if (prec == BTSBOT_BF16) return g7 ? launch_stage2p_t<bf16_t, 7>(a, st) : launch_stage2p_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return g7 ? launch_stage2p_t<f16_t, 7>(a, st) : launch_stage2p_t<f16_t>(a, st);
   if (prec == BTSBOT_FP8) return g7 ? launch_stage2p_t<fp8_t, 7>(a, st) : launch_stage2p_t<fp8_t>(a, st);

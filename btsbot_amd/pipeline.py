@@ -30,6 +30,8 @@ from typing import Iterable, Iterator, Tuple
 
 import torch
 
+from . import _lib
+
 __all__ = ["ScoreStream"]
 
 
@@ -84,8 +86,19 @@ class ScoreStream:
         side = self.streams[k]
         if not self.inputs_ready:
             side.wait_stream(torch.cuda.current_stream(self.device))  # the inputs are ready in the caller's order
+        m = self.models[k]
+        hinted = len(self.models) > 1 and getattr(m, "_handle", None) is not None
+        if hinted:
+            # several forwards in flight: the stage-2 kernel keeps 7 alerts per workgroup at every batch size and so
+            # leaves ~40 % of the CUs to the other stream's kernels (+6 % through this loop at 1024 alerts; a lone
+            # model(...) call is 4 % slower that way, so the hint is taken back right after the launches are queued)
+            _lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", 7)
         with torch.cuda.stream(side), torch.no_grad():
-            out = self.models[k](*inputs)
+            try:
+                out = m(*inputs)
+            finally:
+                if hinted:
+                    _lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", 0)
             done = torch.cuda.Event()
             done.record(side)
         return out, done, inputs

@@ -212,6 +212,12 @@ int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
 int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
                            const int64_t* lo, const int64_t* hi, void* stream);
 
+/* Scheduling hints (host-side state read at launch time; results do not depend on them).
+ *   "stage2p_alerts": alerts resident per workgroup of the stage-2 kernel -- 0 (default): 4, or 7 where that takes fewer
+ *   rounds of one workgroup per CU; 7: always (a scoring loop with several forwards in flight on different streams:
+ *   the kernel then leaves ~40 % of the CUs to the other stream at 1024 alerts); 4: always. */
+int btsbot_set_option(btsbot_handle h, const char* key, int value);
+
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and
  * stage outputs (call before btsbot_reserve()). */
 int btsbot_set_debug(btsbot_handle h, int on);
