@@ -358,31 +358,35 @@ class _HipModel(nn.Module):
         return out
 
     def train(self, mode: bool = True):
-        """nn.Module.train, except that an inference-only image branch (MaxViT: BatchNorm2d folded from its
-        running statistics) keeps its BatchNorm containers in eval mode: ``model.train()`` after a validation
-        pass (train.py:332-340, val.py:55) would otherwise flip them back and the next step would refuse to
-        run.  Calling ``.train()`` on the branch itself still raises at the next forward."""
+        """nn.Module.train, except that a FROZEN image branch with BatchNorm2d (MaxViT with ``requires_grad_(False)`` on
+        its parameters: the regime of the published "-metadata" checkpoints, train.py:224-232) keeps its BatchNorm
+        containers in eval mode: ``model.train()`` after a validation pass (train.py:332-340, val.py:55) would
+        otherwise flip them back and the next step would refuse to run.  A branch with trainable parameters goes to
+        train mode like everything else (batch statistics, the reference's semantics)."""
         super().train(mode)
         if mode and getattr(self, "_inference_only", False):
-            for m in self._image_bn_modules():
-                m.eval()
+            _comb, _meta, imageg = self._slot_groups()
+            if not any(t.requires_grad for t, *_ in imageg):
+                for m in self._image_bn_modules():
+                    m.eval()
         return self
 
     def _check_train_supported(self, keep_image: bool):
-        """The MaxViT image branch is built for eval mode only (BatchNorm2d running statistics folded into the
-        convolutions, no backward).  A training-mode forward is therefore served only with that branch frozen AND
-        in eval mode -- ``model.train(); model.<image branch>.eval()`` with ``requires_grad_(False)`` on its
-        parameters: heads (and the metadata branch) train over fixed image features (the regime the tests' CPU
-        checker restates with ``training=True``).  Anything else raises."""
+        """The MaxViT image branch trains as a whole or not at all: with trainable parameters its BatchNorm2d layers
+        must be in train mode (batch statistics + the backward of every layer: maxvit_train.hip, what
+        ``model.train()`` gives); frozen (``requires_grad_(False)`` on all its parameters) they must be in eval mode
+        (the inference kernels with running statistics folded in; heads and the metadata branch train over fixed
+        image features).  The two mixed cases are not built and raise."""
         if not getattr(self, "_inference_only", False):
             return
-        if keep_image:
+        bn_train = [m.training for m in self._image_bn_modules()]
+        if keep_image and not all(bn_train):
             raise NotImplementedError(
-                f"btsbot_amd.{type(self).__name__}: the backward of the MaxViT image branch is not built; freeze "
-                "it (requires_grad_(False) on its parameters) to train the heads over it")
-        if any(m.training for m in self._image_bn_modules()):
+                f"btsbot_amd.{type(self).__name__}: a trainable MaxViT image branch with BatchNorm2d layers in eval "
+                "mode is not built; call .train() on the branch (batch statistics) or freeze it")
+        if not keep_image and any(bn_train):
             raise NotImplementedError(
-                f"btsbot_amd.{type(self).__name__}: BatchNorm2d batch statistics of the MaxViT image branch are "
+                f"btsbot_amd.{type(self).__name__}: BatchNorm2d batch statistics of a FROZEN MaxViT image branch are "
                 "not built; put the branch in eval mode (e.g. model.train(); model.maxvit_backbone.eval()) or "
                 "call .eval() on the whole model")
 

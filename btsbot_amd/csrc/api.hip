@@ -1050,13 +1050,8 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
     btsbot_set_error("reserve_train: bad argument");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (h->is_maxvit && with_image_grads) {
-    // a frozen, eval-mode MaxViT branch under trainable heads is served by the inference kernels (forward_train with
-    // keep_image_activations = 0); its own training is not built
-    btsbot_set_error("reserve_train: BatchNorm2d batch statistics and the backward of the MaxViT image branch "
-                     "are not built (heads over a frozen, eval-mode branch: with_image_grads = 0)");
-    return BTSBOT_ERR_STATE;
-  }
+  // (MaxViT: with_image_grads = 1 trains the branch -- BatchNorm2d batch statistics, maxvit_train.hip; = 0 serves heads
+  //  over a frozen, eval-mode branch with the inference kernels)
   const bool want_bb = with_image_grads && h->has_image;
   if (h->tcache != nullptr && max_batch <= h->tcache_batch &&
       (!want_bb || (h->bbcache != nullptr && max_batch <= h->bbcache_batch)))
@@ -1071,9 +1066,9 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
   if (want_bb && (h->bbcache == nullptr || max_batch > h->bbcache_batch)) {
     if (h->bbcache) (void)hipFree(h->bbcache);
     h->bbcache = nullptr;
-    HIP_TRY(hipMalloc(&h->bbcache, bb_cache_bytes(h, max_batch)));
+    HIP_TRY(hipMalloc(&h->bbcache, h->is_maxvit ? maxvit_train_cache_bytes(h, max_batch) : bb_cache_bytes(h, max_batch)));
     h->bbcache_batch = max_batch;
-    if (!h->train_packs) {      // the dgrad transposes must be packed too from now on
+    if (!h->train_packs && !h->is_maxvit) {      // the dgrad transposes must be packed too from now on
       h->train_packs = true;
       h->packed = false;
       for (int kd = 0; kd < 2; ++kd) {   // the job tables were built without the transposes: rebuild on the next pack
@@ -1129,7 +1124,11 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
       return BTSBOT_ERR_STATE;
     }
     float* feat = nullptr;
-    TRY(backbone_train_forward(h, triplets, batch, st, &feat));
+    if (h->is_maxvit) {
+      TRY(maxvit_train_forward(h, triplets, batch, master_arena, st, &feat));
+      h->bb_saved = true;
+    } else
+      TRY(backbone_train_forward(h, triplets, batch, st, &feat));
     HIP_TRY(hipMemcpyAsync(train_cache_feat(h, h->tcache, batch), feat,
                            (size_t)batch * c.dims[3] * sizeof(float), hipMemcpyDeviceToDevice,
                            st));
@@ -1180,7 +1179,12 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));
   if (need_img) {
-    TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));   // records the bucket events
+    if (h->is_maxvit) {
+      TRY(side_join(h, st));
+      TRY(maxvit_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));   // records the bucket event
+    } else {
+      TRY(backbone_train_backward(h, h->t_img, dfeat, grad_arena, h->train_batch, st));   // records the bucket events
+    }
   } else {
     TRY(side_join(h, st));
     for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));

@@ -12,6 +12,11 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st);                          // mirr
 size_t maxvit_ws_bytes(const btsbot_ctx* h, int chunk);
 int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float** feat_out);
 void maxvit_free(btsbot_ctx* h);
+// ---- training of the branch (maxvit_train.hip): BatchNorm2d batch statistics forward, backward of every layer; an
+//      fp32 engine whatever the handle's operand mode.  cache = h->bbcache, sized by maxvit_train_cache_bytes(B)
+size_t maxvit_train_cache_bytes(const btsbot_ctx* h, int B);
+int maxvit_train_forward(btsbot_ctx* h, const float* img, int B, float* master_arena, hipStream_t st, float** feat_out);
+int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads, int B, hipStream_t st);
 constexpr int MV_MAX_CHUNK = 1024;  // alerts per workspace chunk the host asks for (about 22 MB of activations each in bf16)
 
 // ---- kernels (maxvit_ops.hip).  `prec` selects the staged activation type T (float / bf16 / f16).

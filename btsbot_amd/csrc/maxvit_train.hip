@@ -1,0 +1,848 @@
+// Training of the MaxViT image branch (timm maxvit_tiny_rw_224 as /root/reference/btsbot/architectures.py:25-101
+// builds it; the reference fine-tunes it end to end: train.py:218-236, 510-527): the training-mode forward --
+// BatchNorm2d on BATCH statistics, running statistics updated in the master arena -- and the backward of every
+// layer: stem convolutions, MBConv (pre-norm, 1x1 expand, depthwise 3x3, squeeze-excite, 1x1 project, pooled /
+// projected shortcut), window and grid attention with the relative-position bias, the MLPs, the final LayerNorm2d
+// and the global pool.  The algorithm is restated (with autograd) in oracle/maxvit_oracle.py, branch_training=True.
+//
+// An fp32 engine of its own, whatever the handle's operand mode: activations are fp32 NHWC rows [B*H*H][C]; every
+// 1x1 convolution / Linear runs on the exact-fp32 MFMA GEMM (gemm.hip), its input gradient on the same GEMM against
+// the transposed filter, its filter gradient on backward.hip's split-K GEMM; what has no GEMM shape (BatchNorm
+// statistics, depthwise 3x3, squeeze-excite, attention inside a 49-token partition) is a small kernel here.  It is
+// correctness-first -- one launch per layer, every intermediate through HBM (~110 MB of cache per alert) -- and
+// says so in DESIGN.md: configs[2], the training benchmark, is ConvNeXt.
+#include <string.h>
+
+#include <vector>
+
+#include "ctx.h"
+#include "maxvit.h"
+#include "maxvit_tables.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f;
+
+#define VTRY(call)                  \
+  do {                              \
+    int _s = (call);                \
+    if (_s != BTSBOT_OK) return _s; \
+  } while (0)
+
+inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+  const float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// ---- per-channel sums over the rows of x [M][C]: sums[c] += sum (x - shift[c]), sums[C + c] += sum (x - shift[c])^2
+__global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                          float* __restrict__ sums, long M, int C) {
+  __shared__ float sh[2][4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  float s = 0.f, q = 0.f;
+  if (c < C) {
+    const float sf = shift != nullptr ? shift[c] : 0.f;
+    for (long r = (long)blockIdx.y * 4 + rl; r < M; r += (long)gridDim.y * 4) {
+      const float v = x[r * C + c] - sf;
+      s += v;
+      q = fmaf(v, v, q);
+    }
+  }
+  sh[0][rl][lane] = s;
+  sh[1][rl][lane] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sums + c, sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane]);
+    atomicAdd(sums + C + c, sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane]);
+  }
+}
+// pass 1 -> mean;  pass 2 (sums taken about the mean) -> rstd, and the running statistics in the master arena
+__global__ void bn_mean_kernel(const float* sums, float* stat, long M, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) stat[c] = sums[c] / (float)M;
+}
+__global__ void bn_finish_kernel(const float* sums, float* stat, float* run_mean, float* run_var, long M, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stat[c] + sums[c] / (float)M;    // (the centred sum is ~0: it only polishes the mean)
+  const float d = sums[c] / (float)M;
+  const float var = fmaxf(sums[C + c] / (float)M - d * d, 0.f);
+  stat[c] = mean;
+  stat[C + c] = rsqrtf(var + BN_EPS);
+  if (run_mean != nullptr) {   // torch: momentum 0.1, the running variance takes the unbiased estimate
+    run_mean[c] = (1.0f - BN_MOM) * run_mean[c] + BN_MOM * mean;
+    run_var[c] = (1.0f - BN_MOM) * run_var[c] + BN_MOM * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+  }
+}
+// y = act(xhat * w + b), xhat = (x - mean) * rstd;  act 0: none, 1: SiLU
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ y, long n, int C, int act) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float z = fmaf((x[i] - stat[c]) * stat[C + c], w[c], b[c]);
+  y[i] = act ? z * sigmoid_f(z) : z;
+}
+// backward sums: sums[c] += sum dz, sums[C + c] += sum dz * xhat, dz = dy * act'(z)
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stat, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ sums, long M,
+                                                          int C, int act) {
+  __shared__ float sh[2][4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  float s = 0.f, q = 0.f;
+  if (c < C) {
+    const float mean = stat[c], rstd = stat[C + c], wc = w[c], bc = b[c];
+    for (long r = (long)blockIdx.y * 4 + rl; r < M; r += (long)gridDim.y * 4) {
+      const float xh = (x[r * C + c] - mean) * rstd;
+      float dz = dy[r * C + c];
+      if (act) dz *= silu_grad(fmaf(xh, wc, bc));
+      s += dz;
+      q = fmaf(dz, xh, q);
+    }
+  }
+  sh[0][rl][lane] = s;
+  sh[1][rl][lane] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sums + c, sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane]);
+    atomicAdd(sums + C + c, sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane]);
+  }
+}
+// dx (+)= w rstd (dz - sum dz / M - xhat sum(dz xhat) / M);  block 0 also adds the parameter gradients
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stat,
+                                    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ sums,
+                                    float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long M, int C,
+                                    int act, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      atomicAdd(dw + c, sums[C + c]);
+      atomicAdd(db + c, sums[c]);
+    }
+  }
+  if (i >= M * C) return;
+  const int c = (int)(i % C);
+  const float rstd = stat[C + c], xh = (x[i] - stat[c]) * rstd;
+  float dz = dy[i];
+  if (act) dz *= silu_grad(fmaf(xh, w[c], b[c]));
+  const float inv = 1.0f / (float)M;
+  const float g = w[c] * rstd * (dz - sums[c] * inv - xh * sums[C + c] * inv);
+  dx[i] = accumulate ? dx[i] + g : g;
+}
+
+// ---- depthwise 3x3, padding 1, stride s: in [B][H][H][C] -> out [B][Ho][Ho][C]; taps w9 [9][C]
+__global__ void dw3_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w9, const float* __restrict__ bias,
+                               float* __restrict__ out, int B, int H, int C, int s) {
+  const int Ho = H / s;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * Ho * Ho * C) return;
+  const int c = (int)(i % C);
+  long p = i / C;
+  const int ox = (int)(p % Ho);
+  p /= Ho;
+  const int oy = (int)(p % Ho), b = (int)(p / Ho);
+  float a = bias[c];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * s + ky - 1;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * s + kx - 1;
+      if (ix < 0 || ix >= H) continue;
+      a = fmaf(w9[(ky * 3 + kx) * C + c], in[(((long)b * H + iy) * H + ix) * C + c], a);
+    }
+  }
+  out[i] = a;
+}
+__global__ void dw3_bwd_in_kernel(const float* __restrict__ dout, const float* __restrict__ w9, float* __restrict__ din,
+                                  int B, int H, int C, int s) {
+  const int Ho = H / s;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * H * H * C) return;
+  const int c = (int)(i % C);
+  long p = i / C;
+  const int ix = (int)(p % H);
+  p /= H;
+  const int iy = (int)(p % H), b = (int)(p / H);
+  float a = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % s != 0 || ty / s >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % s != 0 || tx / s >= Ho) continue;
+      a = fmaf(w9[(ky * 3 + kx) * C + c], dout[(((long)b * Ho + ty / s) * Ho + tx / s) * C + c], a);
+    }
+  }
+  din[i] = a;
+}
+// dw9[t][c] += sum dout * in(shifted by tap t), dbias[c] += sum dout
+__global__ __launch_bounds__(256) void dw3_bwd_w_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                        float* __restrict__ dw9, float* __restrict__ dbias, int B, int H,
+                                                        int C, int s) {
+  __shared__ float sh[10][4][64];
+  const int Ho = H / s;
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  if (c < C) {
+    const long npix = (long)B * Ho * Ho;
+    for (long p = (long)blockIdx.y * 4 + rl; p < npix; p += (long)gridDim.y * 4) {
+      const int ox = (int)(p % Ho), oy = (int)((p / Ho) % Ho), b = (int)(p / ((long)Ho * Ho));
+      const float d = dout[p * C + c];
+      acc[9] += d;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * s + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox * s + kx - 1;
+          if (ix < 0 || ix >= H) continue;
+          acc[ky * 3 + kx] = fmaf(d, in[(((long)b * H + iy) * H + ix) * C + c], acc[ky * 3 + kx]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 10; ++t) sh[t][rl][lane] = acc[t];
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(dw9 + t * C + c, sh[t][0][lane] + sh[t][1][lane] + sh[t][2][lane] + sh[t][3][lane]);
+    atomicAdd(dbias + c, sh[9][0][lane] + sh[9][1][lane] + sh[9][2][lane] + sh[9][3][lane]);
+  }
+}
+
+// ---- per-alert column sums: out[b][c] = scale * sum_p a[b][p][c] * (m ? m[b][p][c] : 1)
+__global__ __launch_bounds__(256) void alert_colsum_kernel(const float* __restrict__ a, const float* __restrict__ m,
+                                                           float* __restrict__ out, int P, int C, float scale) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  float s = 0.f;
+  if (c < C)
+    for (int p = rl; p < P; p += 4) {
+      const long i = ((long)b * P + p) * C + c;
+      s += m != nullptr ? a[i] * m[i] : a[i];
+    }
+  sh[rl][lane] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[(long)b * C + c] = scale * (sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+// small dense layers over the batch (squeeze-excite: B rows): y[b][o] = act(bias[o] + sum_i x[b][i] w[o][i]); act 0 none,
+// 1 SiLU, 2 sigmoid; pre (optional) keeps the pre-activation
+__global__ void lin_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                     float* __restrict__ pre, float* __restrict__ y, int B, int I, int O, int act) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * O) return;
+  const int o = i % O, b = i / O;
+  float a = bias[o];
+  for (int k = 0; k < I; ++k) a = fmaf(x[(long)b * I + k], w[(long)o * I + k], a);
+  if (pre != nullptr) pre[i] = a;
+  y[i] = act == 1 ? a * sigmoid_f(a) : act == 2 ? sigmoid_f(a) : a;
+}
+// dpre[b][o] = dy[b][o] * act'(pre)   (act 1: SiLU from the pre-activation; 2: sigmoid from its OUTPUT in pre)
+__global__ void act_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
+                                     int n, int act) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = pre[i];
+  dpre[i] = dy[i] * (act == 1 ? silu_grad(v) : v * (1.0f - v));
+}
+__global__ void lin_bwd_in_small_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dx,
+                                        int B, int I, int O) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * I) return;
+  const int k = i % I, b = i / I;
+  float a = 0.f;
+  for (int o = 0; o < O; ++o) a = fmaf(dpre[(long)b * O + o], w[(long)o * I + k], a);
+  dx[i] = a;
+}
+__global__ void lin_bwd_w_small_kernel(const float* __restrict__ dpre, const float* __restrict__ x, float* __restrict__ dw,
+                                       float* __restrict__ db, int B, int I, int O) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= O * I) return;
+  const int k = i % I, o = i / I;
+  float a = 0.f, s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dpre[(long)b * O + o];
+    a = fmaf(d, x[(long)b * I + k], a);
+    s += d;
+  }
+  dw[i] += a;
+  if (k == 0) db[o] += s;
+}
+// y[b][p][c] = a[b][p][c] * g[b][c]
+__global__ void gate_mul_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ y, int P, int C,
+                                long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long b = i / ((long)P * C);
+  y[i] = a[i] * g[b * C + c];
+}
+// d[b][p][c] += v[b][c] * scale
+__global__ void bcast_add_kernel(float* __restrict__ d, const float* __restrict__ v, int P, int C, long n, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long b = i / ((long)P * C);
+  d[i] += v[b * C + c] * scale;
+}
+__global__ void bcast_set_kernel(float* __restrict__ d, const float* __restrict__ v, int P, int C, long n, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long b = i / ((long)P * C);
+  d[i] = v[b * C + c] * scale;
+}
+// dx[b][y][x][c] (+)= 0.25 g[b][y / 2][x / 2][c]
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int B, int H, int C, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * H * H * C) return;
+  const int c = (int)(i % C);
+  long p = i / C;
+  const int x = (int)(p % H);
+  p /= H;
+  const int y = (int)(p % H), b = (int)(p / H), Ho = H / 2;
+  const float v = 0.25f * g[(((long)b * Ho + y / 2) * Ho + x / 2) * C + c];
+  dx[i] = accumulate ? dx[i] + v : v;
+}
+__global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+__global__ void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = gelu_erf(pre[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ pre, float* __restrict__ d, long n) {   // d *= gelu'(pre)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] *= gelu_grad(pre[i]);
+}
+// col2im of a 3x3 s1 p1 convolution: din[b][y][x][c] = sum over taps dcol[b][y - ky + 1][x - kx + 1][(ky*3+kx)*C + c]
+__global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ din, int B, int H, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * H * H * C) return;
+  const int c = (int)(i % C);
+  long p = i / C;
+  const int x = (int)(p % H);
+  p /= H;
+  const int y = (int)(p % H), b = (int)(p / H);
+  float a = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int oy = y - ky + 1;
+    if (oy < 0 || oy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ox = x - kx + 1;
+      if (ox < 0 || ox >= H) continue;
+      a += dcol[(((long)b * H + oy) * H + ox) * (9 * C) + (ky * 3 + kx) * C + c];
+    }
+  }
+  din[i] = a;
+}
+// packed convolution gradient [O][(ky*3+kx)*C + c] (row pitch ldp) -> master layout [O][C][3][3], accumulated
+__global__ void unpack_conv3_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int O, int C, int ldp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= O * C * 9) return;
+  const int t = i % 9, c = (i / 9) % C, o = i / (9 * C);
+  g[i] += gp[(long)o * ldp + t * C + c];
+}
+// tap-major depthwise gradient [9][C] -> master [C][1][3][3], accumulated
+__global__ void unpack_dw_grad_kernel(const float* __restrict__ g9, float* __restrict__ g, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * C) return;
+  const int t = i % 9, c = i / 9;
+  g[i] += g9[t * C + c];
+}
+// relative-position bias gradient [heads][49 key][49 query] -> table [169][heads], accumulated
+__global__ void relbias_grad_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int heads) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // [169][heads]
+  if (i >= 169 * heads) return;
+  const int hd = i % heads, idx = i / heads;
+  const int dy = idx / 13 - 6, dx = idx % 13 - 6;
+  float s = 0.f;
+  for (int kj = 0; kj < 49; ++kj) {
+    const int qy = kj / 7 + dy, qx = kj % 7 + dx;
+    if (qy < 0 || qy >= 7 || qx < 0 || qx >= 7) continue;
+    s += dbias[((long)hd * 49 + kj) * 49 + qy * 7 + qx];
+  }
+  dtable[i] += s;
+}
+
+// ---- attention backward: one wave per (alert, partition, head); the forward's conventions (mv_attn_kernel,
+// maxvit_ops.hip): q scaled by 32^-0.5, s[query][key j] = q . k_j + bias_t[head][j][query], softmax over the keys.
+// Phase 1, lane = query t: P[t][:], dP[t][j] = dO_t . v_j, dS[t][j] = P (dP - sum_j P dP), dq_t = SC sum_j dS k_j,
+// dbias[head][j][t] += dS.  Phase 2, lane = key j: dk_j = sum_t dS[t][j] (SC q_t), dv_j = sum_t P[t][j] dO_t.
+__global__ __launch_bounds__(64) void mv_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                         float* __restrict__ dbias, int H, int C, int grid_mode) {
+  __shared__ float ks[49][33];
+  __shared__ float vs[49][33];
+  __shared__ float qs[49][33];     // SC * q
+  __shared__ float dos[49][33];
+  __shared__ float ps[49][50];     // [query][key]
+  __shared__ float dss[49][50];
+  const int heads = C / 32, G = H / 7, nW = G * G;
+  int id = blockIdx.x;
+  const int head = id % heads;
+  id /= heads;
+  const int w = id % nW;
+  const long b = id / nW;
+  const int wy = w / G, wx = w % G;
+  const int t = threadIdx.x;
+  const bool active = t < 49;
+  const int ty = t / 7, tx = t % 7;
+  const int py = grid_mode ? ty * G + wy : wy * 7 + ty;
+  const int px = grid_mode ? tx * G + wx : wx * 7 + tx;
+  const long row = active ? (b * H + py) * H + px : 0;
+  constexpr float SC = 0.17677669529663687f;
+  if (active) {
+    const float* base = qkv + row * 3 * C + head * 96;
+    const float* dob = dout + row * C + head * 32;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+      qs[t][d] = base[d] * SC;
+      ks[t][d] = base[32 + d];
+      vs[t][d] = base[64 + d];
+      dos[t][d] = dob[d];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const float* bt = bias_t + (size_t)head * 2401 + t;
+    float mx = -3.0e38f;
+    for (int j = 0; j < 49; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) a = fmaf(qs[t][d], ks[j][d], a);
+      a += bt[j * 49];
+      ps[t][j] = a;
+      mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < 49; ++j) {
+      const float e = __expf(ps[t][j] - mx);
+      ps[t][j] = e;
+      sum += e;
+    }
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+    for (int j = 0; j < 49; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) dp = fmaf(dos[t][d], vs[j][d], dp);
+      const float p = ps[t][j] * inv;
+      ps[t][j] = p;
+      dss[t][j] = dp;
+      dot = fmaf(p, dp, dot);
+    }
+    float dq[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+    for (int j = 0; j < 49; ++j) {
+      const float ds = ps[t][j] * (dss[t][j] - dot);
+      dss[t][j] = ds;
+      atomicAdd(dbias + ((size_t)head * 49 + j) * 49 + t, ds);
+#pragma unroll
+      for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, ks[j][d], dq[d]);
+    }
+    float* dst = dqkv + row * 3 * C + head * 96;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dst[d] = dq[d] * SC;
+  }
+  __syncthreads();
+  if (active) {   // lane = key t
+    float dk[32], dv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dk[d] = dv[d] = 0.f;
+    for (int q = 0; q < 49; ++q) {
+      const float ds = dss[q][t], p = ps[q][t];
+#pragma unroll
+      for (int d = 0; d < 32; ++d) {
+        dk[d] = fmaf(ds, qs[q][d], dk[d]);
+        dv[d] = fmaf(p, dos[q][d], dv[d]);
+      }
+    }
+    float* dst = dqkv + row * 3 * C + head * 96;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+      dst[32 + d] = dk[d];
+      dst[64 + d] = dv[d];
+    }
+  }
+}
+
+// ---- the engine's cache: every activation the backward needs, carved from one allocation -------------------------
+struct AttnAct {
+  float *n1, *qkv, *o, *y1, *n2, *f1, *gl, *y2;
+};
+struct BlkAct {
+  float *xin, *pool_in, *a0, *c1, *a1, *d2, *a2, *sepool, *rpre, *r, *g, *y;
+  float *st_pre, *st1, *st2;   // BatchNorm batch statistics: mean [C] | rstd [C]
+  AttnAct at[2];
+};
+struct MvtCache {
+  float *col1, *y1, *a1s, *st_stem, *x0, *w1p, *w2p;
+  std::vector<BlkAct> blk;
+  float *xfin;                     // final LayerNorm input = last block's output
+  // backward scratch
+  float *dA, *dB, *dC, *wt, *sums, *dsmall, *dbias, *g9, *gconv, *xn_final;
+  size_t total;
+};
+
+MvtCache carve(const MaxVit* mv, unsigned char* base, int B) {
+  MvtCache k;
+  size_t cur = 0;
+  auto take = [&](size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(base + cur) : nullptr;
+    cur += (floats * 4 + 255) / 256 * 256;
+    return p;
+  };
+  const size_t n = (size_t)B, M0 = n * 12544;
+  k.col1 = take(M0 * 32);
+  k.y1 = take(M0 * 32);
+  k.a1s = take(M0 * 32);
+  k.st_stem = take(64);
+  k.x0 = take(M0 * 64);
+  k.w1p = take(32 * 32);
+  k.w2p = take(64 * 288);
+  float* x = k.x0;
+  for (const MvBlock& b : mv->blocks) {
+    BlkAct a;
+    const size_t Min = n * b.hin * b.hin, Mo = n * b.hout * b.hout;
+    a.xin = x;
+    a.pool_in = b.stride == 2 ? take(Mo * b.cin) : nullptr;
+    a.a0 = take(Min * b.cin);
+    a.c1 = take(Min * b.mid);
+    a.a1 = take(Min * b.mid);
+    a.d2 = take(Mo * b.mid);
+    a.a2 = take(Mo * b.mid);
+    a.sepool = take(n * b.mid);
+    a.rpre = take(n * b.rd);
+    a.r = take(n * b.rd);
+    a.g = take(n * b.mid);
+    a.y = take(Mo * b.c);
+    a.st_pre = take(2 * b.cin);
+    a.st1 = take(2 * b.mid);
+    a.st2 = take(2 * b.mid);
+    float* yin = a.y;
+    for (int g = 0; g < 2; ++g) {
+      AttnAct& t = a.at[g];
+      t.n1 = take(Mo * b.c);
+      t.qkv = take(Mo * 3 * b.c);
+      t.o = take(Mo * b.c);
+      t.y1 = take(Mo * b.c);
+      t.n2 = take(Mo * b.c);
+      t.f1 = take(Mo * 4 * b.c);
+      t.gl = take(Mo * 4 * b.c);
+      t.y2 = take(Mo * b.c);
+      yin = t.y2;
+    }
+    x = yin;
+    k.blk.push_back(a);
+  }
+  k.xfin = x;
+  k.dA = take(M0 * 256);       // the largest gradient maps: [12544][256] per alert (block 0's expanded map)
+  k.dB = take(M0 * 256);
+  k.dC = take(M0 * 288);       // stem: gradient of the im2col matrix [12544][288]; also forward's im2col scratch
+  k.wt = take(2048 * 512);
+  k.sums = take(2 * 2048);
+  k.dsmall = take(n * 2048 * 4);
+  k.dbias = take(32 * 2401);   // gradient of the bias [heads <= 16][49][49] | its forward image
+  k.g9 = take(10 * 2048);
+  k.gconv = take(64 * 288);
+  k.xn_final = take(n * 49 * 512);
+  k.total = cur;
+  return k;
+}
+
+}  // namespace
+
+size_t maxvit_train_cache_bytes(const btsbot_ctx* h, int B) { return carve(h->mv, nullptr, B).total; }
+
+// BatchNorm2d, training mode: batch statistics of x [M][C] into stat (mean | rstd), running statistics updated in the
+// master arena, y = act(...)
+static int bn_train(const btsbot_ctx* h, const float* x, const BnPk& bn, float* stat, float* sums, float* y, long M, int C,
+                    int act, float* master, hipStream_t st) {
+  const float* m = h->mirror;
+  const dim3 grid((C + 63) / 64, (unsigned)(M / 256 > 256 ? 256 : (M / 256 > 0 ? M / 256 : 1)));
+  HIP_TRY(hipMemsetAsync(sums, 0, (size_t)2 * C * 4, st));
+  hipLaunchKernelGGL(col_moments_kernel, grid, dim3(256), 0, st, x, (const float*)nullptr, sums, M, C);
+  hipLaunchKernelGGL(bn_mean_kernel, dim3(nblk(C)), dim3(256), 0, st, sums, stat, M, C);
+  HIP_TRY(hipMemsetAsync(sums, 0, (size_t)2 * C * 4, st));
+  hipLaunchKernelGGL(col_moments_kernel, grid, dim3(256), 0, st, x, (const float*)stat, sums, M, C);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(C)), dim3(256), 0, st, sums, stat, master ? master + bn.rm : nullptr,
+                     master ? master + bn.rv : nullptr, M, C);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(M * C)), dim3(256), 0, st, x, stat, m + bn.w, m + bn.b, y, M * C, C, act);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+// ... and its backward: dy = gradient w.r.t. the layer's output (behind the activation), dx (+)= gradient w.r.t. x
+static int bn_train_bwd(const btsbot_ctx* h, const float* x, const float* dy, const BnPk& bn, const float* stat, float* sums,
+                        float* dx, float* grads, long M, int C, int act, int accumulate, hipStream_t st) {
+  const float* m = h->mirror;
+  const dim3 grid((C + 63) / 64, (unsigned)(M / 256 > 256 ? 256 : (M / 256 > 0 ? M / 256 : 1)));
+  HIP_TRY(hipMemsetAsync(sums, 0, (size_t)2 * C * 4, st));
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, grid, dim3(256), 0, st, x, dy, stat, m + bn.w, m + bn.b, sums, M, C, act);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * C)), dim3(256), 0, st, x, dy, stat, m + bn.w, m + bn.b,
+                     (const float*)sums, dx, grads + bn.w, grads + bn.b, M, C, act, accumulate);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+int maxvit_train_forward(btsbot_ctx* h, const float* img, int B, float* master, hipStream_t st, float** feat_out) {
+  MaxVit* mv = h->mv;
+  const float* m = h->mirror;
+  MvtCache k = carve(mv, h->bbcache, B);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(h->extra + off); };
+  const float* zero = F(mv->p_zero);
+  const float* one = F(mv->p_one);
+  auto gemm = [&](const float* X, const float* W, const float* bias, float* out, long M, int N, int K) {
+    return launch_gemm(BTSBOT_F32, EPI_BIAS, X, W, bias ? bias : zero, nullptr, nullptr, out, (int)M, N, K, st);
+  };
+  auto gemm_resid = [&](const float* X, const float* W, const float* bias, const float* resid, float* out, long M, int N,
+                        int K) {
+    return launch_gemm(BTSBOT_F32, EPI_RESID, X, W, bias ? bias : zero, one, resid, out, (int)M, N, K, st);
+  };
+  const long M0 = (long)B * 12544;
+  // ---- stem: resize + conv 3x3 s2 (im2col GEMM) -> BN + SiLU -> conv 3x3 s1
+  VTRY(launch_mv_pack_stem1(BTSBOT_F32, m + mv->stem1_w, one, k.w1p, st));
+  VTRY(launch_mv_pack_conv3(BTSBOT_F32, m + mv->stem2_w, k.w2p, 64, 32, st));
+  VTRY(launch_mv_resize_im2col(BTSBOT_F32, img, k.col1, B, st));
+  VTRY(gemm(k.col1, k.w1p, nullptr, k.y1, M0, 32, 32));
+  VTRY(bn_train(h, k.y1, mv->stem_bn, k.st_stem, k.sums, k.a1s, M0, 32, 1, master, st));
+  VTRY(launch_mv_im2col3(BTSBOT_F32, k.a1s, k.dC, B, 112, 32, st));
+  VTRY(gemm(k.dC, k.w2p, nullptr, k.x0, M0, 64, 288));
+  if (h->debug && h->taps[0]) HIP_TRY(hipMemcpyAsync(h->taps[0], k.x0, (size_t)M0 * 64 * 4, hipMemcpyDeviceToDevice, st));
+  int stage = 0, jblk = 0;
+  constexpr int DEPTHS[4] = {2, 2, 5, 2};
+  for (size_t bi = 0; bi < mv->blocks.size(); ++bi) {
+    const MvBlock& b = mv->blocks[bi];
+    BlkAct& a = k.blk[bi];
+    const long Min = (long)B * b.hin * b.hin, Mo = (long)B * b.hout * b.hout;
+    const int hw2 = b.hout * b.hout;
+    // shortcut: x | avgpool2(x) | avgpool2(x) Wsc^T -- goes straight into y, the projection adds to it
+    const float* sc = a.xin;
+    if (b.stride == 2) {
+      VTRY(launch_mv_avgpool2(BTSBOT_F32, a.xin, a.pool_in, 0, B, b.hin, b.cin, st));
+      sc = a.pool_in;
+      if (b.sc_w >= 0) {
+        VTRY(gemm(a.pool_in, m + b.sc_w, nullptr, a.y, Mo, b.c, b.cin));
+        sc = a.y;
+      }
+    }
+    VTRY(bn_train(h, a.xin, b.pre, a.st_pre, k.sums, a.a0, Min, b.cin, 0, master, st));
+    VTRY(gemm(a.a0, m + b.c1_w, m + b.c1_b, a.c1, Min, b.mid, b.cin));
+    VTRY(bn_train(h, a.c1, b.n1, a.st1, k.sums, a.a1, Min, b.mid, 1, master, st));
+    VTRY(launch_mv_pack_dw(m + b.c2_w, one, k.g9, b.mid, st));
+    hipLaunchKernelGGL(dw3_fwd_kernel, dim3(nblk(Mo * b.mid)), dim3(256), 0, st, a.a1, k.g9, m + b.c2_b, a.d2, B, b.hin,
+                       b.mid, b.stride);
+    VTRY(bn_train(h, a.d2, b.n2, a.st2, k.sums, a.a2, Mo, b.mid, 1, master, st));
+    // squeeze-excite
+    hipLaunchKernelGGL(alert_colsum_kernel, dim3((b.mid + 63) / 64, B), dim3(256), 0, st, a.a2, (const float*)nullptr,
+                       a.sepool, hw2, b.mid, 1.0f / (float)hw2);
+    hipLaunchKernelGGL(lin_fwd_small_kernel, dim3(nblk((long)B * b.rd)), dim3(256), 0, st, a.sepool, m + b.se1_w,
+                       m + b.se1_b, a.rpre, a.r, B, b.mid, b.rd, 1);
+    hipLaunchKernelGGL(lin_fwd_small_kernel, dim3(nblk((long)B * b.mid)), dim3(256), 0, st, a.r, m + b.se2_w, m + b.se2_b,
+                       (float*)nullptr, a.g, B, b.rd, b.mid, 2);
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(nblk(Mo * b.mid)), dim3(256), 0, st, a.a2, a.g, k.dA, hw2, b.mid, Mo * b.mid);
+    LAUNCH_CHECK();
+    VTRY(gemm_resid(k.dA, m + b.c3_w, nullptr, sc, a.y, Mo, b.c, b.mid));
+    const float* yin = a.y;
+    for (int g = 0; g < 2; ++g) {
+      const AttnPk& p = b.attn[g];
+      AttnAct& t = a.at[g];
+      const int c = b.c;
+      VTRY(launch_mv_ln(BTSBOT_F32, yin, m + p.n1w, m + p.n1b, t.n1, Mo, c, st));
+      VTRY(gemm(t.n1, m + p.qkv_w, m + p.qkv_b, t.qkv, Mo, 3 * c, c));
+      VTRY(launch_mv_pack_relbias(m + p.rel, k.dbias, c / 32, st));
+      VTRY(launch_mv_attn(BTSBOT_F32, t.qkv, k.dbias, t.o, B, b.hout, c, g, st));
+      VTRY(gemm_resid(t.o, m + p.proj_w, m + p.proj_b, yin, t.y1, Mo, c, c));
+      VTRY(launch_mv_ln(BTSBOT_F32, t.y1, m + p.n2w, m + p.n2b, t.n2, Mo, c, st));
+      VTRY(gemm(t.n2, m + p.fc1_w, m + p.fc1_b, t.f1, Mo, 4 * c, c));
+      hipLaunchKernelGGL(gelu_fwd_kernel, dim3(nblk(Mo * 4 * c)), dim3(256), 0, st, t.f1, t.gl, Mo * 4 * c);
+      LAUNCH_CHECK();
+      VTRY(gemm_resid(t.gl, m + p.fc2_w, m + p.fc2_b, t.y1, t.y2, Mo, c, 4 * c));
+      yin = t.y2;
+    }
+    ++jblk;
+    if (jblk == DEPTHS[stage]) {
+      if (h->debug && h->taps[stage + 1])
+        HIP_TRY(hipMemcpyAsync(h->taps[stage + 1], yin, (size_t)Mo * b.c * 4, hipMemcpyDeviceToDevice, st));
+      ++stage;
+      jblk = 0;
+    }
+  }
+  float* feat = k.dsmall;   // [B][512] (copied out by the caller before the backward reuses the scratch)
+  VTRY(launch_mv_final(k.xfin, m + mv->norm_w, m + mv->norm_b, feat, B, 49, 512, st));
+  *feat_out = feat;
+  return BTSBOT_OK;
+}
+
+int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads, int B, hipStream_t st) {
+  MaxVit* mv = h->mv;
+  const float* m = h->mirror;
+  MvtCache k = carve(mv, h->bbcache, B);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(h->extra + off); };
+  const float* zero = F(mv->p_zero);
+  // dX [M][K] = dY [M][N] . W [N][K]  (the GEMM against the transposed filter)
+  auto dgrad = [&](const float* dY, const float* W, float* dX, long M, int N, int K) -> int {
+    VTRY(launch_transpose_f32(W, k.wt, N, K, st));
+    return launch_gemm(BTSBOT_F32, EPI_BIAS, dY, k.wt, zero, nullptr, nullptr, dX, (int)M, K, N, st);
+  };
+  // dW [N][K] += dY^T X, db [N] += column sums of dY
+  auto wgrad = [&](const float* dY, const float* X, float* dW, float* db, long M, int N, int K) -> int {
+    VTRY(launch_wgrad(BTSBOT_F32, dY, X, dW, (int)M, N, K, K, st));
+    return db != nullptr ? launch_colsum(BTSBOT_F32, dY, db, (int)M, N, st) : BTSBOT_OK;
+  };
+  // ---- final LayerNorm2d + global average pool: d(xn)[b][p][c] = dfeat[b][c] / 49
+  float* dy = k.dA;         // gradient w.r.t. the current map [rows][C]
+  float* dt = k.dB;         // second map
+  {
+    const long n = (long)B * 49 * 512;
+    hipLaunchKernelGGL(bcast_set_kernel, dim3(nblk(n)), dim3(256), 0, st, k.xn_final, dfeat, 49, 512, n, 1.0f / 49.0f);
+    LAUNCH_CHECK();
+    VTRY(launch_ln_bwd(k.xfin, k.xn_final, m + mv->norm_w, dy, grads + mv->norm_w, grads + mv->norm_b, (long)B * 49, 512, st));
+  }
+  for (int bi = (int)mv->blocks.size() - 1; bi >= 0; --bi) {
+    const MvBlock& b = mv->blocks[bi];
+    BlkAct& a = k.blk[bi];
+    const long Min = (long)B * b.hin * b.hin, Mo = (long)B * b.hout * b.hout;
+    const int hw2 = b.hout * b.hout, c = b.c;
+    // ---- the two partition-attention layers, grid first (it ran last); dy = d(loss)/d(y2)
+    for (int g = 1; g >= 0; --g) {
+      const AttnPk& p = b.attn[g];
+      AttnAct& t = a.at[g];
+      const float* yin = g == 0 ? a.y : a.at[0].y2;
+      // y2 = y1 + gl W2^T + b2
+      VTRY(wgrad(dy, t.gl, grads + p.fc2_w, grads + p.fc2_b, Mo, c, 4 * c));
+      VTRY(dgrad(dy, m + p.fc2_w, dt, Mo, c, 4 * c));                       // d(gl) [Mo][4c]
+      hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nblk(Mo * 4 * c)), dim3(256), 0, st, t.f1, dt, Mo * 4 * c);
+      LAUNCH_CHECK();
+      VTRY(wgrad(dt, t.n2, grads + p.fc1_w, grads + p.fc1_b, Mo, 4 * c, c));
+      VTRY(dgrad(dt, m + p.fc1_w, k.dC, Mo, 4 * c, c));                     // d(n2) [Mo][c]
+      VTRY(launch_ln_bwd(t.y1, k.dC, m + p.n2w, dt, grads + p.n2w, grads + p.n2b, Mo, c, st));
+      hipLaunchKernelGGL(add_kernel, dim3(nblk(Mo * c)), dim3(256), 0, st, dy, dt, Mo * c);   // dy = d(y1)
+      LAUNCH_CHECK();
+      // y1 = yin + o Wp^T + bp
+      VTRY(wgrad(dy, t.o, grads + p.proj_w, grads + p.proj_b, Mo, c, c));
+      VTRY(dgrad(dy, m + p.proj_w, dt, Mo, c, c));                          // d(o) [Mo][c]
+      const int heads = c / 32;
+      HIP_TRY(hipMemsetAsync(k.dbias, 0, (size_t)heads * 2401 * 4, st));
+      VTRY(launch_mv_pack_relbias(m + p.rel, k.dbias + 16 * 2401, heads, st));   // (bias_t in the slot's second half)
+      {
+        const long blocks = (long)B * (b.hout / 7) * (b.hout / 7) * heads;
+        hipLaunchKernelGGL(mv_attn_bwd_kernel, dim3((unsigned)blocks), dim3(64), 0, st, t.qkv, k.dbias + 16 * 2401, dt, k.dC,
+                           k.dbias, b.hout, c, g);
+        hipLaunchKernelGGL(relbias_grad_kernel, dim3(nblk(169 * heads)), dim3(256), 0, st, k.dbias, grads + p.rel, heads);
+        LAUNCH_CHECK();
+      }
+      VTRY(wgrad(k.dC, t.n1, grads + p.qkv_w, grads + p.qkv_b, Mo, 3 * c, c));
+      VTRY(dgrad(k.dC, m + p.qkv_w, dt, Mo, 3 * c, c));                     // d(n1) [Mo][c]
+      VTRY(launch_ln_bwd(yin, dt, m + p.n1w, k.dC, grads + p.n1w, grads + p.n1b, Mo, c, st));
+      hipLaunchKernelGGL(add_kernel, dim3(nblk(Mo * c)), dim3(256), 0, st, dy, k.dC, Mo * c);   // dy = d(yin)
+      LAUNCH_CHECK();
+    }
+    // ---- MBConv: y = sc + (a2 * g) W3^T;  dy = d(loss)/d(y) [Mo][c]
+    float* dx = dt;           // gradient w.r.t. the block's input [Min][cin], accumulated from three paths
+    // a3 = a2 * g (recomputed), d(a3) = dy W3
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(nblk(Mo * b.mid)), dim3(256), 0, st, a.a2, a.g, k.dC, hw2, b.mid, Mo * b.mid);
+    LAUNCH_CHECK();
+    VTRY(wgrad(dy, k.dC, grads + b.c3_w, nullptr, Mo, c, b.mid));
+    VTRY(dgrad(dy, m + b.c3_w, k.dC, Mo, c, b.mid));                        // d(a3) [Mo][mid]
+    // squeeze-excite: dg[b][c] = sum_p d(a3) a2; d(a2) = d(a3) g (+ the pooled path below)
+    float* dgate = k.dsmall;                    // [B][mid]
+    float* dr = k.dsmall + (size_t)B * 2048;    // [B][rd] and scratch
+    float* dpool = k.dsmall + (size_t)B * 2048 * 2;
+    float* dgpre = k.dsmall + (size_t)B * 2048 * 3;
+    hipLaunchKernelGGL(alert_colsum_kernel, dim3((b.mid + 63) / 64, B), dim3(256), 0, st, (const float*)k.dC,
+                       (const float*)a.a2, dgate, hw2, b.mid, 1.0f);
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(nblk(Mo * b.mid)), dim3(256), 0, st, (const float*)k.dC, a.g, k.dC, hw2, b.mid,
+                       Mo * b.mid);                                           // d(a2) = d(a3) * g, in place
+    hipLaunchKernelGGL(act_bwd_small_kernel, dim3(nblk((long)B * b.mid)), dim3(256), 0, st, (const float*)dgate,
+                       (const float*)a.g, dgpre, B * b.mid, 2);
+    hipLaunchKernelGGL(lin_bwd_w_small_kernel, dim3(nblk((long)b.mid * b.rd)), dim3(256), 0, st, (const float*)dgpre,
+                       (const float*)a.r, grads + b.se2_w, grads + b.se2_b, B, b.rd, b.mid);
+    hipLaunchKernelGGL(lin_bwd_in_small_kernel, dim3(nblk((long)B * b.rd)), dim3(256), 0, st, (const float*)dgpre,
+                       m + b.se2_w, dr, B, b.rd, b.mid);
+    hipLaunchKernelGGL(act_bwd_small_kernel, dim3(nblk((long)B * b.rd)), dim3(256), 0, st, (const float*)dr,
+                       (const float*)a.rpre, dr, B * b.rd, 1);
+    hipLaunchKernelGGL(lin_bwd_w_small_kernel, dim3(nblk((long)b.rd * b.mid)), dim3(256), 0, st, (const float*)dr,
+                       (const float*)a.sepool, grads + b.se1_w, grads + b.se1_b, B, b.mid, b.rd);
+    hipLaunchKernelGGL(lin_bwd_in_small_kernel, dim3(nblk((long)B * b.mid)), dim3(256), 0, st, (const float*)dr, m + b.se1_w,
+                       dpool, B, b.mid, b.rd);
+    hipLaunchKernelGGL(bcast_add_kernel, dim3(nblk(Mo * b.mid)), dim3(256), 0, st, k.dC, (const float*)dpool, hw2, b.mid,
+                       Mo * b.mid, 1.0f / (float)hw2);
+    LAUNCH_CHECK();
+    // BN2 + SiLU: d(d2) in place of d(a2)
+    VTRY(bn_train_bwd(h, a.d2, k.dC, b.n2, a.st2, k.sums, k.dC, grads, Mo, b.mid, 1, 0, st));
+    // depthwise 3x3: filter / bias gradients (tap-major, then into the master layout), input gradient d(a1) [Min][mid]
+    HIP_TRY(hipMemsetAsync(k.g9, 0, (size_t)10 * b.mid * 4, st));
+    {
+      const long npix = Mo;
+      const dim3 grid((b.mid + 63) / 64, (unsigned)(npix / 64 > 256 ? 256 : (npix / 64 > 0 ? npix / 64 : 1)));
+      hipLaunchKernelGGL(dw3_bwd_w_kernel, grid, dim3(256), 0, st, (const float*)a.a1, (const float*)k.dC, k.g9,
+                         grads + b.c2_b, B, b.hin, b.mid, b.stride);
+      hipLaunchKernelGGL(unpack_dw_grad_kernel, dim3(nblk(9L * b.mid)), dim3(256), 0, st, (const float*)k.g9, grads + b.c2_w,
+                         b.mid);
+      VTRY(launch_mv_pack_dw(m + b.c2_w, F(mv->p_one), k.g9, b.mid, st));
+      hipLaunchKernelGGL(dw3_bwd_in_kernel, dim3(nblk(Min * b.mid)), dim3(256), 0, st, (const float*)k.dC, (const float*)k.g9,
+                         dx, B, b.hin, b.mid, b.stride);
+      LAUNCH_CHECK();
+    }
+    // BN1 + SiLU: d(c1) in place; conv1 1x1
+    VTRY(bn_train_bwd(h, a.c1, dx, b.n1, a.st1, k.sums, dx, grads, Min, b.mid, 1, 0, st));
+    VTRY(wgrad(dx, a.a0, grads + b.c1_w, grads + b.c1_b, Min, b.mid, b.cin));
+    VTRY(dgrad(dx, m + b.c1_w, k.dC, Min, b.mid, b.cin));                   // d(a0) [Min][cin]
+    // pre-norm BatchNorm (no activation): d(xin) = its input gradient ...
+    VTRY(bn_train_bwd(h, a.xin, k.dC, b.pre, a.st_pre, k.sums, dx, grads, Min, b.cin, 0, 0, st));
+    // ... plus the shortcut's: dy through identity | avgpool2 | avgpool2 . Wsc
+    if (b.stride == 1) {
+      hipLaunchKernelGGL(add_kernel, dim3(nblk(Min * b.cin)), dim3(256), 0, st, dx, (const float*)dy, Min * b.cin);
+    } else if (b.sc_w >= 0) {
+      VTRY(wgrad(dy, a.pool_in, grads + b.sc_w, nullptr, Mo, c, b.cin));
+      VTRY(dgrad(dy, m + b.sc_w, k.dC, Mo, c, b.cin));
+      hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(nblk(Min * b.cin)), dim3(256), 0, st, (const float*)k.dC, dx, B, b.hin,
+                         b.cin, 1);
+    } else {
+      hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(nblk(Min * b.cin)), dim3(256), 0, st, (const float*)dy, dx, B, b.hin, b.cin,
+                         1);
+    }
+    LAUNCH_CHECK();
+    float* tswap = dy;       // dx becomes the next (earlier) block's dy
+    dy = dx;
+    dt = tswap;
+  }
+  // ---- stem: x0 = im2col3(a1s) W2^T;  a1s = silu(BN(y1));  y1 = col1 W1^T
+  {
+    const long M0 = (long)B * 12544;
+    VTRY(launch_mv_im2col3(BTSBOT_F32, k.a1s, k.dC, B, 112, 32, st));
+    HIP_TRY(hipMemsetAsync(k.gconv, 0, (size_t)64 * 288 * 4, st));
+    VTRY(launch_wgrad(BTSBOT_F32, dy, k.dC, k.gconv, (int)M0, 64, 288, 288, st));
+    hipLaunchKernelGGL(unpack_conv3_grad_kernel, dim3(nblk(64 * 32 * 9)), dim3(256), 0, st, (const float*)k.gconv,
+                       grads + mv->stem2_w, 64, 32, 288);
+    LAUNCH_CHECK();
+    VTRY(dgrad(dy, k.w2p, k.dC, M0, 64, 288));                              // d(col2) [M0][288]
+    hipLaunchKernelGGL(col2im3_kernel, dim3(nblk(M0 * 32)), dim3(256), 0, st, (const float*)k.dC, dt, B, 112, 32);
+    LAUNCH_CHECK();
+    VTRY(bn_train_bwd(h, k.y1, dt, mv->stem_bn, k.st_stem, k.sums, dt, grads, M0, 32, 1, 0, st));
+    HIP_TRY(hipMemsetAsync(k.gconv, 0, (size_t)32 * 32 * 4, st));
+    VTRY(launch_wgrad(BTSBOT_F32, dt, k.col1, k.gconv, (int)M0, 32, 32, 32, st));
+    hipLaunchKernelGGL(unpack_conv3_grad_kernel, dim3(nblk(32 * 3 * 9)), dim3(256), 0, st, (const float*)k.gconv,
+                       grads + mv->stem1_w, 32, 3, 32);
+    LAUNCH_CHECK();
+  }
+  for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));
+  return BTSBOT_OK;
+}

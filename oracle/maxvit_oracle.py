@@ -79,10 +79,18 @@ def block_table(arch: str):
 # --------------------------------------------------------------------------------------
 # pieces
 # --------------------------------------------------------------------------------------
-def bn2d(x: Tensor, sd: SD, p: str) -> Tensor:
-    """BatchNorm2d in eval mode (running statistics)."""
-    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
-                        sd[p + "bias"], False, 0.0, BN_EPS)
+def bn2d(x: Tensor, sd: SD, p: str, batch_stats: bool = False, new_stats: Optional[dict] = None) -> Tensor:
+    """BatchNorm2d: eval mode (running statistics), or -- batch_stats, the training mode the reference fine-tunes the
+    branch in (train.py:218-236: every parameter trainable, model.train()) -- batch statistics, with the running
+    statistics torch would leave behind (momentum 0.1, unbiased variance) collected in `new_stats`."""
+    if not batch_stats:
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
+                            sd[p + "bias"], False, 0.0, BN_EPS)
+    rm, rv = sd[p + "running_mean"].detach().clone(), sd[p + "running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + "weight"], sd[p + "bias"], True, 0.1, BN_EPS)
+    if new_stats is not None:
+        new_stats[p + "running_mean"], new_stats[p + "running_var"] = rm, rv
+    return y
 
 
 def rel_pos_index(ws: int) -> Tensor:
@@ -148,7 +156,8 @@ def partition_attention(x: Tensor, sd: SD, p: str, grid: bool, dim_head: int, ws
     return x + F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
 
 
-def mbconv(x: Tensor, sd: SD, p: str, stride: int) -> Tensor:
+def mbconv(x: Tensor, sd: SD, p: str, stride: int, batch_stats: bool = False,
+           new_stats: Optional[dict] = None) -> Tensor:
     """MbConvBlock, NCHW."""
     if stride == 2:
         sc = F.avg_pool2d(x, 2)
@@ -156,13 +165,13 @@ def mbconv(x: Tensor, sd: SD, p: str, stride: int) -> Tensor:
             sc = F.conv2d(sc, sd[p + "shortcut.expand.weight"])
     else:
         sc = x
-    y = bn2d(x, sd, p + "pre_norm.")
+    y = bn2d(x, sd, p + "pre_norm.", batch_stats, new_stats)
     y = F.conv2d(y, sd[p + "conv1_1x1.weight"], sd[p + "conv1_1x1.bias"])
-    y = F.silu(bn2d(y, sd, p + "norm1."))
+    y = F.silu(bn2d(y, sd, p + "norm1.", batch_stats, new_stats))
     mid = y.shape[1]
     y = F.conv2d(y, sd[p + "conv2_kxk.weight"], sd[p + "conv2_kxk.bias"], stride=stride, padding=1,
                  groups=mid)
-    y = F.silu(bn2d(y, sd, p + "norm2."))
+    y = F.silu(bn2d(y, sd, p + "norm2.", batch_stats, new_stats))
     s = y.mean((2, 3), keepdim=True)
     s = F.silu(F.conv2d(s, sd[p + "se.fc1.weight"], sd[p + "se.fc1.bias"]))
     s = torch.sigmoid(F.conv2d(s, sd[p + "se.fc2.weight"], sd[p + "se.fc2.bias"]))
@@ -179,17 +188,18 @@ def resize(img: Tensor, size: int) -> Tensor:
 
 
 def forward_features(img: Tensor, sd: SD, prefix: str, arch: str,
-                     taps: Optional[dict] = None) -> Tensor:
-    """img [B,3,224,224] -> [B,512,7,7] (after the final LayerNorm2d)."""
+                     taps: Optional[dict] = None, batch_stats: bool = False,
+                     new_stats: Optional[dict] = None) -> Tensor:
+    """img [B,3,224,224] -> [B,512,7,7] (after the final LayerNorm2d).  batch_stats: BatchNorm2d in training mode."""
     a = ARCHS[arch]
     x = F.conv2d(img, sd[prefix + "stem.conv1.weight"], None, stride=2, padding=1)
-    x = F.silu(bn2d(x, sd, prefix + "stem.norm1."))
+    x = F.silu(bn2d(x, sd, prefix + "stem.norm1.", batch_stats, new_stats))
     x = F.conv2d(x, sd[prefix + "stem.conv2.weight"], None, stride=1, padding=1)
     if taps is not None:
         taps["stem"] = x
     for (i, j, _cin, _c, _mid, _rd, stride, _hi, _ho) in block_table(arch):
         p = f"{prefix}stages.{i}.blocks.{j}."
-        x = mbconv(x, sd, p + "conv.", stride)
+        x = mbconv(x, sd, p + "conv.", stride, batch_stats, new_stats)
         if taps is not None:
             taps[f"s{i}b{j}.conv"] = x
         x = x.permute(0, 2, 3, 1)
@@ -215,13 +225,15 @@ def pooled(x: Tensor) -> Tensor:
 # whole models
 # --------------------------------------------------------------------------------------
 def mm_maxvit_forward(sd: SD, config: dict, image: Tensor, meta: Tensor, training: bool = False,
-                      masks: Optional[dict] = None, taps: Optional[dict] = None) -> Tensor:
+                      masks: Optional[dict] = None, taps: Optional[dict] = None, branch_training: bool = False,
+                      new_stats: Optional[dict] = None) -> Tensor:
     """architectures.py:58-101 (keys maxvit_backbone.*, metadata_branch.{0,1,4},
-    combined_head.{0,2,5}); the image branch has BatchNorm: this oracle covers eval mode."""
+    combined_head.{0,2,5}).  The image branch has BatchNorm2d: eval mode (running statistics) unless
+    branch_training, the mode the reference trains the whole model in (batch statistics)."""
     arch = arch_of(config.get("model_kind", "maxvit_tiny_rw_224.sw_in1k"))
     masks = masks or {}
     x = resize(image, ARCHS[arch]["img"])
-    f = pooled(forward_features(x, sd, "maxvit_backbone.", arch, taps))
+    f = pooled(forward_features(x, sd, "maxvit_backbone.", arch, taps, branch_training, new_stats))
     m = CO.metadata_branch(meta, sd, "metadata_branch.", "gelu", True, training,
                            config["meta_dropout"], masks.get("meta"))
     if taps is not None:
@@ -359,9 +371,12 @@ def count_macs(arch: str) -> int:
 
 
 def forward(kind: str, sd: SD, config: dict, image: Optional[Tensor], meta: Optional[Tensor],
-            training: bool = False, masks: Optional[dict] = None) -> Tensor:
+            training: bool = False, masks: Optional[dict] = None, branch_training: bool = False,
+            new_stats: Optional[dict] = None) -> Tensor:
     if kind == "mm_MaxViT":
-        return mm_maxvit_forward(sd, config, image, meta, training, masks)
+        return mm_maxvit_forward(sd, config, image, meta, training, masks, None, branch_training, new_stats)
+    if branch_training:
+        raise NotImplementedError("branch_training is restated for mm_MaxViT")
     if kind == "MaxViT":
         return maxvit_forward(sd, config, image, training, masks)
     if kind == "frozen_fusion":

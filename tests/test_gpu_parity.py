@@ -417,7 +417,7 @@ def test_maxvit_stage_activations_match_oracle(cuda):
 
 def test_maxvit_chunking_independence_and_modes(cuda):
     """Internal workspace chunks (forced to 4 alerts here) and batch permutation do not change a
-    logit; train mode is refused loudly (inference-only row)."""
+    logit; the two mixed training regimes of the branch are refused loudly."""
     kind, cfg, sd = _mv("mm_maxvit")
     img, meta, _ = synthetic_batch(10, seed=4)
     img, meta = img.to(cuda), meta.to(cuda)
@@ -429,11 +429,15 @@ def test_maxvit_chunking_independence_and_modes(cuda):
     perm = torch.randperm(10, generator=torch.Generator().manual_seed(0)).to(cuda)
     assert torch.equal(run_model(kind, m, img[perm].contiguous(), meta[perm].contiguous()), full[perm])
     assert run_model(kind, m, img[:0], meta[:0]).shape == (0, 1)
+    # the two mixed cases are refused loudly: a frozen branch in train mode, a trainable branch in eval mode
+    # (a trainable branch in train mode trains: tests/test_gpu_train.py::test_maxvit_branch_training_matches_autograd)
     m.train()
-    m.maxvit_backbone.train()                       # BatchNorm2d batch statistics of the branch: not built
+    m.maxvit_backbone.eval()                        # eval-mode branch, but its parameters still want gradients
     with pytest.raises(NotImplementedError):
         m(image_input=img, metadata_input=meta)
-    m.maxvit_backbone.eval()                        # eval-mode branch, but its parameters still want gradients
+    for p in m.maxvit_backbone.parameters():
+        p.requires_grad_(False)
+    m.maxvit_backbone.train()                       # frozen, but BatchNorm2d on batch statistics
     with pytest.raises(NotImplementedError):
         m(image_input=img, metadata_input=meta)
 

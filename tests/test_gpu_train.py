@@ -512,3 +512,69 @@ def test_exchange_step_through_the_c_abi_on_a_one_rank_communicator(cuda):
         assert (ma._arena - mb._arena).abs().max().item() <= 1e-5
     finally:
         comm.destroy()
+
+
+def _maxvit_branch_training_errors(cuda, B=4, seed=3):
+    """(logit error, {tensor: relative gradient error}, {buffer: running-stat error}) of a training-mode pass of
+    mm_MaxViT with EVERY parameter trainable against autograd through the oracle (branch_training=True)."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    from oracle import maxvit_oracle as MO
+    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    sd = seeded_state_mv(kind, cfg, seed=seed)
+    img, meta, labels = synthetic_batch(B, seed=4)
+    masks = _masks(kind, cfg, B, seed=9)
+    m = build_model(kind, cfg, sd, cuda, "f32").train()
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    assert all(p.requires_grad for p in m.parameters())
+    logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
+        logits, labels.to(cuda).float().unsqueeze(1))
+    loss.backward()
+    ref = {k: v.clone() for k, v in sd.items()}
+    names = [k for k, _p in m.named_parameters()]
+    for k in names:
+        ref[k].requires_grad_(True)
+    new_stats = {}
+    torch.set_num_threads(16)
+    ref_logits = MO.forward(kind, ref, cfg, img, meta, training=True, masks=masks, branch_training=True,
+                            new_stats=new_stats)
+    O.bce_with_logits(ref_logits, labels.float().unsqueeze(1), 2.0).backward()
+    dl = (logits.detach().cpu() - ref_logits.detach()).abs().max().item() / max(1.0, ref_logits.abs().max().item())
+    got = dict(m.named_parameters())
+    gerr = {}
+    # A bias in front of a BatchNorm on batch statistics (conv1_1x1.bias, conv2_kxk.bias, and pre_norm.bias through the
+    # linear conv1) has an exactly zero gradient: both sides hold summation noise there (eps x the sum of |terms| over
+    # 1e4 .. 1e5 rows).  Those tensors are checked for being noise-sized on BOTH sides -- below 2e-3 of the median
+    # tensor's largest entry -- and every other tensor relative to its own largest entry.
+    mags = sorted(ref[k].grad.abs().max().item() for k in names)
+    med = mags[len(mags) // 2]
+    zero_grad = (".conv.pre_norm.bias", ".conv.conv1_1x1.bias", ".conv.conv2_kxk.bias")
+    for k in names:
+        a, b = got[k].grad.cpu().double(), ref[k].grad.double()
+        if k.endswith(zero_grad):
+            noise = max(a.abs().max().item(), b.abs().max().item()) / med
+            gerr[k] = 0.0 if noise <= 2e-3 else noise
+        else:
+            gerr[k] = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    after = m.state_dict()
+    serr = {k: (after[k].cpu() - v).abs().max().item() / max(1.0, v.abs().max().item()) for k, v in new_stats.items()}
+    return dl, gerr, serr, after, sd
+
+
+def test_maxvit_branch_training_matches_autograd(cuda):
+    """Training OF the MaxViT image branch (the reference fine-tunes the whole model:
+    /root/reference/btsbot/train.py:218-236, 510-527, architectures.py:54-101): mm_MaxViT in train mode with every
+    parameter trainable -- BatchNorm2d on batch statistics, the backward of the stem, MBConv (depthwise 3x3,
+    squeeze-excite, shortcut pool / projection), window and grid attention with the relative-position bias, the MLPs
+    and the final LayerNorm2d + pool -- against torch autograd through oracle/maxvit_oracle.py (branch_training=True),
+    fp32: logits, the gradient of every one of the tensors, and the running statistics BatchNorm2d leaves behind."""
+    dl, gerr, serr, after, sd = _maxvit_branch_training_errors(cuda)
+    assert dl <= 2e-4, f"training-mode logits: {dl}"
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] <= 5e-4, f"gradient mismatch, worst tensors: {worst}"
+    assert len(gerr) > 300                                            # every tensor of the branch and the heads
+    worst_s = sorted(serr.items(), key=lambda kv: -kv[1])[:3]
+    assert worst_s[0][1] <= 1e-4, f"running statistics: {worst_s}"
+    for k, v in after.items():                                        # every BatchNorm counted the batch
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(sd[k]) + 1, k
