@@ -243,14 +243,15 @@ def mm_maxvit_forward(sd: SD, config: dict, image: Tensor, meta: Tensor, trainin
 
 
 def maxvit_forward(sd: SD, config: dict, image: Tensor, training: bool = False,
-                   masks: Optional[dict] = None) -> Tensor:
+                   masks: Optional[dict] = None, branch_training: bool = False,
+                   new_stats: Optional[dict] = None) -> Tensor:
     """architectures.py:25-55: head = global_pool, Linear, GELU, Linear, GELU, Dropout, Linear
     (keys maxvit.head.{1,3,6})."""
     arch = arch_of(config.get("model_kind", "maxvit_tiny_rw_224.sw_in1k"))
     masks = masks or {}
     bp = "maxvit."
     x = resize(image, ARCHS[arch]["img"])
-    f = pooled(forward_features(x, sd, bp, arch))
+    f = pooled(forward_features(x, sd, bp, arch, None, branch_training, new_stats))
     x = F.gelu(F.linear(f, sd[bp + "head.1.weight"], sd[bp + "head.1.bias"]))
     x = F.gelu(F.linear(x, sd[bp + "head.3.weight"], sd[bp + "head.3.bias"]))
     x = CO._drop(x, config["dropout"], masks.get("head") if training else None)
@@ -375,10 +376,10 @@ def forward(kind: str, sd: SD, config: dict, image: Optional[Tensor], meta: Opti
             new_stats: Optional[dict] = None) -> Tensor:
     if kind == "mm_MaxViT":
         return mm_maxvit_forward(sd, config, image, meta, training, masks, None, branch_training, new_stats)
-    if branch_training:
-        raise NotImplementedError("branch_training is restated for mm_MaxViT")
     if kind == "MaxViT":
-        return maxvit_forward(sd, config, image, training, masks)
+        return maxvit_forward(sd, config, image, training, masks, branch_training, new_stats)
+    if branch_training:
+        raise NotImplementedError("branch_training is restated for mm_MaxViT and MaxViT")
     if kind == "frozen_fusion":
         return frozen_fusion_maxvit_forward(sd, config, image, meta, training, masks)
     raise ValueError(kind)

@@ -514,19 +514,26 @@ def test_exchange_step_through_the_c_abi_on_a_one_rank_communicator(cuda):
         comm.destroy()
 
 
-def _maxvit_branch_training_errors(cuda, B=4, seed=3):
-    """(logit error, {tensor: relative gradient error}, {buffer: running-stat error}) of a training-mode pass of
-    mm_MaxViT with EVERY parameter trainable against autograd through the oracle (branch_training=True)."""
+def _maxvit_branch_training_errors(cuda, B=4, seed=3, name="mm_maxvit"):
+    """(logit error, {tensor: relative gradient error}, {buffer: running-stat error}) of a training-mode pass of a
+    MaxViT wiring with EVERY parameter trainable against autograd through the oracle (branch_training=True)."""
     from helpers import MV_CONFIGS, seeded_state_mv
     from oracle import maxvit_oracle as MO
-    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    kind, cfg = MV_CONFIGS[name]
     sd = seeded_state_mv(kind, cfg, seed=seed)
     img, meta, labels = synthetic_batch(B, seed=4)
-    masks = _masks(kind, cfg, B, seed=9)
+    if kind == "MaxViT":
+        mk = (torch.rand(B, cfg["fc2_neurons"], generator=torch.Generator().manual_seed(9)) >= cfg["dropout"]).float()
+        fmasks, masks = {"comb": mk}, {"head": mk}
+    else:
+        fmasks = masks = _masks(kind, cfg, B, seed=9)
     m = build_model(kind, cfg, sd, cuda, "f32").train()
-    m._forced_masks = {k: v.to(torch.uint8) for k, v in masks.items()}
+    m._forced_masks = {k: v.to(torch.uint8) for k, v in fmasks.items()}
     assert all(p.requires_grad for p in m.parameters())
-    logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
+    if kind == "MaxViT":
+        logits = m(input_data=img.to(cuda))
+    else:
+        logits = m(image_input=img.to(cuda), metadata_input=meta.to(cuda))
     loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=cuda))(
         logits, labels.to(cuda).float().unsqueeze(1))
     loss.backward()
@@ -561,14 +568,15 @@ def _maxvit_branch_training_errors(cuda, B=4, seed=3):
     return dl, gerr, serr, after, sd
 
 
-def test_maxvit_branch_training_matches_autograd(cuda):
+@pytest.mark.parametrize("name", ["mm_maxvit", "maxvit"])
+def test_maxvit_branch_training_matches_autograd(cuda, name):
     """Training OF the MaxViT image branch (the reference fine-tunes the whole model:
     /root/reference/btsbot/train.py:218-236, 510-527, architectures.py:54-101): mm_MaxViT in train mode with every
     parameter trainable -- BatchNorm2d on batch statistics, the backward of the stem, MBConv (depthwise 3x3,
     squeeze-excite, shortcut pool / projection), window and grid attention with the relative-position bias, the MLPs
     and the final LayerNorm2d + pool -- against torch autograd through oracle/maxvit_oracle.py (branch_training=True),
     fp32: logits, the gradient of every one of the tensors, and the running statistics BatchNorm2d leaves behind."""
-    dl, gerr, serr, after, sd = _maxvit_branch_training_errors(cuda)
+    dl, gerr, serr, after, sd = _maxvit_branch_training_errors(cuda, name=name)
     assert dl <= 2e-4, f"training-mode logits: {dl}"
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] <= 5e-4, f"gradient mismatch, worst tensors: {worst}"
@@ -578,3 +586,37 @@ def test_maxvit_branch_training_matches_autograd(cuda):
     for k, v in after.items():                                        # every BatchNorm counted the batch
         if k.endswith("num_batches_tracked"):
             assert int(v) == int(sd[k]) + 1, k
+
+
+def test_trainer_trains_the_whole_mm_maxvit(cuda):
+    """Trainer.step (forward with BatchNorm2d batch statistics, BCE, backward of every layer, AdamW) on mm_MaxViT with
+    EVERY parameter trainable (the reference's run_training for a MaxViT model: train.py:218-236): the loss is finite
+    and goes down on a fixed batch, tensors of every part of the model move (stem, MBConv, both attention kinds, the
+    relative-position tables, heads), BatchNorm2d running statistics move and count, and an eval forward afterwards
+    works (operand images re-packed from the updated weights)."""
+    from helpers import MV_CONFIGS, seeded_state_mv
+    from btsbot_amd.train import Trainer
+    kind, cfg = MV_CONFIGS["mm_maxvit"]
+    cfg = dict(cfg, meta_dropout=0.0, comb_dropout=0.0)
+    sd = seeded_state_mv(kind, cfg, seed=3)
+    m = build_model(kind, cfg, sd, cuda, "bf16").train()      # (the branch trains in fp32 whatever the operand mode)
+    img, meta, lab = synthetic_batch(8, seed=6)
+    img, meta, lab = img.to(cuda), meta.to(cuda), lab.to(cuda)
+    tr = Trainer(m, lr=2e-4, betas=(0.9, 0.99), pos_weight=1.0)
+    assert tr.need_image
+    losses = [tr.step(img, meta, lab).item() * 1.0 for _ in range(6)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    after = m.state_dict()
+    moved = lambda k: not torch.equal(after[k].cpu(), sd[k])
+    for k in ("maxvit_backbone.stem.conv1.weight", "maxvit_backbone.stem.conv2.weight",
+              "maxvit_backbone.stages.0.blocks.0.conv.conv2_kxk.weight", "maxvit_backbone.stages.1.blocks.0.conv.shortcut.expand.weight",
+              "maxvit_backbone.stages.2.blocks.3.conv.se.fc1.weight", "maxvit_backbone.stages.3.blocks.1.attn_grid.attn.rel_pos.relative_position_bias_table",
+              "maxvit_backbone.stages.2.blocks.0.attn_block.attn.qkv.weight", "maxvit_backbone.norm.weight",
+              "maxvit_backbone.stem.norm1.running_mean", "combined_head.0.weight", "metadata_branch.1.weight"):
+        assert moved(k), k
+    assert int(after["maxvit_backbone.stem.norm1.num_batches_tracked"]) == int(sd["maxvit_backbone.stem.norm1.num_batches_tracked"]) + 6
+    m.eval()
+    with torch.no_grad():
+        out = m(image_input=img, metadata_input=meta)
+    assert torch.isfinite(out).all()
