@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--maxvit-steps", type=int, default=3,
                     help="steps of the MaxViT inference leg (BASELINE.json configs[3]); 0 = skip")
     ap.add_argument("--maxvit-batch", type=int, default=1024, help="alerts per GPU per MaxViT step")
+    ap.add_argument("--maxvit-train-steps", type=int, default=3,
+                    help="steps of the MaxViT training leg (mm_MaxViT, every parameter trainable); 0 = skip")
+    ap.add_argument("--maxvit-train-batch", type=int, default=64, help="alerts per GPU per MaxViT training step")
     return ap.parse_args()
 
 
@@ -348,6 +351,43 @@ def timed_blocks(run, steps, warmup, fence, dist, dev, blocks=BLOCKS, warm_secon
         times.append(el)
     times.sort()
     return times[len(times) // 2], times, last
+
+
+def maxvit_train_leg(dev, rank, world, dist, fence, args):
+    """Training of the whole mm_MaxViT (image branch included: BatchNorm2d batch statistics, backward of every layer --
+    btsbot_amd/csrc/maxvit_train.hip, an fp32 engine whatever the operand mode) with BCE + AdamW and, with more than
+    one rank, the gradient exchange.  The reference's fine-tuning of a MaxViT model, train.py:218-236, 510-527."""
+    from btsbot_amd.train import Trainer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mv = btsbot_amd.mm_MaxViT(MAXVIT_CONFIG, precision=args.precision)
+    seeded_weights(mv)
+    mv = mv.to(dev).train()
+    img, meta, lab = synthetic_batch(args.maxvit_train_batch, seed=70 + rank)
+    img, meta, lab = img.to(dev), meta.to(dev), lab.to(dev)
+    tr = Trainer(mv, lr=1e-4, betas=(0.99, 0.99), pos_weight=1.0)
+
+    def run(n):
+        o = None
+        for _ in range(n):
+            o = tr.step(img, meta, lab)
+        return o
+
+    el, _, loss = timed_blocks(run, args.maxvit_train_steps, 1, fence, dist, dev, blocks=3, warm_seconds=0.2)
+    total = args.maxvit_train_batch * world * args.maxvit_train_steps
+    # forward + input gradients + filter gradients = 3 x the forward's 10.1 GFLOP per alert
+    step_flop = 3.0 * 10.14e9 * args.maxvit_train_batch
+    return {
+        "workload": "mm_MaxViT (maxvit_tiny_rw_224 on cutouts resized to 224) training step, every parameter trainable: "
+                    "BatchNorm2d batch statistics, BCE, backward of every layer, AdamW; fp32 training engine, "
+                    f"batch={args.maxvit_train_batch} per GPU",
+        "value": round(total / el, 1), "unit": "alerts/s", "per_gpu_batch": args.maxvit_train_batch,
+        "steps": args.maxvit_train_steps, "ms_per_step": round(1e3 * el / args.maxvit_train_steps, 2),
+        "loss_finite": bool(torch.isfinite(loss).item()),
+        "whole_step_tflops": round(step_flop / (el / args.maxvit_train_steps) / 1e12, 2),
+        "note": "correctness-first: one launch per layer, fp32 MFMA GEMMs (157 TFLOP/s peak); the training benchmark "
+                "of BASELINE.json (configs[2]) is the ConvNeXt `train` leg",
+    }
 
 
 def cpu_baseline(sample_batch=256, budget_s=24.0):
@@ -700,6 +740,13 @@ def main():
         except Exception as e:   # noqa: BLE001
             maxvit = {"error": f"{type(e).__name__}: {e}"}
 
+    maxvit_train = None
+    if args.maxvit_train_steps > 0:
+        try:
+            maxvit_train = maxvit_train_leg(dev, rank, world, dist, fence, args)
+        except Exception as e:   # noqa: BLE001
+            maxvit_train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         work = family_work(args.batch, args.precision)
         kernels = {}
@@ -798,6 +845,8 @@ def main():
             line["train"] = train
         if maxvit is not None:
             line["maxvit"] = maxvit
+        if maxvit_train is not None:
+            line["maxvit_train"] = maxvit_train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
