@@ -28,6 +28,9 @@ struct BlkBuf {
   void* da;      // d(loss)/d(fc1 pre-activation), operand type [rows][4C]
   float* dwpart; // dwln_bwd_kernel's partial rows [dwrows][52 C] (nullptr: the block runs the three-launch form)
   int dwrows;
+  float* fS;     // ... and its colsum(dy) [C] (the side stream's fc2_grads_kernel reads and clears it)
+  float* fpart;  // mlp_bwd_kernel's partial filter-gradient tiles (nullptr: the block runs the unfused MLP backward);
+                 // one region per block: the side stream reduces block j's while the chain writes block j-1's
 };
 
 constexpr size_t WPART_FLOATS = (size_t)16 << 20;   // 64 MB: every shape of the pico / nano schedule fits (else atomics)
@@ -41,6 +44,7 @@ struct BBCache {
   void* dyT_down[4];        // operand type [rows_i][C_i]: d(loss)/d(downsample i output) (i >= 1)
   void* dyT_stem;           // operand type [B*225][C0]: gradient behind the stem LayerNorm
   float *G, *S;             // fp32 [max C*4C], [max 4C]
+  float* fS0;               // first of the fused blocks' colsum buffers (they sit directly in front of S), or nullptr
   size_t g_floats;
   float* dpat;              // fp32 [max rows*4Cin]
   float* dwpart;            // fp32 [256][50*Cmax] per-workgroup partials of the depthwise wgrad
@@ -81,6 +85,10 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.da = take(rows * 4 * ch * esz);
       b.dwrows = h->use_dwln && dwln_bwd_supported(STAGE_HW[i], (int)ch) ? dwln_bwd_rows(STAGE_HW[i], (int)ch, B) : 0;
       b.dwpart = b.dwrows ? reinterpret_cast<float*>(take((size_t)b.dwrows * 52 * ch * 4)) : nullptr;
+      b.fpart = h->use_dwln && mlp_bwd_supported(c.precision, (int)ch)
+                    ? reinterpret_cast<float*>(take(mlp_bwd_part_floats((int)ch, (int)rows) * 4))
+                    : nullptr;
+      b.fS = nullptr;
       k.blk[i].push_back(b);
     }
     k.dyT_down[i] = i > 0 ? take(rows * ch * esz) : nullptr;
@@ -92,6 +100,16 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.dyB = reinterpret_cast<float*>(take(maxrc * 4));
   k.dC = reinterpret_cast<float*>(take(maxrc * 4));
   k.dyT_stem = take((size_t)B * 225 * c.dims[0] * esz);
+  for (int i = 0; i < 4; ++i)                                          // the fused blocks' colsum(dy), S, G: one memset
+    for (auto& b : k.blk[i])
+      if (b.fpart != nullptr) b.fS = reinterpret_cast<float*>(take((size_t)c.dims[i] * 4));
+  k.fS0 = nullptr;
+  for (int i = 0; i < 4 && k.fS0 == nullptr; ++i)
+    for (auto& b : k.blk[i])
+      if (b.fS != nullptr) {
+        k.fS0 = b.fS;
+        break;
+      }
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.g_floats = maxc4c;
@@ -200,7 +218,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   const bool fold_cast = prec != BTSBOT_F32;
   // G / S (S directly in front of G) are the accumulators of the fc2 / downsample filter-gradient GEMMs: cleared once
   // here, afterwards every consumer (fc2_grads_kernel, unpack_down_grad_kernel) leaves what it read zero
-  HIP_TRY(hipMemsetAsync(k.S, 0, (size_t)((k.G + k.g_floats) - k.S) * sizeof(float), st));
+  {
+    float* z0 = k.fS0 != nullptr ? k.fS0 : k.S;
+    HIP_TRY(hipMemsetAsync(z0, 0, (size_t)((k.G + k.g_floats) - z0) * sizeof(float), st));
+  }
   // operand-type buffer the consumer after block (i, j) reads its dy from: the block before, else the downsample
   auto next_dyT = [&](int i, int j) -> void* {
     if (j > 0) return k.blk[i][j - 1].dyT;
@@ -220,6 +241,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       if (!dyT_ready)
         TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
+      WgradReduceJob red[2];
+      if (s.fpart != nullptr) {
+        // ---- da, dxn = da W1 and both filter gradients of the MLP in one launch (a recomputed from xn; da, g only on chip)
+        TRYB(launch_mlp_bwd(prec, ch, s.xn, s.dyT, h->extra + b.p_fc1, h->extra + b.p_fc2t, m + b.fc1_b, dxn, s.fpart,
+                            k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red));
+        TRYB(fork());
+      } else {
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
@@ -227,6 +255,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       // ---- dxn = da W1, then the LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
+      }
       void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
       // (the partial rows follow the arena's layout of conv_dw.weight | conv_dw.bias | norm.weight | norm.bias)
       const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
@@ -250,12 +279,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       //      after the chain's launches above (the fork itself sits behind da), so the host's five launches here never
       //      stand between the chain and its next kernel (measured: no difference, the host runs ahead either way)
       //      (the two GEMMs' slice reductions share one launch: separate halves of the partial-tile scratch)
-      WgradReduceJob red[2];
+      if (s.fpart == nullptr) {
       TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart, &red[0]));
       TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart + WPART_FLOATS,
                     &red[1]));
+      }
       TRYB(launch_wgrad_reduce(red, 2, sd));
-      TRYB(launch_fc2_grads(k.G, k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
+      TRYB(launch_fc2_grads(k.G, s.fpart != nullptr ? s.fS : k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
       dyT_ready = nxt != nullptr;
     }

@@ -298,6 +298,14 @@ struct WgradReduceJob {
   float* out;          // out[n][k] += sum over the slices
   int N, K, ldo, gx, gy, nsl, TN, TK;   // nsl == 0: nothing to reduce
 };
+
+// backward of a block's MLP as one kernel (mlp_bwd.hip): 16-bit modes, C in {64, 128}
+bool mlp_bwd_supported(int prec, int C);
+int mlp_bwd_slices(int C, int R);
+size_t mlp_bwd_part_floats(int C, int R);   // scratch for the partial filter-gradient tiles of one block
+int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
+                   float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
+                   WgradReduceJob* jobs);
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
                    int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0,
                    WgradReduceJob* defer = nullptr);   // wgrad.hip: 16-bit modes, colsum optional

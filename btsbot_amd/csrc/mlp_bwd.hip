@@ -1,0 +1,379 @@
+// Backward of a ConvNeXt block's MLP as ONE kernel (gfx950, 16-bit operand modes, C in {64, 128}: the wide-map
+// stages, where every 4C-wide tensor of the unfused backward -- fc1 pre-activation, GELU output, da -- is 118 MB per
+// 1024 alerts and each is written once and read twice).
+//
+//     y = x + gamma * (W2 g + b2),   g = gelu(a),   a = W1 xn + b1
+//
+//   given   xn [R][C] (kept by the forward), dy [R][C] = d(loss)/dy, both in the operand type
+//   writes  dxn [R][C] fp32            = da W1,              da = (dy (gamma W2)) * gelu'(a)
+//           G   [C][4C]   partial tiles = dy^T g             (fc2 / layer-scale gradients follow from it: fc2_grads_kernel)
+//           dW1 [4C][C]   partial tiles = da^T xn
+//           db1 [4C]     += colsum(da)
+// a is RECOMPUTED from xn (one more K = C GEMM, fp32 accumulators: the unfused path differentiated GELU at the
+// 16-bit rounding of a); g and da never leave the CU.  Replaces, for nn.Linear x 2 + GELU of timm's ConvNeXtBlock
+// (reached at /root/reference/btsbot/architectures.py:108,132), what autograd does at /root/reference/btsbot/train.py:526.
+//
+// Mapping.  A wave owns 32 hidden units for the whole kernel; a workgroup of NW waves owns HS = 32 NW of them and walks
+// row tiles of 64 pixels (grid.y = 4C / HS hidden slices, grid.x workgroups stride over the row tiles).  Per row tile:
+//   (1) a  [64 x 32] = xn-tile . W1_w^T      (3) t [64 x 32] = dy-tile . (gamma W2)_w      v_mfma_f32_32x32x16, K = C
+//   (2) g = gelu(a + b1), g' likewise (one v_exp for both)      (4) da = t g'
+//   (5) G_w   [C x 32] += dy-tile^T . g      (6) dW1_w [32 x C] += da^T . xn-tile          K = 64 pixels
+//       The accumulator tiles of (1)/(3) ARE the B / A operands of (5)/(6): the sum runs over their row index, so they
+//       are only converted to 16 bit.  Position 8h + e of k-step s then holds pixel 16 s + 8 (e >> 2) + 4 h + (e & 3);
+//       the other operand -- the transposed row tile -- is read with ds_read_b64_tr_b16 in the same order.
+//   (7) dxn [64 x C] = da [64 x HS] . W1 [HS x C]: da goes through LDS ([hidden][pixel], 8-byte stores) because here the
+//       sum runs over the hidden units of ALL waves; v_mfma_f32_16x16x32, both operands by transposing reads (da, and the
+//       same LDS image of W1 that feeds (1)).  With more than one hidden slice the slices meet in dxn through fp32
+//       atomics on a cleared buffer.
+// The filter-gradient accumulators (2 x C x HS floats per workgroup, half the register budget) leave once, as dense
+// partial tiles in wgrad.hip's layout; wgrad_reduce_kernel adds the workgroups in a fixed order.
+// Two barriers per row tile; the next tile's rows are requested before the tile's work and stored behind its last read.
+#include <stdlib.h>
+
+#include "common.h"
+
+#ifndef MLP_BWD_ABL
+#define MLP_BWD_ABL 0   // development only (tools/unit/mlp_bwd_time.hip): bit mask of phases left out
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <typename T> struct MB;
+template <> struct MB<bf16_t> {
+  static constexpr int DEG = GeluDeg<bf16_t>::value;
+  static __device__ __forceinline__ f32x16 m32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 m16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float v) { return __builtin_bit_cast(short, (bf16_t)v); }
+  static __device__ __forceinline__ float tofloat(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+};
+template <> struct MB<f16_t> {
+  static constexpr int DEG = GeluDeg<f16_t>::value;
+  static __device__ __forceinline__ f32x16 m32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 m16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float v) { return __builtin_bit_cast(short, (f16_t)v); }
+  static __device__ __forceinline__ float tofloat(unsigned short v) { return (float)__builtin_bit_cast(f16_t, v); }
+};
+
+// gelu_poly and its derivative from one exponential (common.h: gelu_poly / gelu_poly_grad)
+template <int DEG> __device__ __forceinline__ void gelu_both(float x, float& g, float& gp) {
+  const float a = __builtin_fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(gelu_q<DEG>(a));
+  g = fmaf(-a, e, relu_f(x));
+  const float d = e * fmaf(a * 0.6931471805599453f, gelu_dq<DEG>(a), 1.0f);
+  gp = x > 0.0f ? 1.0f - d : d;
+}
+
+// ds_read_b64_tr_b16: the 16 lanes of a group address a 4-row x 16-column block (lane = (row q, 4-column piece p)) and
+// lane i of the group receives column i's four row values
+__device__ __forceinline__ s16x4 tr4(const unsigned char* tile, int pitchb, int row0, int col0, int lane) {
+  const int q = (lane >> 2) & 3, p = lane & 3;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + (row0 + q) * pitchb + (col0 + 4 * p) * 2));
+}
+// 16x16x32 operand: column col0 + (lane & 15), reduction rows row0 + 8 (lane >> 4) .. +7
+__device__ __forceinline__ s16x8 tr16(const unsigned char* tile, int pitchb, int row0, int col0, int lane) {
+  const int g = lane >> 4;
+  const s16x4 lo = tr4(tile, pitchb, row0 + 8 * g, col0, lane);
+  const s16x4 hi = tr4(tile, pitchb, row0 + 8 * g + 4, col0, lane);
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// 32x32x16 operand in the accumulator's row order: column col0 + (lane & 31), reduction rows
+// row0 + 4 h + {0..3} and row0 + 8 + 4 h + {0..3}  (h = lane >> 5)
+__device__ __forceinline__ s16x8 trp(const unsigned char* tile, int pitchb, int row0, int col0, int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1;
+  const s16x4 lo = tr4(tile, pitchb, row0 + 4 * h, col0 + 16 * g1, lane);
+  const s16x4 hi = tr4(tile, pitchb, row0 + 8 + 4 * h, col0 + 16 * g1, lane);
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int C, int NW> struct BwdGeo {
+  static constexpr int H = 4 * C, HS = 32 * NW, NH = H / HS, TR = 64, MT = TR / 32;
+  static constexpr int NT = 64 * NW;
+  static constexpr int PX = 2 * C + 16;         // bytes per staged row of xn / dy / W1 (C values + 16: b128 row reads of 16 rows
+                                                // start on 16 different 4-bank groups)
+  static constexpr int PD = 2 * TR + 16;        // bytes per da row [hidden][pixel]
+  static constexpr int XB = TR * PX;
+  static constexpr int OFF_X = 0, OFF_Y = XB, OFF_W1 = 2 * XB, OFF_DA = OFF_W1 + HS * PX;
+  static constexpr int BYTES = OFF_DA + HS * PD;
+  static constexpr int LCH = TR * C / 8 / NT;   // 16-byte pieces per thread, tile and tensor
+  static constexpr int CT = C / 32, KC = C / 16;
+  static constexpr int TPW = (TR / 16) * (C / 16) / NW;   // 16x16 tiles of dxn per wave (one row of tiles)
+  static_assert(H % HS == 0 && (TR * C / 8) % NT == 0 && (C / 16) % TPW == 0 && NT % C == 0, "geometry");
+};
+
+template <typename T, int C, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ xn, const T* __restrict__ dy,
+                                                          const T* __restrict__ w1, const T* __restrict__ w2g,
+                                                          const float* __restrict__ b1, float* __restrict__ dxn,
+                                                          float* __restrict__ partG, float* __restrict__ partW,
+                                                          float* __restrict__ db1, float* __restrict__ Ssum, int R) {
+  using G = BwdGeo<C, NW>;
+  using M = MB<T>;
+  constexpr int PX = G::PX, PD = G::PD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int hs0 = (int)blockIdx.y * G::HS;
+  const int hid = hs0 + 32 * wave + lr;   // the lane's hidden unit in steps (1)-(6)
+
+  for (int q = tid; q < G::HS * C / 8; q += G::NT) {
+    const int r = q / (C / 8), cc = q % (C / 8);
+    *reinterpret_cast<u32x4*>(sm + G::OFF_W1 + r * PX + cc * 16) =
+        *reinterpret_cast<const u32x4*>(w1 + (size_t)(hs0 + r) * C + 8 * cc);
+  }
+  s16x8 w2f[G::KC];
+#pragma unroll
+  for (int kc = 0; kc < G::KC; ++kc)
+    w2f[kc] = *reinterpret_cast<const s16x8*>(w2g + (size_t)hid * C + 16 * kc + 8 * lh);
+  const float b1v = b1[hid];
+
+  f32x16 gG[G::CT], gW[G::CT];
+#pragma unroll
+  for (int i = 0; i < G::CT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gG[i][r] = 0.f;
+      gW[i][r] = 0.f;
+    }
+  float sb1 = 0.f, ssum = 0.f;
+  constexpr int SGRP = G::NT / C;            // colsum(dy): thread = (channel, row group)
+  const int scol = tid % C, srg = tid / C;
+
+  const int ntiles = (R + G::TR - 1) / G::TR;
+  u32x4 rx[G::LCH], ry[G::LCH];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int s = 0; s < G::LCH; ++s) {
+      const int q = tid + G::NT * s, r = q / (C / 8), cc = q % (C / 8);
+      const int m = t * G::TR + r;
+      const bool ok = m < R;
+      const size_t off = (size_t)(ok ? m : 0) * C + 8 * cc;
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(xn + off);
+      const u32x4 vy = *reinterpret_cast<const u32x4*>(dy + off);
+      rx[s] = ok ? vx : u32x4{0u, 0u, 0u, 0u};
+      ry[s] = ok ? vy : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int s = 0; s < G::LCH; ++s) {
+      const int q = tid + G::NT * s, r = q / (C / 8), cc = q % (C / 8);
+      *reinterpret_cast<u32x4*>(sm + G::OFF_X + r * PX + cc * 16) = rx[s];
+      *reinterpret_cast<u32x4*>(sm + G::OFF_Y + r * PX + cc * 16) = ry[s];
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    fetch(t);
+    stash();
+  }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < ntiles;   // workgroup-uniform
+    if (more) fetch(tn);
+
+    // ---- (1) a = xn W1^T, (3) t = dy (gamma W2): rows of the tile x the wave's 32 hidden units
+    f32x16 a[G::MT], tt[G::MT];
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        a[mt][r] = 0.f;
+        tt[mt][r] = 0.f;
+      }
+    if (!(MLP_BWD_ABL & 16))
+#pragma unroll
+    for (int kc = 0; kc < G::KC; ++kc) {
+      const s16x8 bw = *reinterpret_cast<const s16x8*>(sm + G::OFF_W1 + (32 * wave + lr) * PX + (16 * kc + 8 * lh) * 2);
+#pragma unroll
+      for (int mt = 0; mt < G::MT; ++mt) {
+        const int o = (32 * mt + lr) * PX + (16 * kc + 8 * lh) * 2;
+        const s16x8 ax = *reinterpret_cast<const s16x8*>(sm + G::OFF_X + o);
+        const s16x8 ay = *reinterpret_cast<const s16x8*>(sm + G::OFF_Y + o);
+        a[mt] = M::m32(ax, bw, a[mt]);
+        tt[mt] = M::m32(ay, w2f[kc], tt[mt]);
+      }
+    }
+    // ---- (2) g, g'; (4) da; both as 16-bit operands of the filter-gradient products (k-step = 8 accumulator registers)
+    s16x8 gq[G::MT][2], dq[G::MT][2];
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float g, gp;
+        if (MLP_BWD_ABL & 1) {
+          g = a[mt][r] + b1v;
+          gp = 1.f;
+        } else
+        gelu_both<M::DEG>(a[mt][r] + b1v, g, gp);
+        const float da = tt[mt][r] * gp;
+        sb1 += da;
+        gq[mt][r >> 3][r & 7] = M::cvt(g);
+        dq[mt][r >> 3][r & 7] = M::cvt(da);
+      }
+    // da -> LDS [hidden][pixel]: accumulator registers 4 rq .. 4 rq + 3 are pixels 32 mt + 8 rq + 4 h + {0..3}
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const s16x8 v = dq[mt][rq >> 1];
+        const int e = (rq & 1) * 4;
+        *reinterpret_cast<s16x4*>(sm + G::OFF_DA + (32 * wave + lr) * PD + (32 * mt + 8 * rq + 4 * lh) * 2) =
+            s16x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+      }
+    // ---- (5) G_w += dy^T g, (6) dW1_w += da^T xn
+    if (!(MLP_BWD_ABL & 2))
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * mt + 16 * ks;
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+          const s16x8 fy = trp(sm + G::OFF_Y, PX, r0, 32 * ct, lane);
+          const s16x8 fx = trp(sm + G::OFF_X, PX, r0, 32 * ct, lane);
+          gG[ct] = M::m32(fy, gq[mt][ks], gG[ct]);
+          gW[ct] = M::m32(dq[mt][ks], fx, gW[ct]);
+        }
+      }
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int r = 0; r < G::TR / SGRP; ++r)
+        ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(sm + G::OFF_Y + (srg + SGRP * r) * PX + scol * 2));
+    }
+    __syncthreads();   // da is complete; nobody reads the row tiles any more
+    if (more) stash();
+    // ---- (7) dxn = da W1: the wave's TPW tiles of 16 pixels x 16 channels (one tile row)
+    constexpr int NTC = C / 16;
+    const int mi = wave * G::TPW / NTC, ni0 = wave * G::TPW % NTC;
+    f32x4 dx[G::TPW];
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) dx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(MLP_BWD_ABL & 4))
+#pragma unroll 2
+    for (int ks = 0; ks < G::HS / 32; ++ks) {
+      const s16x8 af = tr16(sm + G::OFF_DA, PD, 32 * ks, 16 * mi, lane);
+#pragma unroll
+      for (int i = 0; i < G::TPW; ++i) {
+        const s16x8 bf = tr16(sm + G::OFF_W1, PX, 32 * ks, 16 * (ni0 + i), lane);
+        dx[i] = M::m16(af, bf, dx[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = t * G::TR + 16 * mi + 4 * (lane >> 4) + r;
+        const int ch = 16 * (ni0 + i) + (lane & 15);
+        if (row < R && !(MLP_BWD_ABL & 8)) {
+          if (G::NH == 1)
+            dxn[(size_t)row * C + ch] = dx[i][r];
+          else
+            atomicAdd(dxn + (size_t)row * C + ch, dx[i][r]);
+        }
+      }
+    __syncthreads();   // the next tile's rows are in LDS; da may be overwritten
+  }
+
+  // ---- the workgroup's filter-gradient tiles (wgrad.hip's partial layout: [slice][hidden slice][rows][cols])
+  const size_t pslot = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
+  float* pg = partG + pslot * (C * G::HS);
+  float* pw = partW + pslot * (G::HS * C);
+#pragma unroll
+  for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      pg[(32 * ct + rr) * G::HS + 32 * wave + lr] = gG[ct][r];   // G  [channel][hidden]
+      pw[(32 * wave + rr) * C + 32 * ct + lr] = gW[ct][r];       // dW1 [hidden][channel]
+    }
+  sb1 += __shfl_xor(sb1, 32);
+  if (lh == 0) atomicAdd(db1 + hid, sb1);
+  if (blockIdx.y == 0) {   // (every LDS read of the loop is behind its last barrier)
+    float* red = reinterpret_cast<float*>(sm);
+    red[tid] = ssum;
+    __syncthreads();
+    if (tid < C) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < SGRP; ++g) v += red[tid + C * g];
+      atomicAdd(Ssum + tid, v);
+    }
+  }
+}
+
+template <typename T, int C, int NW>
+int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1, float* dxn,
+                   float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs) {
+  using G = BwdGeo<C, NW>;
+  auto kern = mlp_bwd_kernel<T, C, NW>;
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES));
+    attr = true;
+  }
+  const int gx = mlp_bwd_slices(C, R);
+  if (G::NH > 1) HIP_TRY(hipMemsetAsync(dxn, 0, (size_t)R * C * sizeof(float), st));
+  float* partG = part;
+  float* partW = part + (size_t)gx * G::NH * C * G::HS;
+  hipLaunchKernelGGL(kern, dim3(gx, G::NH), dim3(G::NT), G::BYTES, st, reinterpret_cast<const T*>(xn),
+                     reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(w1), reinterpret_cast<const T*>(w2g), b1,
+                     dxn, partG, partW, db1, Ssum, R);
+  LAUNCH_CHECK();
+  jobs[0] = WgradReduceJob{partG, Gacc, C, 4 * C, 4 * C, 1, G::NH, gx, C, G::HS};
+  jobs[1] = WgradReduceJob{partW, dW1, 4 * C, C, C, G::NH, 1, gx, G::HS, C};
+  return BTSBOT_OK;
+}
+
+template <typename T>
+int mlp_bwd_t(int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1, float* dxn,
+              float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs) {
+  if (C == 64) return mlp_bwd_launch<T, 64, 8>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+  return mlp_bwd_launch<T, 128, 4>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+}
+
+}  // namespace
+
+bool mlp_bwd_supported(int prec, int C) {
+  static const bool off = getenv("BTSBOT_AMD_NO_MLP_BWD") != nullptr;
+  return !off && (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128);
+}
+
+// workgroups along the rows (= slices of the partial tiles)
+int mlp_bwd_slices(int C, int R) {
+  const int ntiles = (R + 63) / 64;
+  const int want = C == 64 ? 256 : 64;   // x the hidden slices (1 / 4): one workgroup per CU
+  return ntiles < want ? (ntiles > 0 ? ntiles : 1) : want;
+}
+
+size_t mlp_bwd_part_floats(int C, int R) { return (size_t)mlp_bwd_slices(C, R) * 2 * C * 4 * C; }
+
+// jobs[0] (G += ...) and jobs[1] (dW1 += ...) describe the slice reductions for launch_wgrad_reduce(); db1 and
+// Ssum [C] (+= colsum(dy)) are accumulated here (atomics).  dxn is overwritten.
+int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
+                   float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
+                   WgradReduceJob* jobs) {
+  jobs[0].nsl = jobs[1].nsl = 0;
+  if (R <= 0) return BTSBOT_OK;
+  if (!mlp_bwd_supported(prec, C)) {
+    btsbot_set_error("mlp_bwd: unsupported (prec %d, C %d)", prec, C);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  if (prec == BTSBOT_BF16) return mlp_bwd_t<bf16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+  return mlp_bwd_t<f16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+}
