@@ -329,6 +329,9 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->use_s3 = !(n3 != nullptr && n3[0] == '1');
     const char* ndl = getenv("BTSBOT_AMD_NO_DWLN");
     h->use_dwln = !(ndl != nullptr && ndl[0] == '1');
+    const char* mbc = getenv("BTSBOT_AMD_MLP_BWD_C");
+    const char* nmb = getenv("BTSBOT_AMD_NO_MLP_BWD");
+    h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 64;
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
   }
@@ -514,7 +517,8 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_cast(BTSBOT_F16, m + b.fc1_w, h->extra + b.p_x2_w1, (int64_t)4 * ch * ch, st));
           TRY(launch_rowscale_cast(BTSBOT_F16, m + b.fc2_w, m + b.gamma, h->extra + b.p_x2_w2g, ch, 4 * ch, st));
         }
-        if (b.fused && !train_only)
+        // (the training forward of the blocks whose backward is mlp_bwd_kernel runs the fused MLP too)
+        if (b.fused && (!train_only || h->mlp_fused(ch)))
           TRY(launch_pack_fused_mlp(c.precision, ch, m + b.fc1_w, m + b.fc2_w,
                                     h->extra + b.p_fused, st));
       }

@@ -79,15 +79,15 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.xin = reinterpret_cast<float*>(take(rows * ch * 4));
       b.d = reinterpret_cast<float*>(take(rows * ch * 4));
       b.xn = take(rows * ch * esz);
-      b.a = take(rows * 4 * ch * esz);
-      b.h = take(rows * 4 * ch * esz);
+      const bool keep4c = !h->mlp_fused((int)ch);   // fused blocks keep nothing 4C-wide (mlp_bwd.hip recomputes fc1)
+      b.a = keep4c ? take(rows * 4 * ch * esz) : nullptr;
+      b.h = keep4c ? take(rows * 4 * ch * esz) : nullptr;
       b.dyT = take(rows * ch * esz);
-      b.da = take(rows * 4 * ch * esz);
+      b.da = keep4c ? take(rows * 4 * ch * esz) : nullptr;
       b.dwrows = h->use_dwln && dwln_bwd_supported(STAGE_HW[i], (int)ch) ? dwln_bwd_rows(STAGE_HW[i], (int)ch, B) : 0;
       b.dwpart = b.dwrows ? reinterpret_cast<float*>(take((size_t)b.dwrows * 52 * ch * 4)) : nullptr;
-      b.fpart = h->use_dwln && mlp_bwd_supported(c.precision, (int)ch)
-                    ? reinterpret_cast<float*>(take(mlp_bwd_part_floats((int)ch, (int)rows) * 4))
-                    : nullptr;
+      b.fpart = h->mlp_fused((int)ch) ? reinterpret_cast<float*>(take(mlp_bwd_part_floats((int)ch, (int)rows) * 4))
+                                      : nullptr;
       b.fS = nullptr;
       k.blk[i].push_back(b);
     }
@@ -160,6 +160,12 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       float* xout = j + 1 < nblk ? k.blk[i][j + 1].xin : k.xs[i];
       TRYB(launch_dwconv_ln(c.precision, s.xin, reinterpret_cast<const float*>(h->extra + b.p_dw),
                             m + b.dw_b, m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, st, s.d));
+      if (s.fpart != nullptr) {
+        // the block's backward recomputes fc1 (mlp_bwd.hip): neither the pre-activation nor the GELU output is kept
+        TRYB(launch_fused_mlp(c.precision, ch, s.xn, h->extra + b.p_fused, m + b.fc1_b, m + b.fc2_b, m + b.gamma, xout,
+                              rows, st, nullptr, nullptr, nullptr, 0, s.xin));
+        continue;
+      }
       TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
                        reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, st));
       TRYB(launch_gemm(c.precision, EPI_RESID, s.h, h->extra + b.p_fc2, m + b.fc2_b, m + b.gamma,

@@ -263,7 +263,7 @@ int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, voi
 int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
                      const float* b2, const float* gamma, float* x, int M, hipStream_t st,
                      void* post_out = nullptr, const float* pw = nullptr, const float* pb = nullptr,
-                     int post_mode = 0);
+                     int post_mode = 0, const float* xres = nullptr);   // xres: residual source when it is not x itself
 
 // stage-0 megakernel (stage0b.hip): stem + 2 blocks + downsample in one launch, 16-bit modes, C0 = 64
 struct Stage0Args;

@@ -136,6 +136,15 @@ struct btsbot_ctx {
   std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()
   size_t side_used = 0;
   bool use_dwln = true;    // BTSBOT_AMD_NO_DWLN=1: LayerNorm / depthwise backward as three launches (A/B timing)
+  // widths whose block MLP runs fused in the training step (fused_mlp forward that keeps nothing 4C-wide + mlp_bwd_kernel):
+  // 64 by default; BTSBOT_AMD_MLP_BWD_C=128 / =0 (both) / BTSBOT_AMD_NO_MLP_BWD=1 (none) for A/B runs and tests.  C = 128
+  // is correct but not the default: its four hidden slices meet in dxn through 25 M fp32 atomics (47 of its 107 us at
+  // 1024 alerts) and the step is 0.04 ms faster with the unfused stage 1
+  int mlp_bwd_only = 64;
+  bool mlp_fused(int ch) const {
+    return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused &&
+           mlp_bwd_supported(cfg.precision, ch) && fused_mlp_supported(cfg.precision, ch);
+  }
   bool use_side = true;    // BTSBOT_AMD_NO_SIDE_STREAM=1: the whole backward on the caller's stream (A/B timing)
 
   unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1

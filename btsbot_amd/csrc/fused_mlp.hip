@@ -59,8 +59,10 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
     const T* __restrict__ xn, const unsigned char* __restrict__ wpk, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, float* x, int M, int ntiles,
     T* __restrict__ post_out = nullptr, const float* __restrict__ pw = nullptr,
-    const float* __restrict__ pb = nullptr, int post_mode = 0) {
+    const float* __restrict__ pb = nullptr, int post_mode = 0, const float* xres = nullptr) {
+  // xres: where the residual rows are read (the training forward keeps a block's input); x itself when omitted
   using G = FusedGeom<C>;
+  if (xres == nullptr) xres = x;
   using frag = typename M32<T>::frag;
   constexpr int KS1 = C / 16;   // k-steps of GEMM1
   constexpr int CT = G::CP / 32;   // 32-channel output tiles of GEMM2 (the last one ragged when C % 32 != 0)
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
         for (int q = 0; q < 4; ++q)
           if (ct * 32 + 8 * q < C)
             rres[PRE_R ? ct : 0][q] =
-                *reinterpret_cast<const float4*>(x + (size_t)mc * C + ct * 32 + 8 * q + 4 * h);
+                *reinterpret_cast<const float4*>(xres + (size_t)mc * C + ct * 32 + 8 * q + 4 * h);
     }
     {
       const int tn = tile + (int)gridDim.x;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(512, C <= 64 ? 4 : 2) void fused_mlp_kernel(
           const float4 bv = *reinterpret_cast<const float4*>(b2 + c);
           const float4 gv = *reinterpret_cast<const float4*>(gamma + c);
           float4* px = reinterpret_cast<float4*>(x + (size_t)m * C + c);
-          float4 r = PRE_R ? rres[PRE_R ? ct : 0][q] : *px;
+          float4 r = PRE_R ? rres[PRE_R ? ct : 0][q] : *reinterpret_cast<const float4*>(xres + (size_t)m * C + c);
           r.x += gv.x * (yacc[ct][4 * q + 0] + bv.x);
           r.y += gv.y * (yacc[ct][4 * q + 1] + bv.y);
           r.z += gv.z * (yacc[ct][4 * q + 2] + bv.z);
@@ -303,7 +305,7 @@ __global__ void pack_fused_kernel(const float* __restrict__ w1, const float* __r
 template <typename T, int C>
 int launch_fused_cfg(const void* xn, const void* wpk, const float* b1, const float* b2,
                      const float* gamma, float* x, int M, hipStream_t st, void* post_out,
-                     const float* pw, const float* pb, int post_mode) {
+                     const float* pw, const float* pb, int post_mode, const float* xres = nullptr) {
   using G = FusedGeom<C>;
   const size_t lds = 2 * (size_t)G::CHUNKBYTES + 4 * C * sizeof(float);
   auto kern = fused_mlp_kernel<T, C>;
@@ -318,7 +320,7 @@ int launch_fused_cfg(const void* xn, const void* wpk, const float* b1, const flo
   const int grid = ntiles < maxwg ? ntiles : maxwg;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, reinterpret_cast<const T*>(xn),
                      reinterpret_cast<const unsigned char*>(wpk), b1, b2, gamma, x, M, ntiles,
-                     reinterpret_cast<T*>(post_out), pw, pb, post_out ? post_mode : 0);
+                     reinterpret_cast<T*>(post_out), pw, pb, post_out ? post_mode : 0, xres);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -363,25 +365,25 @@ int launch_pack_fused_mlp(int prec, int C, const float* w1, const float* w2, voi
 
 int launch_fused_mlp(int prec, int C, const void* xn, const void* wpk, const float* b1,
                      const float* b2, const float* gamma, float* x, int M, hipStream_t st,
-                     void* post_out, const float* pw, const float* pb, int post_mode) {
+                     void* post_out, const float* pw, const float* pb, int post_mode, const float* xres) {
   if (M <= 0) return BTSBOT_OK;
   if (prec == BTSBOT_BF16 && C == 64)
-    return launch_fused_cfg<bf16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
+    return launch_fused_cfg<bf16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode, xres);
   if (prec == BTSBOT_BF16 && C == 128)
-    return launch_fused_cfg<bf16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
+    return launch_fused_cfg<bf16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode, xres);
   if (prec == BTSBOT_F16 && C == 64)
-    return launch_fused_cfg<f16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
+    return launch_fused_cfg<f16_t, 64>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode, xres);
   if (prec == BTSBOT_F16 && C == 128)
-    return launch_fused_cfg<f16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode);
+    return launch_fused_cfg<f16_t, 128>(xn, wpk, b1, b2, gamma, x, M, st, post_out, pw, pb, post_mode, xres);
   // convnext_nano's stages 0-1 (no second output: post_mode is a MaxViT feature)
   if (post_out == nullptr && prec == BTSBOT_BF16 && C == 80)
-    return launch_fused_cfg<bf16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+    return launch_fused_cfg<bf16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0, xres);
   if (post_out == nullptr && prec == BTSBOT_BF16 && C == 160)
-    return launch_fused_cfg<bf16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+    return launch_fused_cfg<bf16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0, xres);
   if (post_out == nullptr && prec == BTSBOT_F16 && C == 80)
-    return launch_fused_cfg<f16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+    return launch_fused_cfg<f16_t, 80>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0, xres);
   if (post_out == nullptr && prec == BTSBOT_F16 && C == 160)
-    return launch_fused_cfg<f16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0);
+    return launch_fused_cfg<f16_t, 160>(xn, wpk, b1, b2, gamma, x, M, st, nullptr, nullptr, nullptr, 0, xres);
   btsbot_set_error("fused_mlp: unsupported (prec %d, C %d)", prec, C);
   return BTSBOT_ERR_INVALID_ARG;
 }

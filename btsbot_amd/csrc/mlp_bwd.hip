@@ -105,9 +105,11 @@ template <int C, int NW> struct BwdGeo {
   static constexpr int PX = 2 * C + 16;         // bytes per staged row of xn / dy / W1 (C values + 16: b128 row reads of 16 rows
                                                 // start on 16 different 4-bank groups)
   static constexpr int PD = 2 * TR + 16;        // bytes per da row [hidden][pixel]
-  static constexpr int XB = TR * PX;
-  static constexpr int OFF_X = 0, OFF_Y = XB, OFF_W1 = 2 * XB, OFF_DA = OFF_W1 + HS * PX;
-  static constexpr int BYTES = OFF_DA + HS * PD;
+  static constexpr int XB = TR * PX;            // one row tile of one tensor
+  static constexpr int XY = 2 * XB;             // xn tile + dy tile; two of those (the next tile lands while this one is read)
+  static constexpr int DAB = HS * PD;           // one da image; two of those (tile t's is read while tile t+1's is written)
+  static constexpr int OFF_W1 = 2 * XY, OFF_DA = OFF_W1 + HS * PX;
+  static constexpr int BYTES = OFF_DA + 2 * DAB;
   static constexpr int LCH = TR * C / 8 / NT;   // 16-byte pieces per thread, tile and tensor
   static constexpr int CT = C / 32, KC = C / 16;
   static constexpr int TPW = (TR / 16) * (C / 16) / NW;   // 16x16 tiles of dxn per wave (one row of tiles)
@@ -138,7 +140,17 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
 #pragma unroll
   for (int kc = 0; kc < G::KC; ++kc)
     w2f[kc] = *reinterpret_cast<const s16x8*>(w2g + (size_t)hid * C + 16 * kc + 8 * lh);
-  const float b1v = b1[hid];
+  float b1v = b1[hid];
+  // Re-define the loop-invariant operands behind their loads: hipcc's wait-count pass otherwise keeps them "possibly in
+  // flight" around the loop's back edge and puts s_waitcnt vmcnt(0) in front of their first use in EVERY iteration --
+  // directly behind the row prefetch, i.e. a whole HBM round trip per tile.
+  asm volatile("" : "+v"(b1v));
+#pragma unroll
+  for (int kc = 0; kc < G::KC; ++kc) {
+    u32x4 v = __builtin_bit_cast(u32x4, w2f[kc]);
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    w2f[kc] = __builtin_bit_cast(s16x8, v);
+  }
 
   f32x16 gG[G::CT], gW[G::CT];
 #pragma unroll
@@ -154,120 +166,39 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
 
   const int ntiles = (R + G::TR - 1) / G::TR;
   u32x4 rx[G::LCH], ry[G::LCH];
+  // rows beyond R: the load repeats row 0 and the dy piece is cleared on its way into LDS (dy = 0 makes the row's
+  // t, da and its share of G, dW1, db1 and colsum(dy) vanish whatever xn holds).  The select sits in stash(), behind
+  // the tile's work: in fetch() it put an s_waitcnt vmcnt(0) -- a whole HBM round trip -- at the top of every tile
   auto fetch = [&](int t) {
 #pragma unroll
     for (int s = 0; s < G::LCH; ++s) {
       const int q = tid + G::NT * s, r = q / (C / 8), cc = q % (C / 8);
       const int m = t * G::TR + r;
-      const bool ok = m < R;
-      const size_t off = (size_t)(ok ? m : 0) * C + 8 * cc;
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(xn + off);
-      const u32x4 vy = *reinterpret_cast<const u32x4*>(dy + off);
-      rx[s] = ok ? vx : u32x4{0u, 0u, 0u, 0u};
-      ry[s] = ok ? vy : u32x4{0u, 0u, 0u, 0u};
+      const size_t off = (size_t)(m < R ? m : 0) * C + 8 * cc;
+      rx[s] = *reinterpret_cast<const u32x4*>(xn + off);
+      ry[s] = *reinterpret_cast<const u32x4*>(dy + off);
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf, int t) {
 #pragma unroll
     for (int s = 0; s < G::LCH; ++s) {
       const int q = tid + G::NT * s, r = q / (C / 8), cc = q % (C / 8);
-      *reinterpret_cast<u32x4*>(sm + G::OFF_X + r * PX + cc * 16) = rx[s];
-      *reinterpret_cast<u32x4*>(sm + G::OFF_Y + r * PX + cc * 16) = ry[s];
+      const bool ok = t * G::TR + r < R;
+      *reinterpret_cast<u32x4*>(sm + buf * G::XY + r * PX + cc * 16) = rx[s];
+      *reinterpret_cast<u32x4*>(sm + buf * G::XY + G::XB + r * PX + cc * 16) = ok ? ry[s] : u32x4{0u, 0u, 0u, 0u};
     }
   };
-
-  int t = blockIdx.x;
-  if (t < ntiles) {
-    fetch(t);
-    stash();
-  }
-  __syncthreads();
-  for (; t < ntiles; t += gridDim.x) {
-    const int tn = t + (int)gridDim.x;
-    const bool more = tn < ntiles;   // workgroup-uniform
-    if (more) fetch(tn);
-
-    // ---- (1) a = xn W1^T, (3) t = dy (gamma W2): rows of the tile x the wave's 32 hidden units
-    f32x16 a[G::MT], tt[G::MT];
-#pragma unroll
-    for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        a[mt][r] = 0.f;
-        tt[mt][r] = 0.f;
-      }
-    if (!(MLP_BWD_ABL & 16))
-#pragma unroll
-    for (int kc = 0; kc < G::KC; ++kc) {
-      const s16x8 bw = *reinterpret_cast<const s16x8*>(sm + G::OFF_W1 + (32 * wave + lr) * PX + (16 * kc + 8 * lh) * 2);
-#pragma unroll
-      for (int mt = 0; mt < G::MT; ++mt) {
-        const int o = (32 * mt + lr) * PX + (16 * kc + 8 * lh) * 2;
-        const s16x8 ax = *reinterpret_cast<const s16x8*>(sm + G::OFF_X + o);
-        const s16x8 ay = *reinterpret_cast<const s16x8*>(sm + G::OFF_Y + o);
-        a[mt] = M::m32(ax, bw, a[mt]);
-        tt[mt] = M::m32(ay, w2f[kc], tt[mt]);
-      }
-    }
-    // ---- (2) g, g'; (4) da; both as 16-bit operands of the filter-gradient products (k-step = 8 accumulator registers)
-    s16x8 gq[G::MT][2], dq[G::MT][2];
-#pragma unroll
-    for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float g, gp;
-        if (MLP_BWD_ABL & 1) {
-          g = a[mt][r] + b1v;
-          gp = 1.f;
-        } else
-        gelu_both<M::DEG>(a[mt][r] + b1v, g, gp);
-        const float da = tt[mt][r] * gp;
-        sb1 += da;
-        gq[mt][r >> 3][r & 7] = M::cvt(g);
-        dq[mt][r >> 3][r & 7] = M::cvt(da);
-      }
-    // da -> LDS [hidden][pixel]: accumulator registers 4 rq .. 4 rq + 3 are pixels 32 mt + 8 rq + 4 h + {0..3}
-#pragma unroll
-    for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const s16x8 v = dq[mt][rq >> 1];
-        const int e = (rq & 1) * 4;
-        *reinterpret_cast<s16x4*>(sm + G::OFF_DA + (32 * wave + lr) * PD + (32 * mt + 8 * rq + 4 * lh) * 2) =
-            s16x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
-      }
-    // ---- (5) G_w += dy^T g, (6) dW1_w += da^T xn
-    if (!(MLP_BWD_ABL & 2))
-#pragma unroll
-    for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int r0 = 32 * mt + 16 * ks;
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct) {
-          const s16x8 fy = trp(sm + G::OFF_Y, PX, r0, 32 * ct, lane);
-          const s16x8 fx = trp(sm + G::OFF_X, PX, r0, 32 * ct, lane);
-          gG[ct] = M::m32(fy, gq[mt][ks], gG[ct]);
-          gW[ct] = M::m32(dq[mt][ks], fx, gW[ct]);
-        }
-      }
-    if (blockIdx.y == 0) {
-#pragma unroll
-      for (int r = 0; r < G::TR / SGRP; ++r)
-        ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(sm + G::OFF_Y + (srg + SGRP * r) * PX + scol * 2));
-    }
-    __syncthreads();   // da is complete; nobody reads the row tiles any more
-    if (more) stash();
-    // ---- (7) dxn = da W1: the wave's TPW tiles of 16 pixels x 16 channels (one tile row)
-    constexpr int NTC = C / 16;
-    const int mi = wave * G::TPW / NTC, ni0 = wave * G::TPW % NTC;
+  // ---- (7) dxn = da W1 for the tile whose da image is complete: the wave's TPW tiles of 16 pixels x 16 channels
+  constexpr int NTC = C / 16;
+  const int mi = wave * G::TPW / NTC, ni0 = wave * G::TPW % NTC;
+  auto dxn_tile = [&](int tile, const unsigned char* DA) {
     f32x4 dx[G::TPW];
 #pragma unroll
     for (int i = 0; i < G::TPW; ++i) dx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!(MLP_BWD_ABL & 4))
 #pragma unroll 2
     for (int ks = 0; ks < G::HS / 32; ++ks) {
-      const s16x8 af = tr16(sm + G::OFF_DA, PD, 32 * ks, 16 * mi, lane);
+      const s16x8 af = tr16(DA, PD, 32 * ks, 16 * mi, lane);
 #pragma unroll
       for (int i = 0; i < G::TPW; ++i) {
         const s16x8 bf = tr16(sm + G::OFF_W1, PX, 32 * ks, 16 * (ni0 + i), lane);
@@ -278,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     for (int i = 0; i < G::TPW; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = t * G::TR + 16 * mi + 4 * (lane >> 4) + r;
+        const int row = tile * G::TR + 16 * mi + 4 * (lane >> 4) + r;
         const int ch = 16 * (ni0 + i) + (lane & 15);
         if (row < R && !(MLP_BWD_ABL & 8)) {
           if (G::NH == 1)
@@ -287,8 +218,117 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
             atomicAdd(dxn + (size_t)row * C + ch, dx[i][r]);
         }
       }
-    __syncthreads();   // the next tile's rows are in LDS; da may be overwritten
+  };
+
+  // One barrier per row tile.  Iteration t: the rows of tile t are in row buffer p, the da image of tile t - 1 in da
+  // buffer p ^ 1.  Program order per wave (MT = 2 units of 32 pixels):
+  //     dxn(t - 1), A(0) | A(1) with GELU(0) | C(0) with GELU(1) | C(1)        A = steps (1)(3), C = steps (5)(6)
+  // so that the matrix work of one unit is issued between the VALU work of the other.
+  int t = blockIdx.x, p = 0, tprev = -1;
+  if (t < ntiles) {
+    fetch(t);
+    stash(0, t);
   }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x, p ^= 1) {
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < ntiles;   // workgroup-uniform
+    if (more) fetch(tn);
+    const unsigned char* X = sm + p * G::XY;
+    const unsigned char* Y = X + G::XB;
+    unsigned char* DA = sm + G::OFF_DA + p * G::DAB;
+    if (tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
+
+    f32x16 a[G::MT], tt[G::MT];
+    s16x8 gq[G::MT][2], dq[G::MT][2];
+    // the k-th of unit mt's 2 KC products of steps (1)(3)
+    auto stepA = [&](int mt, int k) {
+      if (MLP_BWD_ABL & 16) return;
+      const int kc = k >> 1, o = (32 * mt + lr) * PX + (16 * kc + 8 * lh) * 2;
+      if (!(k & 1)) {
+        const s16x8 bw = *reinterpret_cast<const s16x8*>(sm + G::OFF_W1 + (32 * wave + lr) * PX + (16 * kc + 8 * lh) * 2);
+        a[mt] = M::m32(*reinterpret_cast<const s16x8*>(X + o), bw, a[mt]);
+      } else {
+        tt[mt] = M::m32(*reinterpret_cast<const s16x8*>(Y + o), w2f[kc], tt[mt]);
+      }
+    };
+    // the k-th of unit mt's 4 CT products of steps (5)(6): k-step ks = 16 pixels = 8 accumulator registers
+    auto stepC = [&](int mt, int k) {
+      if (MLP_BWD_ABL & 2) return;
+      const int ks = k / (2 * G::CT), ct = (k / 2) % G::CT, r0 = 32 * mt + 16 * ks;
+      if (!(k & 1))
+        gG[ct] = M::m32(trp(Y, PX, r0, 32 * ct, lane), gq[mt][ks], gG[ct]);
+      else
+        gW[ct] = M::m32(dq[mt][ks], trp(X, PX, r0, 32 * ct, lane), gW[ct]);
+    };
+    // (2)(4) for accumulator registers r0 .. r0 + n - 1 of unit mt
+    auto gelu = [&](int mt, int r0, int n) {
+#pragma unroll
+      for (int r = r0; r < r0 + n; ++r) {
+        float g, gp;
+        if (MLP_BWD_ABL & 1) {
+          g = a[mt][r] + b1v;
+          gp = 1.f;
+        } else
+          gelu_both<M::DEG>(a[mt][r] + b1v, g, gp);
+        const float da = tt[mt][r] * gp;
+        sb1 += da;
+        gq[mt][r >> 3][r & 7] = M::cvt(g);
+        dq[mt][r >> 3][r & 7] = M::cvt(da);
+      }
+    };
+    // da -> LDS [hidden][pixel]: accumulator registers 4 rq .. 4 rq + 3 are pixels 32 mt + 8 rq + 4 h + {0..3}
+    auto da_out = [&](int mt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const s16x8 v = dq[mt][rq >> 1];
+        const int e = (rq & 1) * 4;
+        *reinterpret_cast<s16x4*>(DA + (32 * wave + lr) * PD + (32 * mt + 8 * rq + 4 * lh) * 2) =
+            s16x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+      }
+    };
+    constexpr int NA = 2 * G::KC, NC = 4 * G::CT;   // products per unit
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        a[mt][r] = 0.f;
+        tt[mt][r] = 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) stepA(0, k);
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt) {
+      // GELU of unit mt in 8 pieces of 2 values, the matrix products of the neighbouring units between them
+      constexpr int NP = 8;
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) {
+        if (mt + 1 < G::MT) {
+#pragma unroll
+          for (int k = pc * NA / NP; k < (pc + 1) * NA / NP; ++k) stepA(mt + 1, k);
+        }
+        if (mt > 0) {
+#pragma unroll
+          for (int k = pc * NC / NP; k < (pc + 1) * NC / NP; ++k) stepC(mt - 1, k);
+        }
+        gelu(mt, 2 * pc, 2);
+      }
+      da_out(mt);
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) stepC(G::MT - 1, k);
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int r = 0; r < G::TR / SGRP; ++r)
+        ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(Y + (srg + SGRP * r) * PX + scol * 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (keeps the wait for the fetched rows down here)
+    if (more) stash(p ^ 1, tn);
+    __syncthreads();   // da image p and row buffer p ^ 1 are complete; everybody is done with row buffer p and da image p ^ 1
+    tprev = t;
+  }
+  if (tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
+  __syncthreads();   // (the colsum below reuses the row buffers)
 
   // ---- the workgroup's filter-gradient tiles (wgrad.hip's partial layout: [slice][hidden slice][rows][cols])
   const size_t pslot = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
@@ -350,8 +390,7 @@ int mlp_bwd_t(int C, const void* xn, const void* dy, const void* w1, const void*
 }  // namespace
 
 bool mlp_bwd_supported(int prec, int C) {
-  static const bool off = getenv("BTSBOT_AMD_NO_MLP_BWD") != nullptr;
-  return !off && (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128);
+  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128);
 }
 
 // workgroups along the rows (= slices of the partial tiles)
