@@ -390,6 +390,13 @@ extern "C" int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_inf
   } while (0)
 
 static int pack_impl(btsbot_handle h, const float* master, void* stream, bool train_only);
+int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
+int side_join(btsbot_ctx* h, hipStream_t st);
+int pack_sync(btsbot_ctx* h, hipStream_t st) {
+  if (!h->pack_on_side) return BTSBOT_OK;
+  h->pack_on_side = false;
+  return side_join(h, st);
+}
 
 extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* stream) {
   return pack_impl(h, master, stream, false);
@@ -414,9 +421,16 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     HIP_TRY(hipMalloc(&h->mirror, (size_t)h->total_floats * 4));
     HIP_TRY(hipMalloc(&h->extra, h->extra_bytes > 0 ? h->extra_bytes : 256));
   }
+  TRY(pack_sync(h, st));   // (a pack nobody consumed yet still reads the mirror on the side stream)
   HIP_TRY(hipMemcpyAsync(h->mirror, master, (size_t)h->total_floats * 4, hipMemcpyDeviceToDevice,
                          st));
   const float* m = h->mirror;
+  if (train_only && h->has_image && !h->is_maxvit && h->use_side && h->side != nullptr) {
+    hipStream_t sp = st;
+    TRY(side_fork(h, st, &sp));   // behind the mirror copy
+    st = sp;
+    h->pack_on_side = true;
+  }
   // The plain element maps (casts, transposes, the downsample re-orderings) run as ONE launch over a job
   // table built on the first pack of each kind: mirror and extra never move, so the table is static.
   // BTSBOT_AMD_PACK_UNBATCHED=1 keeps one launch per operand (A/B and parity).
@@ -1024,6 +1038,7 @@ extern "C" int btsbot_forward(btsbot_handle h, const float* triplets, const floa
     return BTSBOT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  TRY(pack_sync(h, st));
   for (int b0 = 0; b0 < batch; b0 += h->max_chunk) {
     const int nb = batch - b0 < h->max_chunk ? batch - b0 : h->max_chunk;
     TRY(forward_chunk(h, triplets ? triplets + (size_t)b0 * 3 * 63 * 63 : nullptr,
@@ -1122,6 +1137,8 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
   hipStream_t st = (hipStream_t)stream;
   h->bb_saved = false;
   h->t_img = triplets;
+  // (the ConvNeXt training forward waits for the packing launches behind its stem, backbone_train.hip)
+  if (!(h->has_image && keep_image_activations && !h->is_maxvit)) TRY(pack_sync(h, st));
   if (h->has_image && keep_image_activations) {
     if (h->bbcache == nullptr || batch > h->bbcache_batch) {
       btsbot_set_error("forward_train: reserve_train(%d, with_image_grads=1) first", batch);

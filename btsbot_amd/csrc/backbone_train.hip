@@ -144,6 +144,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   auto stage_in = [&](int i) { return h->blocks[i].empty() ? k.xs[i] : k.blk[i][0].xin; };
   TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
                    B, c.dims[0], st, k.stem_pre));   // (the pre-LayerNorm output is kept for the backward)
+  TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
     if (i > 0) {

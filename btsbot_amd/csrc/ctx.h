@@ -135,6 +135,10 @@ struct btsbot_ctx {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()
   size_t side_used = 0;
+  // btsbot_pack_params_train() queues its packing launches on `side` behind the mirror copy: they then overlap the
+  // first kernel of the training forward (the stem reads the fp32 mirror only).  Every consumer of the operand images
+  // calls pack_sync() first.
+  bool pack_on_side = false;
   bool use_dwln = true;    // BTSBOT_AMD_NO_DWLN=1: LayerNorm / depthwise backward as three launches (A/B timing)
   // widths whose block MLP runs fused in the training step (fused_mlp forward that keeps nothing 4C-wide + mlp_bwd_kernel):
   // 64 by default; BTSBOT_AMD_MLP_BWD_C=128 / =0 (both) / BTSBOT_AMD_NO_MLP_BWD=1 (none) for A/B runs and tests.  C = 128
@@ -159,3 +163,5 @@ struct btsbot_ctx {
 // `st` so far (*sd = st when the second stream is off); side_join: `st` waits for everything queued on the side.
 int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
 int side_join(btsbot_ctx* h, hipStream_t st);
+
+int pack_sync(btsbot_ctx* h, hipStream_t st);   // api.hip
