@@ -319,13 +319,24 @@ int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st) {
     }
   if (n == 0) return BTSBOT_OK;
   if (n == 1) a.j[1] = a.j[0];
-  // one small output with many slices: four slice groups per output
-  if (n == 1 && a.j[0].N * a.j[0].K <= 16384 && a.j[0].nsl >= 64) {
-    a.nblk0 = (a.j[0].N * a.j[0].K + 63) / 64;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(a.nblk0), dim3(256), 0, st, a);
-  } else {
+  // many slices per output (the stem's 64 x 48 filter over ~400 slices; mlp_bwd_kernel's 256 workgroup partials of a
+  // block's two 64 x 256 filter gradients: one thread per output walked 256 dependent-latency loads, 76-118 us next to
+  // the chain's kernels): four or eight slice groups per output
+  int minsl = a.j[0].nsl;
+  for (int i = 1; i < n; ++i) minsl = a.j[i].nsl < minsl ? a.j[i].nsl : minsl;
+  const bool small = n == 1 ? a.j[0].N * a.j[0].K <= 16384 : a.j[0].N * a.j[0].K + a.j[1].N * a.j[1].K <= 65536;
+  auto blocks = [&](int opb) {
+    nblk[0] = (a.j[0].N * a.j[0].K + opb - 1) / opb;
+    nblk[1] = n > 1 ? (a.j[1].N * a.j[1].K + opb - 1) / opb : 0;
     a.nblk0 = nblk[0];
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nblk[0] + nblk[1]), dim3(256), 0, st, a);
+    return nblk[0] + nblk[1];
+  };
+  if (small && minsl >= 128 && n == 2) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(blocks(32)), dim3(256), 0, st, a);
+  } else if (small && minsl >= 64) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks(64)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks(256)), dim3(256), 0, st, a);
   }
   LAUNCH_CHECK();
   return BTSBOT_OK;
