@@ -355,7 +355,8 @@ def timed_blocks(run, steps, warmup, fence, dist, dev, blocks=BLOCKS, warm_secon
 
 def maxvit_train_leg(dev, rank, world, dist, fence, args):
     """Training of the whole mm_MaxViT (image branch included: BatchNorm2d batch statistics, backward of every layer --
-    btsbot_amd/csrc/maxvit_train.hip, an fp32 engine whatever the operand mode) with BCE + AdamW and, with more than
+    btsbot_amd/csrc/maxvit_train.hip: the 1x1 convolutions / Linear layers on the 16-bit MFMA GEMMs in the 16-bit modes,
+    everything else fp32) with BCE + AdamW and, with more than
     one rank, the gradient exchange.  The reference's fine-tuning of a MaxViT model, train.py:218-236, 510-527."""
     from btsbot_amd.train import Trainer
     with warnings.catch_warnings():
@@ -379,14 +380,15 @@ def maxvit_train_leg(dev, rank, world, dist, fence, args):
     step_flop = 3.0 * 10.14e9 * args.maxvit_train_batch
     return {
         "workload": "mm_MaxViT (maxvit_tiny_rw_224 on cutouts resized to 224) training step, every parameter trainable: "
-                    "BatchNorm2d batch statistics, BCE, backward of every layer, AdamW; fp32 training engine, "
+                    "BatchNorm2d batch statistics, BCE, backward of every layer, AdamW; GEMM operands in the mode's type, the rest fp32, "
                     f"batch={args.maxvit_train_batch} per GPU",
         "value": round(total / el, 1), "unit": "alerts/s", "per_gpu_batch": args.maxvit_train_batch,
         "steps": args.maxvit_train_steps, "ms_per_step": round(1e3 * el / args.maxvit_train_steps, 2),
         "loss_finite": bool(torch.isfinite(loss).item()),
         "whole_step_tflops": round(step_flop / (el / args.maxvit_train_steps) / 1e12, 2),
-        "note": "correctness-first: one launch per layer, fp32 MFMA GEMMs (157 TFLOP/s peak); the training benchmark "
-                "of BASELINE.json (configs[2]) is the ConvNeXt `train` leg",
+        "note": "correctness-first: one launch per layer, every intermediate through HBM (GEMMs are ~15 % of the step; "
+                "attention / depthwise / BatchNorm backward kernels the rest); the training benchmark of BASELINE.json "
+                "(configs[2]) is the ConvNeXt `train` leg",
     }
 
 

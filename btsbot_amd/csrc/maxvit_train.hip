@@ -244,8 +244,20 @@ __global__ void lin_fwd_small_kernel(const float* __restrict__ x, const float* _
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * O) return;
   const int o = i % O, b = i / O;
-  float a = bias[o];
-  for (int k = 0; k < I; ++k) a = fmaf(x[(long)b * I + k], w[(long)o * I + k], a);
+  // (four chains: one chain over up to 2048 inputs was 58 us of exposed load + FMA latency on a 64-row batch)
+  float a0 = bias[o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* xp = x + (long)b * I;
+  const float* wp = w + (long)o * I;
+  int k = 0;
+#pragma unroll 2
+  for (; k + 3 < I; k += 4) {
+    a0 = fmaf(xp[k], wp[k], a0);
+    a1 = fmaf(xp[k + 1], wp[k + 1], a1);
+    a2 = fmaf(xp[k + 2], wp[k + 2], a2);
+    a3 = fmaf(xp[k + 3], wp[k + 3], a3);
+  }
+  for (; k < I; ++k) a0 = fmaf(xp[k], wp[k], a0);
+  const float a = (a0 + a1) + (a2 + a3);
   if (pre != nullptr) pre[i] = a;
   y[i] = act == 1 ? a * sigmoid_f(a) : act == 2 ? sigmoid_f(a) : a;
 }
@@ -262,9 +274,19 @@ __global__ void lin_bwd_in_small_kernel(const float* __restrict__ dpre, const fl
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * I) return;
   const int k = i % I, b = i / I;
-  float a = 0.f;
-  for (int o = 0; o < O; ++o) a = fmaf(dpre[(long)b * O + o], w[(long)o * I + k], a);
-  dx[i] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four chains (as lin_fwd_small_kernel: 137 us with one)
+  const float* dp = dpre + (long)b * O;
+  const float* wp = w + k;
+  int o = 0;
+#pragma unroll 2
+  for (; o + 3 < O; o += 4) {
+    a0 = fmaf(dp[o], wp[(long)o * I], a0);
+    a1 = fmaf(dp[o + 1], wp[(long)(o + 1) * I], a1);
+    a2 = fmaf(dp[o + 2], wp[(long)(o + 2) * I], a2);
+    a3 = fmaf(dp[o + 3], wp[(long)(o + 3) * I], a3);
+  }
+  for (; o < O; ++o) a0 = fmaf(dp[o], wp[(long)o * I], a0);
+  dx[i] = (a0 + a1) + (a2 + a3);
 }
 __global__ void lin_bwd_w_small_kernel(const float* __restrict__ dpre, const float* __restrict__ x, float* __restrict__ dw,
                                        float* __restrict__ db, int B, int I, int O) {
@@ -484,6 +506,8 @@ __global__ __launch_bounds__(64) void mv_attn_bwd_kernel(const float* __restrict
 }
 
 // ---- the engine's cache: every activation the backward needs, carved from one allocation -------------------------
+constexpr size_t MVT_WPART_FLOATS = (size_t)16 << 20;
+
 struct AttnAct {
   float *n1, *qkv, *o, *y1, *n2, *f1, *gl, *y2;
 };
@@ -498,6 +522,9 @@ struct MvtCache {
   float *xfin;                     // final LayerNorm input = last block's output
   // backward scratch
   float *dA, *dB, *dC, *wt, *sums, *dsmall, *dbias, *g9, *gconv, *xn_final;
+  // 16-bit operand modes: the GEMMs' operands are cast per call into these (fp32 everywhere else)
+  void *x16, *d16, *w16;
+  float* wpart;                    // partial tiles of the 16-bit filter-gradient GEMM (two-pass reduction)
   size_t total;
 };
 
@@ -563,6 +590,10 @@ MvtCache carve(const MaxVit* mv, unsigned char* base, int B) {
   k.g9 = take(10 * 2048);
   k.gconv = take(64 * 288);
   k.xn_final = take(n * 49 * 512);
+  k.x16 = take(M0 * 288 / 2);
+  k.d16 = take(M0 * 288 / 2);
+  k.w16 = take(2048 * 512 / 2);
+  k.wpart = take(MVT_WPART_FLOATS);
   k.total = cur;
   return k;
 }
@@ -608,12 +639,22 @@ int maxvit_train_forward(btsbot_ctx* h, const float* img, int B, float* master, 
   auto F = [&](size_t off) { return reinterpret_cast<float*>(h->extra + off); };
   const float* zero = F(mv->p_zero);
   const float* one = F(mv->p_one);
-  auto gemm = [&](const float* X, const float* W, const float* bias, float* out, long M, int N, int K) {
-    return launch_gemm(BTSBOT_F32, EPI_BIAS, X, W, bias ? bias : zero, nullptr, nullptr, out, (int)M, N, K, st);
+  // 16-bit operand modes: the 1x1 convolutions / Linear layers run the LDS-DMA GEMMs on operands cast per call (fp32
+  // accumulation, fp32 results; the split mode keeps cfg.precision = fp32 and with it the exact GEMMs)
+  const int prec = h->cfg.precision;
+  const bool lowp = prec == BTSBOT_BF16 || prec == BTSBOT_F16;
+  auto gemm = [&](const float* X, const float* W, const float* bias, float* out, long M, int N, int K) -> int {
+    if (!lowp) return launch_gemm(BTSBOT_F32, EPI_BIAS, X, W, bias ? bias : zero, nullptr, nullptr, out, (int)M, N, K, st);
+    VTRY(launch_cast(prec, X, k.x16, (int64_t)M * K, st));
+    VTRY(launch_cast(prec, W, k.w16, (int64_t)N * K, st));
+    return launch_gemm(prec, EPI_BIAS, k.x16, k.w16, bias ? bias : zero, nullptr, nullptr, out, (int)M, N, K, st);
   };
   auto gemm_resid = [&](const float* X, const float* W, const float* bias, const float* resid, float* out, long M, int N,
-                        int K) {
-    return launch_gemm(BTSBOT_F32, EPI_RESID, X, W, bias ? bias : zero, one, resid, out, (int)M, N, K, st);
+                        int K) -> int {
+    if (!lowp) return launch_gemm(BTSBOT_F32, EPI_RESID, X, W, bias ? bias : zero, one, resid, out, (int)M, N, K, st);
+    VTRY(launch_cast(prec, X, k.x16, (int64_t)M * K, st));
+    VTRY(launch_cast(prec, W, k.w16, (int64_t)N * K, st));
+    return launch_gemm(prec, EPI_RESID, k.x16, k.w16, bias ? bias : zero, one, resid, out, (int)M, N, K, st);
   };
   const long M0 = (long)B * 12544;
   // ---- stem: resize + conv 3x3 s2 (im2col GEMM) -> BN + SiLU -> conv 3x3 s1
@@ -696,13 +737,32 @@ int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, f
   MvtCache k = carve(mv, h->bbcache, B);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(h->extra + off); };
   const float* zero = F(mv->p_zero);
+  const int prec = h->cfg.precision;
+  const bool lowp = prec == BTSBOT_BF16 || prec == BTSBOT_F16;   // (16-bit GEMM operands: see maxvit_train_forward)
   // dX [M][K] = dY [M][N] . W [N][K]  (the GEMM against the transposed filter)
+  // (a filter gradient directly in front of the input gradient of the same layer has already cast dY)
+  const float* d16_src = nullptr;
+  int64_t d16_n = 0;
   auto dgrad = [&](const float* dY, const float* W, float* dX, long M, int N, int K) -> int {
+    if (lowp) {
+      if (!(d16_src == dY && d16_n == (int64_t)M * N)) VTRY(launch_cast(prec, dY, k.d16, (int64_t)M * N, st));
+      d16_src = nullptr;
+      VTRY(launch_transpose_cast(prec, W, nullptr, k.w16, N, K, st));
+      return launch_gemm(prec, EPI_BIAS, k.d16, k.w16, zero, nullptr, nullptr, dX, (int)M, K, N, st);
+    }
     VTRY(launch_transpose_f32(W, k.wt, N, K, st));
     return launch_gemm(BTSBOT_F32, EPI_BIAS, dY, k.wt, zero, nullptr, nullptr, dX, (int)M, K, N, st);
   };
   // dW [N][K] += dY^T X, db [N] += column sums of dY
   auto wgrad = [&](const float* dY, const float* X, float* dW, float* db, long M, int N, int K) -> int {
+    d16_src = nullptr;
+    if (lowp && N % 8 == 0 && K % 8 == 0) {
+      VTRY(launch_cast(prec, dY, k.d16, (int64_t)M * N, st));
+      d16_src = dY;
+      d16_n = (int64_t)M * N;
+      VTRY(launch_cast(prec, X, k.x16, (int64_t)M * K, st));
+      return launch_wgrad16(prec, k.d16, k.x16, dW, db, (int)M, N, K, K, st, k.wpart, MVT_WPART_FLOATS);
+    }
     VTRY(launch_wgrad(BTSBOT_F32, dY, X, dW, (int)M, N, K, K, st));
     return db != nullptr ? launch_colsum(BTSBOT_F32, dY, db, (int)M, N, st) : BTSBOT_OK;
   };
@@ -829,7 +889,7 @@ int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, f
     const long M0 = (long)B * 12544;
     VTRY(launch_mv_im2col3(BTSBOT_F32, k.a1s, k.dC, B, 112, 32, st));
     HIP_TRY(hipMemsetAsync(k.gconv, 0, (size_t)64 * 288 * 4, st));
-    VTRY(launch_wgrad(BTSBOT_F32, dy, k.dC, k.gconv, (int)M0, 64, 288, 288, st));
+    VTRY(wgrad(dy, k.dC, k.gconv, nullptr, M0, 64, 288));
     hipLaunchKernelGGL(unpack_conv3_grad_kernel, dim3(nblk(64 * 32 * 9)), dim3(256), 0, st, (const float*)k.gconv,
                        grads + mv->stem2_w, 64, 32, 288);
     LAUNCH_CHECK();
@@ -838,7 +898,7 @@ int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, f
     LAUNCH_CHECK();
     VTRY(bn_train_bwd(h, k.y1, dt, mv->stem_bn, k.st_stem, k.sums, dt, grads, M0, 32, 1, 0, st));
     HIP_TRY(hipMemsetAsync(k.gconv, 0, (size_t)32 * 32 * 4, st));
-    VTRY(launch_wgrad(BTSBOT_F32, dt, k.col1, k.gconv, (int)M0, 32, 32, 32, st));
+    VTRY(wgrad(dt, k.col1, k.gconv, nullptr, M0, 32, 32));
     hipLaunchKernelGGL(unpack_conv3_grad_kernel, dim3(nblk(32 * 3 * 9)), dim3(256), 0, st, (const float*)k.gconv,
                        grads + mv->stem1_w, 32, 3, 32);
     LAUNCH_CHECK();
