@@ -207,30 +207,39 @@ def test_load_hf_model_maxvit_metadata_from_local_dir(tmp_path, monkeypatch):
 
 def test_maxvit_train_mode_gate_is_host_logic():
     """Which training-mode calls of the MaxViT wirings are served is decided on the host before any kernel runs
-    (architectures._check_train_supported): refused while a BatchNorm2d holder of the image branch is in train
-    mode or the branch wants gradients; accepted once the branch is frozen and in eval mode.  No GPU needed."""
+    (architectures._check_train_supported): the image branch trains as a whole (every BatchNorm2d holder in train mode:
+    batch statistics + the backward of every layer) or is frozen and in eval mode (heads train over fixed features);
+    the two mixed regimes are refused.  ``model.train()`` picks the regime from the branch's requires_grad flags.
+    No GPU needed."""
     from helpers import MV_CONFIGS
     kind, cfg = MV_CONFIGS["mm_maxvit"]
     m = _build(kind, cfg).train()
     bn = m._image_bn_modules()
-    # stem norm1 + per block (pre-norm, norm1 after conv1, norm2 after the depthwise conv) + a norm in each of the
-    # four down-sampling shortcuts?  -- count them from the state dict instead of by recall:
     n_bn = sum(1 for k in m.state_dict() if k.startswith("maxvit_backbone.") and k.endswith("running_mean"))
     assert len(bn) == n_bn and n_bn > 30
-    # model.train() leaves the inference-only branch's BatchNorm2d holders in eval mode (a validation pass
-    # followed by model.train() must not switch batch statistics on: train.py:332-340) ...
-    assert m.training and not any(b.training for b in bn)
-    m._check_train_supported(False)
-    # ... asking for batch statistics explicitly is refused
-    m.maxvit_backbone.train()
-    assert all(b.training for b in bn)
-    with pytest.raises(NotImplementedError, match="BatchNorm2d"):
-        m._check_train_supported(False)
+    # every parameter trainable: model.train() is the reference's (batch statistics everywhere) and the branch trains
+    assert m.training and all(b.training for b in bn)
+    m._check_train_supported(True)
+    with pytest.raises(NotImplementedError, match="FROZEN"):
+        m._check_train_supported(False)                   # batch statistics without the branch's backward: refused
+    # an eval-mode branch: heads train over its fixed features, its own gradients are refused
     m.maxvit_backbone.eval()
     assert m.training and not any(b.training for b in bn)
-    m._check_train_supported(False)                       # frozen eval-mode branch: served
-    with pytest.raises(NotImplementedError, match="backward"):
-        m._check_train_supported(True)                    # ... but not its own gradients
+    m._check_train_supported(False)
+    with pytest.raises(NotImplementedError, match="eval"):
+        m._check_train_supported(True)
+    # a FROZEN branch: model.train() (e.g. after a validation pass, train.py:332-340) keeps its BatchNorm2d holders
+    # in eval mode, so the next step is served
+    m.maxvit_backbone.requires_grad_(False)
+    m.eval()
+    m.train()
+    assert m.training and not any(b.training for b in bn)
+    m._check_train_supported(False)
+    # ... and thawing it brings batch statistics back
+    m.maxvit_backbone.requires_grad_(True)
+    m.train()
+    assert all(b.training for b in bn)
+    m._check_train_supported(True)
     # the ConvNeXt wirings are not gated at all
     from helpers import CONFIGS
     kind2, cfg2 = CONFIGS["mm_pico"]
