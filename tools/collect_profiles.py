@@ -51,6 +51,10 @@ try:   # training-step kernel stats and the MFMA-utilisation pass (tools/round_e
                    check=True, stdout=subprocess.DEVNULL)
 except ValueError:
     print("no train_trace / mfma pass under gpurun_out/final (older round_end.sh)")
+if glob.glob("gpurun_out/final/pmc_fetch_train/*/*_counter_collection.csv"):   # HBM-side bytes of a training step
+    import subprocess
+    subprocess.run([sys.executable, "tools/train_traffic.py", "gpurun_out/final/pmc_fetch_train", "gpurun_out/final/pmc_write_train",
+                    f"profiles/{tag}_pmc_traffic_train.json"], check=True)
 for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt")):   # tools/nano_bench.py; train step default vs
     if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
         shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")

@@ -24,5 +24,11 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 --maxvit-train-steps 0 $PROF > $O/pmc_write.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 --maxvit-steps 1 --maxvit-batch 256 --maxvit-train-steps 0 $PROF > $O/mfma.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 20 --maxvit-steps 0 --maxvit-train-steps 0 $PROF > $O/train_trace.log 2>&1
-echo "chain rc=$?" > $O/chain.log
-cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace; do tail -n 1 $O/$f.log | cut -c1-200; done
+rc=$?
+if [ $rc = 0 ]; then
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_train -- python3 tools/train_bench.py 1024 bf16 5 > $O/pmc_fetch_train.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_train -- python3 tools/train_bench.py 1024 bf16 5 > $O/pmc_write_train.log 2>&1
+rc=$?
+fi
+echo "chain rc=$rc" > $O/chain.log
+cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace pmc_fetch_train pmc_write_train; do tail -n 1 $O/$f.log | cut -c1-200; done
