@@ -334,7 +334,14 @@ def timed_blocks(run, steps, warmup, fence, dist, dev, blocks=BLOCKS, warm_secon
         last = run(warmup)
     fence()
     t_end = time.perf_counter() + warm_seconds
-    while time.perf_counter() < t_end:
+    while True:
+        go = time.perf_counter() < t_end
+        if dist is not None:   # every rank must run the same number of blocks: `run` may contain collectives
+            g = torch.tensor([1.0 if go else 0.0], device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MIN)
+            go = g.item() > 0.5
+        if not go:
+            break
         last = run(steps)
         torch.cuda.synchronize(dev)
     times = []
