@@ -24,10 +24,15 @@
 //   (7) dxn [64 x C] = da [64 x HS] . W1 [HS x C]: da goes through LDS ([hidden][pixel], 8-byte stores) because here the
 //       sum runs over the hidden units of ALL waves; v_mfma_f32_16x16x32, both operands by transposing reads (da, and the
 //       same LDS image of W1 that feeds (1)).  With more than one hidden slice the slices meet in dxn through fp32
-//       atomics on a cleared buffer.
+//       atomics on a cleared buffer (C = 128: four slices, 25 M atomics per block at 1024 alerts -- 47 of its 107 us,
+//       which is why that width is not the default, ctx.h).
 // The filter-gradient accumulators (2 x C x HS floats per workgroup, half the register budget) leave once, as dense
-// partial tiles in wgrad.hip's layout; wgrad_reduce_kernel adds the workgroups in a fixed order.
-// Two barriers per row tile; the next tile's rows are requested before the tile's work and stored behind its last read.
+// partial tiles in wgrad.hip's layout; wgrad_reduce_kernel adds the workgroups in a fixed order.  colsum(dy) (the
+// layer-scale / fc2-bias gradients need it) and colsum(da) = db1 are summed on the way.
+// ONE barrier per row tile: the row tiles and the da image are double-buffered, dxn of tile t - 1 is computed in
+// iteration t, the next tile's rows are requested at the top of an iteration and stored behind its last read.  Per wave
+// the products of one 32-pixel unit are issued between the GELU pieces of the other (A(0) | A(1) + GELU(0) | C(0) +
+// GELU(1) | C(1)).  Measured and what bounds it: DESIGN.md section 5b, profiles/r03_mlp_bwd_kernel.txt.
 #include <stdlib.h>
 
 #include "common.h"
