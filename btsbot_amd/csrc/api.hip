@@ -331,7 +331,7 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->use_dwln = !(ndl != nullptr && ndl[0] == '1');
     const char* mbc = getenv("BTSBOT_AMD_MLP_BWD_C");
     const char* nmb = getenv("BTSBOT_AMD_NO_MLP_BWD");
-    h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 64;
+    h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
   }

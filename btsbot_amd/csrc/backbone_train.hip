@@ -67,7 +67,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
     cur += al(bytes);
     return p;
   };
-  size_t maxrc = 0, maxc4c = 0, maxpat = 0;
+  size_t maxrc = 0, maxc4c = 0, maxpat = 0, maxplanes = 0;
   k.blk.resize(4);
   for (int i = 0; i < 4; ++i) {
     const size_t rows = (size_t)B * STAGE_HW[i] * STAGE_HW[i], ch = c.dims[i];
@@ -93,11 +93,12 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
     }
     k.dyT_down[i] = i > 0 ? take(rows * ch * esz) : nullptr;
     if (rows * ch > maxrc) maxrc = rows * ch;
+    if (h->mlp_fused((int)ch) && rows * ch * mlp_bwd_planes((int)ch) > maxplanes) maxplanes = rows * ch * mlp_bwd_planes((int)ch);
     if (4 * ch * ch > maxc4c) maxc4c = 4 * ch * ch;
     if (i > 0 && 4 * ch * c.dims[i - 1] > maxc4c) maxc4c = 4 * ch * c.dims[i - 1];
   }
   k.dyA = reinterpret_cast<float*>(take(maxrc * 4));
-  k.dyB = reinterpret_cast<float*>(take(maxrc * 4));
+  k.dyB = reinterpret_cast<float*>(take((maxplanes > maxrc ? maxplanes : maxrc) * 4));   // dxn, possibly as addend planes
   k.dC = reinterpret_cast<float*>(take(maxrc * 4));
   k.dyT_stem = take((size_t)B * 225 * c.dims[0] * esz);
   for (int i = 0; i < 4; ++i)                                          // the fused blocks' colsum(dy), S, G: one memset
@@ -249,6 +250,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
       WgradReduceJob red[2];
+      const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
+      // (the hidden slices of the 128-channel form hand dxn over as addend planes: dwln_bwd_kernel is their reader)
+      const int planes = s.fpart != nullptr ? mlp_bwd_planes(ch) : 1;
+      if (planes > 1 && !(s.dwpart != nullptr && adjacent)) {
+        btsbot_set_error("backward: the fused MLP backward of a %d-channel block needs dwln_bwd_kernel behind it", ch);
+        return BTSBOT_ERR_STATE;
+      }
       if (s.fpart != nullptr) {
         // ---- da, dxn = da W1 and both filter gradients of the MLP in one launch (a recomputed from xn; da, g only on chip)
         TRYB(launch_mlp_bwd(prec, ch, s.xn, s.dyT, h->extra + b.p_fc1, h->extra + b.p_fc2t, m + b.fc1_b, dxn, s.fpart,
@@ -265,10 +273,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       }
       void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
       // (the partial rows follow the arena's layout of conv_dw.weight | conv_dw.bias | norm.weight | norm.bias)
-      const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
       if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
-        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st));
+        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
+                             planes, (size_t)rows * ch));
         pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
       } else if (hw == 1 && h->use_dwln && ch <= 640) {
         // ---- 1x1 maps: the same three steps per (alert, channel) in one launch

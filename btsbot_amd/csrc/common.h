@@ -303,6 +303,9 @@ struct WgradReduceJob {
 bool mlp_bwd_supported(int prec, int C);
 int mlp_bwd_slices(int C, int R);
 size_t mlp_bwd_part_floats(int C, int R);   // scratch for the partial filter-gradient tiles of one block
+// dxn leaves as mlp_bwd_planes(C) addend planes, R * C floats apart (C = 128: one per hidden slice; the reader adds them:
+// launch_dwln_bwd's nplanes)
+int mlp_bwd_planes(int C);
 int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
                    float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
                    WgradReduceJob* jobs);
@@ -339,7 +342,8 @@ int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const fl
 bool dwln_bwd_supported(int HW, int C);
 int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) one launch writes
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st);
+                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes = 1,
+                    size_t pstride = 0);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
 int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,

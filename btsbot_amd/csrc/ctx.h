@@ -141,12 +141,12 @@ struct btsbot_ctx {
   bool pack_on_side = false;
   bool use_dwln = true;    // BTSBOT_AMD_NO_DWLN=1: LayerNorm / depthwise backward as three launches (A/B timing)
   // widths whose block MLP runs fused in the training step (fused_mlp forward that keeps nothing 4C-wide + mlp_bwd_kernel):
-  // 64 by default; BTSBOT_AMD_MLP_BWD_C=128 / =0 (both) / BTSBOT_AMD_NO_MLP_BWD=1 (none) for A/B runs and tests.  C = 128
-  // is correct but not the default: its four hidden slices meet in dxn through 25 M fp32 atomics (47 of its 107 us at
-  // 1024 alerts) and the step is 0.04 ms faster with the unfused stage 1
-  int mlp_bwd_only = 64;
+  // 64 and 128.  BTSBOT_AMD_MLP_BWD_C=64 / =128 restricts it to one width, BTSBOT_AMD_NO_MLP_BWD=1 switches it off (A/B
+  // runs and tests).  The 128-channel form hands dxn over as four addend planes which only dwln_bwd_kernel reads, so it
+  // is tied to that kernel (BTSBOT_AMD_NO_DWLN keeps stage 1 unfused).
+  int mlp_bwd_only = 0;
   bool mlp_fused(int ch) const {
-    return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused &&
+    return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused && (ch == 64 || use_dwln) &&
            mlp_bwd_supported(cfg.precision, ch) && fused_mlp_supported(cfg.precision, ch);
   }
   bool use_side = true;    // BTSBOT_AMD_NO_SIDE_STREAM=1: the whole backward on the caller's stream (A/B timing)

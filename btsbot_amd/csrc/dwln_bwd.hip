@@ -25,7 +25,9 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ g, const float* __restrict__ xin,
                                                       const float* __restrict__ w, float* dy,
                                                       void* __restrict__ out16, int prec16,
-                                                      float* __restrict__ partials, int B, int ga) {
+                                                      float* __restrict__ partials, int B, int ga, int nplanes,
+                                                      size_t pstride) {
+  // dxn may arrive as `nplanes` addends, pstride floats apart (mlp_bwd_kernel's hidden slices each write their own)
   extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [NA P][C] | ds [NA P][C] | flipped taps [49][C]
   constexpr int P = HW * HW, PA = NA * P;   // NA alerts share a pass (3x3 maps: their latencies are paid once)
   constexpr int LPR = C / 4, R = 64 / LPR, NW = NT / 64;   // lanes per pixel row, rows per wave pass, waves
@@ -84,6 +86,13 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
         const int rr = ok[u] ? r : 0;
         v[u] = *reinterpret_cast<const float4*>(d + base + (size_t)rr * C + 4 * l);
         dx[u] = *reinterpret_cast<const float4*>(dxn + base + (size_t)rr * C + 4 * l);
+        for (int pl = 1; pl < nplanes; ++pl) {
+          const float4 e = *reinterpret_cast<const float4*>(dxn + pl * pstride + base + (size_t)rr * C + 4 * l);
+          dx[u].x += e.x;
+          dx[u].y += e.y;
+          dx[u].z += e.z;
+          dx[u].w += e.w;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -229,7 +238,7 @@ template <int HW, int C, int NT, int NA> struct DwlnCfg {
 
 template <int HW, int C, int NT, int NA>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                void* out16, int prec16, float* partials, int B, hipStream_t st) {
+                void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes, size_t pstride) {
   using K = DwlnCfg<HW, C, NT, NA>;
   constexpr int G = NT / C;
   static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
@@ -240,7 +249,7 @@ int dwln_launch(const float* d, const float* dxn, const float* g, const float* x
     attr = true;
   }
   hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT, NA>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
-                     out16, prec16, partials, B, K::ga(B));
+                     out16, prec16, partials, B, K::ga(B), nplanes, pstride);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -263,11 +272,12 @@ int dwln_bwd_rows(int HW, int C, int B) {
 // [C] LayerNorm weight | [C] LayerNorm bias gradients of one workgroup -- the master arena's layout of those four
 // tensors, so the caller finishes with ONE column sum of the rows into the arena (launch_colsum, any stream).
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st) {
+                    void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes,
+                    size_t pstride) {
   if (B <= 0) return BTSBOT_OK;
-  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
-  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
-  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st);
+  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
+  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
+  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
 }

@@ -23,9 +23,9 @@
 //       the other operand -- the transposed row tile -- is read with ds_read_b64_tr_b16 in the same order.
 //   (7) dxn [64 x C] = da [64 x HS] . W1 [HS x C]: da goes through LDS ([hidden][pixel], 8-byte stores) because here the
 //       sum runs over the hidden units of ALL waves; v_mfma_f32_16x16x32, both operands by transposing reads (da, and the
-//       same LDS image of W1 that feeds (1)).  With more than one hidden slice the slices meet in dxn through fp32
-//       atomics on a cleared buffer (C = 128: four slices, 25 M atomics per block at 1024 alerts -- 47 of its 107 us,
-//       which is why that width is not the default, ctx.h).
+//       same LDS image of W1 that feeds (1)).  With more than one hidden slice (C = 128: four) every slice stores
+//       its own addend plane of dxn and the reader -- dwln_bwd_kernel -- adds them (fp32 atomics on a cleared buffer
+//       were 47 of the kernel's 107 us at 1024 alerts, and not reproducible).
 // The filter-gradient accumulators (2 x C x HS floats per workgroup, half the register budget) leave once, as dense
 // partial tiles in wgrad.hip's layout; wgrad_reduce_kernel adds the workgroups in a fixed order.  colsum(dy) (the
 // layer-scale / fc2-bias gradients need it) and colsum(da) = db1 are summed on the way.
@@ -217,10 +217,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
         const int row = tile * G::TR + 16 * mi + 4 * (lane >> 4) + r;
         const int ch = 16 * (ni0 + i) + (lane & 15);
         if (row < R && !(MLP_BWD_ABL & 8)) {
-          if (G::NH == 1)
-            dxn[(size_t)row * C + ch] = dx[i][r];
-          else
-            atomicAdd(dxn + (size_t)row * C + ch, dx[i][r]);
+          // (more than one hidden slice: every slice stores its own addend plane, R * C floats apart)
+          dxn[(size_t)blockIdx.y * R * C + (size_t)row * C + ch] = dx[i][r];
         }
       }
   };
@@ -373,7 +371,6 @@ int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w
     attr = true;
   }
   const int gx = mlp_bwd_slices(C, R);
-  if (G::NH > 1) HIP_TRY(hipMemsetAsync(dxn, 0, (size_t)R * C * sizeof(float), st));
   float* partG = part;
   float* partW = part + (size_t)gx * G::NH * C * G::HS;
   hipLaunchKernelGGL(kern, dim3(gx, G::NH), dim3(G::NT), G::BYTES, st, reinterpret_cast<const T*>(xn),
@@ -398,6 +395,8 @@ bool mlp_bwd_supported(int prec, int C) {
   return (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 128);
 }
 
+int mlp_bwd_planes(int C) { return C == 128 ? 4 : 1; }   // = BwdGeo<128, 4>::NH
+
 // workgroups along the rows (= slices of the partial tiles)
 int mlp_bwd_slices(int C, int R) {
   const int ntiles = (R + 63) / 64;
@@ -408,7 +407,8 @@ int mlp_bwd_slices(int C, int R) {
 size_t mlp_bwd_part_floats(int C, int R) { return (size_t)mlp_bwd_slices(C, R) * 2 * C * 4 * C; }
 
 // jobs[0] (G += ...) and jobs[1] (dW1 += ...) describe the slice reductions for launch_wgrad_reduce(); db1 and
-// Ssum [C] (+= colsum(dy)) are accumulated here (atomics).  dxn is overwritten.
+// Ssum [C] (+= colsum(dy)) are accumulated here (atomics).  dxn is overwritten: mlp_bwd_planes(C) addend planes of
+// R * C floats (C = 128: its four hidden slices; the reader adds them, launch_dwln_bwd's nplanes).
 int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
                    float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
                    WgradReduceJob* jobs) {

@@ -325,18 +325,18 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
     assert not torch.equal(want, run_model(kind, build_model(kind, cfg, sd, cuda, "bf16"), img, meta))
 
 
-@pytest.mark.parametrize("mlp", ["default", "both_widths", "unfused"])
+@pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused"])
 @pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     """The 16-bit training schedule (LDS-DMA GEMMs with the GELU_SAVE / DGELU / PLAIN epilogues, the MFMA
     filter-gradient GEMM with its two-pass slice reduction, depthwise / LayerNorm backward on saved maps)
     against autograd through the fp32 oracle.  B = 24 so the filter-gradient GEMMs of stages 0-1 really split
     their reduction.  Bound: share of each tensor's largest gradient entry (measured at this batch: f16 0.34 %, bf16 2.0 %).
-    ``mlp``: the blocks of the 64-channel stage run the fused MLP forward and mlp_bwd_kernel (default; 5400 rows = 84
-    row tiles and a ragged one), the 128-channel stage too (1176 rows: four hidden slices meeting in dxn), or none
-    (the switches are read when the handle is created)."""
-    if mlp == "both_widths":
-        monkeypatch.setenv("BTSBOT_AMD_MLP_BWD_C", "0")
+    ``mlp``: the blocks of the 64- and 128-channel stages run the fused MLP forward and mlp_bwd_kernel (default; 5400
+    rows = 84 row tiles and a ragged one; 1176 rows in four hidden slices whose addend planes of dxn dwln_bwd_kernel
+    adds), the 64-channel stage only, or none (the switches are read when the handle is created)."""
+    if mlp == "stage0_only":
+        monkeypatch.setenv("BTSBOT_AMD_MLP_BWD_C", "64")
     elif mlp == "unfused":
         monkeypatch.setenv("BTSBOT_AMD_NO_MLP_BWD", "1")
     kind, cfg = CONFIGS["mm_pico"]

@@ -8,7 +8,8 @@ fdir, wdir, out = sys.argv[1:4]
 
 
 def load(d, name):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)   # gpurun merges every call's files
     a = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:

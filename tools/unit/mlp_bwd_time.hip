@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
   for (auto& v : hw) v = 0x3d00 + (rand() & 0xff) + ((rand() & 1) << 15);
   void *xn, *dy, *w1, *w2; float *b1, *dxn, *part, *G, *dW, *db;
   hipMalloc(&xn, hx.size() * 2); hipMalloc(&dy, hx.size() * 2); hipMalloc(&w1, hw.size() * 2); hipMalloc(&w2, hw.size() * 2);
-  hipMalloc(&b1, H * 4); hipMalloc(&dxn, (size_t)R * C * 4); hipMalloc(&part, mlp_bwd_part_floats(C, R) * 4);
+  hipMalloc(&b1, H * 4); hipMalloc(&dxn, (size_t)R * C * 4 * mlp_bwd_planes(C)); hipMalloc(&part, mlp_bwd_part_floats(C, R) * 4);
   hipMalloc(&G, (size_t)C * H * 4); hipMalloc(&dW, (size_t)C * H * 4); hipMalloc(&db, H * 4);
   hipMemcpy(xn, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dy, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(w1, hw.data(), hw.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w2, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
