@@ -37,6 +37,20 @@
 
 #include "common.h"
 
+#ifndef MLP_BWD_STAMP
+#define MLP_BWD_STAMP 0   // development only: per-phase s_memtime stamps of the 4th tile of workgroup 0 (into `stamps`)
+#endif
+#if MLP_BWD_STAMP
+__device__ unsigned long long mlp_bwd_stamps[8 * 16];
+#define MB_STAMP(i)                                                                                 \
+  do {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && it == 3 && lane == 0) mlp_bwd_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  } while (0)
+#else
+#define MB_STAMP(i)
+#endif
 #ifndef MLP_BWD_ABL
 #define MLP_BWD_ABL 0   // development only (tools/unit/mlp_bwd_time.hip): bit mask of phases left out
 #endif
@@ -200,14 +214,25 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     f32x4 dx[G::TPW];
 #pragma unroll
     for (int i = 0; i < G::TPW; ++i) dx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(MLP_BWD_ABL & 4))
-#pragma unroll 2
-    for (int ks = 0; ks < G::HS / 32; ++ks) {
-      const s16x8 af = tr16(DA, PD, 32 * ks, 16 * mi, lane);
+    if (!(MLP_BWD_ABL & 4)) {
+      // fragments of k-step ks + 1 are requested before the products of k-step ks (left to itself the compiler waits
+      // for each k-step's six transposing reads right in front of its products: 8 x ~250 cycles of LDS latency per
+      // tile, a quarter of the tile's time in the in-kernel stamps)
+      constexpr int NKS = G::HS / 32;
+      s16x8 af[2], bf[2][G::TPW];
+      af[0] = tr16(DA, PD, 0, 16 * mi, lane);
 #pragma unroll
-      for (int i = 0; i < G::TPW; ++i) {
-        const s16x8 bf = tr16(sm + G::OFF_W1, PX, 32 * ks, 16 * (ni0 + i), lane);
-        dx[i] = M::m16(af, bf, dx[i]);
+      for (int i = 0; i < G::TPW; ++i) bf[0][i] = tr16(sm + G::OFF_W1, PX, 0, 16 * (ni0 + i), lane);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < NKS) {
+          af[nxt] = tr16(DA, PD, 32 * (ks + 1), 16 * mi, lane);
+#pragma unroll
+          for (int i = 0; i < G::TPW; ++i) bf[nxt][i] = tr16(sm + G::OFF_W1, PX, 32 * (ks + 1), 16 * (ni0 + i), lane);
+        }
+#pragma unroll
+        for (int i = 0; i < G::TPW; ++i) dx[i] = M::m16(af[cur], bf[cur][i], dx[i]);
       }
     }
 #pragma unroll
@@ -233,7 +258,9 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     stash(0, t);
   }
   __syncthreads();
-  for (; t < ntiles; t += gridDim.x, p ^= 1) {
+  int it = 0;
+  for (; t < ntiles; t += gridDim.x, p ^= 1, ++it) {
+    MB_STAMP(0);
     const int tn = t + (int)gridDim.x;
     const bool more = tn < ntiles;   // workgroup-uniform
     if (more) fetch(tn);
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     const unsigned char* Y = X + G::XB;
     unsigned char* DA = sm + G::OFF_DA + p * G::DAB;
     if (tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
+    MB_STAMP(1);
 
     f32x16 a[G::MT], tt[G::MT];
     s16x8 gq[G::MT][2], dq[G::MT][2];
@@ -300,6 +328,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
       }
 #pragma unroll
     for (int k = 0; k < NA; ++k) stepA(0, k);
+    MB_STAMP(2);
 #pragma unroll
     for (int mt = 0; mt < G::MT; ++mt) {
       // GELU of unit mt in 8 pieces of 2 values, the matrix products of the neighbouring units between them
@@ -317,17 +346,22 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
         gelu(mt, 2 * pc, 2);
       }
       da_out(mt);
+      MB_STAMP(3 + mt);
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) stepC(G::MT - 1, k);
+    MB_STAMP(5);
     if (blockIdx.y == 0) {
 #pragma unroll
       for (int r = 0; r < G::TR / SGRP; ++r)
         ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(Y + (srg + SGRP * r) * PX + scol * 2));
     }
     __builtin_amdgcn_sched_barrier(0);   // (keeps the wait for the fetched rows down here)
+    MB_STAMP(6);
     if (more) stash(p ^ 1, tn);
+    MB_STAMP(7);
     __syncthreads();   // da image p and row buffer p ^ 1 are complete; everybody is done with row buffer p and da image p ^ 1
+    MB_STAMP(8);
     tprev = t;
   }
   if (tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);

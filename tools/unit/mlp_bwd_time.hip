@@ -25,6 +25,18 @@ int main(int argc, char** argv) {
   for (int i = 0; i < N; ++i) launch_mlp_bwd(BTSBOT_BF16, C, xn, dy, w1, w2, b1, dxn, part, G, db, dW, db, R, 0, jobs);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
+#if MLP_BWD_STAMP
+  {
+    unsigned long long hs[8 * 16];
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(mlp_bwd_stamps), sizeof(hs));
+    const char* names[] = {"dxn(t-1)", "A(0)", "unit 0: A(1) + GELU", "unit 1: C(0) + GELU", "C(1)", "colsum(dy)", "stash", "barrier"};
+    for (int w = 0; w < 8; w += (C == 64 ? 1 : 2)) {
+      printf("wave %d (s_memtime ticks of 10 ns):", w);
+      for (int i = 0; i < 8; ++i) printf("  %s %lld", names[i], (long long)(hs[w * 16 + i + 1] - hs[w * 16 + i]));
+      printf("  | tile %lld\n", (long long)(hs[w * 16 + 8] - hs[w * 16 + 0]));
+    }
+  }
+#endif
   printf("C=%d R=%d abl=%d: %.1f us per launch (%s)\n", C, R, MLP_BWD_ABL, ms * 1000 / N, hipGetErrorString(hipGetLastError()));
   return 0;
 }
