@@ -267,7 +267,13 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     const unsigned char* X = sm + p * G::XY;
     const unsigned char* Y = X + G::XB;
     unsigned char* DA = sm + G::OFF_DA + p * G::DAB;
-    if (tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
+    // Two waves share a SIMD (NW = 8) and the tile is VALU-issue bound on GELU + GELU': the older wave (0-3) wins the
+    // arbitration, so in lockstep the younger one's GELU waits for it and the older one then idles at the barrier
+    // (stamps: 1650 vs 3300 cycles for the same work).  The older half therefore runs the LDS / matrix-pipe bound
+    // dxn(t - 1) BEHIND its GELU work and the younger half in front: the older half's VALU phase faces the younger
+    // half's dxn phase and the other way round.
+    const bool dxn_late = NW == 8 && wave < NW / 2;   // wave-uniform
+    if (!dxn_late && tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
     MB_STAMP(1);
 
     f32x16 a[G::MT], tt[G::MT];
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
         ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(Y + (srg + SGRP * r) * PX + scol * 2));
     }
     __builtin_amdgcn_sched_barrier(0);   // (keeps the wait for the fetched rows down here)
+    if (dxn_late && tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
     MB_STAMP(6);
     if (more) stash(p ^ 1, tn);
     MB_STAMP(7);

@@ -29,9 +29,9 @@ int main(int argc, char** argv) {
   {
     unsigned long long hs[8 * 16];
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(mlp_bwd_stamps), sizeof(hs));
-    const char* names[] = {"dxn(t-1)", "A(0)", "unit 0: A(1) + GELU", "unit 1: C(0) + GELU", "C(1)", "colsum(dy)", "stash", "barrier"};
+    const char* names[] = {"dxn(t-1)", "A(0)", "unit 0: A(1) + GELU", "unit 1: C(0) + GELU", "C(1)", "colsum(dy) [+ dxn(t-1) in waves 0-3]", "stash", "barrier"};
     for (int w = 0; w < 8; w += (C == 64 ? 1 : 2)) {
-      printf("wave %d (s_memtime ticks of 10 ns):", w);
+      printf("wave %d (shader clocks):", w);
       for (int i = 0; i < 8; ++i) printf("  %s %lld", names[i], (long long)(hs[w * 16 + i + 1] - hs[w * 16 + i]));
       printf("  | tile %lld\n", (long long)(hs[w * 16 + 8] - hs[w * 16 + 0]));
     }
