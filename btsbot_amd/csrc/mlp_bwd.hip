@@ -132,7 +132,7 @@ template <int C, int NW> struct BwdGeo {
   static constexpr int LCH = TR * C / 8 / NT;   // 16-byte pieces per thread, tile and tensor
   static constexpr int CT = C / 32, KC = C / 16;
   static constexpr int TPW = (TR / 16) * (C / 16) / NW;   // 16x16 tiles of dxn per wave (one row of tiles)
-  static_assert(H % HS == 0 && (TR * C / 8) % NT == 0 && (C / 16) % TPW == 0 && NT % C == 0, "geometry");
+  static_assert(H % HS == 0 && (TR * C / 8) % NT == 0 && (C / 16) % TPW == 0 && NT % (C / NH) == 0 && TR % (NT / (C / NH)) == 0, "geometry");
 };
 
 template <typename T, int C, int NW>
@@ -180,8 +180,10 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
       gW[i][r] = 0.f;
     }
   float sb1 = 0.f, ssum = 0.f;
-  constexpr int SGRP = G::NT / C;            // colsum(dy): thread = (channel, row group)
-  const int scol = tid % C, srg = tid / C;
+  // colsum(dy): every hidden slice sums C / NH of the channels (one slice doing all of them was 6 % behind the others
+  // per tile); thread = (channel of the slice's share, row group)
+  constexpr int SC = C / G::NH, SGRP = G::NT / SC;
+  const int scol = (int)blockIdx.y * SC + tid % SC, srg = tid / SC;
 
   const int ntiles = (R + G::TR - 1) / G::TR;
   u32x4 rx[G::LCH], ry[G::LCH];
@@ -235,17 +237,21 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
         for (int i = 0; i < G::TPW; ++i) dx[i] = M::m16(af[cur], bf[cur][i], dx[i]);
       }
     }
+    // (every slice stores its own addend plane, R * C floats apart; one plane when the workgroup owns all hidden units)
+    float* o = dxn + (size_t)blockIdx.y * R * C + (size_t)(tile * G::TR + 16 * mi + 4 * (lane >> 4)) * C + 16 * ni0 + (lane & 15);
+    if (MLP_BWD_ABL & 8) return;
+    if (tile * G::TR + G::TR <= R) {   // whole tile inside the map (workgroup-uniform): no per-row masks
 #pragma unroll
-    for (int i = 0; i < G::TPW; ++i)
+      for (int i = 0; i < G::TPW; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tile * G::TR + 16 * mi + 4 * (lane >> 4) + r;
-        const int ch = 16 * (ni0 + i) + (lane & 15);
-        if (row < R && !(MLP_BWD_ABL & 8)) {
-          // (more than one hidden slice: every slice stores its own addend plane, R * C floats apart)
-          dxn[(size_t)blockIdx.y * R * C + (size_t)row * C + ch] = dx[i][r];
-        }
-      }
+        for (int r = 0; r < 4; ++r) o[r * C + 16 * i] = dx[i][r];
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tile * G::TR + 16 * mi + 4 * (lane >> 4) + r < R) o[r * C + 16 * i] = dx[i][r];
+    }
   };
 
   // One barrier per row tile.  Iteration t: the rows of tile t are in row buffer p, the da image of tile t - 1 in da
@@ -357,11 +363,9 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int k = 0; k < NC; ++k) stepC(G::MT - 1, k);
     MB_STAMP(5);
-    if (blockIdx.y == 0) {
 #pragma unroll
-      for (int r = 0; r < G::TR / SGRP; ++r)
-        ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(Y + (srg + SGRP * r) * PX + scol * 2));
-    }
+    for (int r = 0; r < G::TR / SGRP; ++r)
+      ssum += M::tofloat(*reinterpret_cast<const unsigned short*>(Y + (srg + SGRP * r) * PX + scol * 2));
     __builtin_amdgcn_sched_barrier(0);   // (keeps the wait for the fetched rows down here)
     if (dxn_late && tprev >= 0) dxn_tile(tprev, sm + G::OFF_DA + (p ^ 1) * G::DAB);
     MB_STAMP(6);
@@ -388,15 +392,15 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     }
   sb1 += __shfl_xor(sb1, 32);
   if (lh == 0) atomicAdd(db1 + hid, sb1);
-  if (blockIdx.y == 0) {   // (every LDS read of the loop is behind its last barrier)
+  {   // (every LDS read of the loop is behind its last barrier)
     float* red = reinterpret_cast<float*>(sm);
     red[tid] = ssum;
     __syncthreads();
-    if (tid < C) {
+    if (tid < SC) {
       float v = 0.f;
 #pragma unroll
-      for (int g = 0; g < SGRP; ++g) v += red[tid + C * g];
-      atomicAdd(Ssum + tid, v);
+      for (int g = 0; g < SGRP; ++g) v += red[tid + SC * g];
+      atomicAdd(Ssum + (int)blockIdx.y * SC + tid, v);
     }
   }
 }
