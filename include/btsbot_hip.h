@@ -52,9 +52,11 @@ enum btsbot_wiring {
   BTSBOT_FROZEN_FUSION = 2, /* frozen_fusion   architectures.py:296-372 (ConvNeXt + um_nn, ReLU)*/
   BTSBOT_UM_NN = 3,         /* um_nn           architectures.py:277-293 (metadata only)         */
   BTSBOT_MM_MAXVIT = 4,     /* mm_MaxViT       architectures.py:58-101 (maxvit_tiny_rw_224 + GELU heads);
-                               the image branch runs in eval mode only (BatchNorm2d running statistics, no
-                               backward): reserve_train(with_image_grads = 1) returns BTSBOT_ERR_STATE;
-                               heads / metadata branch train over it with with_image_grads = 0           */
+                               the image branch trains (BatchNorm2d batch statistics + the backward of every
+                               layer, reserve_train(with_image_grads = 1)) or stays a frozen eval-mode branch
+                               under trainable heads / metadata branch (with_image_grads = 0); the two mixed
+                               regimes (frozen branch on batch statistics, trainable branch on running
+                               statistics) return BTSBOT_ERR_STATE                                        */
   BTSBOT_MAXVIT = 5,        /* MaxViT          architectures.py:25-55  (image only)             */
   BTSBOT_FROZEN_FUSION_MAXVIT = 6 /* frozen_fusion with a MaxViT image branch (head stripped to its global
                                pool, architectures.py:304-308) + um_nn metadata branch, ReLU fusion head:
@@ -68,8 +70,9 @@ enum btsbot_precision {
   BTSBOT_BF16 = 1, /* v_mfma_f32_16x16x32_bf16                                                   */
   BTSBOT_F16 = 2,  /* v_mfma_f32_16x16x32_f16 (same rate as bf16, 3 more mantissa bits)          */
   BTSBOT_FP8 = 3,  /* inference only: the bf16 schedule with the pointwise convolutions of stages 2-3
-                      (55 % of the FLOPs, the filter-streaming-bound part) on v_mfma_*_fp8_fp8, OCP e4m3,
-                      one power-of-two scale per filter; training entry points behave as BTSBOT_BF16 */
+                      (55 % of the FLOPs, the filter-streaming-bound part) on the block-scaled fp8 MFMA
+                      (v_mfma_scale_f32_16x16x128_f8f6f4 / 32x32x64), OCP e4m3 operands; scaling: see
+                      DESIGN.md section 2; training entry points behave as BTSBOT_BF16 */
   BTSBOT_F16X2 = 4 /* split operands: every MFMA operand of the pointwise / downsample convolutions is an f16
                       head plus an f16 remainder (x = hi + lo, 22 significant bits), a product is three
                       v_mfma_f32_*_f16 (hi*hi + hi*lo + lo*hi) -- scores within 1e-4 of the fp32 reference at
