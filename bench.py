@@ -99,9 +99,10 @@ CONFIG = dict(model_name="mm_ConvNeXt", model_kind="convnext_pico.d1_in1k", pret
               comb_dropout=0.2)
 
 
-def seeded_weights(model, seed=3):
-    """Random 'trained-like' weights written straight into the model (layer-scale ~1 so every block
-    contributes; there are no checkpoints offline)."""
+def seeded_weights(model, seed=3, layer_scale=1.0):
+    """Random weights written straight into the model (there are no checkpoints offline).  layer_scale ~1 (the
+    benchmarked stress case: every block contributes fully, the worst case for a 16-bit operand) or ~0.1 (what a trained
+    ConvNeXt's gamma looks like): the same draws, only the `gamma` tensors scaled."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for k, v in model.state_dict().items():
@@ -111,7 +112,9 @@ def seeded_weights(model, seed=3):
                 v.copy_(torch.rand(v.shape, generator=g) + 0.5)
             elif k.endswith("running_mean"):
                 v.copy_(torch.randn(v.shape, generator=g) * 0.5)
-            elif k.endswith("gamma") or (v.dim() == 1 and k.endswith("weight")):
+            elif k.endswith("gamma"):
+                v.copy_(layer_scale * (1.0 + 0.1 * torch.randn(v.shape, generator=g)))
+            elif v.dim() == 1 and k.endswith("weight"):
                 v.copy_(1.0 + 0.1 * torch.randn(v.shape, generator=g))
             elif v.dim() == 1:
                 v.copy_(0.05 * torch.randn(v.shape, generator=g))
@@ -450,6 +453,19 @@ def parity_vs_oracle(model, img, meta, n=256):
                 oracle="oracle/convnext_oracle.py, fp32 CPU, same weights")
 
 
+def trained_like_parity(precision, dev, img, meta, layer_scale=0.1):
+    """Parity of one operand mode with trained-like layer scale (gamma ~ 0.1 instead of the benchmark's ~1): what a
+    user of a trained checkpoint sees.  No timing: the kernels do not depend on the values."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = btsbot_amd.mm_ConvNeXt(CONFIG, precision=precision)
+    seeded_weights(m, layer_scale=layer_scale)
+    m = m.to(dev).eval()
+    out = parity_vs_oracle(m, img, meta)
+    out["weights"] = f"seeded random, layer-scale ~{layer_scale}"
+    return out
+
+
 def precision_leg(precision, dev, img, meta, steps, warmup, fence, dist, world, with_parity=True):
     """The same workload in another MFMA operand mode (f16: same matrix rate as bf16, scores within 1e-4 of the
     oracle; f32: the exact-fp32 parity mode), with its own parity figures."""
@@ -527,9 +543,14 @@ def dev_of(t):
     return t.device
 
 
-def train_leg(dev, rank, world, dist, fence, args):
+def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None):
     """BASELINE.json configs[2]: the training step of mm_ConvNeXt, every parameter trainable."""
     from btsbot_amd.train import Trainer
+    import copy
+    if precision is not None:
+        args = copy.copy(args)
+        args.precision = precision
+        args.train_steps = steps or args.train_steps
     tcfg = dict(CONFIG, meta_dropout=0.25, comb_dropout=0.2)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -555,6 +576,7 @@ def train_leg(dev, rank, world, dist, fence, args):
         "steps": args.train_steps, "ms_per_step": round(1e3 * tel / args.train_steps, 3),
         "blocks_ms_per_step": [round(1e3 * b / args.train_steps, 3) for b in tblocks],
         "loss_finite": bool(torch.isfinite(tloss).item()),
+        "operands": args.precision,
     }
     # whole-step roofline: forward + input gradients + filter gradients = 3 x the forward's algorithmic FLOP
     step_flop = 3.0 * (133701376 + 210000) * args.train_batch
@@ -607,6 +629,14 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ranks_seen = 1
+    if dist is not None:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(round(one.item()))
+        if ranks_seen != world:
+            raise SystemExit(f"rank {rank}: the {dist.get_backend()} group spans {ranks_seen} ranks, WORLD_SIZE={world}")
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -679,6 +709,13 @@ def main():
     parity, legs = None, {}
     if not args.no_extra_legs:
         parity = parity_vs_oracle(model, img, meta) if rank == 0 else None
+        if rank == 0:
+            # both ends for a configs[1] user: the stress weights above and trained-like layer scale (gamma ~ 0.1)
+            for prec in ("bf16", "f16", "fp8"):
+                try:
+                    legs[f"{prec}_trained_like"] = {"parity": trained_like_parity(prec, dev, img, meta)}
+                except Exception as e:   # noqa: BLE001
+                    legs[f"{prec}_trained_like"] = {"error": f"{type(e).__name__}: {e}"}
         for prec in ("f16x2", "f16", "bf16", "f32"):
             if prec == args.precision:
                 continue
@@ -742,6 +779,17 @@ def main():
             train = train_leg(dev, rank, world, dist, fence, args)
         except Exception as e:   # noqa: BLE001
             train = {"error": f"{type(e).__name__}: {e}"}
+        if args.precision != "f32" and not args.no_extra_legs:
+            # the reference's own arithmetic is fp32 (/root/reference/btsbot/train.py:141,525-527: no autocast): the same
+            # step on exact-fp32 MFMA operands beside the 16-bit one
+            try:
+                t32 = train_leg(dev, rank, world, dist, fence, args, precision="f32", steps=max(3, args.train_steps // 4))
+                t32.pop("roofline", None)
+                if isinstance(train, dict):
+                    train["f32"] = t32
+            except Exception as e:   # noqa: BLE001
+                if isinstance(train, dict):
+                    train["f32"] = {"error": f"{type(e).__name__}: {e}"}
     maxvit = None
     if args.maxvit_steps > 0:
         try:
@@ -811,6 +859,10 @@ def main():
                 "precision": args.precision, "weights": "seeded random, layer-scale ~1",
                 "parallelism": f"{world} independent replicas, batch-sharded, no collective",
                 "pipeline_depth": headline_depth,
+                "drop_in_value": round(total_alerts / serial_elapsed, 1),
+                "drop_in_ms_per_step": round(1e3 * serial_elapsed / args.steps, 4),
+                "drop_in_api": "plain model(image_input=, metadata_input=) calls on one stream "
+                               "(/root/reference/btsbot/inference_example.py:84)",
                 "api": ("btsbot_amd.ScoreStream (the library's scoring loop: consecutive batches on alternating HIP "
                         "streams)" if headline_depth > 1 else "drop-in model(image_input=, metadata_input=) calls"),
             },
@@ -850,6 +902,10 @@ def main():
         if dist is not None:
             line["collective"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
                                       note="inference: no data-path collective; training leg: bucketed all-reduce")
+        # self-check of a multi-GPU run: how many ranks the collective backend really spans (an all-reduce of ones),
+        # and what the gradient exchange costs per step when it is exposed
+        line["rccl_ranks_seen"] = ranks_seen
+        line["allreduce_exposed_ms_per_step"] = (train or {}).get("allreduce_exposed_ms_per_step") if world > 1 else 0.0
         if train is not None:
             line["train"] = train
         if maxvit is not None:

@@ -592,6 +592,14 @@ extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
     h->s2p_alerts_hint = value;
     return BTSBOT_OK;
   }
+  if (strcmp(key, "exchange") == 0) {
+    if (value != 0 && value != 1) {
+      btsbot_set_error("set_option: exchange is 0 (one all-reduce per span) or 1 (reduce-scatter + all-gather), got %d", value);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    h->exchange_mode = value;
+    return BTSBOT_OK;
+  }
   btsbot_set_error("set_option: unknown option '%s'", key);
   return BTSBOT_ERR_INVALID_ARG;
 }
@@ -1211,6 +1219,7 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));
   }
   h->bucket_recorded = true;
+  h->last_grad_arena = grad_arena;
   return BTSBOT_OK;
 }
 
@@ -1276,19 +1285,53 @@ extern "C" int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream
 // wins).
 namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-nccl_allreduce_fn resolve_allreduce() {
-  static nccl_allreduce_fn fn = [] {
+typedef int (*nccl_reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_comm_int_fn)(void*, int*);
+struct RcclApi {
+  nccl_allreduce_fn all_reduce = nullptr;
+  nccl_reduce_scatter_fn reduce_scatter = nullptr;
+  nccl_allgather_fn all_gather = nullptr;
+  nccl_comm_int_fn count = nullptr, user_rank = nullptr;
+  std::string error;   // why the library or a symbol could not be resolved (dlerror() is consumed by its first reader)
+};
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
     void* lib = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (lib != nullptr) break;
     }
-    return lib != nullptr ? reinterpret_cast<nccl_allreduce_fn>(dlsym(lib, "ncclAllReduce")) : nullptr;
+    if (lib == nullptr) {
+      const char* e = dlerror();
+      a.error = std::string("dlopen(librccl.so.1): ") + (e != nullptr ? e : "not found");
+      return a;
+    }
+    auto sym = [&](const char* name) -> void* {
+      void* p = dlsym(lib, name);
+      if (p == nullptr && a.error.empty()) {
+        const char* e = dlerror();
+        a.error = std::string("dlsym(") + name + "): " + (e != nullptr ? e : "missing");
+      }
+      return p;
+    };
+    a.all_reduce = reinterpret_cast<nccl_allreduce_fn>(sym("ncclAllReduce"));
+    a.reduce_scatter = reinterpret_cast<nccl_reduce_scatter_fn>(sym("ncclReduceScatter"));
+    a.all_gather = reinterpret_cast<nccl_allgather_fn>(sym("ncclAllGather"));
+    a.count = reinterpret_cast<nccl_comm_int_fn>(sym("ncclCommCount"));
+    a.user_rank = reinterpret_cast<nccl_comm_int_fn>(sym("ncclCommUserRank"));
+    return a;
   }();
-  return fn;
+  return api;
 }
 }  // namespace
 
+// Two forms of the exchange (btsbot_set_option(h, "exchange", 0 | 1)):
+//   0  one ncclAllReduce per span (RCCL picks ring / tree);
+//   1  the direct form SURVEY.md section 5.8 recommends for xGMI's point-to-point links: ncclReduceScatter of the span
+//      (every rank ends up owning the sum of its 1 / N slice) followed by ncclAllGather, both in place; what is left of
+//      a span after N equal slices (< N floats) goes through a small ncclAllReduce.
 extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
                                       const int64_t* lo, const int64_t* hi, void* stream) {
   if (h == nullptr || nccl_comm == nullptr || grads == nullptr || nspans < 0 || (nspans > 0 && (bucket == nullptr || lo == nullptr || hi == nullptr))) {
@@ -1299,10 +1342,25 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
     btsbot_set_error("allreduce_grads: btsbot_backward() has not run on this handle");
     return BTSBOT_ERR_STATE;
   }
-  nccl_allreduce_fn allreduce = resolve_allreduce();
-  if (allreduce == nullptr) {
-    btsbot_set_error("allreduce_grads: cannot load RCCL (librccl.so.1: %s)", dlerror());
+  if (h->last_grad_arena != nullptr && grads != h->last_grad_arena) {
+    // the bucket events belong to the arena the last btsbot_backward() wrote: any other pointer would be reduced behind
+    // events that say nothing about it
+    btsbot_set_error("allreduce_grads: `grads` (%p) is not the arena the last btsbot_backward() wrote (%p)", (void*)grads,
+                     (void*)h->last_grad_arena);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const RcclApi& api = rccl_api();
+  if (api.all_reduce == nullptr || (h->exchange_mode == 1 && (api.reduce_scatter == nullptr || api.all_gather == nullptr ||
+                                                              api.count == nullptr || api.user_rank == nullptr))) {
+    btsbot_set_error("allreduce_grads: cannot load RCCL (%s)", api.error.empty() ? "symbol missing" : api.error.c_str());
     return BTSBOT_ERR_STATE;
+  }
+  int nranks = 1, rank = 0;
+  if (h->exchange_mode == 1) {
+    if (api.count(nccl_comm, &nranks) != 0 || api.user_rank(nccl_comm, &rank) != 0 || nranks < 1 || rank < 0 || rank >= nranks) {
+      btsbot_set_error("allreduce_grads: ncclCommCount / ncclCommUserRank failed on this communicator");
+      return BTSBOT_ERR_HIP;
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   if (h->xchg == nullptr) {
@@ -1318,10 +1376,29 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
     // the collective of a span starts as soon as the backward pass has written its bucket, on the library's exchange
     // stream: the rest of the backward keeps the caller's stream
     HIP_TRY(hipStreamWaitEvent(h->xchg, h->bucket_ev[bucket[i]], 0));
-    const int rc = allreduce(grads + lo[i], grads + lo[i], (size_t)(hi[i] - lo[i]), /* ncclFloat32 */ 7, /* ncclSum */ 0,
-                             nccl_comm, h->xchg);
+    float* base = grads + lo[i];
+    const size_t n = (size_t)(hi[i] - lo[i]);
+    int rc = 0;
+    const char* what = "ncclAllReduce";
+    if (h->exchange_mode == 1 && nranks > 1) {
+      const size_t slice = n / (size_t)nranks, body = slice * (size_t)nranks;
+      if (slice > 0) {
+        what = "ncclReduceScatter";
+        rc = api.reduce_scatter(base, base + (size_t)rank * slice, slice, /* ncclFloat32 */ 7, /* ncclSum */ 0, nccl_comm, h->xchg);
+        if (rc == 0) {
+          what = "ncclAllGather";
+          rc = api.all_gather(base + (size_t)rank * slice, base, slice, 7, nccl_comm, h->xchg);
+        }
+      }
+      if (rc == 0 && body < n) {
+        what = "ncclAllReduce (remainder)";
+        rc = api.all_reduce(base + body, base + body, n - body, 7, 0, nccl_comm, h->xchg);
+      }
+    } else {
+      rc = api.all_reduce(base, base, n, /* ncclFloat32 */ 7, /* ncclSum */ 0, nccl_comm, h->xchg);
+    }
     if (rc != 0) {
-      btsbot_set_error("allreduce_grads: ncclAllReduce of span %d returned %d", i, rc);
+      btsbot_set_error("allreduce_grads: %s of span %d returned %d", what, i, rc);
       return BTSBOT_ERR_HIP;
     }
   }

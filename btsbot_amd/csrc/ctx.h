@@ -130,6 +130,8 @@ struct btsbot_ctx {
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
+  int exchange_mode = 0;             // btsbot_set_option("exchange"): 0 all-reduce per span, 1 reduce-scatter + all-gather
+  const float* last_grad_arena = nullptr;   // what the last btsbot_backward() wrote (the bucket events belong to it)
   hipEvent_t xchg_done = nullptr;
   // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
   hipStream_t side = nullptr;

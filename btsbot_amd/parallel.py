@@ -67,19 +67,62 @@ def plan_exchange(ranges: Sequence[Tuple[int, int]],
     return plan
 
 
+def exchange_mode() -> str:
+    """``BTSBOT_AMD_EXCHANGE``: "allreduce" (default: one all-reduce per span) or "rs_ag" (the direct form SURVEY.md
+    section 5.8 recommends for xGMI's point-to-point links: reduce-scatter, then all-gather, in place)."""
+    import os
+    m = os.environ.get("BTSBOT_AMD_EXCHANGE", "allreduce")
+    if m not in ("allreduce", "rs_ag"):
+        raise ValueError(f"BTSBOT_AMD_EXCHANGE={m!r}: expected 'allreduce' or 'rs_ag'")
+    return m
+
+
+def _span_collectives(flat: torch.Tensor, mode: str, group, async_op: bool):
+    """The collectives of ONE span (a 1-D view of the arena), summed over the ranks in place; returns the work handles.
+    rs_ag: every rank receives the sum of its 1 / N slice (reduce-scatter), then all slices travel to everyone
+    (all-gather); what is left after N equal slices (< N floats) is all-reduced.  On backends without the tensor forms
+    (gloo) the same data flow is spelled with reduce-to-owner + broadcast-from-owner per slice."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = flat.numel()
+    backend = dist.get_backend(group)
+    if mode == "allreduce" or world == 1 or n < world or (backend != "nccl" and flat.device.type != "cpu"):
+        # (gloo has no reduce() for device tensors: the one-GPU rehearsals stay on all_reduce)
+        return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)]
+    slice_n = n // world
+    body = flat[:slice_n * world]
+    mine = body[rank * slice_n:(rank + 1) * slice_n]
+    works = []
+    if backend == "nccl":
+        works.append(dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        works.append(dist.all_gather_into_tensor(body, mine, group=group, async_op=async_op))
+    else:
+        for r in range(world):
+            works.append(dist.reduce(body[r * slice_n:(r + 1) * slice_n], dst=dist.get_global_rank(group, r) if group else r,
+                                     op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        for r in range(world):
+            works.append(dist.broadcast(body[r * slice_n:(r + 1) * slice_n], src=dist.get_global_rank(group, r) if group else r,
+                                        group=group, async_op=async_op))
+    if slice_n * world < n:
+        works.append(dist.all_reduce(flat[slice_n * world:], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+    return works
+
+
 class GradExchange:
     """The exchange step of one training iteration over a flat gradient arena.
 
-    ``exchange(grads, wait_bucket)`` issues one all-reduce per planned span.  On a HIP device the collectives
+    ``exchange(grads, wait_bucket)`` issues the collectives of one planned span after the other (``exchange_mode()``:
+    one all-reduce per span, or reduce-scatter + all-gather).  On a HIP device the collectives
     go to a side stream: ``wait_bucket(bucket, stream)`` (``btsbot_wait_grad_bucket``) makes that stream wait
     for the bucket's gradients, and the caller's stream waits for every collective before it returns to the
     optimiser.  On CPU tensors (gloo) the calls are synchronous and ``wait_bucket`` is not used.
     """
 
     def __init__(self, ranges: Sequence[Tuple[int, int]],
-                 buckets: Optional[Sequence[Tuple[int, int]]] = None, group=None):
+                 buckets: Optional[Sequence[Tuple[int, int]]] = None, group=None, mode: Optional[str] = None):
         self.group = group
         self.plan = plan_exchange(ranges, buckets)
+        self.mode = mode or exchange_mode()
         self._side = None
 
     def exchange(self, grads: torch.Tensor,
@@ -89,7 +132,7 @@ class GradExchange:
         import torch.distributed as dist
         if grads.device.type != "cuda":
             for _b, lo, hi in self.plan:
-                dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                _span_collectives(grads[lo:hi], self.mode, self.group, async_op=False)
             return grads
         dev = grads.device
         if self._side is None:
@@ -102,8 +145,7 @@ class GradExchange:
                     wait_bucket(b, self._side.cuda_stream)     # the side stream waits for the bucket's kernels
                 else:
                     self._side.wait_stream(main)
-                works.append(dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+                works.extend(_span_collectives(grads[lo:hi], self.mode, self.group, async_op=True))
         for w in works:
             w.wait()                                            # the caller's stream waits for the collective
         main.wait_stream(self._side)

@@ -211,14 +211,18 @@ int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
  * Local gradients are already scaled by 1 / n_global (btsbot_bce_fwd_bwd), so SUM is the global-batch mean's
  * gradient.  No host synchronisation.  RCCL is resolved at the first call (dlopen of librccl.so.1: the copy already
  * in the process, e.g. PyTorch's, wins) -- the communicator must come from that library; BTSBOT_ERR_STATE if there is
- * none. */
+ * none.  `grads` must be the arena the last btsbot_backward() wrote (the bucket events belong to it;
+ * BTSBOT_ERR_INVALID_ARG otherwise).  btsbot_set_option(h, "exchange", 1) switches every span from one ncclAllReduce
+ * to the direct form for xGMI's point-to-point links: ncclReduceScatter (each rank owns the sum of its 1 / N slice)
+ * + ncclAllGather, in place, plus a small ncclAllReduce for what is left after N equal slices. */
 int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
                            const int64_t* lo, const int64_t* hi, void* stream);
 
 /* Scheduling hints (host-side state read at launch time; results do not depend on them).
  *   "stage2p_alerts": alerts resident per workgroup of the stage-2 kernel -- 0 (default): 4, or 7 where that takes fewer
  *   rounds of one workgroup per CU; 7: always (a scoring loop with several forwards in flight on different streams:
- *   the kernel then leaves ~40 % of the CUs to the other stream at 1024 alerts); 4: always. */
+ *   the kernel then leaves ~40 % of the CUs to the other stream at 1024 alerts); 4: always.
+ *   "exchange": form of btsbot_allreduce_grads' collectives -- 0 (default) all-reduce, 1 reduce-scatter + all-gather. */
 int btsbot_set_option(btsbot_handle h, const char* key, int value);
 
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and

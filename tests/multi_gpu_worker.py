@@ -96,6 +96,21 @@ def main():
         torch.cuda.synchronize(dev)
         if rank == 0:
             res["grad_err_c_abi"] = (g3 - rg).abs().max().item() / scale
+        # ... and in its reduce-scatter + all-gather form (btsbot_set_option(h, "exchange", 1)), then the same form
+        # through torch.distributed (BTSBOT_AMD_EXCHANGE=rs_ag)
+        from btsbot_amd import _lib
+        _lib.check(_lib.lib().btsbot_set_option(m._handle.ptr, b"exchange", 1), "set_option")
+        _l4, g4 = tr_c.gradients(img[lo:hi].contiguous(), None, lab[lo:hi].contiguous())
+        g4 = g4.clone()
+        _lib.check(_lib.lib().btsbot_set_option(m._handle.ptr, b"exchange", 0), "set_option")
+        tr_rs = Trainer(m, lr=1e-4)
+        tr_rs.exchange.mode = "rs_ag"
+        _l5, g5 = tr_rs.gradients(img[lo:hi].contiguous(), None, lab[lo:hi].contiguous())
+        g5 = g5.clone()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            res["grad_err_c_abi_rs_ag"] = (g4 - rg).abs().max().item() / scale
+            res["grad_err_rs_ag"] = (g5 - rg).abs().max().item() / scale
         comm.destroy()
     del m, tr
 

@@ -163,8 +163,12 @@ def _exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_trainer_exchange_plan_and_broadcast(world):
+def test_trainer_exchange_plan_and_broadcast(world, mode, monkeypatch):
+    """(mode: one all-reduce per span, or BTSBOT_AMD_EXCHANGE=rs_ag -- reduce-scatter to the slice owners + all-gather,
+    spelled with reduce / broadcast on gloo; spans that do not divide by the world size leave a remainder all-reduce)"""
+    monkeypatch.setenv("BTSBOT_AMD_EXCHANGE", mode)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -58,6 +58,8 @@ def _assert_result(res, world):
     assert res["replicas_identical_after_steps"] and res["loss_finite"], res
     if res["backend"] == "nccl":
         assert res["grad_err_c_abi"] <= 2e-5, res              # btsbot_allreduce_grads on a raw RCCL communicator
+        assert res["grad_err_c_abi_rs_ag"] <= 2e-5, res        # ... as reduce-scatter + all-gather
+        assert res["grad_err_rs_ag"] <= 2e-5, res              # the same form through torch.distributed
 
 
 def test_two_gpus_rccl(tmp_path):
