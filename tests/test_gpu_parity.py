@@ -228,6 +228,27 @@ def test_full_size_batch_matches_oracle(cuda, prec):
     print(f"B=1024 {prec}: max|dscore| {ds:.3e}")
 
 
+@pytest.mark.timeout(900)
+def test_f16x2_meets_the_north_star_on_five_weight_seeds(cuda):
+    """The mode that claims the north star's 1e-4 must not owe it to one draw of the weights: five seeded weight sets
+    (stress case, layer scale gamma ~ 1) x 1024 alerts each (a fresh synthetic batch per seed), every score against the
+    fp32 oracle, asserted against the constant itself (/root/reference/btsbot/to_onnx.py:135-137 is the reference's own
+    notion of equal outputs).  The per-seed maxima are printed; VERDICT r3 asks for <= 5e-5 (a 2x margin)."""
+    kind, cfg = CONFIGS["mm_pico"]
+    worst = []
+    for seed in (3, 11, 12, 13, 14):
+        sd = seeded_state(kind, cfg, seed=seed)
+        img, meta, _ = synthetic_batch(1024, seed=20 + seed)
+        ref = _oracle(kind, cfg, sd, img, meta)
+        m = build_model(kind, cfg, sd, cuda, "f16x2")
+        out = run_model(kind, m, img.to(cuda), meta.to(cuda)).cpu()
+        ds = (torch.sigmoid(out) - torch.sigmoid(ref)).abs()
+        worst.append(ds.max().item())
+        print(f"f16x2 weight seed {seed}: max|dscore| {worst[-1]:.3e}, rms {ds.pow(2).mean().sqrt().item():.3e}")
+        del m
+    assert max(worst) <= NORTH_STAR, worst
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16", "fp8"])
 def test_seven_alerts_per_workgroup_form_of_stage2(cuda, prec):
     """stage2p.hip keeps 7 alerts (63 of 64 MFMA columns) per workgroup instead of 4 when the batch is large enough
