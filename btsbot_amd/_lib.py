@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbtsbot_hip.so")
+# (BTSBOT_AMD_LIB: another build of the same library, for A/B timing of kernel variants -- tools/build_variant.sh)
+LIB_PATH = os.environ.get("BTSBOT_AMD_LIB") or os.path.join(_HERE, "libbtsbot_hip.so")
 ABI_VERSION = 1
 
 OK = 0

@@ -365,8 +365,13 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
           for (int xb = 0; xb < 2; ++xb) acc[yb][xb] = f32x4{dwbias[gi], dwbias[gi], dwbias[gi], dwbias[gi]};
         const unsigned char* lb = pl + al * PL_AL + (16 * (2 * wave + gi) + db) * 8;
+#ifdef S1_EXP_NODW
+#pragma unroll 1
+        for (int sx = 0; sx < 0; ++sx) {
+#else
 #pragma unroll
         for (int sx = 0; sx < 11; ++sx) {
+#endif
           frag4 bq[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q)
@@ -556,7 +561,9 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         LS(1);
         // raw barrier: __syncthreads() would also wait vmcnt(0) while an LDS-DMA is in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the last step is home
+#ifndef S1_EXP_NOBAR
         __builtin_amdgcn_s_barrier();   // W1(ch+2), W2(ch) have landed for everyone; W1(ch+1), W2(ch-1) are read out
+#endif
         LS(2);
         frag a2[CT][2];
         const unsigned char* w2s = w2slot(ch % NSLOT);
@@ -578,8 +585,14 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
             hn = SCM<T>::run(a1[r], xf[r], hn);
             if (X2) hn = SCM<T>::run(a1[r], xfl[r], hn);
           }
+#ifdef S1_EXP_NOGELU
+          g[r] = hc[r];
+#else
           g[r] = gelu_for<T>(hc[r]);
+#endif
+#ifndef S1_EXP_NODMA
           if (r & 1) issue_piece(kdma, r >> 1);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         LS(5);
@@ -594,8 +607,13 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         for (int ct = 0; ct < CT; ++ct) {
           x[ct] = SCM<T>::run(a2[ct][0], hf, x[ct]);
           if (X2) x[ct] = SCM<T>::run(a2[ct][0], hfl, x[ct]);
+#ifdef S1_EXP_NOGELU
+          g[8 + 2 * ct] = hc[8 + 2 * ct];
+          g[9 + 2 * ct] = hc[9 + 2 * ct];
+#else
           g[8 + 2 * ct] = gelu_for<T>(hc[8 + 2 * ct]);
           g[9 + 2 * ct] = gelu_for<T>(hc[9 + 2 * ct]);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         if (!LAST) bias_acc(ch + 2, hc);
@@ -612,6 +630,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         }
         LS(7);
       };
+#ifndef S1_EXP_NOLOOP
 #pragma unroll 1
       for (int ch = 0; ch < NCH - 2; ch += 2) {
         step(std::false_type{}, ch, hacc[0], hacc[1]);
@@ -619,6 +638,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       }
       step(std::false_type{}, NCH - 2, hacc[0], hacc[1]);
       step(std::true_type{}, NCH - 1, hacc[1], hacc[0]);
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last prefetches (unused) are not left in flight
 #ifdef S1_LOOPSTAMP
       if (a.wgt != nullptr && blockIdx.x == 0 && tid == 0 && j == 0)
@@ -683,8 +703,13 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
     const int oy = oo / 3, ox = oo - oy * 3;
     f32x16 acc;
     constexpr int RPT = KSD / RING;   // ring rounds per output tile
+#ifdef S1_EXP_NODS
+#pragma unroll 1
+    for (int rd = 0; rd < 0; ++rd) {
+#else
 #pragma unroll 1
     for (int rd = 0; rd < NSTEP / RING; ++rd) {
+#endif
       const int cot = wave + 4 * (rd / RPT);
       if (rd % RPT == 0) {
 #pragma unroll

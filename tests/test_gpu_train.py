@@ -370,7 +370,7 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
 # <= 2x what the bf16 step measures against autograd through the fp32 oracle at this batch (profiles/r04_train_b1024.txt).
 # The per-channel sums over every pixel of the batch (conv_dw.bias, norm.bias, gamma) cancel, so the operand rounding of
 # their terms weighs more than in the filter gradients.
-FULL_BATCH_BOUNDS_BF16 = (("gamma", 0.09), ("norm.bias", 0.09), ("conv_dw.bias", 0.09), ("", 0.06))
+FULL_BATCH_BOUNDS_BF16 = (("gamma", 0.035), ("norm.bias", 0.03), ("conv_dw.bias", 0.04), ("", 0.036))
 
 
 def _bound_for(name, table):
@@ -425,7 +425,7 @@ def test_training_at_the_full_batch_matches_oracle(cuda):
         dl = (got_logits - ref_logits).abs().max().item() / max(ref_logits.abs().max().item(), 1e-6)
         print(f"{tag} vs oracle at B={B}: logits rel {dl:.2e}; worst per class " +
               "; ".join(f"{c or 'other'} {e:.2e} ({k})" for c, (e, k) in worst.items()))
-        assert dl <= 2e-2, (tag, dl)
+        assert dl <= 2.6e-2, (tag, dl)   # (measured 1.1e-2 fused, 1.3e-2 unfused)
 
     check("fused", *grads())
     mp = pytest.MonkeyPatch()
@@ -436,9 +436,27 @@ def test_training_at_the_full_batch_matches_oracle(cuda):
         mp.undo()
 
 
-# loss band of the trajectory test below: |loss_16bit(t) - loss_fp32(t)| <= LOSS_BAND[prec] * max(loss_fp32(t), 0.05) at every
-# step (<= 2x measured, profiles/r04_train_trajectory.txt)
-LOSS_BAND = {"bf16": 0.10, "f16": 0.03}
+# band of the trajectory test below: |loss_16bit(t) - loss_fp32(t)| <= LOSS_BAND[prec][0] + LOSS_BAND[prec][1] * loss_fp32(t)
+# at every step (<= 2x measured, profiles/r04_train_trajectory.txt)
+LOSS_BAND = {"bf16": (0.004, 0.04), "f16": (0.003, 0.02)}
+# ... and of the distance between the two final parameter vectors relative to the distance the fp32 recipe travelled
+# (measured 3.1e-2 bf16, 7.9e-3 f16)
+PARAM_DRIFT = {"bf16": 0.06, "f16": 0.016}
+
+
+def _learnable_batches(n_batches, B):
+    """Synthetic alerts whose label can be learnt: a fixed linear probe of the standardised metadata plus the brightness
+    of the difference cutout's centre (the benchmark's Bernoulli(0.5) labels carry nothing to fit)."""
+    g = torch.Generator().manual_seed(77)
+    probe = torch.randn(25, generator=g)
+    out = []
+    for t in range(n_batches):
+        img, meta, _ = synthetic_batch(B, seed=100 + t)
+        z = (meta - meta.mean(0)) / (meta.std(0) + 1e-6)
+        peak = img[:, 2, 29:34, 29:34].mean((1, 2))
+        lab = ((z @ probe) / 5.0 + (peak - peak.median()) / (peak.std() + 1e-9) > 0).long()
+        out.append((img, meta, lab))
+    return out
 
 
 @pytest.mark.timeout(900)
@@ -446,15 +464,17 @@ LOSS_BAND = {"bf16": 0.10, "f16": 0.03}
 def test_16bit_training_follows_the_fp32_recipe(cuda, prec):
     """The reference trains in fp32 (/root/reference/btsbot/train.py:141,171,185,525-527: no autocast).  Fifty
     ``Trainer.step``s with 16-bit MFMA operands against the fp32 recipe itself -- autograd through the oracle +
-    BCEWithLogitsLoss + torch.optim.AdamW -- on the same fifty 64-alert batches (train.py's batch size, prod_config.json:8),
-    dropout 0, from the same seeded weights: the two loss curves stay within LOSS_BAND of each other at every step, both
-    fall, and the distance between the two final parameter vectors is reported relative to the distance either one
-    travelled."""
+    BCEWithLogitsLoss(pos_weight) + torch.optim.AdamW -- on the same sequence of 64-alert batches (train.py's batch size,
+    prod_config.json:8; two batches of learnable labels visited in turn, so that fifty steps are enough for the loss to
+    fall from 0.86 to below 0.1), dropout 0, from the same seeded weights: the two loss curves stay within LOSS_BAND of
+    each other at every step, both fall below a quarter of where they started, and the distance between the two final
+    parameter vectors is reported relative to the distance the fp32 recipe travelled."""
     kind, cfg0 = CONFIGS["mm_pico"]
     cfg = dict(cfg0, meta_dropout=0.0, comb_dropout=0.0)
     sd0 = seeded_state(kind, cfg, seed=3, gamma=0.3)
-    steps, B, lr, betas, pw = 50, 64, 1e-3, (0.9, 0.999), 1.5
-    batches = [synthetic_batch(B, seed=100 + t) for t in range(steps)]
+    steps, B, lr, betas, pw = 50, 64, 1e-4, (0.9, 0.999), 1.5
+    two = _learnable_batches(2, B)
+    batches = [two[t % 2] for t in range(steps)]
 
     # --- the fp32 recipe on the host
     sd = {k: v.clone() for k, v in sd0.items()}
@@ -479,22 +499,26 @@ def test_16bit_training_follows_the_fp32_recipe(cuda, prec):
     # --- the same fifty steps on the GPU
     m = build_model(kind, cfg, sd0, cuda, prec).train()
     tr = Trainer(m, lr=lr, betas=betas, pos_weight=pw)
-    got_loss = []
-    for img, meta, lab in batches:
-        got_loss.append(tr.step(img.to(cuda), meta.to(cuda), lab.to(cuda)))
-    got_loss = torch.stack(got_loss).cpu().tolist()
+    tr.lrs = [lr]        # (the schedule's epoch-0 value with warmup 0 is 0.01 lr, train.py:249-260's quirk: not the subject here)
+    dbatches = [tuple(t.to(cuda) for t in b) for b in two]
+    got_loss = [tr.step(*dbatches[t % 2]) for t in range(steps)]
+    got = np.array(torch.stack(got_loss).cpu().tolist())
 
-    ref_loss, got = np.array(ref_loss), np.array(got_loss)
-    dev = np.abs(got - ref_loss) / np.maximum(ref_loss, 0.05)
+    ref_loss = np.array(ref_loss)
+    a0, a1 = LOSS_BAND[prec]
+    excess = np.abs(got - ref_loss) / (a0 + a1 * ref_loss)
     trained = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
     num = sum(((trained[k] - sd[k].detach().double()) ** 2).sum().item() for k in params)
     den = sum(((sd[k].detach().double() - sd0[k].double()) ** 2).sum().item() for k in params)
-    print(f"{prec}: loss fp32 {ref_loss[0]:.4f} -> {ref_loss[-5:].mean():.4f}, {prec} {got[0]:.4f} -> {got[-5:].mean():.4f}; "
-          f"worst relative loss deviation {dev.max():.3e} at step {int(dev.argmax())}; "
+    print(f"{prec}: fp32 loss {np.round(ref_loss[::7], 3).tolist()}")
+    print(f"{prec}: {prec} loss {np.round(got[::7], 3).tolist()}")
+    print(f"{prec}: worst |dloss| {np.abs(got - ref_loss).max():.3e} at step {int(np.abs(got - ref_loss).argmax())} "
+          f"(fp32 loss there {ref_loss[int(np.abs(got - ref_loss).argmax())]:.3f}); band use {excess.max():.2f}; "
           f"|p_{prec} - p_fp32| / |p_fp32 - p_0| = {np.sqrt(num / den):.3e}")
-    assert ref_loss[-5:].mean() < 0.8 * ref_loss[:5].mean(), "the fp32 recipe itself must train on this problem"
-    assert got[-5:].mean() < 0.8 * got[:5].mean()
-    assert dev.max() <= LOSS_BAND[prec], (prec, dev.max(), int(dev.argmax()))
+    assert ref_loss[-3:].mean() < 0.25 * ref_loss[0], "the fp32 recipe itself must train on this problem"
+    assert got[-3:].mean() < 0.25 * got[0]
+    assert excess.max() <= 1.0, (prec, excess.max(), int(excess.argmax()))
+    assert np.sqrt(num / den) <= PARAM_DRIFT[prec], (prec, np.sqrt(num / den))
     for k in ("metadata_branch.0.running_mean", "metadata_branch.0.running_var"):
         a, b = trained[k], sd[k].detach().double()
         assert (a - b).abs().max().item() <= 1e-3 * max(b.abs().max().item(), 1.0), k
