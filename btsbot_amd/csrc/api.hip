@@ -75,7 +75,10 @@ int build_tables(btsbot_ctx* h) {
     h->stem_lnb = add_param(h, "stem.1.bias", {c0});
     h->stage0 = stage0_supported(h->prec_s01(), c0) && c.depths[0] == 2;
     h->p_stem16 = bump(cur, (size_t)c0 * 48 * esz);   // stem filter in the operand type
-    if (h->x2 && h->stage0) h->p_x2_stem = bump(cur, (size_t)c0 * 48 * 2);
+    if (h->x2 && h->stage0) {
+      h->p_x2_stem = bump(cur, (size_t)c0 * 48 * 2);
+      h->p_x2_stemlo = bump(cur, (size_t)c0 * 48 * 2);
+    }
     h->stage1 = stage1_supported(h->prec_s01(), c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
     h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
@@ -123,6 +126,8 @@ int build_tables(btsbot_ctx* h) {
         if (h->x2 && ((i == 0 && h->stage0) || (i == 1 && h->stage1))) {
           b.p_x2_w1 = bump(cur, (size_t)4 * ch * ch * 2);
           b.p_x2_w2g = bump(cur, (size_t)4 * ch * ch * 2);
+          b.p_x2_w1lo = bump(cur, (size_t)4 * ch * ch * 2);
+          b.p_x2_w2glo = bump(cur, (size_t)4 * ch * ch * 2);
         }
         if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
@@ -527,9 +532,11 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
-        if (b.p_x2_w1 != 0 && !train_only) {   // split mode, stages 0-1: the pointwise filters stay plain f16
+        if (b.p_x2_w1 != 0 && !train_only) {   // split mode, stages 0-1: the pointwise filters as f16 heads + remainders
           TRY(launch_cast(BTSBOT_F16, m + b.fc1_w, h->extra + b.p_x2_w1, (int64_t)4 * ch * ch, st));
           TRY(launch_rowscale_cast(BTSBOT_F16, m + b.fc2_w, m + b.gamma, h->extra + b.p_x2_w2g, ch, 4 * ch, st));
+          TRY(launch_rowscale_cast_lo(m + b.fc1_w, nullptr, h->extra + b.p_x2_w1lo, 4 * ch, ch, st));
+          TRY(launch_rowscale_cast_lo(m + b.fc2_w, m + b.gamma, h->extra + b.p_x2_w2glo, ch, 4 * ch, st));
         }
         // (the training forward of the blocks whose backward is mlp_bwd_kernel runs the fused MLP too)
         if (b.fused && (!train_only || h->mlp_fused(ch)))
@@ -540,6 +547,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   }
   if (convnext && h->x2 && h->stage0 && !train_only) {
     TRY(launch_cast(BTSBOT_F16, m + h->stem_w, h->extra + h->p_x2_stem, (int64_t)c.dims[0] * 48, st));
+    TRY(launch_rowscale_cast_lo(m + h->stem_w, nullptr, h->extra + h->p_x2_stemlo, c.dims[0], 48, st));
     TRY(launch_pack_down_split(m + h->down[1].w, h->extra + h->down[1].p_x2_w, h->extra + h->down[1].p_x2_wlo, c.dims[1],
                                c.dims[0], st));
   }
@@ -742,6 +750,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       memset(&a, 0, sizeof(a));
       a.img = img;
       a.stem_w = h->extra + (h->x2 ? h->p_x2_stem : h->p_stem16);
+      a.stem_w_lo = h->x2 ? h->extra + h->p_x2_stemlo : nullptr;
       a.stem_b = m + h->stem_b;
       a.stem_lnw = m + h->stem_lnw;
       a.stem_lnb = m + h->stem_lnb;
@@ -756,6 +765,8 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.blk[j].gamma = m + b.gamma;
         a.blk[j].w1 = h->extra + (h->x2 ? b.p_x2_w1 : b.p_fc1);
         a.blk[j].w2g = h->extra + (h->x2 ? b.p_x2_w2g : b.p_fc2g);
+        a.blk[j].w1_lo = h->x2 ? h->extra + b.p_x2_w1lo : nullptr;
+        a.blk[j].w2g_lo = h->x2 ? h->extra + b.p_x2_w2glo : nullptr;
         a.blk[j].par = h->extra + b.p_s0par;
       }
       a.ds_lnw = m + h->down[1].ln_w;
@@ -819,6 +830,8 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
           a.blk[j].gamma = m + b.gamma;
           a.blk[j].w1 = h->extra + (h->x2 ? b.p_x2_w1 : b.p_fc1);
           a.blk[j].w2g = h->extra + (h->x2 ? b.p_x2_w2g : b.p_fc2g);
+          a.blk[j].w1_lo = h->x2 ? h->extra + b.p_x2_w1lo : nullptr;
+          a.blk[j].w2g_lo = h->x2 ? h->extra + b.p_x2_w2glo : nullptr;
           a.blk[j].par = h->extra + b.p_s0par;
         }
         a.ds_lnw = m + h->down[2].ln_w;

@@ -660,6 +660,24 @@ int launch_scale_cast(int prec, const float* in, const float* scale, void* out, 
   return BTSBOT_OK;
 }
 
+__global__ __launch_bounds__(256) void rowscale_cast_lo_kernel(const float* __restrict__ in, const float* __restrict__ rowscale,
+                                                              f16_t* __restrict__ out, long n, int cols) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = rowscale != nullptr ? in[i] * rowscale[i / cols] : in[i];
+  const f16_t hi = (f16_t)v;
+  out[i] = (f16_t)(v - (float)hi);
+}
+
+int launch_rowscale_cast_lo(const float* in, const float* rowscale, void* out, int rows, int cols, hipStream_t st) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return BTSBOT_OK;
+  hipLaunchKernelGGL(rowscale_cast_lo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, rowscale,
+                     reinterpret_cast<f16_t*>(out), n, cols);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st) {
   const long n = (long)rows * cols;

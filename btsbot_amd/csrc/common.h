@@ -316,6 +316,9 @@ int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st);
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]
+// f16 remainder image of launch_rowscale_cast(BTSBOT_F16, ...): out[r][c] = f16(v - f16(v)), v = in[r][c] * rowscale[r] (rowscale
+// may be NULL: v = in[r][c]) -- the second half of a split operand (BTSBOT_F16X2)
+int launch_rowscale_cast_lo(const float* in, const float* rowscale, void* out, int rows, int cols, hipStream_t st);
 int launch_scale_cast(int prec, const float* in, const float* scale, void* out, long n, int C,
                       hipStream_t st);
 int launch_fc2_grads(float* G, float* S, const float* w2, const float* b2,

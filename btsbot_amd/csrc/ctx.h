@@ -20,7 +20,8 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip / stage3.hip: fc1 / gamma * fc2 filters as MFMA A fragments
   size_t p_scales = 0;           // fp8 mode: {S1, 1/S1, S2, 1/S2} of those two
-  size_t p_x2_w1 = 0, p_x2_w2g = 0;   // split mode, stages 0-1: fc1 / gamma * fc2 filters as plain f16 (stage0b / stage1b)
+  size_t p_x2_w1 = 0, p_x2_w2g = 0;   // split mode, stages 0-1: fc1 / gamma * fc2 filters, f16 heads (stage0b / stage1b)
+  size_t p_x2_w1lo = 0, p_x2_w2glo = 0;   // ... and their f16 remainders, same layouts
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
   bool fused;
 };
@@ -68,7 +69,7 @@ struct btsbot_ctx {
   int64_t bn_w, bn_b, bn_rm, bn_rv, m1_w, m1_b, m2_w, m2_b;
   int64_t comb_w[3], comb_b[3];
   size_t p_m1, p_m2, p_comb[3], p_bn_scale, p_bn_shift, p_stem16 = 0;
-  size_t p_x2_stem = 0;    // split mode: the stem filter as plain f16 (stage0b)
+  size_t p_x2_stem = 0, p_x2_stemlo = 0;    // split mode: the stem filter's f16 heads / remainders (stage0b)
   int prec_head() const { return x2 ? BTSBOT_F16 : cfg.precision; }   // head16.hip splits its operands in every mode
   int prec_s01() const { return x2 ? BTSBOT_F16X2 : cfg.precision; }   // operand mode of stage0b.hip / stage1b.hip
   size_t p_m1h = 0, p_m2h = 0, p_combh[3] = {0, 0, 0};   // head16.hip: the Linear filters as split A fragments

@@ -12,10 +12,13 @@ struct Stage0Blk {
   const unsigned char* w1;    // plain 16-bit fc1 filter [4C][C]              (stage0b.hip / stage1b.hip)
   const unsigned char* par;   // fp32 parameter image of the block (stage0b.hip: launch_pack_s0par)
   const unsigned char* w2g;   // gamma-scaled 16-bit fc2 filter [C][4C]       (stage0b.hip / stage1b.hip)
+  const unsigned char* w1_lo;   // split mode (BTSBOT_F16X2): the f16 remainders of w1 / w2g, same layouts; else unused
+  const unsigned char* w2g_lo;
 };
 struct Stage0Args {
   const float* img;       // [B][3][63][63]
   const void* stem_w;     // [64][48] 16-bit
+  const void* stem_w_lo;  // split mode: its f16 remainders
   const float* stem_b;
   const float* stem_lnw;
   const float* stem_lnb;

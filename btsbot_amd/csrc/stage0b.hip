@@ -77,11 +77,18 @@ static_assert(PF_B2 + C == PF_FLOATS, "parameter image layout");
 constexpr int PARB = TW_BYTES + PF_FLOATS * 4;    // 45056
 // split mode (BTSBOT_F16X2): the taps' f16 remainders follow their heads, the fp32 part comes last
 constexpr int PARB_X2 = 2 * TW_BYTES + PF_FLOATS * 4;
-constexpr int OFF_RING = PLB;
-constexpr int OFF_B1 = OFF_RING + RINGB;          // 256 + 64 floats: this block's fc1 bias, gamma*b2
-constexpr int OFF_ST = OFF_B1 + (HID + C) * 4;    // LayerNorm (rstd, -mean * rstd) per padded pixel slot: 2 x 256 floats
-constexpr int LDS_BYTES = OFF_ST + 2 * 256 * 4;   // 79104: two workgroups per CU
-static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
+// LDS layout.  Split mode (X2): a second planar image behind the first (the f16 remainders of the map the depthwise phase
+// reads) and chunks of twice the size (the filters' remainders behind their heads) -- 154,880 bytes, one workgroup per CU.
+template <bool X2> struct S0L {
+  static constexpr int PLANES = X2 ? 2 : 1;
+  static constexpr int CHB = X2 ? 2 * CHUNKB : CHUNKB;     // bytes of a ring slot
+  static constexpr int OFF_RING = PLANES * PLB;
+  static constexpr int OFF_B1 = OFF_RING + NSLOT * CHB;    // 256 + 64 floats: this block's fc1 bias, gamma*b2
+  static constexpr int OFF_ST = OFF_B1 + (HID + C) * 4;    // LayerNorm (rstd, -mean * rstd) per padded pixel slot: 2 x 256 floats
+  static constexpr int LDS_BYTES = OFF_ST + 2 * 256 * 4;   // 79104 (two workgroups per CU) / 154880
+};
+static_assert(S0L<false>::LDS_BYTES <= 81920, "two workgroups per CU");
+static_assert(S0L<true>::LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 constexpr float LN_EPS = 1e-6f;
 
 #define SB_STAMP(i)                                                                \
@@ -165,15 +172,20 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
 
 // this lane's pixel (32 of its 64 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
 // image; the zero padding around the 15x15 map is never touched
-template <typename T>
+// (LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind -- split mode)
+template <typename T, int LOPLANE = 0>
 __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
   const int y = p / HW, xx = p - y * HW;
   unsigned char* dst = pl + (xx >> 2) * PL_XQ + (y + 3) * 8 + (xx & 3) * 2 + h * 4 * PL_CH;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = (T)x[ct][r];
+    for (int r = 0; r < 16; ++r) {
+      const T hi = (T)x[ct][r];
+      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = hi;
+      if (LOPLANE > 0)
+        *reinterpret_cast<T*>(dst + LOPLANE + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = (T)(x[ct][r] - (float)hi);
+    }
 }
 
 __device__ __forceinline__ void regs_to_tap(const f32x16 (&x)[CT], float* tap, int h) {
@@ -227,12 +239,15 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* map = smem;     // [pixel][channel] image (MLP operand, downsample input)
   unsigned char* pl = smem;      // planar image (depthwise operand): same bytes, never live together
-  unsigned char* ring = smem + OFF_RING;
-  float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
+  using L = S0L<X2>;
+  constexpr int CHB = L::CHB;
+  constexpr int PLO = X2 ? PLB : 0;                  // split mode: the planar image of the remainders
+  unsigned char* ring = smem + L::OFF_RING;
+  float* b1s = reinterpret_cast<float*>(smem + L::OFF_B1);
   float* b2s = b1s + HID;
-  float* part = reinterpret_cast<float*>(ring + 2 * CHUNKB);   // LayerNorm partial sums [2][4 waves][256 slots]:
+  float* part = reinterpret_cast<float*>(ring + 2 * CHB);      // LayerNorm partial sums [2][4 waves][256 slots]:
                                                                // ring slot 2 is idle until the MLP's first chunk
-  float* st = reinterpret_cast<float*>(smem + OFF_ST);
+  float* st = reinterpret_cast<float*>(smem + L::OFF_ST);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   };
   load_block_params(0);   // lands under the stem
   auto zero_planar = [&]() {
-    for (int i = tid; i < PLB / 16; i += 256) reinterpret_cast<uint4*>(pl)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < L::PLANES * PLB / 16; i += 256) reinterpret_cast<uint4*>(pl)[i] = make_uint4(0u, 0u, 0u, 0u);
   };
   zero_planar();
   __syncthreads();
@@ -281,12 +296,15 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   {
     const float* src = a.img + (size_t)alert * 3 * 63 * 63;
     const T* sw = reinterpret_cast<const T*>(a.stem_w);
-    frag af[3][CT];
+    frag af[3][CT], afl[X2 ? 3 : 1][CT];
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct) {
         af[ci][ct] = *reinterpret_cast<const frag*>(sw + (ct * 32 + lr) * 48 + ci * 16 + h * 8);
+        if (X2)
+          afl[ci][ct] = *reinterpret_cast<const frag*>(reinterpret_cast<const T*>(a.stem_w_lo) + (ct * 32 + lr) * 48 + ci * 16 + h * 8);
+      }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int pc = live[t] ? pix[t] : 0;
@@ -306,17 +324,27 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
         const float* r0 = src + (ci * 63 + 4 * py + 2 * h) * 63 + 4 * px;
         const f4u v0 = *reinterpret_cast<const f4u*>(r0);
         const f4u v1 = *reinterpret_cast<const f4u*>(r0 + 63);
-        frag bf;
+        frag bf, bfl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           bf[e] = (T)v0.v[e];
           bf[4 + e] = (T)v1.v[e];
+          if (X2) {
+            bfl[e] = (T)(v0.v[e] - (float)bf[e]);
+            bfl[4 + e] = (T)(v1.v[e] - (float)bf[4 + e]);
+          }
         }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) x[t][ct] = SBM<T>::run(af[ci][ct], bf, x[t][ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          if (X2) {
+            x[t][ct] = SBM<T>::run(afl[ci][ct], bf, x[t][ct]);
+            x[t][ct] = SBM<T>::run(af[ci][ct], bfl, x[t][ct]);
+          }
+          x[t][ct] = SBM<T>::run(af[ci][ct], bf, x[t][ct]);
+        }
       }
       ln_regs(x[t], a.stem_lnw, a.stem_lnb, h, x[t]);
-      if (live[t]) regs_to_planar<T>(x[t], pl, pix[t], h);
+      if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
       if (a.tap_stem != nullptr && live[t])
         regs_to_tap(x[t], a.tap_stem + ((size_t)alert * P + pix[t]) * C, h);
     }
@@ -338,16 +366,21 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
     //      pieces 4..7: gamma*W2 columns 32*ch .. +31 of the 64 channel rows, 64-byte rows,
     //                   chunk c of row r at position c ^ F[(r >> 2) & 3]
     const unsigned char* wsrc[2];
+    const unsigned char* wsrcl[2];   // split mode: the same pieces of the remainder images, 8 KB further into the slot
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave * 2 + i;
       if (pc < 4) {
         const int m = pc * 8 + (lane >> 3);
         const int hid = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);   // swap bits 2 and 3
-        wsrc[i] = bk.w1 + (size_t)hid * (C * 2) + (((lane & 7) ^ ((m >> 1) & 7)) << 4);
+        const size_t o = (size_t)hid * (C * 2) + (((lane & 7) ^ ((m >> 1) & 7)) << 4);
+        wsrc[i] = bk.w1 + o;
+        wsrcl[i] = X2 ? bk.w1_lo + o : nullptr;
       } else {
         const int r = (pc - 4) * 16 + (lane >> 2);
-        wsrc[i] = bk.w2g + (size_t)r * (HID * 2) + (((lane & 3) ^ swz4(r)) << 4);
+        const size_t o = (size_t)r * (HID * 2) + (((lane & 3) ^ swz4(r)) << 4);
+        wsrc[i] = bk.w2g + o;
+        wsrcl[i] = X2 ? bk.w2g_lo + o : nullptr;
       }
     }
     // chunk ch adds 32 W1 rows (4096 B) resp. 32 W2 columns (64 B)
@@ -356,8 +389,15 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)ch * wstep0),
-                                         (lptr_t)(ring + (ch % NSLOT) * CHUNKB + (wave * 2 + i) * 1024),
+                                         (lptr_t)(ring + (ch % NSLOT) * CHB + (wave * 2 + i) * 1024),
                                          16, 0, 0);
+      if (X2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrcl[i] + (size_t)ch * wstep0),
+                                           (lptr_t)(ring + (ch % NSLOT) * CHB + CHUNKB + (wave * 2 + i) * 1024),
+                                           16, 0, 0);
+      }
     };
     SB_STAMP(3 + 5 * j);
 
@@ -375,10 +415,12 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
       const unsigned char* lb = pl + dch * PL_CH + dj * 8;
 #pragma unroll
       for (int s = 0; s < 19; ++s) {
-        frag4 bq[4];
+        frag4 bq[4], bql[X2 ? 4 : 1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
           bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + s * 8));
+          if (X2) bql[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + q * PL_XQ + s * 8));
+        }
         if (s == 0) {
           // the taps are in registers by now: only now queue the filter chunks (a wait for an ordinary load
           // placed behind an LDS-DMA would wait for the DMA too)
@@ -397,8 +439,11 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
             for (int xb = 0; xb < 4; ++xb) {
               const int q = xb + rbi - 1;
               if (q < 0 || q > 3) continue;
+              if (X2) {   // remainders first (small terms into the accumulator before the large one)
+                acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
+                acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bql[q], acc[yb][xb]);
+              }
               acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
-              if (X2) acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
             }
         }
       }
@@ -493,7 +538,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
 #pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
         // this wave's pieces of chunk ch have landed once only the younger chunk is outstanding
-        if (ch + 1 < NCH) wait_vm<2>();
+        if (ch + 1 < NCH) wait_vm<X2 ? 4 : 2>();
         else wait_vm<0>();
         // raw barrier: __syncthreads() would also wait vmcnt(0) while an LDS-DMA is in flight and so drain the two
         // chunks this ring keeps ahead (the chunk time then IS the DMA latency, ~2k cycles for ~1k of work)
@@ -502,18 +547,21 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
         // the LN image is dead once every wave holds its xf: clear it for the next block's planar image
         // (whose padding must read as zero) while the matrix pipe works
         if (ch == 1 && j == 0) zero_planar();
-        const unsigned char* w1s = ring + (ch % NSLOT) * CHUNKB;
+        const unsigned char* w1s = ring + (ch % NSLOT) * CHB;
         const unsigned char* w2s = w1s + 4096;
-        frag a1[4], a2[CT][2];
+        frag a1[4], a2[CT][2], a1l[X2 ? 4 : 1], a2l[X2 ? CT : 1][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
           a1[ks] = *reinterpret_cast<const frag*>(w1s + lr * 128 + (((ks * 2 + h) ^ ((lr >> 1) & 7)) << 4));
+          if (X2) a1l[ks] = *reinterpret_cast<const frag*>(w1s + CHUNKB + lr * 128 + (((ks * 2 + h) ^ ((lr >> 1) & 7)) << 4));
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int r = ct * 32 + lr;
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
+            if (X2) a2l[ct][s2] = *reinterpret_cast<const frag*>(w2s + CHUNKB + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
         // (inline asm: behind a compiler-visible ds_read of anything but the ring hipcc waits vmcnt(0) -- it cannot
         //  tell that the bias words are not an LDS-DMA destination -- and the ring's two chunks in flight are gone)
@@ -537,8 +585,11 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
             for (int e = 0; e < 4; ++e) hacc[t][4 * qd + e] = bq[qd][e];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
+            if (X2) {
+              hacc[t] = SBM<T>::run(a1l[ks], xf[t][ks], hacc[t]);
+              hacc[t] = SBM<T>::run(a1[ks], xfl[t][ks], hacc[t]);
+            }
             hacc[t] = SBM<T>::run(a1[ks], xf[t][ks], hacc[t]);
-            if (X2) hacc[t] = SBM<T>::run(a1[ks], xfl[t][ks], hacc[t]);
           }
         }
         // (issued here, not at the barrier: an LDS-DMA holds the issuing wave ~90 cycles per
@@ -558,8 +609,11 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
+              if (X2) {
+                x[t][ct] = SBM<T>::run(a2l[ct][s2], hf, x[t][ct]);
+                x[t][ct] = SBM<T>::run(a2[ct][s2], hfl, x[t][ct]);
+              }
               x[t][ct] = SBM<T>::run(a2[ct][s2], hf, x[t][ct]);
-              if (X2) x[t][ct] = SBM<T>::run(a2[ct][s2], hfl, x[t][ct]);
             }
           }
         }
@@ -569,7 +623,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
         load_block_params(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          if (live[t]) regs_to_planar<T>(x[t], pl, pix[t], h);
+          if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
       }
     }
     SB_STAMP(6 + 5 * j);   // MLP done
@@ -590,7 +644,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
     for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const frag*>(dw + ks * 16);
     // (every wave loaded its xf from the last block's LN image before that MLP's second barrier)
     constexpr int MAPB = 256 * PITCH;   // split mode: the remainder image follows (into the filter ring's bytes)
-    static_assert(2 * MAPB <= OFF_B1, "two [pixel][channel] images in front of the bias words");
+    static_assert(2 * MAPB <= L::OFF_B1, "two [pixel][channel] images in front of the bias words");
     if (X2) __syncthreads();            // ... which every wave must have read out
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -675,6 +729,7 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
 template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
   auto kern = stage0b_kernel<T, X2, WPS>;
   static bool attr_set = false;
+  constexpr int LDS_BYTES = S0L<X2>::LDS_BYTES;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -691,13 +746,8 @@ template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const S
 // ---- this translation unit (stage0x.hip) holds only the split-operand instantiation: co-compiled instantiations of
 //      one kernel template share the register allocator's context and move each other's spills
 int launch_stage0b_x2(const Stage0Args& a, hipStream_t st) {
-  // one workgroup per CU with 512 registers (WPS 1) or two with 256 and spills (WPS 2): measured on MI355X at B = 1024,
-  // stage0b 246 / 229 us, stage1b 165 / 183 us -- each kernel defaults to its faster form; BTSBOT_AMD_X2_WPS=1|2 forces one
-  static const int wps = [] {
-    const char* e = getenv("BTSBOT_AMD_X2_WPS");
-    return e != nullptr && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 2;
-  }();
-  return wps == 2 ? launch_stage0b_t<f16_t, true, 2>(a, st) : launch_stage0b_t<f16_t, true, 1>(a, st);
+  // (one workgroup per CU -- the two planar images and the doubled filter ring take 155 KB of LDS -- with 512 registers)
+  return launch_stage0b_t<f16_t, true, 1>(a, st);
 }
 int launch_pack_s0par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, const float* b1,
                          const float* b2, const float* gamma, void* out, hipStream_t st) {
@@ -743,8 +793,9 @@ int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st) {
   if (prec == BTSBOT_BF16) return launch_stage0b_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage0b_t<f16_t>(a, st);
   if (prec == BTSBOT_F16X2) {
-    if (a.ds_w_lo == nullptr) {
-      btsbot_set_error("stage0b: the split mode needs the downsample filter's remainders (ds_w_lo)");
+    if (a.ds_w_lo == nullptr || a.stem_w_lo == nullptr || a.blk[0].w1_lo == nullptr || a.blk[0].w2g_lo == nullptr ||
+        a.blk[1].w1_lo == nullptr || a.blk[1].w2g_lo == nullptr) {
+      btsbot_set_error("stage0b: the split mode needs the remainder images (ds_w_lo, stem_w_lo, w1_lo, w2g_lo)");
       return BTSBOT_ERR_INVALID_ARG;
     }
     return launch_stage0b_x2(a, st);

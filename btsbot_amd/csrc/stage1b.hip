@@ -66,11 +66,20 @@ constexpr int CHUNKB = 16384, HALFB = CHUNKB / 2, NCH = HID / 32, NSLOT = 3;
 // planar image of the depthwise phase: [alert][x quad 0..1][row 0..6, 7 = zeros][channel, pitch 136][4 x]
 constexpr int PL_ROW = 136 * 8, PL_XQ = 8 * PL_ROW, PL_AL = 2 * PL_XQ, PLB = G * PL_AL;   // 1088, 8704, 17408, 34816
 constexpr int OFF_PL = 2 * CHUNKB;                // ring slots 0, 1 | planar image = ring slot 2 + 18 KB
-constexpr int OFF_B1 = OFF_PL + PLB;              // 512 floats fc1 bias + 128 floats gamma*b2
-constexpr int OFF_PART = OFF_B1 + (HID + C) * 4;  // LayerNorm partial sums [2][4 waves][128 slots]
-constexpr int OFF_ST = OFF_PART + 2 * 4 * 128 * 4;   // (rstd, -mean * rstd) per padded pixel slot [2][128]
-constexpr int LDS_BYTES = OFF_ST + 2 * 128 * 4;   // 75264: two workgroups per CU
-static_assert(MAPB <= 2 * CHUNKB && 4 * HALFB <= PLB && LDS_BYTES <= 80 * 1024, "LDS layout");
+// Split mode (X2): a second planar image behind the first (the remainders of the map the depthwise phase reads), ring slots of
+// twice the size (a filter piece's remainders 8 KB behind its heads): the W1 slots and W2 slot 0 (64 KB) lie in the two
+// planar images, W2 slots 1, 2 in a region of their own -- 142,848 bytes, one workgroup per CU.
+template <bool X2> struct S1L {
+  static constexpr int PLANES = X2 ? 2 : 1;
+  static constexpr int SLB = X2 ? 2 * HALFB : HALFB;            // bytes of a W1 / W2 ring slot
+  static constexpr int OFF_W2X = OFF_PL + PLANES * PLB;         // X2 only: W2 slots 1, 2
+  static constexpr int OFF_B1 = OFF_W2X + (X2 ? 2 * SLB : 0);   // 512 floats fc1 bias + 128 floats gamma*b2
+  static constexpr int OFF_PART = OFF_B1 + (HID + C) * 4;       // LayerNorm partial sums [2][4 waves][128 slots]
+  static constexpr int OFF_ST = OFF_PART + 2 * 4 * 128 * 4;     // (rstd, -mean * rstd) per padded pixel slot [2][128]
+  static constexpr int LDS_BYTES = OFF_ST + 2 * 128 * 4;        // 75264: two workgroups per CU / 142848
+  static_assert(4 * SLB <= PLANES * PLB, "W1 slots + W2 slot 0 inside the planar images");
+};
+static_assert(MAPB <= 2 * CHUNKB && S1L<false>::LDS_BYTES <= 80 * 1024 && S1L<true>::LDS_BYTES <= 160 * 1024, "LDS layout");
 constexpr float LN_EPS = 1e-6f;
 // per-block parameter image in HBM (launch_pack_s1par): Toeplitz taps in the operand type
 //   [r = ky * 3 + (rb + 1)][channel][i][k] = W[channel][ky][4 rb + k - i + 3]   (0 outside the 7 taps)
@@ -180,7 +189,8 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
 
 // this lane's pixel (64 of its 128 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
 // image; p = alert * 49 + y * 7 + x
-template <typename T>
+// (LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind -- split mode)
+template <typename T, int LOPLANE = 0>
 __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
   const int al = p >= PA ? 1 : 0, pp = p - al * PA;
   const int y = pp / HW, xx = pp - y * HW;
@@ -188,8 +198,11 @@ __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned c
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = (T)x[ct][r];
+    for (int r = 0; r < 16; ++r) {
+      const T hi = (T)x[ct][r];
+      *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = hi;
+      if (LOPLANE > 0) *reinterpret_cast<T*>(dst + LOPLANE + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = (T)(x[ct][r] - (float)hi);
+    }
 }
 
 // X2 (BTSBOT_F16X2, T = f16): as in stage0b.hip -- LayerNorm outputs and hidden activations as f16 head + remainder
@@ -203,14 +216,18 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* pl = smem + OFF_PL;                 // planar image; its first 16 KB double as ring slot 2
   unsigned char* stg = smem;                         // LN image [98][PITCH] in ring slots 0..1
-  float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
+  using L = S1L<X2>;
+  constexpr int SLB = L::SLB;
+  constexpr int PLO = X2 ? PLB : 0;                  // split mode: the planar image of the remainders
+  float* b1s = reinterpret_cast<float*>(smem + L::OFF_B1);
   float* b2s = b1s + HID;
-  float* part = reinterpret_cast<float*>(smem + OFF_PART);
-  float* st = reinterpret_cast<float*>(smem + OFF_ST);
-  // filter rings, 3 slots of 8 KB each: the W1 slots and W2 slot 0 lie in the planar image (dead once the depthwise
-  // phase is over, so the first chunk is requested under the LayerNorm), W2 slots 1, 2 in the LN image's bytes
-  auto w1slot = [&](int sl) { return pl + sl * HALFB; };
-  auto w2slot = [&](int sl) { return sl == 0 ? pl + 3 * HALFB : smem + (sl - 1) * HALFB; };
+  float* part = reinterpret_cast<float*>(smem + L::OFF_PART);
+  float* st = reinterpret_cast<float*>(smem + L::OFF_ST);
+  // filter rings, 3 slots of 8 KB each (split mode: 16 KB, the remainders behind the heads): the W1 slots and W2 slot 0
+  // lie in the planar image(s) (dead once the depthwise phase is over, so the first chunk is requested under the
+  // LayerNorm), W2 slots 1, 2 in the LN image's bytes (split mode: in a region of their own)
+  auto w1slot = [&](int sl) { return pl + sl * SLB; };
+  auto w2slot = [&](int sl) { return sl == 0 ? pl + 3 * SLB : (X2 ? smem + L::OFF_W2X : smem) + (sl - 1) * SLB; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
@@ -224,13 +241,17 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   SC_STAMP(0);
   // what the live writes never touch and the depthwise products read: the zero rows and column 7
   auto zero_pads = [&]() {
-    for (int i = tid; i < 4 * PL_ROW / 16; i += 256) {
-      const int blk = i / (PL_ROW / 16), o = i - blk * (PL_ROW / 16);
-      *reinterpret_cast<uint4*>(pl + (blk >> 1) * PL_AL + (blk & 1) * PL_XQ + 7 * PL_ROW + o * 16) = make_uint4(0u, 0u, 0u, 0u);
-    }
-    for (int i = tid; i < G * HW * C; i += 256) {
-      const int al = i / (HW * C), r = (i / C) % HW, c = i % C;
-      *reinterpret_cast<unsigned short*>(pl + al * PL_AL + PL_XQ + r * PL_ROW + c * 8 + 6) = 0;
+#pragma unroll
+    for (int pn = 0; pn < L::PLANES; ++pn) {
+      unsigned char* pb = pl + pn * PLB;
+      for (int i = tid; i < 4 * PL_ROW / 16; i += 256) {
+        const int blk = i / (PL_ROW / 16), o = i - blk * (PL_ROW / 16);
+        *reinterpret_cast<uint4*>(pb + (blk >> 1) * PL_AL + (blk & 1) * PL_XQ + 7 * PL_ROW + o * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      for (int i = tid; i < G * HW * C; i += 256) {
+        const int al = i / (HW * C), r = (i / C) % HW, c = i % C;
+        *reinterpret_cast<unsigned short*>(pb + al * PL_AL + PL_XQ + r * PL_ROW + c * 8 + 6) = 0;
+      }
     }
   };
   zero_pads();
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   {
     f32x16 x0[CT];
     load_x(xsrc, x0);
-    if (inmap) regs_to_planar<T>(x0, pl, p, h);
+    if (inmap) regs_to_planar<T, PLO>(x0, pl, p, h);
   }
   SC_STAMP(1);
 
@@ -303,16 +324,21 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
     //      pieces 8..15: gamma*W2 columns 32*ch .. +31 of the 128 channel rows, 64-byte rows,
     //                    chunk c of row r at position c ^ F[(r >> 2) & 3]
     const unsigned char* wsrc[4];
+    const unsigned char* wsrcl[4];   // split mode: the same pieces of the remainder images, 8 KB further into the slot
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = wave * 4 + i;
       if (pc < 8) {
         const int m = pc * 4 + (lane >> 4);
         const int hid = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);   // swap bits 2 and 3
-        wsrc[i] = bk.w1 + (size_t)hid * (C * 2) + (((lane & 15) ^ (m & 15)) << 4);
+        const size_t o = (size_t)hid * (C * 2) + (((lane & 15) ^ (m & 15)) << 4);
+        wsrc[i] = bk.w1 + o;
+        wsrcl[i] = X2 ? bk.w1_lo + o : nullptr;
       } else {
         const int r = (pc - 8) * 16 + (lane >> 2);
-        wsrc[i] = bk.w2g + (size_t)r * (HID * 2) + (((lane & 3) ^ swz4(r)) << 4);
+        const size_t o = (size_t)r * (HID * 2) + (((lane & 3) ^ swz4(r)) << 4);
+        wsrc[i] = bk.w2g + o;
+        wsrcl[i] = X2 ? bk.w2g_lo + o : nullptr;
       }
     }
     // chunk k adds 32 W1 rows (8192 B) resp. 32 W2 columns (64 B)
@@ -326,13 +352,23 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
                                          (lptr_t)(dst + i * 1024), 16, 0, 0);
+      if (X2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrcl[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
+                                           (lptr_t)(dst + HALFB + i * 1024), 16, 0, 0);
+      }
     };
     // one of the four pieces (the chunk loop spreads them over its MFMAs: four LDS-DMAs back to back held the wave
     // for 230-420 cycles at the vector-memory port, a fifth of a step)
-    auto issue_piece = [&](int k, int i) {
+    auto issue_piece = [&](int k, int i) {   // (split mode: pieces 4..7 are the remainders)
       unsigned char* dst = (w1wave ? w1slot(k % NSLOT) : w2slot(k % NSLOT)) + (wave & 1) * 4096;
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
-                                       (lptr_t)(dst + i * 1024), 16, 0, 0);
+      if (X2 && i >= 4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrcl[i & 3] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
+                                         (lptr_t)(dst + HALFB + (i & 3) * 1024), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)((k + rot) & (NCH - 1)) * wstep0),
+                                         (lptr_t)(dst + i * 1024), 16, 0, 0);
     };
     SC_STAMP(3 + 5 * j);
 
@@ -372,10 +408,12 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
         for (int sx = 0; sx < 11; ++sx) {
 #endif
-          frag4 bq[2];
+          frag4 bq[2], bql[X2 ? 2 : 1];
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
+          for (int q = 0; q < 2; ++q) {
             bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + rofs[sx]));
+            if (X2) bql[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + q * PL_XQ + rofs[sx]));
+          }
 #pragma unroll
           for (int yb = 0; yb < 2; ++yb) {
             const int ky = sx - 4 * yb;
@@ -386,8 +424,11 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
               for (int xb = 0; xb < 2; ++xb) {
                 const int q = xb + rbi - 1;
                 if (q < 0 || q > 1) continue;
+                if (X2) {   // remainders first
+                  acc[yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
+                  acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bql[q], acc[yb][xb]);
+                }
                 acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
-                if (X2) acc[yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
               }
           }
         }
@@ -516,11 +557,14 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
           for (int e = 0; e < 4; ++e) acc[4 * qd + e] = bv[e];
         }
       };
+      frag a1l[X2 ? KS1 : 1];   // split mode: the W1 fragments' remainders, read with their heads
       auto read_a1 = [&](int k, frag (&a1)[KS1]) {
         const unsigned char* w1s = w1slot(k % NSLOT);
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
+        for (int ks = 0; ks < KS1; ++ks) {
           a1[ks] = *reinterpret_cast<const frag*>(w1s + lr * 256 + (((ks * 2 + h) ^ (lr & 15)) << 4));
+          if (X2) a1l[ks] = *reinterpret_cast<const frag*>(w1s + HALFB + lr * 256 + (((ks * 2 + h) ^ (lr & 15)) << 4));
+        }
       };
 #ifdef S1_LOOPSTAMP
       unsigned long long lts[16];
@@ -534,15 +578,18 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       f32x16 hacc[2];
       frag a1[KS1];
       {   // prologue: chunk 0's fc1, then the operands of step 0
-        wait_vm<4>();   // W1(0) (and x) landed; at most this wave's youngest group is still out
+        wait_vm<X2 ? 8 : 4>();   // W1(0) (and x) landed; at most this wave's youngest group is still out
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         bias_acc(0, hacc[0]);
         read_a1(0, a1);
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
+          if (X2) {
+            hacc[0] = SCM<T>::run(a1l[ks], xf[ks], hacc[0]);
+            hacc[0] = SCM<T>::run(a1[ks], xfl[ks], hacc[0]);
+          }
           hacc[0] = SCM<T>::run(a1[ks], xf[ks], hacc[0]);
-          if (X2) hacc[0] = SCM<T>::run(a1[ks], xfl[ks], hacc[0]);
         }
         __builtin_amdgcn_sched_barrier(0);
         wait_vm<0>();   // W1(1), W1(2) / W2(1)
@@ -557,7 +604,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         constexpr bool LAST = decltype(last_c)::value;
         LS(0);
         // VM order of a wave: W1 waves W1(0..ch+3), W2 waves W2(0..ch+1); both need all but their youngest group
-        wait_vm<4>();
+        wait_vm<X2 ? 8 : 4>();
         LS(1);
         // raw barrier: __syncthreads() would also wait vmcnt(0) while an LDS-DMA is in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the last step is home
@@ -565,7 +612,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         __builtin_amdgcn_s_barrier();   // W1(ch+2), W2(ch) have landed for everyone; W1(ch+1), W2(ch-1) are read out
 #endif
         LS(2);
-        frag a2[CT][2];
+        frag a2[CT][2], a2l[X2 ? CT : 1][2];
         const unsigned char* w2s = w2slot(ch % NSLOT);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -573,6 +620,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
           for (int s2 = 0; s2 < 2; ++s2) {
             const int r = ct * 32 + lr;
             a2[ct][s2] = *reinterpret_cast<const frag*>(w2s + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
+            if (X2) a2l[ct][s2] = *reinterpret_cast<const frag*>(w2s + HALFB + r * 64 + (((s2 * 2 + h) ^ swz4(r)) << 4));
           }
         LS(3);
         const int kdma = ch + (w1wave ? 4 : 2);   // (indices past the last chunk wrap: harmless reloads into dead slots)
@@ -582,8 +630,11 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           if (!LAST) {
+            if (X2) {
+              hn = SCM<T>::run(a1l[r], xf[r], hn);
+              hn = SCM<T>::run(a1[r], xfl[r], hn);
+            }
             hn = SCM<T>::run(a1[r], xf[r], hn);
-            if (X2) hn = SCM<T>::run(a1[r], xfl[r], hn);
           }
 #ifdef S1_EXP_NOGELU
           g[r] = hc[r];
@@ -591,7 +642,8 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
           g[r] = gelu_for<T>(hc[r]);
 #endif
 #ifndef S1_EXP_NODMA
-          if (r & 1) issue_piece(kdma, r >> 1);
+          if (X2) issue_piece(kdma, r);
+          else if (r & 1) issue_piece(kdma, r >> 1);
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -605,8 +657,11 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
+          if (X2) {
+            x[ct] = SCM<T>::run(a2l[ct][0], hf, x[ct]);
+            x[ct] = SCM<T>::run(a2[ct][0], hfl, x[ct]);
+          }
           x[ct] = SCM<T>::run(a2[ct][0], hf, x[ct]);
-          if (X2) x[ct] = SCM<T>::run(a2[ct][0], hfl, x[ct]);
 #ifdef S1_EXP_NOGELU
           g[8 + 2 * ct] = hc[8 + 2 * ct];
           g[9 + 2 * ct] = hc[9 + 2 * ct];
@@ -625,8 +680,11 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
         LS(6);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
+          if (X2) {
+            x[ct] = SCM<T>::run(a2l[ct][1], hf, x[ct]);
+            x[ct] = SCM<T>::run(a2[ct][1], hfl, x[ct]);
+          }
           x[ct] = SCM<T>::run(a2[ct][1], hf, x[ct]);
-          if (X2) x[ct] = SCM<T>::run(a2[ct][1], hfl, x[ct]);
         }
         LS(7);
       };
@@ -648,7 +706,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       if (j == 0) {      // next block's depthwise operand; chunk 15 (slot 2 = the same bytes) must be read out first
         __syncthreads();
         zero_pads();
-        if (inmap) regs_to_planar<T>(x, pl, p, h);
+        if (inmap) regs_to_planar<T, PLO>(x, pl, p, h);
         if (live) {
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
@@ -679,7 +737,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       ln_regs(x, a.ds_lnw, a.ds_lnb, h, xn);
       if (inmap) regs_to_map<T, X2 ? MAPB : 0>(xn, stg, p, h);   // (split: the remainder image behind it, dead bytes too)
     }
-    static_assert(2 * MAPB <= OFF_B1, "two [pixel][channel] images in front of the bias words");
+    static_assert(2 * MAPB <= L::OFF_B1, "two [pixel][channel] images in front of the bias words");
     // this wave's output tiles wave, wave + 4 (32 channels each) x 32 k-steps: 64 filter fragments packed as
     // MFMA A operands (1 KiB each, launch_pack_frag32), a ring of 16 in flight
     constexpr int KSD = 4 * C / 16, RING = X2 ? 8 : 16, NSTEP = 2 * KSD;
@@ -801,6 +859,7 @@ __global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ 
 template <typename T, bool X2 = false, int WPS = 2> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
   auto kern = stage1b_kernel<T, X2, WPS>;
   static bool attr_set = false;
+  constexpr int LDS_BYTES = S1L<X2>::LDS_BYTES;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -816,13 +875,12 @@ template <typename T, bool X2 = false, int WPS = 2> int launch_stage1b_t(const S
 #ifdef STAGE1B_X2_TU
 // ---- this translation unit (stage1x.hip) holds only the split-operand instantiations (see stage0b.hip)
 int launch_stage1b_x2(const Stage1Args& a, hipStream_t st) {
-  // one workgroup per CU with 512 registers (WPS 1) or two with 256 and spills (WPS 2): measured on MI355X at B = 1024,
-  // stage0b 246 / 229 us, stage1b 165 / 183 us -- each kernel defaults to its faster form; BTSBOT_AMD_X2_WPS=1|2 forces one
-  static const int wps = [] {
-    const char* e = getenv("BTSBOT_AMD_X2_WPS");
-    return e != nullptr && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 1;
-  }();
-  return wps == 2 ? launch_stage1b_t<f16_t, true, 2>(a, st) : launch_stage1b_t<f16_t, true, 1>(a, st);
+  // (one workgroup per CU -- two planar images, doubled ring slots: 143 KB of LDS -- with 512 registers)
+  if (a.blk[0].w1_lo == nullptr || a.blk[0].w2g_lo == nullptr || a.blk[1].w1_lo == nullptr || a.blk[1].w2g_lo == nullptr) {
+    btsbot_set_error("stage1b: the split mode needs the filters' remainder images (w1_lo, w2g_lo)");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  return launch_stage1b_t<f16_t, true, 1>(a, st);
 }
 int launch_pack_s1par_x2(const float* taps, const float* dw_b, const float* ln_w, const float* ln_b, void* out,
                          hipStream_t st) {
