@@ -677,6 +677,8 @@ def test_exchange_step_through_the_c_abi_on_a_one_rank_communicator(cuda):
         import ctypes as C
         _lib.check(_lib.lib().btsbot_set_option(ma._handle.ptr, b"exchange", 1), "set_option")
         _lc, gc = ta.gradients(img, meta, lab)
+        gc = gc.clone()
+        tb.gradients(img, meta, lab)      # (keeps the two models' BatchNorm running statistics in step)
         torch.cuda.synchronize()
         assert (gc - gb).abs().max().item() <= 2e-5 * scale
         assert _lib.lib().btsbot_set_option(ma._handle.ptr, b"exchange", 2) != 0
