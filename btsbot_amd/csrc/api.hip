@@ -339,6 +339,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
+    const char* det = getenv("BTSBOT_AMD_DETERMINISTIC");
+    h->deterministic = det != nullptr && det[0] == '1';
   }
   *out = h;
   return BTSBOT_OK;
@@ -353,6 +355,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   if (h->ws && h->ws_owned) (void)hipFree(h->ws);
   if (h->tcache) (void)hipFree(h->tcache);
   if (h->bbcache) (void)hipFree(h->bbcache);
+  if (h->det_scratch) (void)hipFree(h->det_scratch);
   if (h->mv) maxvit_free(h);
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
@@ -598,6 +601,18 @@ extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
       return BTSBOT_ERR_INVALID_ARG;
     }
     h->s2p_alerts_hint = value;
+    return BTSBOT_OK;
+  }
+  if (strcmp(key, "deterministic") == 0) {
+    if (value != 0 && value != 1) {
+      btsbot_set_error("set_option: deterministic is 0 or 1, got %d", value);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    if (value == 1 && h->det_scratch == nullptr && h->tcache != nullptr) {
+      btsbot_set_error("set_option: deterministic = 1 must be set before btsbot_reserve_train() (it sizes a scratch there)");
+      return BTSBOT_ERR_STATE;
+    }
+    h->deterministic = value == 1;
     return BTSBOT_OK;
   }
   if (strcmp(key, "exchange") == 0) {
@@ -1093,6 +1108,10 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
   // (MaxViT: with_image_grads = 1 trains the branch -- BatchNorm2d batch statistics, maxvit_train.hip; = 0 serves heads
   //  over a frozen, eval-mode branch with the inference kernels)
   const bool want_bb = with_image_grads && h->has_image;
+  if (h->deterministic && h->det_scratch == nullptr) {   // partial rows of the batch reductions (common.h: det_add)
+    h->det_floats = (size_t)16 << 20;
+    HIP_TRY(hipMalloc(&h->det_scratch, h->det_floats * sizeof(float)));
+  }
   if (h->tcache != nullptr && max_batch <= h->tcache_batch &&
       (!want_bb || (h->bbcache != nullptr && max_batch <= h->bbcache_batch)))
     return BTSBOT_OK;
@@ -1217,6 +1236,11 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
   if (h->use_side && h->side == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   h->side_used = 0;
+  // deterministic mode: the launchers below take their partial rows from this scratch (fixed-order reductions)
+  struct DetScope {
+    explicit DetScope(btsbot_ctx* c) { det_begin(c->deterministic ? c->det_scratch : nullptr, c->det_floats); }
+    ~DetScope() { det_end(); }
+  } det_scope(h);
   float* dfeat = nullptr;
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));

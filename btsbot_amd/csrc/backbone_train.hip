@@ -187,7 +187,16 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
 static int wgrad_cs(int prec, const void* D, const void* A, float* out, float* cs, int M, int N,
                     int K, int ldo, hipStream_t st, float* part = nullptr, WgradReduceJob* defer = nullptr) {
   if (defer != nullptr) defer->nsl = 0;
-  if (prec != BTSBOT_F32) return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS, defer);
+  if (prec != BTSBOT_F32) {
+    // (deterministic mode: the column sum as a launch of its own -- inside the filter-gradient GEMM its slices meet
+    //  through atomics; launch_colsum writes partial rows and adds them in a fixed order)
+    float* probe = det_alloc(0);
+    if (probe != nullptr && cs != nullptr) {
+      const int rc = launch_wgrad16(prec, D, A, out, nullptr, M, N, K, ldo, st, part, WPART_FLOATS, defer);
+      return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
+    }
+    return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS, defer);
+  }
   const int rc = launch_wgrad(prec, D, A, out, M, N, K, ldo, st);
   return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ D,
 // meet in LDS so that every column costs ONE atomic per block (same-address atomics serialise).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* out, int M,
-                                                     int N, int mslice) {
+                                                     int N, int mslice, float* part) {
   __shared__ float sh[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
   }
   sh[rg][cl] = s0 + s1;
   __syncthreads();
-  if (rg == 0 && n < N) atomicAdd(out + n, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+  if (rg == 0 && n < N) det_add(out + n, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl], part, (size_t)blockIdx.y * N + n);
 }
 
 // out[m][c] = (T)(in[m][c] * scale[c])   (scale may be null)
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ dxn,
                                                      const float* __restrict__ g, float* dd,
                                                      float* dg, float* dbeta, long rows, int C,
-                                                     void* __restrict__ out16, int prec16, int patch_hw) {
+                                                     void* __restrict__ out16, int prec16, int patch_hw,
+                                                     float* part) {
   const int lane = threadIdx.x & 63;
   const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
   float gl[CPT], adg[CPT], adb[CPT];
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
-    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+    det_add(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c], part, (size_t)blockIdx.x * 2 * C + c);
+    det_add(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c], part, (size_t)blockIdx.x * 2 * C + C + c);
   }
 }
 
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void ln_dw1_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ g, const float* __restrict__ xin,
                                                          const float* __restrict__ wc, float* dy,
                                                          void* __restrict__ out16, int prec16, float* dg, float* dbeta,
-                                                         float* dw, float* dbias, long rows, int C) {
+                                                         float* dw, float* dbias, long rows, int C, float* part) {
   const int lane = threadIdx.x & 63;
   const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
   float gl[CPT], wl[CPT], adg[CPT], adb[CPT], adw[CPT], adc[CPT];
@@ -377,10 +378,11 @@ __global__ __launch_bounds__(256) void ln_dw1_bwd_kernel(const float* __restrict
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
-    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
-    atomicAdd(dw + (size_t)c * 49 + 24, sh[2][0][c] + sh[2][1][c] + sh[2][2][c] + sh[2][3][c]);
-    atomicAdd(dbias + c, sh[3][0][c] + sh[3][1][c] + sh[3][2][c] + sh[3][3][c]);
+    const size_t row = (size_t)blockIdx.x * 4 * C;
+    det_add(dg + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c], part, row + c);
+    det_add(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c], part, row + C + c);
+    det_add(dw + (size_t)c * 49 + 24, sh[2][0][c] + sh[2][1][c] + sh[2][2][c] + sh[2][3][c], part, row + 2 * C + c);
+    det_add(dbias + c, sh[3][0][c] + sh[3][1][c] + sh[3][2][c] + sh[3][3][c], part, row + 3 * C + c);
   }
 }
 
@@ -606,9 +608,14 @@ int colsum_t(const void* in, float* out, int M, int N, hipStream_t st) {
   if (nsl < 1) nsl = 1;
   const int mslice = (M + nsl - 1) / nsl;
   dim3 grid(nb, (M + mslice - 1) / mslice);
+  float* part = det_alloc((size_t)grid.y * N);
   hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(in), out,
-                     M, N, mslice);
+                     M, N, mslice, part);
   LAUNCH_CHECK();
+  if (part != nullptr) {
+    const DetOut o{out, 1};
+    return launch_det_reduce(part, (int)grid.y, N, 1, &o, st);
+  }
   return BTSBOT_OK;
 }
 
@@ -628,6 +635,58 @@ int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int 
   if (M <= 0) return BTSBOT_OK;
   BY_PREC(prec, wgrad_t<float>(D, A, out, M, N, K, ldo, st),
           wgrad_t<bf16_t>(D, A, out, M, N, K, ldo, st), wgrad_t<f16_t>(D, A, out, M, N, K, ldo, st))
+}
+
+// ---- deterministic mode: the scratch of the running backward call (thread-local: launchers run on the caller's thread)
+namespace {
+thread_local float* g_det_base = nullptr;
+thread_local size_t g_det_cap = 0, g_det_used = 0;
+
+// 32 columns x 8 row groups per workgroup: group q adds rows q, q + 8, ... in order, the groups meet in LDS in order
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nrows, int C, int W,
+                                                         DetOut o0, DetOut o1, DetOut o2, DetOut o3) {
+  __shared__ float sh[8][32];
+  const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (col < W)
+    for (int r = q; r < nrows; r += 8) s += part[(size_t)r * W + col];
+  sh[q][cl] = s;
+  __syncthreads();
+  if (q == 0 && col < W) {
+    float t = sh[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += sh[i][cl];
+    const int o = col / C, c = col - o * C;
+    const DetOut d = o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o3;
+    d.ptr[(size_t)c * d.stride] += t;
+  }
+}
+}  // namespace
+
+void det_begin(float* base, size_t floats) {
+  g_det_base = base;
+  g_det_cap = base != nullptr ? floats : 0;
+  g_det_used = 0;
+}
+void det_end() { det_begin(nullptr, 0); }
+float* det_alloc(size_t floats) {
+  if (g_det_base == nullptr || g_det_used + floats > g_det_cap) return nullptr;
+  float* p = g_det_base + g_det_used;
+  g_det_used += (floats + 63) / 64 * 64;
+  return p;
+}
+int launch_det_reduce(const float* part, int nrows, int C, int nout, const DetOut* outs, hipStream_t st) {
+  if (nout < 1 || nout > 4) {
+    btsbot_set_error("det_reduce: %d outputs", nout);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  const int W = nout * C;
+  DetOut o[4] = {outs[0], outs[0], outs[0], outs[0]};
+  for (int i = 0; i < nout; ++i) o[i] = outs[i];
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((W + 31) / 32), dim3(256), 0, st, part, nrows, C, W, o[0], o[1], o[2], o[3]);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
 }
 
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st) {
@@ -720,7 +779,8 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
                                                             const float* __restrict__ dxn,
                                                             const float* __restrict__ g, float* dd,
                                                             float* dg, float* dbeta, long rows,
-                                                            void* __restrict__ out16, int prec16, int patch_hw) {
+                                                            void* __restrict__ out16, int prec16, int patch_hw,
+                                                            float* part) {
   constexpr int C = 4 * LPR, R = 64 / LPR;       // rows per wave pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -819,8 +879,8 @@ __global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(const float* __restr
       a += sh[0][j][c];
       b += sh[1][j][c];
     }
-    atomicAdd(dg + c, a);
-    atomicAdd(dbeta + c, b);
+    det_add(dg + c, a, part, (size_t)blockIdx.x * 2 * C + c);
+    det_add(dbeta + c, b, part, (size_t)blockIdx.x * 2 * C + C + c);
   }
 }
 
@@ -838,19 +898,25 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
     const int rpb = 4 * (C == 64 ? 4 : 2) * 2;   // rows per block pass
     long nb = (rows + rpb - 1) / rpb;
     if (nb > cap) nb = cap;
+    float* part = det_alloc((size_t)nb * 2 * C);
     if (C == 64)
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<16>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows, out16, prec16, patch_hw);
+                         dd, dg, dbeta, rows, out16, prec16, patch_hw, part);
     else
       hipLaunchKernelGGL((ln_bwd_narrow_kernel<32>), dim3((unsigned)nb), dim3(256), 0, st, d, dxn, g,
-                         dd, dg, dbeta, rows, out16, prec16, patch_hw);
+                         dd, dg, dbeta, rows, out16, prec16, patch_hw, part);
     LAUNCH_CHECK();
+    if (part != nullptr) {
+      const DetOut o[2] = {{dg, 1}, {dbeta, 1}};
+      return launch_det_reduce(part, (int)nb, C, 2, o, st);
+    }
     return BTSBOT_OK;
   }
   const int cpt = (C + 63) / 64;
+  float* part = det_alloc((size_t)blocks * 2 * C);
 #define LNB(CPT)                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, \
-                     dd, dg, dbeta, rows, C, out16, prec16, patch_hw)
+                     dd, dg, dbeta, rows, C, out16, prec16, patch_hw, part)
   if (cpt <= 1) LNB(1);
   else if (cpt <= 2) LNB(2);
   else if (cpt <= 4) LNB(4);
@@ -863,6 +929,10 @@ int launch_ln_bwd(const float* d, const float* dxn, const float* g, float* dd, f
   }
 #undef LNB
   LAUNCH_CHECK();
+  if (part != nullptr) {
+    const DetOut o[2] = {{dg, 1}, {dbeta, 1}};
+    return launch_det_reduce(part, (int)blocks, C, 2, o, st);
+  }
   return BTSBOT_OK;
 }
 
@@ -875,9 +945,10 @@ int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const fl
   if (blocks > 32) blocks = 32;   // 4 x <= 32 same-address atomics per channel: with 256 workgroups the step was 0.04 ms slower
   const float* wc = w + (size_t)24 * C;
   const int cpt = (C + 63) / 64;
+  float* part = det_alloc((size_t)blocks * 4 * C);
 #define LD1(CPT)                                                                                       \
   hipLaunchKernelGGL((ln_dw1_bwd_kernel<CPT>), dim3((unsigned)blocks), dim3(256), 0, st, d, dxn, g, xin, wc, dy, \
-                     out16, prec16, dg, dbeta, dw, dbias, rows, C)
+                     out16, prec16, dg, dbeta, dw, dbias, rows, C, part)
   if (cpt <= 8) LD1(8);
   else if (cpt <= 10) LD1(10);
   else {
@@ -886,6 +957,10 @@ int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const fl
   }
 #undef LD1
   LAUNCH_CHECK();
+  if (part != nullptr) {
+    const DetOut o[4] = {{dg, 1}, {dbeta, 1}, {dw + 24, 49}, {dbias, 1}};
+    return launch_det_reduce(part, (int)blocks, C, 4, o, st);
+  }
   return BTSBOT_OK;
 }
 

@@ -193,6 +193,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v + w;
 }
 
+// ---------------------------------------------------------------------------------------
+// Deterministic batch reductions (btsbot_set_option(h, "deterministic", 1) / BTSBOT_AMD_DETERMINISTIC=1): the kernels of
+// the ConvNeXt training step that meet across workgroups through fp32 atomics -- LayerNorm / depthwise parameter
+// gradients, column sums, the fc1-bias gradient of the fused MLP backward -- write one partial row per workgroup instead
+// (`part`, from the scratch of the running btsbot_backward() call) and launch_det_reduce() adds the rows in a fixed order
+// behind them on the same stream: two identical backward passes then agree bit for bit.  part == nullptr: atomics.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void det_add(float* out, float v, float* part, size_t slot) {
+  if (part != nullptr) part[slot] = v;
+  else atomicAdd(out, v);
+}
+struct DetOut { float* ptr; int stride; };   // column c of output o goes to ptr[c * stride]
+void det_begin(float* base, size_t floats);  // the scratch of this thread's btsbot_backward() call (base == nullptr: mode off)
+void det_end();
+float* det_alloc(size_t floats);             // nullptr when the mode is off (or the scratch is exhausted: atomics then)
+// outs[o].ptr[c * stride] += sum over rows r (in order) of part[r * nout * C + o * C + c]
+int launch_det_reduce(const float* part, int nrows, int C, int nout, const DetOut* outs, hipStream_t st);
+
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == ACT_GELU) return gelu_erf(x);

@@ -131,6 +131,9 @@ struct btsbot_ctx {
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
+  bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
+  float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)
+  size_t det_floats = 0;
   int exchange_mode = 0;             // btsbot_set_option("exchange"): 0 all-reduce per span, 1 reduce-scatter + all-gather
   const float* last_grad_arena = nullptr;   // what the last btsbot_backward() wrote (the bucket events belong to it)
   hipEvent_t xchg_done = nullptr;

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
                                                           const T* __restrict__ w1, const T* __restrict__ w2g,
                                                           const float* __restrict__ b1, float* __restrict__ dxn,
                                                           float* __restrict__ partG, float* __restrict__ partW,
-                                                          float* __restrict__ db1, float* __restrict__ Ssum, int R) {
+                                                          float* __restrict__ db1, float* __restrict__ Ssum, int R,
+                                                          float* detb, float* dets) {
   using G = BwdGeo<C, NW>;
   using M = MB<T>;
   constexpr int PX = G::PX, PD = G::PD;
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
       pw[(32 * wave + rr) * C + 32 * ct + lr] = gW[ct][r];       // dW1 [hidden][channel]
     }
   sb1 += __shfl_xor(sb1, 32);
-  if (lh == 0) atomicAdd(db1 + hid, sb1);
+  // (deterministic mode: one partial row per row slice for db1 [4 C] and one for colsum(dy) [C], launch_det_reduce)
+  if (lh == 0) det_add(db1 + hid, sb1, detb, (size_t)blockIdx.x * (4 * C) + hid);
   {   // (every LDS read of the loop is behind its last barrier)
     float* red = reinterpret_cast<float*>(sm);
     red[tid] = ssum;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
       float v = 0.f;
 #pragma unroll
       for (int g = 0; g < SGRP; ++g) v += red[tid + SC * g];
-      atomicAdd(Ssum + (int)blockIdx.y * SC + tid, v);
+      det_add(Ssum + (int)blockIdx.y * SC + tid, v, dets, (size_t)blockIdx.x * C + (int)blockIdx.y * SC + tid);
     }
   }
 }
@@ -418,10 +420,18 @@ int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w
   const int gx = mlp_bwd_slices(C, R);
   float* partG = part;
   float* partW = part + (size_t)gx * G::NH * C * G::HS;
+  float* detb = det_alloc((size_t)gx * 4 * C);
+  float* dets = detb != nullptr ? det_alloc((size_t)gx * C) : nullptr;
+  if (dets == nullptr) detb = nullptr;
   hipLaunchKernelGGL(kern, dim3(gx, G::NH), dim3(G::NT), G::BYTES, st, reinterpret_cast<const T*>(xn),
                      reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(w1), reinterpret_cast<const T*>(w2g), b1,
-                     dxn, partG, partW, db1, Ssum, R);
+                     dxn, partG, partW, db1, Ssum, R, detb, dets);
   LAUNCH_CHECK();
+  if (detb != nullptr) {
+    const DetOut ob{db1, 1}, os{Ssum, 1};
+    if (launch_det_reduce(detb, gx, 4 * C, 1, &ob, st) != BTSBOT_OK || launch_det_reduce(dets, gx, C, 1, &os, st) != BTSBOT_OK)
+      return BTSBOT_ERR_HIP;
+  }
   jobs[0] = WgradReduceJob{partG, Gacc, C, 4 * C, 4 * C, 1, G::NH, gx, C, G::HS};
   jobs[1] = WgradReduceJob{partW, dW1, 4 * C, C, C, G::NH, 1, gx, G::HS, C};
   return BTSBOT_OK;

@@ -222,7 +222,11 @@ int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int n
  *   "stage2p_alerts": alerts resident per workgroup of the stage-2 kernel -- 0 (default): 4, or 7 where that takes fewer
  *   rounds of one workgroup per CU; 7: always (a scoring loop with several forwards in flight on different streams:
  *   the kernel then leaves ~40 % of the CUs to the other stream at 1024 alerts); 4: always.
- *   "exchange": form of btsbot_allreduce_grads' collectives -- 0 (default) all-reduce, 1 reduce-scatter + all-gather. */
+ *   "exchange": form of btsbot_allreduce_grads' collectives -- 0 (default) all-reduce, 1 reduce-scatter + all-gather.
+ *   "deterministic" (also BTSBOT_AMD_DETERMINISTIC=1 at btsbot_create; set before btsbot_reserve_train): 1 = the batch
+ *   reductions of the ConvNeXt training step that meet through fp32 atomics (LayerNorm / depthwise parameter gradients,
+ *   column sums, the fused MLP backward's bias gradient) write partial rows and add them in a fixed order instead: two
+ *   identical btsbot_backward() calls give bit-identical gradients (16-bit modes; ~25 small extra launches per step). */
 int btsbot_set_option(btsbot_handle h, const char* key, int value);
 
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and

@@ -524,6 +524,37 @@ def test_16bit_training_follows_the_fp32_recipe(cuda, prec):
         assert (a - b).abs().max().item() <= 1e-3 * max(b.abs().max().item(), 1.0), k
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_deterministic_option_gives_bit_identical_gradients(cuda, monkeypatch, prec):
+    """btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: the batch reductions that otherwise meet through
+    fp32 atomics (LayerNorm / depthwise parameter gradients, column sums, the fused MLP backward's bias gradient) write
+    partial rows and add them in a fixed order -- two identical passes must agree bit for bit in EVERY gradient, and with
+    the default (atomic) path to the rounding of a different summation order."""
+    kind, cfg0 = CONFIGS["mm_pico"]
+    cfg = dict(cfg0, meta_dropout=0.0, comb_dropout=0.0)
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, lab = synthetic_batch(160, seed=4)
+    img, meta, lab = img.to(cuda), meta.to(cuda), lab.to(cuda)
+
+    def grads(n):
+        m = build_model(kind, cfg, sd, cuda, prec).train()
+        tr = Trainer(m, lr=1e-4)
+        out = []
+        for _ in range(n):
+            _l, g = tr.gradients(img, meta, lab)
+            torch.cuda.synchronize()
+            out.append(g.clone())
+        return out
+
+    plain = grads(1)[0]
+    monkeypatch.setenv("BTSBOT_AMD_DETERMINISTIC", "1")
+    a, b, c = grads(3)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(b, c), (a - b).abs().max().item()
+    scale = plain.abs().max().item()
+    assert (a - plain).abs().max().item() <= 2e-5 * scale
+
+
 def test_process_wide_switches_in_a_child_process(cuda):
     """The A/B switches that the library reads once per process (one launch per packed operand, no epilogue
     prefetch in the LDS-DMA GEMM, atomics instead of the two-pass filter-gradient reduction, no one-slot ring)
