@@ -70,7 +70,12 @@ class ScoreStream:
             side.wait_stream(cur)
 
     def refresh(self):
-        """Copy the first model's parameters into the replicas (after they changed)."""
+        """Copy the first model's parameters into the replicas (after they changed).  The caller's stream first waits for
+        every side stream: a replica's queued work (a forward, or the arena -> mirror copy of its pending re-pack) must
+        not overlap the overwrite of its parameters."""
+        cur = torch.cuda.current_stream(self.device)
+        for side in self.streams:
+            cur.wait_stream(side)
         sd = self.models[0].state_dict()
         for twin in self.models[1:]:
             twin.load_state_dict(sd)

@@ -26,7 +26,7 @@ def _load():
 
 
 class RcclComm:
-    """``RcclComm(rank, world, unique_id=None)``: rank 0 calls ``RcclComm.unique_id()`` and ships the 128 bytes to the
+    """``RcclComm(rank, world, unique_id)``: rank 0 calls ``RcclComm.unique_id()`` and ships the 128 bytes to the
     other ranks (any channel); every rank then constructs its communicator with the same id, with its GPU current."""
 
     def __init__(self, rank: int, world: int, unique_id: bytes):

@@ -136,7 +136,10 @@ int btsbot_param_info_at(btsbot_handle h, int index, btsbot_param_info* out);
 int btsbot_pack_params(btsbot_handle h, const float* master_arena, void* stream);
 /* The same for a training loop that differentiates the image branch (btsbot_forward_train with
  * keep_image_activations != 0): skips the operand images only the fused inference kernels read; an inference
- * btsbot_forward() afterwards needs a full btsbot_pack_params() first (it returns BTSBOT_ERR_STATE otherwise). */
+ * btsbot_forward() afterwards needs a full btsbot_pack_params() first (it returns BTSBOT_ERR_STATE otherwise).
+ * Stream rule for both: the forward / forward_train that consumes a pack must be queued on the SAME stream as the pack
+ * (or on one the caller has ordered behind it): part of the re-pack runs on a stream of the handle's own, which the
+ * consumer joins on its stream, but the arena -> mirror copy is ordered by the pack's stream alone. */
 int btsbot_pack_params_train(btsbot_handle h, const float* master_arena, void* stream);
 
 /* Workspace: activations of one chunk of alerts.  reserve() (re)allocates for chunks of up to
