@@ -413,22 +413,40 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
         for (int xb = 0; xb < 4; ++xb) acc[yb][xb] = f32x4{dwbias, dwbias, dwbias, dwbias};
       const unsigned char* lb = pl + dch * PL_CH + dj * 8;
-#pragma unroll
-      for (int s = 0; s < 19; ++s) {
-        frag4 bq[4], bql[X2 ? 4 : 1];
+      // (the row step's four reads are requested a whole step -- 10 to 48 products -- ahead of their use: read and used in
+      //  the same step, every step began with an exposed LDS round trip, 19 per block, about as long as the products)
+      frag4 bq[2][4], bql[X2 ? 2 : 1][X2 ? 4 : 1];
+      auto read_step = [&](int s, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + s * 8));
-          if (X2) bql[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + q * PL_XQ + s * 8));
+          bq[buf][q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + s * 8));
+          if (X2) bql[buf][q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + q * PL_XQ + s * 8));
         }
+      };
+      read_step(0, 0);
+#ifdef S0_EXP_NODW
+#pragma unroll 1
+      for (int s = 0; s < 1; ++s) {
+#else
+#pragma unroll
+      for (int s = 0; s < 19; ++s) {
+#endif
+        // (touching this step's fragments makes hipcc wait for them HERE, while they are the only LDS reads in flight:
+        //  placed by itself the wait lands behind the next step's reads -- lgkmcnt(0), their whole latency exposed)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          asm volatile("" : "+v"(bq[s & 1][q]));
+          if (X2) asm volatile("" : "+v"(bql[X2 ? s & 1 : 0][X2 ? q : 0]));
+        }
+        if (s + 1 < 19) read_step(s + 1, (s + 1) & 1);
         if (s == 0) {
           // the taps are in registers by now: only now queue the filter chunks (a wait for an ordinary load
           // placed behind an LDS-DMA would wait for the DMA too)
           __builtin_amdgcn_sched_barrier(0);
           issue(0);
           issue(1);
-          __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int yb = 0; yb < 4; ++yb) {
           const int ky = s - 4 * yb;
@@ -440,12 +458,13 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
               const int q = xb + rbi - 1;
               if (q < 0 || q > 3) continue;
               if (X2) {   // remainders first (small terms into the accumulator before the large one)
-                acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
-                acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bql[q], acc[yb][xb]);
+                acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
+                acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bql[X2 ? s & 1 : 0][X2 ? q : 0], acc[yb][xb]);
               }
-              acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+              acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int yb = 0; yb < 4; ++yb)
@@ -459,8 +478,12 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
     //      the 4 waves through LDS; single-pass variance
     {
       float s1[4], s2[4];
+#ifdef S0_EXP_NOLNRED
+      for (int i = 0; i < 4; ++i) { s1[i] = v[i]; s2[i] = v[i + 4] * v[i + 4] + 1.f; }
+#else
       block_reduce64<false>(v, lane, s1);
       block_reduce64<true>(v, lane, s2);
+#endif
       const int slot = (4 * dyb + dj) * 16 + 4 * dxb;
       *reinterpret_cast<float4*>(part + wave * 256 + slot) = make_float4(s1[0], s1[1], s1[2], s1[3]);
       *reinterpret_cast<float4*>(part + 1024 + wave * 256 + slot) = make_float4(s2[0], s2[1], s2[2], s2[3]);
@@ -535,8 +558,13 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
             x[t][ct][4 * qd + 3] += bv.w;
           }
         }
+#ifdef S0_EXP_NOLOOP
+#pragma unroll 1
+      for (int ch = 0; ch < 0; ++ch) {
+#else
 #pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
+#endif
         // this wave's pieces of chunk ch have landed once only the younger chunk is outstanding
         if (ch + 1 < NCH) wait_vm<X2 ? 4 : 2>();
         else wait_vm<0>();
@@ -603,7 +631,11 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
             frag hf, hfl;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
+#ifdef S0_EXP_NOGELU
+              const float gv = hacc[t][8 * s2 + r];
+#else
               const float gv = gelu_for<T>(hacc[t][8 * s2 + r]);
+#endif
               hf[r] = (T)gv;
               if (X2) hfl[r] = (T)(gv - (float)hf[r]);
             }

@@ -393,27 +393,48 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
           for (int r = 0; r < TW_R; ++r) twl[r] = __builtin_bit_cast(frag4, twsrc[TW_BYTES / 8 + r * 512 + 64]);
         }
       }
+      // Both alerts of a row step together (8 to 16 products per step), the NEXT step's four reads requested in front of
+      // them: read and used in the same step, each of a block's 44 steps began with an exposed LDS round trip.
+      f32x4 acc[G][2][2];
 #pragma unroll
-      for (int al = 0; al < G; ++al) {
-        f32x4 acc[2][2];
+      for (int al = 0; al < G; ++al)
 #pragma unroll
         for (int yb = 0; yb < 2; ++yb)
 #pragma unroll
-          for (int xb = 0; xb < 2; ++xb) acc[yb][xb] = f32x4{dwbias[gi], dwbias[gi], dwbias[gi], dwbias[gi]};
-        const unsigned char* lb = pl + al * PL_AL + (16 * (2 * wave + gi) + db) * 8;
-#ifdef S1_EXP_NODW
-#pragma unroll 1
-        for (int sx = 0; sx < 0; ++sx) {
-#else
+          for (int xb = 0; xb < 2; ++xb) acc[al][yb][xb] = f32x4{dwbias[gi], dwbias[gi], dwbias[gi], dwbias[gi]};
+      const unsigned char* lb = pl + (16 * (2 * wave + gi) + db) * 8;
+      frag4 bq[2][G][2], bql[X2 ? 2 : 1][G][X2 ? 2 : 1];
+      auto read_step = [&](int sx, int buf) {
 #pragma unroll
-        for (int sx = 0; sx < 11; ++sx) {
-#endif
-          frag4 bq[2], bql[X2 ? 2 : 1];
+        for (int al = 0; al < G; ++al)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            bq[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + q * PL_XQ + rofs[sx]));
-            if (X2) bql[q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + q * PL_XQ + rofs[sx]));
+            bq[buf][al][q] = __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + al * PL_AL + q * PL_XQ + rofs[sx]));
+            if (X2)
+              bql[buf][al][q] =
+                  __builtin_bit_cast(frag4, *reinterpret_cast<const uint2*>(lb + PLB + al * PL_AL + q * PL_XQ + rofs[sx]));
           }
+      };
+      read_step(0, 0);
+#ifdef S1_EXP_NODW
+#pragma unroll 1
+      for (int sx = 0; sx < 0; ++sx) {
+#else
+#pragma unroll
+      for (int sx = 0; sx < 11; ++sx) {
+#endif
+        // (touching this step's fragments makes hipcc wait for them here, while they are the only LDS reads in flight)
+#pragma unroll
+        for (int al = 0; al < G; ++al)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            asm volatile("" : "+v"(bq[sx & 1][al][q]));
+            if (X2) asm volatile("" : "+v"(bql[X2 ? sx & 1 : 0][al][X2 ? q : 0]));
+          }
+        if (sx + 1 < 11) read_step(sx + 1, (sx + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int al = 0; al < G; ++al)
 #pragma unroll
           for (int yb = 0; yb < 2; ++yb) {
             const int ky = sx - 4 * yb;
@@ -425,20 +446,22 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
                 const int q = xb + rbi - 1;
                 if (q < 0 || q > 1) continue;
                 if (X2) {   // remainders first
-                  acc[yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[q], acc[yb][xb]);
-                  acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bql[q], acc[yb][xb]);
+                  acc[al][yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
+                  acc[al][yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bql[X2 ? sx & 1 : 0][al][X2 ? q : 0], acc[al][yb][xb]);
                 }
-                acc[yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[q], acc[yb][xb]);
+                acc[al][yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
               }
           }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int al = 0; al < G; ++al)
 #pragma unroll
         for (int yb = 0; yb < 2; ++yb)
 #pragma unroll
           for (int xb = 0; xb < 2; ++xb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[gi][al][yb * 8 + xb * 4 + i] = acc[yb][xb][i];
-      }
+            for (int i = 0; i < 4; ++i) v[gi][al][yb * 8 + xb * 4 + i] = acc[al][yb][xb][i];
     }
     SC_STAMP(4 + 5 * j);   // depthwise done
     // ---- LayerNorm over the 128 channels of a pixel: this wave's 2 groups in the lane, its 16 blocks by the
