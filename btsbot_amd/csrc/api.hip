@@ -339,6 +339,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
+    const char* ns16 = getenv("BTSBOT_AMD_NO_STEM16");
+    h->use_stem16 = !(ns16 != nullptr && ns16[0] == '1');
     const char* det = getenv("BTSBOT_AMD_DETERMINISTIC");
     h->deterministic = det != nullptr && det[0] == '1';
   }
@@ -804,6 +806,9 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
       }));
     } else {
       TRY(timed(h, CAT_STEM, st, [&] {
+        if (h->use_stem16 && !h->x2 && stem16_supported(c.precision, c.dims[0]))
+          return launch_stem16(c.precision, img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x, nb,
+                               c.dims[0], st);
         return launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, x,
                            nb, c.dims[0], st);
       }));

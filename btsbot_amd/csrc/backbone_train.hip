@@ -143,8 +143,14 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   // straight into the buffer its consumer keeps: the stem / downsample into block 0's xin, block j's
   // fc2 (+ residual) into block j+1's xin, the stage's last block into xs[i].
   auto stage_in = [&](int i) { return h->blocks[i].empty() ? k.xs[i] : k.blk[i][0].xin; };
-  TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
-                   B, c.dims[0], st, k.stem_pre));   // (the pre-LayerNorm output is kept for the backward)
+  // (the pre-LayerNorm output is kept for the backward; 16-bit modes: the matrix-pipe stem, which like stem_kernel reads
+  //  nothing packed -- the operand re-pack of this step runs on the side stream meanwhile)
+  if (h->use_stem16 && stem16_supported(c.precision, c.dims[0]))
+    TRYB(launch_stem16(c.precision, img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0), B,
+                       c.dims[0], st, k.stem_pre));
+  else
+    TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
+                     B, c.dims[0], st, k.stem_pre));
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;

@@ -259,6 +259,11 @@ int launch_gemm2_batched_resid(int prec, const void* X, const void* W, const flo
 int launch_stem(const float* img, const float* w48xC, const float* bias, const float* lnw,
                 const float* lnb, float* out, int B, int C0, hipStream_t st, float* pre_out = nullptr);
 
+// the same on the matrix pipe for the 16-bit modes (stem16.hip): w is the fp32 filter [C0][48], converted in registers
+bool stem16_supported(int prec, int C0);
+int launch_stem16(int prec, const float* img, const float* w, const float* bias, const float* lnw, const float* lnb,
+                  float* out, int B, int C0, hipStream_t st, float* pre_out = nullptr);
+
 // depthwise 7x7 p3 (+bias) + LayerNorm over C.  x [B,HW*HW,C] fp32 -> xn [B,HW*HW,C] prec-typed.
 // wdw is tap-major [49][C] fp32.
 // dsave != NULL: also the pre-LayerNorm map d = dwconv(x) + bias, [B,HW*HW,C] fp32 (kept for the backward)

@@ -131,6 +131,7 @@ struct btsbot_ctx {
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
+  bool use_stem16 = true;            // BTSBOT_AMD_NO_STEM16=1: the fp32 VALU stem in the 16-bit modes too (A/B, parity)
   bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
   float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)
   size_t det_floats = 0;

@@ -228,6 +228,20 @@ def test_full_size_batch_matches_oracle(cuda, prec):
     print(f"B=1024 {prec}: max|dscore| {ds:.3e}")
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_nano_full_size_batch_matches_oracle(cuda, prec):
+    """convnext_nano -- the reference classes' default `model_kind` (/root/reference/btsbot/architectures.py:107,128) -- with
+    the LS head, at the benchmark's batch (1024 alerts) against the oracle: the per-op schedule (matrix-pipe stem, LDS-staged
+    depthwise + LayerNorm, fused MLP for the 80- and 160-channel stages, LDS-DMA GEMMs, the stage-3 and head kernels)."""
+    kind, cfg = CONFIGS["mm_nano_ls"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(1024, seed=2)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    ds = _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
+    print(f"nano B=1024 {prec}: max|dscore| {ds:.3e}")
+
+
 @pytest.mark.timeout(900)
 def test_f16x2_meets_the_north_star_on_five_weight_seeds(cuda):
     """The mode that claims the north star's 1e-4 must not owe it to one draw of the weights: five seeded weight sets
@@ -371,12 +385,14 @@ def test_adamw_kernel(cuda):
 
 
 @pytest.mark.parametrize("env", ["BTSBOT_AMD_NO_STAGE2", "BTSBOT_AMD_NO_STAGE0", "BTSBOT_AMD_NO_STAGE1", "BTSBOT_AMD_NO_S3",
-                                 "BTSBOT_AMD_NO_HEAD16"])
+                                 "BTSBOT_AMD_NO_HEAD16", "BTSBOT_AMD_NO_STAGE0,BTSBOT_AMD_NO_STEM16"])
 @pytest.mark.parametrize("prec", ["bf16", "f16", "f16x2"])
 def test_alternative_schedules_match_oracle(cuda, monkeypatch, env, prec):
     """The library's schedule switches (read at model creation) fall back from a stage's fused kernel to
-    the per-op launches the other widths (convnext_nano) run -- they must hold the same parity bound."""
-    monkeypatch.setenv(env, "1")
+    the per-op launches the other widths (convnext_nano) run -- they must hold the same parity bound.
+    (NO_STAGE0 runs the matrix-pipe stem of the per-op schedule, stem16.hip; with NO_STEM16 the fp32 stem_kernel.)"""
+    for e in env.split(","):
+        monkeypatch.setenv(e, "1")
     kind, cfg = CONFIGS["mm_pico"]
     sd = seeded_state(kind, cfg, seed=3)
     img, meta, _ = synthetic_batch(21, seed=5)
