@@ -598,8 +598,8 @@ extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
     return BTSBOT_ERR_INVALID_ARG;
   }
   if (strcmp(key, "stage2p_alerts") == 0) {
-    if (value != 0 && value != 4 && value != 7) {
-      btsbot_set_error("set_option: stage2p_alerts is 0 (automatic), 4 or 7, got %d", value);
+    if (value != 0 && value != 4 && value != 5 && value != 7) {
+      btsbot_set_error("set_option: stage2p_alerts is 0 (automatic), 4, 5 or 7, got %d", value);
       return BTSBOT_ERR_INVALID_ARG;
     }
     h->s2p_alerts_hint = value;

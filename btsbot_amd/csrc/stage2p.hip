@@ -746,20 +746,26 @@ int stage2p_alerts_per_workgroup(int B, int hint) {
     const char* e = getenv("BTSBOT_AMD_S2P_G");
     return e != nullptr ? atoi(e) : 0;
   }();
-  if (forced == 4 || forced == 7) return forced;
+  if (forced == 4 || forced == 5 || forced == 7) return forced;
   // the caller's hint (btsbot_set_option): a scoring loop that keeps several forwards in flight on different streams
   // asks for 7 at every batch size -- at 1024 alerts the kernel then occupies 147 CUs instead of 256 for 116 instead of
   // 105 us, and the other stream's kernels take the rest (measured: +6 % through ScoreStream, -4 % for serial calls)
-  if (hint == 4 || hint == 7) return hint;
-  const int r4 = ((B + 3) / 4 + 255) / 256, r7 = ((B + 6) / 7 + 255) / 256;
-  return r7 < r4 ? 7 : 4;
+  if (hint == 4 || hint == 5 || hint == 7) return hint;
+  // 5 alerts (45 of the same 48 columns as 4: no more matrix work per workgroup, a fifth fewer workgroups streaming the
+  // filters -- 100.7 against 105.7 us at 1024 alerts, where 205 workgroups leave 51 CUs and a fifth of the L2 traffic
+  // unused) unless 7 take fewer rounds of one workgroup per CU
+  const int r5 = ((B + 4) / 5 + 255) / 256, r7 = ((B + 6) / 7 + 255) / 256;
+  return r7 < r5 ? 7 : 5;
 }
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
-  const bool g7 = stage2p_alerts_per_workgroup(a.B, a.alerts_hint) == 7;
-  if (prec == BTSBOT_BF16) return g7 ? launch_stage2p_t<bf16_t, 7>(a, st) : launch_stage2p_t<bf16_t>(a, st);
-  if (prec == BTSBOT_F16) return g7 ? launch_stage2p_t<f16_t, 7>(a, st) : launch_stage2p_t<f16_t>(a, st);
+  const int gsel = stage2p_alerts_per_workgroup(a.B, a.alerts_hint);
+  const bool g7 = gsel == 7, g5 = gsel == 5;
+  if (prec == BTSBOT_BF16)
+    return g7 ? launch_stage2p_t<bf16_t, 7>(a, st) : g5 ? launch_stage2p_t<bf16_t, 5>(a, st) : launch_stage2p_t<bf16_t>(a, st);
+  if (prec == BTSBOT_F16)
+    return g7 ? launch_stage2p_t<f16_t, 7>(a, st) : g5 ? launch_stage2p_t<f16_t, 5>(a, st) : launch_stage2p_t<f16_t>(a, st);
   if (prec == BTSBOT_FP8) return g7 ? launch_stage2p_t<fp8_t, 7>(a, st) : launch_stage2p_t<fp8_t>(a, st);
   if (prec == BTSBOT_F16X2) return launch_stage2p_t<f16x2_t>(a, st);
   btsbot_set_error("stage2p: unsupported precision %d", prec);

@@ -46,6 +46,9 @@ def _replica(model):
     return twin.to(dev).eval()
 
 
+_S2P_HINT = int(__import__("os").environ.get("BTSBOT_AMD_S2P_HINT", "7"))   # (developer A/B: 5 or 7)
+
+
 class ScoreStream:
     def __init__(self, model, depth: int = 2, inputs_ready: bool = False):
         if depth < 1:
@@ -97,7 +100,7 @@ class ScoreStream:
             # several forwards in flight: the stage-2 kernel keeps 7 alerts per workgroup at every batch size and so
             # leaves ~40 % of the CUs to the other stream's kernels (+6 % through this loop at 1024 alerts; a lone
             # model(...) call is 4 % slower that way, so the hint is taken back right after the launches are queued)
-            _lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", 7)
+            _lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", _S2P_HINT)
         with torch.cuda.stream(side), torch.no_grad():
             try:
                 out = m(*inputs)

@@ -222,8 +222,8 @@ int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int n
                            const int64_t* lo, const int64_t* hi, void* stream);
 
 /* Scheduling hints (host-side state read at launch time; results do not depend on them).
- *   "stage2p_alerts": alerts resident per workgroup of the stage-2 kernel -- 0 (default): 4, or 7 where that takes fewer
- *   rounds of one workgroup per CU; 7: always (a scoring loop with several forwards in flight on different streams:
+ *   "stage2p_alerts": alerts resident per workgroup of the stage-2 kernel -- 0 (default): 5, or 7 where that takes fewer
+ *   rounds of one workgroup per CU; 4 / 5: always (36 / 45 of the same 48 matrix columns); 7: always (a scoring loop with several forwards in flight on different streams:
  *   the kernel then leaves ~40 % of the CUs to the other stream at 1024 alerts); 4: always.
  *   "exchange": form of btsbot_allreduce_grads' collectives -- 0 (default) all-reduce, 1 reduce-scatter + all-gather.
  *   "deterministic" (also BTSBOT_AMD_DETERMINISTIC=1 at btsbot_create; set before btsbot_reserve_train): 1 = the batch
