@@ -766,8 +766,10 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
     return g7 ? launch_stage2p_t<bf16_t, 7>(a, st) : g5 ? launch_stage2p_t<bf16_t, 5>(a, st) : launch_stage2p_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16)
     return g7 ? launch_stage2p_t<f16_t, 7>(a, st) : g5 ? launch_stage2p_t<f16_t, 5>(a, st) : launch_stage2p_t<f16_t>(a, st);
-  if (prec == BTSBOT_FP8) return g7 ? launch_stage2p_t<fp8_t, 7>(a, st) : launch_stage2p_t<fp8_t>(a, st);
-  if (prec == BTSBOT_F16X2) return launch_stage2p_t<f16x2_t>(a, st);
+  if (prec == BTSBOT_FP8)
+    return g7 ? launch_stage2p_t<fp8_t, 7>(a, st) : g5 ? launch_stage2p_t<fp8_t, 5>(a, st) : launch_stage2p_t<fp8_t>(a, st);
+  // (split mode: the doubled planes of 7 alerts do not fit the LDS: 5 wherever more than 4 were chosen)
+  if (prec == BTSBOT_F16X2) return gsel == 4 ? launch_stage2p_t<f16x2_t>(a, st) : launch_stage2p_t<f16x2_t, 5>(a, st);
   btsbot_set_error("stage2p: unsupported precision %d", prec);
   return BTSBOT_ERR_INVALID_ARG;
 }
