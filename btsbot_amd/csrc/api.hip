@@ -339,6 +339,11 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
+    // (opt-in: measured 252-259 us per launch with its 360 MB of kept rows against 100 us for the inference form -- the
+    //  same as the per-op launches it replaces)
+    const char* nst = getenv("BTSBOT_AMD_S2P_TRAIN");
+    h->s2p_train = h->stage2p && h->use_s2p && !h->x2 && !h->fp8 &&
+                   (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nst != nullptr && nst[0] == '1';
     const char* ns16 = getenv("BTSBOT_AMD_NO_STEM16");
     h->use_stem16 = !(ns16 != nullptr && ns16[0] == '1');
     const char* det = getenv("BTSBOT_AMD_DETERMINISTIC");
@@ -520,7 +525,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (!train_only)
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
-        if (i == 2 && h->stage2p && !train_only) {
+        if (i == 2 && h->stage2p && (!train_only || h->s2p_train)) {
           float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, sc, st));
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, sc + 2, st));
@@ -558,7 +563,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   }
   if (convnext && h->stage1 && !train_only)
     TRY(launch_pack_frag32(h->prec_s01(), m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
-  if (convnext && h->stage2p && !train_only)
+  if (convnext && h->stage2p && (!train_only || h->s2p_train))
     TRY(launch_pack_s2p(h->prec_down3(), m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], nullptr, st));
   if (h->head16 && !train_only) {

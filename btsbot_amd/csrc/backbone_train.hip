@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "ctx.h"
+#include "stage2p.h"
 
 namespace {
 
@@ -154,7 +155,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0) {
+    if (i > 0 && !(i == 3 && h->s2p_train)) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
@@ -162,6 +163,44 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
                        m + h->down[i].b, nullptr, nullptr, stage_in(i), rows, ch, 4 * cin, st));
     }
     const size_t nblk = h->blocks[i].size();
+    if (i == 2 && h->s2p_train) {
+      // Stage 2 and the last downsample as ONE launch: the inference kernel's keeping form (stage2p.hip, TRAIN) writes
+      // what the backward reads -- every block's input, depthwise output, LayerNorm output, fc1 pre-activation and GELU,
+      // the stage output, the downsample's patch rows -- on its way.  Replaces 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM.
+      Stage2pArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x_in = stage_in(2);
+      a.depth = (int)nblk;
+      for (size_t j = 0; j < nblk; ++j) {
+        const BlockPk& b = h->blocks[2][j];
+        const BlkBuf& sb = k.blk[2][j];
+        a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+        a.blk[j].dw_b = m + b.dw_b;
+        a.blk[j].ln_w = m + b.ln_w;
+        a.blk[j].ln_b = m + b.ln_b;
+        a.blk[j].b1 = m + b.fc1_b;
+        a.blk[j].b2 = m + b.fc2_b;
+        a.blk[j].gamma = m + b.gamma;
+        a.blk[j].w1p = h->extra + b.p_w1p;
+        a.blk[j].w2p = h->extra + b.p_w2p;
+        a.keep[j].xin = j == 0 ? nullptr : sb.xin;
+        a.keep[j].d = sb.d;
+        a.keep[j].xn = sb.xn;
+        a.keep[j].a = sb.a;
+        a.keep[j].hh = sb.h;
+      }
+      a.ds_lnw = m + h->down[3].ln_w;
+      a.ds_lnb = m + h->down[3].ln_b;
+      a.ds_wp = h->extra + h->down[3].p_wp;
+      a.ds_b = m + h->down[3].b;
+      a.out = stage_in(3);
+      a.tap_stage = k.xs[2];
+      a.ds_patches = k.patches[3];
+      a.B = B;
+      a.train = 1;
+      TRYB(launch_stage2p(c.precision, a, st));
+      continue;
+    }
     for (size_t j = 0; j < nblk; ++j) {
       const BlockPk& b = h->blocks[i][j];
       const BlkBuf& s = k.blk[i][j];

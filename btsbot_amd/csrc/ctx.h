@@ -131,6 +131,8 @@ struct btsbot_ctx {
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
+  bool s2p_train = false;            // the training forward of stage 2 runs stage2p_kernel's keeping form (16-bit modes;
+                                     // BTSBOT_AMD_S2P_TRAIN=1 turns it on: no faster than the per-op launches)
   bool use_stem16 = true;            // BTSBOT_AMD_NO_STEM16=1: the fp32 VALU stem in the 16-bit modes too (A/B, parity)
   bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
   float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)

@@ -59,6 +59,7 @@ template <typename T> struct MP16 {
   template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
     *reinterpret_cast<quad*>(p) = pack4(v);
   }
+  static __device__ __forceinline__ float roundtrip(float v) { return (float)(T)v; }
   static __device__ __forceinline__ frag pack8(const float (&v)[8]) {
     frag o;
 #pragma unroll
@@ -114,6 +115,7 @@ template <> struct MP<f16x2_t> {
     *reinterpret_cast<f16x4v*>(p) = o.hi;
     *reinterpret_cast<f16x4v*>(p + PLANE) = o.lo;
   }
+  static __device__ __forceinline__ float roundtrip(float v) { return v; }   // (no training form)
   static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
@@ -155,6 +157,7 @@ template <> struct MP<fp8_t> {
   template <int PLANE> static __device__ __forceinline__ void st4(unsigned char* p, const float (&v)[4]) {
     *reinterpret_cast<quad*>(p) = pack4(v);
   }
+  static __device__ __forceinline__ float roundtrip(float v) { return v; }   // (no training form)
   static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
   }
@@ -193,6 +196,9 @@ template <typename T, int G> struct Lds {
   static constexpr int OFF_H = OFF_XN + NPL * XN_PLANE;
   static constexpr int OFF_B1 = OFF_H + 2 * H_IMG;            // fc1 bias [1024] f32
   static constexpr int BYTES = OFF_B1 + HID * 4;              // G = 4: 104704 (split: 160768); G = 7: 141312
+  // training forward: two more hidden-sized images (the fc1 pre-activation of a chunk, kept for the backward)
+  static constexpr int OFF_A = BYTES;
+  static constexpr int BYTES_TRAIN = BYTES + 2 * H_IMG;
 };
 static_assert(Lds<f16x2_t, 4>::BYTES <= 160 * 1024 && Lds<bf16_t, 7>::BYTES <= 160 * 1024, "the images fit one CU");
 constexpr float LN_EPS = 1e-6f;
@@ -209,7 +215,7 @@ __device__ __forceinline__ float half_sum(float v) {
   return v + w;
 }
 
-template <typename T, int G>
+template <typename T, int G, bool TRAIN = false>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
   constexpr int KSTEP = MP<T>::KSTEP, VPL = KSTEP / 4, KS1 = C / KSTEP, KS2 = CHUNK / KSTEP, KH = HID / KSTEP;
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   unsigned char* xn = smem + OFF_XN;
   unsigned char* hb = smem + Lds<T, G>::OFF_H;   // two hidden images, H_IMG bytes apart
   float* b1s = reinterpret_cast<float*>(smem + Lds<T, G>::OFF_B1);
+  unsigned char* ab = smem + Lds<T, G>::OFF_A;   // (training forward) two pre-activation images, H_IMG bytes apart
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
@@ -309,6 +316,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       for (int n = 0; n < NB; ++n) {
         const int p = 16 * n + col;
         if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
+        if (TRAIN && a.keep[j].xin != nullptr && p < nlive)
+          *reinterpret_cast<f32x4*>(a.keep[j].xin + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
       }
     }
     __syncthreads();
@@ -342,6 +351,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     b1s[tid + NT] = b1b;
     __syncthreads();
     S2P_STAMP(3 + 8 * j);
+    if (TRAIN) {   // the depthwise output before the LayerNorm (it stays in xl until the next block's map)
+      float* dst = a.keep[j].d + (size_t)alert0 * 9 * C;
+      for (int i = tid; i < nlive * (C / 4); i += NT) {
+        const int p = i / (C / 4), c4 = i - p * (C / 4);
+        *reinterpret_cast<f32x4*>(dst + (size_t)p * C + 4 * c4) = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * c4);
+      }
+    }
     // ---- LayerNorm over the 256 channels of a pixel: half wave = pixel, lane = 8 channels
     for (int p = 2 * wave + (lane >> 5); p < NPX; p += 2 * NW) {
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31));
@@ -361,6 +377,14 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
+    if (TRAIN) {   // the LayerNorm output rows (16-byte pieces: C * ESZ / 16 per row)
+      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep[j].xn) + (size_t)alert0 * 9 * C * ESZ;
+      constexpr int PPR = C * ESZ / 16;
+      for (int i = tid; i < nlive * PPR; i += NT) {
+        const int p = i / PPR, c = i - p * PPR;
+        *reinterpret_cast<uint4*>(dst + (size_t)p * C * ESZ + 16 * c) = *reinterpret_cast<const uint4*>(xn + p * XNP + 16 * c);
+      }
+    }
     frag xr[XRES > 0 ? XRES : 1][NB];
 #pragma unroll
     for (int s = 0; s < XRES; ++s)
@@ -390,9 +414,23 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // P = which of the two hidden images this chunk writes (the other one holds chunk ch - 1's).
     // The next chunk's 16 fragment loads are spread over the k-steps: issued in one burst they hold every wave at the
     // CU's one vector-memory port for ~2k cycles before its first product.
+    // training forward: rows of chunk `kc`'s two images (pre-activation, GELU) -> the kept [row][1024] arrays
+    auto keep_chunk = [&](int kc, int img) {
+      constexpr int PPR = CHUNK * ESZ / 16;   // 16-byte pieces per pixel row of a chunk
+      unsigned char* da = reinterpret_cast<unsigned char*>(a.keep[j].a) + ((size_t)alert0 * 9 * HID + (size_t)kc * CHUNK) * ESZ;
+      unsigned char* dh = reinterpret_cast<unsigned char*>(a.keep[j].hh) + ((size_t)alert0 * 9 * HID + (size_t)kc * CHUNK) * ESZ;
+      for (int i = tid; i < nlive * PPR; i += NT) {
+        const int pr = i / PPR, c = i - pr * PPR;
+        *reinterpret_cast<uint4*>(da + (size_t)pr * HID * ESZ + 16 * c) =
+            *reinterpret_cast<const uint4*>(ab + img * H_IMG + pr * HP + 16 * c);
+        *reinterpret_cast<uint4*>(dh + (size_t)pr * HID * ESZ + 16 * c) =
+            *reinterpret_cast<const uint4*>(hb + img * H_IMG + pr * HP + 16 * c);
+      }
+    };
     auto step = [&](auto P, auto FIRST, int ch) {
       constexpr int p = decltype(P)::value;
       constexpr bool first = decltype(FIRST)::value;
+
       // (after the stage's last chunk the fc1 loads below re-read this block's first chunk: an unconditional load
       //  keeps the k-step loops free of branches -- hipcc waits vmcnt(0) behind every conditional load)
       const Stage2pBlk& nb = ch + 1 < NCHUNK ? bk : a.blk[j + 1 < a.depth ? j + 1 : j];
@@ -437,6 +475,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         a1[s] = MP<T>::gld(src1, f1 + s, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // (training forward) chunk ch - 1's images are complete and live through this step: their rows leave behind the
+      // fc1 products' issue, under their execution
+      if (TRAIN && !first) keep_chunk(ch - 1, 1 - p);
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
       // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
       unsigned char* hcur = hb + p * H_IMG;
@@ -475,8 +516,19 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         }
         if (s < NB) {
           float hv[4];
+          if (TRAIN) {
+            // the backward differentiates GELU at the ROUNDED pre-activation (as gemm2.hip's GELU_SAVE epilogue does)
+            float av[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = gelu_for<typename GeluOf2<T>::type>(F8 ? hacc[s][r] * is1 : hacc[s][r]);
+            for (int r = 0; r < 4; ++r) {
+              av[r] = MP<T>::roundtrip(hacc[s][r]);
+              hv[r] = gelu_for<typename GeluOf2<T>::type>(av[r]);
+            }
+            MP<T>::template st4<H_PLANE>(ab + p * H_IMG + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ, av);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = gelu_for<typename GeluOf2<T>::type>(F8 ? hacc[s][r] * is1 : hacc[s][r]);
+          }
           MP<T>::template st4<H_PLANE>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ, hv);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -486,6 +538,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // the fc2 half of a step of its own: the block's last chunk (the residual must be complete before the next
     // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 0
     auto fc2_tail = [&]() {
+      if (TRAIN) keep_chunk(NCHUNK - 1, 1);
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const void* src2 = nb.w2p;
       const size_t f2 = (size_t)(2 * wave) * KH;
@@ -580,6 +633,16 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
   }
   __syncthreads();
+  if (TRAIN) {   // the downsample's patch rows [alert][q = 2 ky + kx][256] = LayerNorm'd pixels 3 ky + kx
+    constexpr int PPR = C * MP<TD>::ESZ / 16;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(a.ds_patches) + (size_t)alert0 * 4 * C * MP<TD>::ESZ;
+    const int nal = nlive / 9;
+    for (int i = tid; i < nal * 4 * PPR; i += NT) {
+      const int r = i / PPR, c = i - r * PPR, al2 = r >> 2, q = r & 3;
+      *reinterpret_cast<uint4*>(dst + (size_t)r * C * MP<TD>::ESZ + 16 * c) =
+          *reinterpret_cast<const uint4*>(xn + (9 * al2 + 3 * (q >> 1) + (q & 1)) * XND + 16 * c);
+    }
+  }
   {
     S2P_STAMP(57);
     // out[alert][co] = b[co] + sum_k Wd[co][k] patch[alert][k],  k = (2 ky + kx) * 256 + c  ->  pixel 3 ky + kx.
@@ -686,15 +749,15 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
       (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
-template <typename T, int G = S2P_ALERTS> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
-  auto kern = stage2p_kernel<T, G>;
+template <typename T, int G = S2P_ALERTS, bool TRAIN = false> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+  auto kern = stage2p_kernel<T, G, TRAIN>;
+  constexpr int lds_bytes = TRAIN ? Lds<T, G>::BYTES_TRAIN : Lds<T, G>::BYTES;
+  static_assert(lds_bytes <= 160 * 1024, "the images fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Lds<T, G>::BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  constexpr int lds_bytes = Lds<T, G>::BYTES;   // (a comma inside the launch macro's arguments would split them)
   hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), lds_bytes, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
@@ -760,6 +823,23 @@ int stage2p_alerts_per_workgroup(int B, int hint) {
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
+  if (a.train) {   // the training forward: 16-bit modes, 4 or 5 alerts per workgroup (7 would not leave room for its images)
+    for (int j = 0; j < a.depth; ++j)
+      if (a.keep[j].d == nullptr || a.keep[j].xn == nullptr || a.keep[j].a == nullptr || a.keep[j].hh == nullptr ||
+          (j > 0 && a.keep[j].xin == nullptr)) {
+        btsbot_set_error("stage2p: the training forward needs every kept buffer of block %d", j);
+        return BTSBOT_ERR_INVALID_ARG;
+      }
+    if (a.ds_patches == nullptr || a.tap_stage == nullptr) {
+      btsbot_set_error("stage2p: the training forward needs ds_patches and the stage output (tap_stage)");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    const bool g4 = stage2p_alerts_per_workgroup(a.B, a.alerts_hint) == 4;
+    if (prec == BTSBOT_BF16) return g4 ? launch_stage2p_t<bf16_t, 4, true>(a, st) : launch_stage2p_t<bf16_t, 5, true>(a, st);
+    if (prec == BTSBOT_F16) return g4 ? launch_stage2p_t<f16_t, 4, true>(a, st) : launch_stage2p_t<f16_t, 5, true>(a, st);
+    btsbot_set_error("stage2p: the training forward runs in the bf16 / f16 modes, not %d", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   const int gsel = stage2p_alerts_per_workgroup(a.B, a.alerts_hint);
   const bool g7 = gsel == 7, g5 = gsel == 5;
   if (prec == BTSBOT_BF16)
