@@ -761,7 +761,13 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
 template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
   auto kern = stage0b_kernel<T, X2, WPS>;
   static bool attr_set = false;
-  constexpr int LDS_BYTES = S0L<X2>::LDS_BYTES;
+  // (BTSBOT_AMD_S0_ONE_WG=1: developer probe -- the LDS request padded so that ONE workgroup fits a CU: how the kernel's
+  //  time scales from one to two waves per SIMD says what two more would buy)
+  static const int pad = [] {
+    const char* e = getenv("BTSBOT_AMD_S0_ONE_WG");
+    return e != nullptr && e[0] == '1' && !X2 ? 90 * 1024 - S0L<X2>::LDS_BYTES : 0;
+  }();
+  const int LDS_BYTES = S0L<X2>::LDS_BYTES + pad;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
