@@ -24,7 +24,7 @@ def agg(path, name):
 
 
 def family(k):
-    m = re.search(r"\d+([a-z_0-9]+_kernel)", k)
+    m = re.search(r"(?:::|N_1\d+?)([a-z][a-z_0-9]*_kernel)", k)   # mangled (N_1<len>name) or demangled (::name<...>) symbols
     return m.group(1) if m else k.split("(")[0][:40]
 
 
