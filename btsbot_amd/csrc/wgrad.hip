@@ -248,6 +248,61 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceJobs a) {
   if (live) J.out[(size_t)n * J.ldo + k] += tot;
 }
 
+// The same sum, laid out for the memory system: a workgroup owns 128 consecutive floats of the partial-tile layout
+// (512 bytes of every slice) and its eight 32-lane groups walk the slices s = group, group + 8, ... with 16-byte loads,
+// four independent accumulators each, and meet in LDS in a fixed order.  (The one-thread-per-output walk above moved
+// 0.5-1.8 TB/s over 33-134 MB of partials per launch -- 73-110 us behind stage 0's fused MLP backward.)
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(ReduceJobs a) {
+  const bool second = (int)blockIdx.x >= a.nblk0;
+  const WgradReduceJob& J = a.j[second ? 1 : 0];
+  const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const size_t tile = (size_t)J.TN * J.TK, per_slice = (size_t)J.gx * J.gy * tile;
+  const size_t e = ((size_t)((int)blockIdx.x - (second ? a.nblk0 : 0)) * 32 + q) * 4;   // first of this thread's 4 floats
+  const bool inside = e < per_slice;
+  const int t = inside ? (int)(e / tile) : 0;
+  const int r = inside ? (int)(e - (size_t)t * tile) : 0;
+  const int nl = r / J.TK, kl = r - nl * J.TK;
+  const int tx = t % J.gx, ty = t / J.gx;
+  const int n = tx * J.TN + nl, k = ty * J.TK + kl;
+  const bool live = inside && n < J.N && k < J.K;    // (K is a multiple of 4: the four floats are live together)
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto add = [](float4& d, const float4 v) {
+    d.x += v.x;
+    d.y += v.y;
+    d.z += v.z;
+    d.w += v.w;
+  };
+  if (live) {
+    const float* p = J.part + e;
+    int s = sg;
+    for (; s + 24 < J.nsl; s += 32) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * per_slice);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 8) * per_slice);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(s + 16) * per_slice);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(s + 24) * per_slice);
+      add(s0, v0);
+      add(s1, v1);
+      add(s2, v2);
+      add(s3, v3);
+    }
+    for (; s < J.nsl; s += 8) add(s0, *reinterpret_cast<const float4*>(p + (size_t)s * per_slice));
+  }
+  add(s0, s1);
+  add(s2, s3);
+  add(s0, s2);
+  __shared__ float4 sh[8][32];
+  sh[sg][q] = s0;
+  __syncthreads();
+  if (sg != 0 || !live) return;
+  float4 tot = sh[0][q];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) add(tot, sh[g][q]);
+  float4* o = reinterpret_cast<float4*>(J.out + (size_t)n * J.ldo + k);
+  float4 cur = *o;
+  add(cur, tot);
+  *o = cur;
+}
+
 template <typename T, int TN, int TK>
 int wgrad2_launch(const void* D, const void* A, float* out, float* colsum, int M, int N, int K,
                   int ldo, hipStream_t st, float* part, size_t part_floats, WgradReduceJob* defer) {
@@ -319,6 +374,25 @@ int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st) {
     }
   if (n == 0) return BTSBOT_OK;
   if (n == 1) a.j[1] = a.j[0];
+  {
+    // the 16-byte form wherever the outputs allow it (every arena tensor does: 16-byte aligned, K a multiple of 4)
+    static const bool old_form = [] {
+      const char* e = getenv("BTSBOT_AMD_WGRAD_REDUCE1");   // 1: the one-thread-per-output kernels (A/B)
+      return e != nullptr && e[0] == '1';
+    }();
+    bool ok = !old_form;
+    for (int i = 0; i < n; ++i)
+      ok = ok && (a.j[i].K % 4 == 0) && (a.j[i].TK % 4 == 0) && (a.j[i].ldo % 4 == 0) &&
+           (((uintptr_t)a.j[i].out & 15) == 0) && (((uintptr_t)a.j[i].part & 15) == 0);
+    if (ok) {
+      auto nb = [](const WgradReduceJob& j) { return (int)(((size_t)j.gx * j.gy * j.TN * j.TK + 127) / 128); };
+      a.nblk0 = nb(a.j[0]);
+      const int total = a.nblk0 + (n > 1 ? nb(a.j[1]) : 0);
+      hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(total), dim3(256), 0, st, a);
+      LAUNCH_CHECK();
+      return BTSBOT_OK;
+    }
+  }
   // many slices per output (the stem's 64 x 48 filter over ~400 slices; mlp_bwd_kernel's 256 workgroup partials of a
   // block's two 64 x 256 filter gradients: one thread per output walked 256 dependent-latency loads, 76-118 us next to
   // the chain's kernels): four or eight slice groups per output

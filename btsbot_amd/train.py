@@ -49,6 +49,9 @@ def lr_schedule(lr: float, epochs: int, warmup_epochs: int) -> Sequence[float]:
     return out
 
 
+_EAGER_REPACK = os.environ.get("BTSBOT_AMD_EAGER_REPACK", "1") != "0"
+
+
 class Trainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, pos_weight: float = 1.0, epochs: int = 1,
@@ -170,6 +173,12 @@ class Trainer:
                         self.betas[0], self.betas[1], self.eps, self.wd, self.t, st),
                         "btsbot_adamw_step")
             m.mark_weights_dirty()
+            if _EAGER_REPACK and self.need_image:
+                # the operand images of the NEXT step, queued now: the library packs them on its side stream, under the
+                # next step's mask draws and stem instead of in front of its first consumer (BTSBOT_AMD_EAGER_REPACK=0: A/B)
+                if getattr(m, "_reserved_image", False):
+                    with torch.cuda.device(dev):
+                        m._prepare(dev, grads.numel() and self.last_logits.numel(), train_only=True)
         return loss
 
 
