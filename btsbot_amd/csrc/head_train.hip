@@ -65,6 +65,29 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ 
   outa[(size_t)m * ldo + n] = v;
 }
 
+// outa[m*ldo + n] = dropout(act(pre[m][n]))      (behind the MFMA GEMM that wrote `pre` for a wide layer)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ pre, float* __restrict__ outa, int ldo,
+                                                      int M, int N, int act, const uint8_t* __restrict__ mask,
+                                                      float keep_scale) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * N) return;
+  const int m = idx / N, n = idx - m * N;
+  float v = act_fwd(pre[idx], act);
+  if (mask != nullptr) v = mask[idx] ? v * keep_scale : 0.f;
+  outa[(size_t)m * ldo + n] = v;
+}
+
+// A fusion layer wide enough for the matrix pipe (the 1024 x 640 x 128 first layer: 42 us forward, 28 us input gradient
+// as one thread per output walking K) goes through gemm.hip's exact-fp32 MFMA GEMM: both operands are K-contiguous as
+// stored ([N][K] filter for the forward, the packed transpose [K][N] for the input gradient).
+static bool wide_layer(int M, int N, int K, int ldi) {
+  static const bool off = [] {
+    const char* e = getenv("BTSBOT_AMD_HEAD_NO_GEMM");   // 1: every head layer on the per-output kernels (A/B)
+    return e != nullptr && e[0] == '1';
+  }();
+  return !off && ldi == K && K % 4 == 0 && N % 4 == 0 && (long)M * N * K >= (1L << 24);
+}
+
 // dpre[m][n] = dout[m*ldd + n] * act'(pre[m][n]) * mask * keep_scale     (in place allowed)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, int ldd,
                                                       const float* __restrict__ pre, float* dpre,
@@ -421,10 +444,17 @@ int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* lo
     const bool last = i + 1 == h->n_comb;
     // Dropout sits after the activation of the layer BEFORE the final Linear (architectures.py:162)
     const bool drop = !last && i + 2 == h->n_comb && c.comb_dropout > 0.f;
-    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * N), dim3(256), 0, st, in, ldi,
-                       reinterpret_cast<const float*>(h->extra + h->p_comb[i]), m + h->comb_b[i],
-                       p.pre[i], p.actv[i], N, M, N, K, last ? ACT_NONE : h->act,
-                       drop ? comb_mask : nullptr, ksc);
+    if (wide_layer(M, N, K, ldi)) {
+      TRY_RET(launch_gemm(BTSBOT_F32, EPI_BIAS, in, m + h->comb_w[i], m + h->comb_b[i], nullptr, nullptr, p.pre[i], M, N,
+                          K, st));
+      hipLaunchKernelGGL(act_fwd_kernel, g1((long)M * N), dim3(256), 0, st, p.pre[i], p.actv[i], N, M, N,
+                         last ? ACT_NONE : h->act, drop ? comb_mask : nullptr, ksc);
+    } else {
+      hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * N), dim3(256), 0, st, in, ldi,
+                         reinterpret_cast<const float*>(h->extra + h->p_comb[i]), m + h->comb_b[i],
+                         p.pre[i], p.actv[i], N, M, N, K, last ? ACT_NONE : h->act,
+                         drop ? comb_mask : nullptr, ksc);
+    }
     LAUNCH_CHECK();
     in = p.actv[i];
     ldi = N;
@@ -456,8 +486,13 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
     const int N = h->comb_dims[i + 1], K = h->comb_dims[i];
     if (i == 0 && !want_dz) break;
     float* din = p.dbuf[i];
-    hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dout[i], m + h->comb_w[i],
-                       din, K, M, N, K);
+    if (wide_layer(M, K, N, N)) {   // din[m][k] = sum_n dout[m][n] Wt[k][n]
+      TRY_RET(launch_gemm(BTSBOT_F32, EPI_PLAIN, dout[i], h->extra + h->p_comb[i], nullptr, nullptr, nullptr, din, M, K,
+                          N, st));
+    } else {
+      hipLaunchKernelGGL(lin_bwd_in_kernel, g1((long)M * K), dim3(256), 0, st, dout[i], m + h->comb_w[i],
+                         din, K, M, N, K);
+    }
     LAUNCH_CHECK();
     if (i > 0) {   // through dropout + activation of layer i-1
       const bool drop = i + 1 == h->n_comb && c.comb_dropout > 0.f;
