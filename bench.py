@@ -543,14 +543,15 @@ def dev_of(t):
     return t.device
 
 
-def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None):
+def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None, batch=None):
     """BASELINE.json configs[2]: the training step of mm_ConvNeXt, every parameter trainable."""
     from btsbot_amd.train import Trainer
     import copy
-    if precision is not None:
+    if precision is not None or batch is not None:
         args = copy.copy(args)
-        args.precision = precision
+        args.precision = precision or args.precision
         args.train_steps = steps or args.train_steps
+        args.train_batch = batch or args.train_batch
     tcfg = dict(CONFIG, meta_dropout=0.25, comb_dropout=0.2)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -777,6 +778,9 @@ def main():
     if args.train_steps > 0:
         try:
             train = train_leg(dev, rank, world, dist, fence, args)
+            hk = depthwise_norm_hbm(args)
+            if hk is not None:
+                train["depthwise_norm_hbm"] = hk
         except Exception as e:   # noqa: BLE001
             train = {"error": f"{type(e).__name__}: {e}"}
         if args.precision != "f32" and not args.no_extra_legs:
@@ -790,6 +794,17 @@ def main():
             except Exception as e:   # noqa: BLE001
                 if isinstance(train, dict):
                     train["f32"] = {"error": f"{type(e).__name__}: {e}"}
+            # the same step on 4 x the alerts per GPU: at 1024 alerts stages 2-3 (9216 / 1024 pixel rows) and the ~260
+            # launches of a step leave the chip partly idle; what a user who is free to choose the batch gets
+            try:
+                big = train_leg(dev, rank, world, dist, fence, args, steps=max(3, args.train_steps // 4),
+                                batch=4 * args.train_batch)
+                big.pop("roofline", None)
+                if isinstance(train, dict):
+                    train["batch_x4"] = big
+            except Exception as e:   # noqa: BLE001
+                if isinstance(train, dict):
+                    train["batch_x4"] = {"error": f"{type(e).__name__}: {e}"}
     maxvit = None
     if args.maxvit_steps > 0:
         try:
@@ -944,6 +959,21 @@ def pmc_traffic(kernel, args):
         return None
     return {"bytes_per_launch": hits[0]["traffic_bytes"], "source": "profiles/" + os.path.basename(f),
             "measured_in_this_run": False}
+
+
+def depthwise_norm_hbm(args):
+    """Achieved HBM GB/s of the depthwise / normalisation kernels of the training step against the 8 TB/s peak, from
+    the newest committed summary (profiles/r*_depthwise_norm_hbm.json, tools/hbm_kernels.py: PMC bytes per launch over
+    the kernel trace's average launch duration, same workload).  Not measured in this run; tagged with its file."""
+    if args.precision != "bf16" or args.train_batch != 1024:
+        return None
+    f = _newest_profile("r*_depthwise_norm_hbm.json")
+    if f is None:
+        return None
+    with open(f) as fh:
+        d = json.load(fh)
+    return {"bound": "hbm", "peak": d["peak_gbs"], "unit": "GB/s", "kernels": d["kernels"],
+            "source": "profiles/" + os.path.basename(f), "measured_in_this_run": False}
 
 
 def pmc_mfma_busy(kernel, args):

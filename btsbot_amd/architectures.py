@@ -320,15 +320,30 @@ class _HipModel(nn.Module):
         the ones a test planted in ``_forced_masks``)."""
         forced = getattr(self, "_forced_masks", None)
         a = self._cfg_args
+        layers = (("meta", a["meta_fc1"], a["meta_dropout"]), ("comb", a["comb_fc2"], a["comb_dropout"]))
+        drawn = [(n, w, p) for n, w, p in layers if w > 0 and p > 0.0 and not (forced is not None and n in forced)]
+        fresh = {}
+        if drawn:
+            # both masks from ONE draw and ONE compare (two launches instead of six small ones in front of every step):
+            # the thresholds of the layers side by side in a cached vector, the bool result viewed as bytes
+            key = (batch, str(dev), tuple(drawn))
+            cache = getattr(self, "_mask_thr", None)
+            if cache is None or cache[0] != key:
+                thr = torch.cat([torch.full((batch * w,), float(p), dtype=torch.float32) for _n, w, p in drawn]).to(dev)
+                self._mask_thr = cache = (key, thr)
+            keep = torch.rand(cache[1].numel(), device=dev, generator=generator) >= cache[1]
+            off = 0
+            for n, w, _p in drawn:
+                fresh[n] = keep[off:off + batch * w].view(batch, w).view(torch.uint8)
+                off += batch * w
         out = []
-        for name, width, p in (("meta", a["meta_fc1"], a["meta_dropout"]),
-                               ("comb", a["comb_fc2"], a["comb_dropout"])):
+        for name, width, p in layers:
             if width <= 0 or p <= 0.0:
                 out.append(None)
             elif forced is not None and name in forced:
                 out.append(forced[name].to(device=dev, dtype=torch.uint8).contiguous())
             else:
-                out.append((torch.rand(batch, width, device=dev, generator=generator) >= p).to(torch.uint8))
+                out.append(fresh[name])
         return out
 
     def _run_train(self, image, meta):

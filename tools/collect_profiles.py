@@ -55,6 +55,9 @@ if glob.glob("gpurun_out/final/pmc_fetch_train/*/*_counter_collection.csv"):   #
     import subprocess
     subprocess.run([sys.executable, "tools/train_traffic.py", "gpurun_out/final/pmc_fetch_train", "gpurun_out/final/pmc_write_train",
                     f"profiles/{tag}_pmc_traffic_train.json"], check=True)
+if os.path.exists(f"profiles/{tag}_pmc_traffic_train.json") and os.path.exists(f"profiles/{tag}_kernel_stats_train_bf16_b1024.csv"):
+    import subprocess
+    subprocess.run([sys.executable, "tools/hbm_kernels.py", tag], check=True, stdout=subprocess.DEVNULL)
 for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt")):   # tools/nano_bench.py; train step default vs
     if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
         shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")
