@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32", "fp8", "f16x2"])
     ap.add_argument("--batch", type=int, default=1024, help="alerts per GPU per step")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="batches in flight on alternating HIP streams in the timed loop (btsbot_amd.ScoreStream); "
                          "1 = plain model(...) calls on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -742,7 +742,8 @@ def main():
                     m8 = btsbot_amd.mm_ConvNeXt(CONFIG, precision="fp8")
                 seeded_weights(m8)
                 m8 = m8.to(dev).eval()
-                sc8 = btsbot_amd.ScoreStream(m8, depth=2, inputs_ready=True)
+                d8 = max(2, args.pipeline_depth)
+                sc8 = btsbot_amd.ScoreStream(m8, depth=d8, inputs_ready=True)
 
                 def run8(n):
                     o = None
@@ -755,7 +756,7 @@ def main():
                 legs["fp8_batch8192"] = dict(
                     value=round(8192 * world * n8 / e8, 1), unit="alerts/s", steps=n8, ms_per_step=round(1e3 * e8 / n8, 4),
                     workload="BASELINE.json configs[4]: mm_ConvNeXt-pico, fp8 MFMA in stages 2-3, 8192 synthetic alerts per "
-                             "call, two calls in flight (ScoreStream)")
+                             f"call, {d8} calls in flight (ScoreStream)")
 
                 def run8_plain(n):
                     with torch.no_grad():

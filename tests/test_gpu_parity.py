@@ -497,8 +497,8 @@ def test_maxvit_alternative_kernels_match_oracle(cuda, monkeypatch, env, prec):
 
 
 def test_score_stream_matches_plain_calls(cuda):
-    """btsbot_amd.ScoreStream keeps two batches in flight on two HIP streams (own replica each): same logits, in
-    order, as plain model(...) calls, also for ragged batch sizes and an odd number of batches."""
+    """btsbot_amd.ScoreStream keeps two / three batches in flight on as many HIP streams (own replica each): same
+    logits, in order, as plain model(...) calls, also for ragged batch sizes and a batch count the depth does not divide."""
     import btsbot_amd
     kind, cfg = CONFIGS["mm_pico"]
     m = build_model(kind, cfg, seeded_state(kind, cfg, seed=3), cuda, "bf16")
@@ -508,13 +508,13 @@ def test_score_stream_matches_plain_calls(cuda):
         batches.append((img.to(cuda), meta.to(cuda)))
     with torch.no_grad():
         ref = [m(image_input=a, metadata_input=b).clone() for a, b in batches]
-    scorer = btsbot_amd.ScoreStream(m, depth=2)
-    for _ in range(2):                                   # the second round reuses the streams and replicas
-        outs = list(scorer.map(batches))
-        torch.cuda.synchronize()
-        assert len(outs) == len(ref)
-        for o, r in zip(outs, ref):
-            assert o.shape == r.shape and torch.equal(o, r)
+    for scorer in (btsbot_amd.ScoreStream(m, depth=2), btsbot_amd.ScoreStream(m)):   # (the default: three in flight)
+        for _ in range(2):                               # the second round reuses the streams and replicas
+            outs = list(scorer.map(batches))
+            torch.cuda.synchronize()
+            assert len(outs) == len(ref)
+            for o, r in zip(outs, ref):
+                assert o.shape == r.shape and torch.equal(o, r)
     with pytest.raises(RuntimeError):
         btsbot_amd.ScoreStream(m.train(), depth=2)
     # a frozen_fusion replica takes its branches from the state dict, not from the checkpoint files
