@@ -35,3 +35,16 @@ print(f"{kind} B={B} {prec}: {dt*1e3:.3f} ms/step  {B/dt:.0f} alerts/s  finite={
 for k, (ms, cnt) in sorted(prof.items(), key=lambda x: -x[1][0]):
     if cnt:
         print(f"  {k:28s} {cnt:3d} launches {ms*1e3:8.1f} us")
+# the same model through the streaming scorer (three batches in flight)
+sc = btsbot_amd.ScoreStream(m, inputs_ready=True)
+n = 60
+for _ in range(2):
+    for o in sc.map(((img, meta) for _ in range(n)), lag=n):
+        pass
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
+for o in sc.map(((img, meta) for _ in range(n)), lag=n):
+    pass
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"  ScoreStream(depth=3): {dt*1e3:.3f} ms/batch  {B/dt:.0f} alerts/s")
