@@ -178,7 +178,7 @@ class Trainer:
                 # next step's mask draws and stem instead of in front of its first consumer (BTSBOT_AMD_EAGER_REPACK=0: A/B)
                 if getattr(m, "_reserved_image", False):
                     with torch.cuda.device(dev):
-                        m._prepare(dev, grads.numel() and self.last_logits.numel(), train_only=True)
+                        m._prepare(dev, int(self.last_logits.numel()), train_only=True)   # (one logit per alert)
         return loss
 
 
