@@ -49,6 +49,25 @@ def test_op_dwconv_ln(cuda, prec, hw, c):
     assert _rel(out.cpu(), ref) <= TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("c", [64, 80])
+def test_op_dwconv_ln_15x15_at_the_full_batch(cuda, prec, c):
+    """BASELINE.json's batch (1024 alerts; an odd count too: C = 80 runs two alerts per workgroup): the matrix-pipe
+    depthwise + LayerNorm of the 15x15 maps (dw15.hip) against the fp32 per-tap kernel on the same device tensors --
+    every alert, not only the first workgroups'."""
+    g = torch.Generator().manual_seed(c)
+    for B in (1024, 1023):
+        x = torch.randn(B, 15, 15, c, generator=g).to(cuda)
+        w = (torch.randn(c, 1, 7, 7, generator=g) / 7.0).to(cuda)
+        b, lw, lb = (0.1 * torch.randn(c, generator=g).to(cuda) for _ in range(3))
+        lw = lw + 1.0
+        ref = ops.dwconv_ln(x, w, b, lw, lb, precision="f32")
+        out = ops.dwconv_ln(x, w, b, lw, lb, precision=prec)
+        assert out.dtype == DT[prec] and out.shape == ref.shape
+        err = (out.float() - ref).abs().amax(dim=(1, 2, 3)) / ref.abs().amax()
+        assert float(err.max()) <= TOL[prec], (B, int(err.argmax()), float(err.max()))
+
+
 @pytest.mark.parametrize("c0", [64, 80])
 def test_op_stem(cuda, c0):
     g = torch.Generator().manual_seed(c0)
