@@ -262,10 +262,10 @@ int launch_stem(const float* img, const float* w48xC, const float* bias, const f
 // the same on the matrix pipe for the 16-bit modes (stem16.hip): w is the fp32 filter [C0][48], converted in registers
 bool stem16_supported(int prec, int C0);
 // depthwise 7x7 + LayerNorm of a 15x15 map on the matrix pipe (dw15.hip): 16-bit modes, C in {64, 80}; the map enters
-// the products rounded to the operand type (launch_dwconv_ln routes the inference forward there; BTSBOT_AMD_NO_DW15=1)
+// the products rounded to the operand type (launch_dwconv_ln routes the inference forward there; BTSBOT_AMD_NO_DW15=1: A/B)
 bool dw15_supported(int prec, int C);
 int launch_dw15_ln(int prec, const float* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb,
-                   void* xn, int B, int C, hipStream_t st, float* dsave = nullptr);
+                   void* xn, int B, int C, hipStream_t st);
 int launch_stem16(int prec, const float* img, const float* w, const float* bias, const float* lnw, const float* lnb,
                   float* out, int B, int C0, hipStream_t st, float* pre_out = nullptr);
 

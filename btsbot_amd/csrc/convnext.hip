@@ -489,13 +489,10 @@ int launch_dwconv_ln(int prec, const float* x, const float* wdw, const float* bd
                      hipStream_t st, float* dsave) {
   if (B <= 0) return BTSBOT_OK;
   // 15x15 maps of the inference forward, 16-bit modes: on the matrix pipe (the training forward keeps the per-tap kernel:
-  // its backward differentiates the convolution of the fp32 map)
-  static const bool dw15_train = [] {
-    const char* e = getenv("BTSBOT_AMD_DW15_TRAIN");   // 1: the training forward too (A/B)
-    return e != nullptr && e[0] == '1';
-  }();
-  if (HW == 15 && (dsave == nullptr || dw15_train) && dw15_supported(prec, C))
-    return launch_dw15_ln(prec, x, wdw, bdw, lnw, lnb, xn, B, C, st, dsave);
+  // its backward differentiates the convolution of the fp32 map.  Routed there too it held the oracle bounds of
+  // tests/test_gpu_train.py and was worth 17 us of the 2.75 ms step: not taken)
+  if (HW == 15 && dsave == nullptr && dw15_supported(prec, C))
+    return launch_dw15_ln(prec, x, wdw, bdw, lnw, lnb, xn, B, C, st);
   switch (prec) {
     case BTSBOT_F32: return launch_dw_typed<float>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st, dsave);
     case BTSBOT_BF16: return launch_dw_typed<bf16_t>(x, wdw, bdw, lnw, lnb, xn, B, HW, C, st, dsave);

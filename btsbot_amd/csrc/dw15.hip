@@ -87,8 +87,7 @@ template <typename T, int C>
 __global__ __launch_bounds__(L15<C>::NT * L15<C>::TEAMS, L15<C>::TEAMS == 2 ? 3 : 2) void dw15_ln_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                                              const float* __restrict__ bdw,
                                                              const float* __restrict__ lnw,
-                                                             const float* __restrict__ lnb, T* __restrict__ xn, int B,
-                                                             float* __restrict__ dsave) {
+                                                             const float* __restrict__ lnb, T* __restrict__ xn, int B) {
   using L = L15<C>;
   constexpr int NW = L::NW, NT = L::NT, PITCH = L::PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -205,19 +204,6 @@ __global__ __launch_bounds__(L15<C>::NT * L15<C>::TEAMS, L15<C>::TEAMS == 2 ? 3 
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[yb * 16 + xb * 4 + i] = acc[yb][xb][i];
     }
-    // (training) the pre-LayerNorm map: 16 consecutive channels of a pixel per 16-lane group = 64-byte pieces
-    if (dsave != nullptr && live) {
-      float* dd = dsave + (size_t)a * P * C + dch;
-#pragma unroll
-      for (int yb = 0; yb < 4; ++yb)
-#pragma unroll
-        for (int xb = 0; xb < 4; ++xb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int yy = 4 * yb + dj, xx = 4 * xb + i;
-            if (yy < HW && xx < HW) dd[(size_t)(yy * HW + xx) * C] = v[yb * 16 + xb * 4 + i];
-          }
-    }
     // ---- LayerNorm over the C channels of a pixel: this wave's 16 blocks (transposing lane reduction), then the
     //      waves through LDS; single-pass variance
     {
@@ -277,7 +263,7 @@ __global__ __launch_bounds__(L15<C>::NT * L15<C>::TEAMS, L15<C>::TEAMS == 2 ? 3 
 
 template <typename T, int C>
 int launch_dw15_t(const float* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, void* xn, int B,
-                  hipStream_t st, float* dsave) {
+                  hipStream_t st) {
   auto kern = dw15_ln_kernel<T, C>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -288,7 +274,7 @@ int launch_dw15_t(const float* x, const float* wdw, const float* bdw, const floa
   constexpr int TEAMS = L15<C>::TEAMS;
   const int grid = TEAMS == 2 ? (B + 1) / 2 : (B > 512 ? 512 : B);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(L15<C>::NT * TEAMS), L15<C>::BYTES * TEAMS, st, x, wdw, bdw, lnw, lnb,
-                     reinterpret_cast<T*>(xn), B, dsave);
+                     reinterpret_cast<T*>(xn), B);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -303,16 +289,15 @@ bool dw15_supported(int prec, int C) {
   return !off && (prec == BTSBOT_BF16 || prec == BTSBOT_F16) && (C == 64 || C == 80);
 }
 
-// wdw: the depthwise filter tap-major [49][C] fp32; x: [B][225][C] fp32; xn: [B][225][C] in the operand type;
-// dsave (optional): the pre-LayerNorm map [B][225][C] fp32
+// wdw: the depthwise filter tap-major [49][C] fp32; x: [B][225][C] fp32; xn: [B][225][C] in the operand type
 int launch_dw15_ln(int prec, const float* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb,
-                   void* xn, int B, int C, hipStream_t st, float* dsave) {
+                   void* xn, int B, int C, hipStream_t st) {
   if (B <= 0) return BTSBOT_OK;
   if (!(prec == BTSBOT_BF16 || prec == BTSBOT_F16) || !(C == 64 || C == 80)) {
     btsbot_set_error("dw15_ln: unsupported (prec %d, C %d)", prec, C);
     return BTSBOT_ERR_INVALID_ARG;
   }
-#define DW15(TT, CC) return launch_dw15_t<TT, CC>(x, wdw, bdw, lnw, lnb, xn, B, st, dsave)
+#define DW15(TT, CC) return launch_dw15_t<TT, CC>(x, wdw, bdw, lnw, lnb, xn, B, st)
   if (prec == BTSBOT_BF16) {
     if (C == 64) DW15(bf16_t, 64);
     DW15(bf16_t, 80);

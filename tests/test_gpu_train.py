@@ -561,7 +561,8 @@ def test_deterministic_option_gives_bit_identical_gradients(cuda, monkeypatch, p
 
 def test_process_wide_switches_in_a_child_process(cuda):
     """The A/B switches that the library reads once per process (one launch per packed operand, no epilogue
-    prefetch in the LDS-DMA GEMM, atomics instead of the two-pass filter-gradient reduction, no one-slot ring)
+    prefetch in the LDS-DMA GEMM, atomics instead of the two-pass filter-gradient reduction, no one-slot ring, the
+    per-tap 15x15 depthwise, per-output head layers, the one-thread-per-output slice reduction, no early re-pack)
     cannot be flipped inside this process: ONE child runs the 16-bit gradient test and the mm_pico forward
     parity with all of them set."""
     import subprocess, sys
@@ -569,20 +570,12 @@ def test_process_wide_switches_in_a_child_process(cuda):
         pytest.skip("already the child")
     env = dict(os.environ, BTSBOT_AMD_TEST_CHILD="1", BTSBOT_AMD_PACK_UNBATCHED="1",
                BTSBOT_AMD_GEMM2_NO_PREFETCH="1", BTSBOT_AMD_WGRAD_ATOMIC="1", BTSBOT_AMD_GEMM2_NO_1SLOT="1",
-               BTSBOT_AMD_NO_DW15="1", BTSBOT_AMD_HEAD_NO_GEMM="1")
+               BTSBOT_AMD_NO_DW15="1", BTSBOT_AMD_HEAD_NO_GEMM="1", BTSBOT_AMD_WGRAD_REDUCE1="1",
+               BTSBOT_AMD_EAGER_REPACK="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "tests/test_gpu_train.py::test_full_backward_16bit",
                         "tests/test_gpu_parity.py::test_forward_matches_oracle"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    # the second set: the one-thread-per-output slice reduction, the matrix-pipe depthwise + LayerNorm in the TRAINING
-    # forward too (its map enters the products rounded to the operand type), no early re-pack behind the optimiser
-    env = dict(os.environ, BTSBOT_AMD_TEST_CHILD="1", BTSBOT_AMD_WGRAD_REDUCE1="1", BTSBOT_AMD_DW15_TRAIN="1",
-               BTSBOT_AMD_EAGER_REPACK="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "tests/test_gpu_train.py::test_full_backward_16bit",
-                        "tests/test_gpu_train.py::test_training_at_the_full_batch_matches_oracle"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
