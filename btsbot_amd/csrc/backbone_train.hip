@@ -155,7 +155,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
   for (int i = 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0 && !(i == 3 && h->s2p_train)) {
+    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light))) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
@@ -163,6 +163,56 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
                        m + h->down[i].b, nullptr, nullptr, stage_in(i), rows, ch, 4 * cin, st));
     }
     const size_t nblk = h->blocks[i].size();
+    if (i == 2 && h->s2p_light) {
+      // Stage 2 and the last downsample as ONE launch of the inference kernel, which also leaves every block's input map,
+      // the stage output and the downsample's patch rows (100 us instead of 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM =
+      // 316 us in the chain).  What else the backward reads -- depthwise output, LayerNorm output, fc1 pre-activation and
+      // GELU of every block -- is recomputed from those inputs by the per-op kernels on the side stream, last block
+      // first, beside the chain's stage 3, heads, loss and their backward; the chain's stage-2 backward waits for it.
+      Stage2pArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x_in = stage_in(2);
+      a.depth = (int)nblk;
+      for (size_t j = 0; j < nblk; ++j) {
+        const BlockPk& b = h->blocks[2][j];
+        a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+        a.blk[j].dw_b = m + b.dw_b;
+        a.blk[j].ln_w = m + b.ln_w;
+        a.blk[j].ln_b = m + b.ln_b;
+        a.blk[j].b1 = m + b.fc1_b;
+        a.blk[j].b2 = m + b.fc2_b;
+        a.blk[j].gamma = m + b.gamma;
+        a.blk[j].w1p = h->extra + b.p_w1p;
+        a.blk[j].w2p = h->extra + b.p_w2p;
+        a.keep[j].xin = j == 0 ? nullptr : k.blk[2][j].xin;
+      }
+      a.ds_lnw = m + h->down[3].ln_w;
+      a.ds_lnb = m + h->down[3].ln_b;
+      a.ds_wp = h->extra + h->down[3].p_wp;
+      a.ds_b = m + h->down[3].b;
+      a.out = stage_in(3);
+      a.tap_stage = k.xs[2];
+      a.ds_patches = k.patches[3];
+      a.B = B;
+      a.train = 2;
+      a.alerts_hint = h->s2p_alerts_hint;
+      TRYB(launch_stage2p(c.precision, a, st));
+      if (h->use_side && h->side == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      if (h->s2_ready == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->s2_ready, hipEventDisableTiming));
+      hipStream_t sd = st;
+      TRYB(side_fork(h, st, &sd));
+      for (int j = (int)nblk - 1; j >= 0; --j) {
+        const BlockPk& b = h->blocks[2][j];
+        const BlkBuf& s = k.blk[2][j];
+        TRYB(launch_dwconv_ln(c.precision, s.xin, reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
+                              m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, sd, s.d));
+        TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
+                         reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, sd));
+      }
+      HIP_TRY(hipEventRecord(h->s2_ready, sd));
+      h->s2_pending = sd != st;
+      continue;
+    }
     if (i == 2 && h->s2p_train) {
       // Stage 2 and the last downsample as ONE launch: the inference kernel's keeping form (stage2p.hip, TRAIN) writes
       // what the backward reads -- every block's input, depthwise output, LayerNorm output, fc1 pre-activation and GELU,
@@ -264,10 +314,11 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   hipStream_t sd = st;
   // dwln_bwd_kernel leaves one partial row per workgroup; the column sum that folds them into the arena is queued on
   // the side stream at the next fork (it then sees the kernel's rows) instead of behind the kernel in the chain
-  struct { const float* part; float* dst; int rows, cols; } pend = {nullptr, nullptr, 0, 0};
+  struct { const float* part; float* dst; int rows, cols; } pend = {nullptr, nullptr, 0, 0};   // cols == 0: dw3 compact rows
   auto fork = [&]() -> int {
     TRYB(side_fork(h, st, &sd));
-    if (pend.rows > 0) TRYB(launch_colsum(BTSBOT_F32, pend.part, pend.dst, pend.rows, pend.cols, sd));
+    if (pend.rows > 0 && pend.cols == 0) TRYB(launch_dw3_rows(pend.part, pend.dst, pend.rows, sd));
+    else if (pend.rows > 0) TRYB(launch_colsum(BTSBOT_F32, pend.part, pend.dst, pend.rows, pend.cols, sd));
     pend.rows = 0;
     return BTSBOT_OK;
   };
@@ -296,6 +347,10 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
+    if (i == 2 && h->s2_pending) {   // the light forward's recompute of this stage's kept tensors (side stream)
+      HIP_TRY(hipStreamWaitEvent(st, h->s2_ready, 0));
+      h->s2_pending = false;
+    }
     for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
       const BlockPk& b = h->blocks[i][j];
       const BlkBuf& s = k.blk[i][j];
@@ -327,7 +382,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       }
       void* nxt = fold_cast ? next_dyT(i, j) : nullptr;
       // (the partial rows follow the arena's layout of conv_dw.weight | conv_dw.bias | norm.weight | norm.bias)
-      if (s.dwpart != nullptr && adjacent) {
+      if (s.dwpart != nullptr && adjacent && dw3_bwd_active(hw, ch)) {
+        // ---- 3x3 maps: the same in their own kernel (d recomputed from x_in; compact rows, reduced by launch_dw3_rows)
+        TRYB(launch_dw3ln_bwd(m + b.dw_b, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, st, planes,
+                              (size_t)rows * ch));
+        pend = {s.dwpart, grads + b.dw_w, dw3_rows(B), 0};
+      } else if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
         TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
                              planes, (size_t)rows * ch));

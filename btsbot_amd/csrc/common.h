@@ -375,6 +375,12 @@ int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) 
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes = 1,
                     size_t pstride = 0);
+// 3x3 maps of 256 channels: their own kernel (d recomputed from x_in, compact partial rows) and its row reduction
+bool dw3_bwd_active(int HW, int C);
+int dw3_rows(int B);
+int launch_dw3ln_bwd(const float* dwb, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                     void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes = 1, size_t pstride = 0);
+int launch_dw3_rows(const float* partials, float* out, int nrows, hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
 int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,

@@ -133,6 +133,13 @@ struct btsbot_ctx {
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
   bool s2p_train = false;            // the training forward of stage 2 runs stage2p_kernel's keeping form (16-bit modes;
                                      // BTSBOT_AMD_S2P_TRAIN=1 turns it on: no faster than the per-op launches)
+  // Light training forward of stage 2 (opt-in, BTSBOT_AMD_S2P_LIGHT=1; 16-bit modes): stage2p_kernel's inference form + each block's input
+  // map; the backward's other operands (depthwise output, LayerNorm output, fc1 pre-activation, GELU) are recomputed by
+  // the per-op kernels on the side stream, beside the chain's stage 3 / heads / loss, and `s2_ready` tells the chain's
+  // stage-2 backward that they are there.  Not faster than the per-op forward: see api.hip where the switch is read.
+  bool s2p_light = false;
+  hipEvent_t s2_ready = nullptr;
+  bool s2_pending = false;           // the last training forward queued that recompute: the backward waits for s2_ready
   bool use_stem16 = true;            // BTSBOT_AMD_NO_STEM16=1: the fp32 VALU stem in the 16-bit modes too (A/B, parity)
   bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
   float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)

@@ -14,6 +14,8 @@
 // runs both convolutions off the two LDS maps.  Filter-gradient taps stay in registers across the workgroup's alerts
 // and leave, with the LayerNorm parameter gradients, as one partial row per workgroup which the caller column-sums
 // into the arena (<= 64 atomics per column there instead of one per workgroup here).  fp32 throughout (every mode).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -228,6 +230,167 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---- 3x3 maps (stage 2: 256 channels): thread = channel, an alert's nine pixels of dxn / x_in / dy in registers.
+// The depthwise output d is RECOMPUTED from x_in (81 FMAs) instead of read; both backward convolutions are 81 register
+// FMAs per alert; the LayerNorm sums over the 256 channels are wave sums that meet through 16-byte LDS rows.  One alert
+// per pass and <= 168 registers: three workgroups per CU cover each other's load latencies and barriers (two alerts per
+// pass took 306 registers, one workgroup per CU: 43 us).  The workgroup leaves a COMPACT partial row, tap-major
+// [25 live taps | bias | LayerNorm weight | LayerNorm bias][256] = 28 KB of coalesced stores (the general kernel's row is
+// the arena's [C][49] layout: 52 KB per workgroup in 4-byte pieces 196 bytes apart, 27 MB per launch for 9.4 MB tensors);
+// dw3_rows_kernel adds the rows into the arena.  The general kernel above spends a 3x3 map's pass in its phase latencies
+// and took 31-36 us per launch (six launches per step in the chain) + 18-23 us for the column sum of its rows.
+constexpr int DW3_ROW = 28;   // floats per channel of a compact partial row
+__global__ __launch_bounds__(256, 3) void dw3ln_bwd_kernel(const float* __restrict__ dwb, const float* __restrict__ dxn,
+                                                           const float* __restrict__ g, const float* __restrict__ xin,
+                                                           const float* __restrict__ w, float* dy,
+                                                           void* __restrict__ out16, int prec16,
+                                                           float* __restrict__ partials, int B, int ga, int nplanes,
+                                                           size_t pstride) {
+  constexpr int C = 256;
+  __shared__ __attribute__((aligned(16))) float red[4][9][4];   // [set][pixel][wave]
+  const int c = threadIdx.x, lane = c & 63, wv = c >> 6;
+  float wt[25];   // central 5x5 of the 7x7 taps (the others never meet a 3x3 map)
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) wt[ky * 5 + kx] = w[((ky + 1) * 7 + kx + 1) * C + c];
+  const float gc = g[c], bias = dwb[c];
+  float acc[25], ab = 0.f, adg = 0.f, adb = 0.f;
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+  // every lane ends with the four waves' total of pixel p's value, set s
+  auto put = [&](int s, int p, float v) {
+    const float t = wave_sum(v);
+    if (lane == 0) red[s][p][wv] = t;
+  };
+  auto get = [&](int s, int p) {
+    const float4 r = *reinterpret_cast<const float4*>(&red[s][p][0]);
+    return (r.x + r.y) + (r.z + r.w);
+  };
+  const int a0 = blockIdx.x * ga, a1 = min(B, a0 + ga);
+  for (int a = a0; a < a1; ++a) {
+    const size_t base = (size_t)a * 9 * C + c;
+    float xv[9], gx[9], yv[9], dv[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      xv[p] = xin[base + p * C];
+      gx[p] = dxn[base + p * C];
+      yv[p] = dy[base + p * C];
+    }
+    for (int pl = 1; pl < nplanes; ++pl)
+#pragma unroll
+      for (int p = 0; p < 9; ++p) gx[p] += dxn[pl * pstride + base + p * C];
+    // d[o] = bias + sum_i w[iy - oy + 2][ix - ox + 2] x[i]   (the forward's dw3_ln_kernel, same order of taps)
+#pragma unroll
+    for (int o = 0; o < 9; ++o) dv[o] = bias;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+          const int iy = o / 3 + ky - 2, ix = o % 3 + kx - 2;
+          if (iy >= 0 && iy < 3 && ix >= 0 && ix < 3) dv[o] = fmaf(xv[iy * 3 + ix], wt[ky * 5 + kx], dv[o]);
+        }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) put(0, p, dv[p]);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      dv[p] -= get(0, p) * (1.f / C);
+      put(1, p, dv[p] * dv[p]);
+    }
+    __syncthreads();
+    float rstd[9], t1[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      rstd[p] = rsqrtf(get(1, p) * (1.f / C) + LN_EPS);
+      dv[p] *= rstd[p];                 // xhat
+      t1[p] = gx[p] * gc;
+      adg += gx[p] * dv[p];
+      adb += gx[p];
+      put(2, p, t1[p]);
+      put(3, p, t1[p] * dv[p]);
+    }
+    __syncthreads();
+    float dd[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      const float st = get(2, p) * (1.f / C), stx = get(3, p) * (1.f / C);
+      dd[p] = rstd[p] * (t1[p] - st - dv[p] * stx);
+      ab += dd[p];
+    }
+    // dx[i] += w[..] dd[o],  dW[..] += dd[o] x[i]
+#pragma unroll
+    for (int o = 0; o < 9; ++o)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int t = (i / 3 - o / 3 + 2) * 5 + (i % 3 - o % 3 + 2);
+        yv[i] = fmaf(wt[t], dd[o], yv[i]);
+        acc[t] = fmaf(dd[o], xv[i], acc[t]);
+      }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      dy[base + p * C] = yv[p];
+      if (out16 != nullptr) {
+        if (prec16 == BTSBOT_BF16) reinterpret_cast<bf16_t*>(out16)[base + p * C] = (bf16_t)yv[p];
+        else reinterpret_cast<f16_t*>(out16)[base + p * C] = (f16_t)yv[p];
+      }
+    }
+  }
+  float* row = partials + (size_t)blockIdx.x * DW3_ROW * C + c;
+#pragma unroll
+  for (int t = 0; t < 25; ++t) row[t * C] = acc[t];
+  row[25 * C] = ab;
+  row[26 * C] = adg;
+  row[27 * C] = adb;
+}
+
+// arena[...] += sum over the compact rows.  out = the gradient of conv_dw.weight; conv_dw.bias, norm.weight and
+// norm.bias follow it (the arena's order: [C][49] | [C] | [C] | [C]).  Workgroup = 64 columns x 4 row groups over one
+// slice of the rows; the slices meet in the arena through one atomic per column and slice.
+__global__ __launch_bounds__(256) void dw3_rows_kernel(const float* __restrict__ rows, float* out, int nrows, int rslice) {
+  constexpr int C = 256, N = DW3_ROW * C;
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  const int rbeg = blockIdx.y * rslice, rend = min(nrows, rbeg + rslice);
+  float s0 = 0.f, s1 = 0.f;
+  int r = rbeg + rg;
+  for (; r + 4 < rend; r += 8) {
+    s0 += rows[(size_t)r * N + n];
+    s1 += rows[(size_t)(r + 4) * N + n];
+  }
+  if (r < rend) s0 += rows[(size_t)r * N + n];
+  sh[rg][cl] = s0 + s1;
+  __syncthreads();
+  if (rg != 0) return;
+  const float v = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  const int t = n / C, c = n - t * C;
+  const int o = t < 25 ? c * 49 + (t / 5 + 1) * 7 + t % 5 + 1 : (49 + t - 25) * C + c;
+  if (gridDim.y == 1) out[o] += v;   // (one slice: a fixed order of additions, the deterministic mode)
+  else atomicAdd(out + o, v);
+}
+
+// workgroups of the 3x3 kernel: at most 512 (up to three fit a CU), each a whole number of alerts
+int dw3_ga(int B) {
+  static const int wgs = [] {
+    const char* e = getenv("BTSBOT_AMD_DW3_WGS");   // tuning knob
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? v : 512;
+  }();
+  const int per = (B + wgs - 1) / wgs;
+  return per < 1 ? 1 : per;
+}
+int dw3_grid(int B) { return (B + dw3_ga(B) - 1) / dw3_ga(B); }
+bool dw3_old() {
+  static const bool v = [] {
+    const char* e = getenv("BTSBOT_AMD_DW3_OLD");   // 1: the general kernel on the 3x3 maps too (A/B timing)
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
+
 template <int HW, int C, int NT, int NA> struct DwlnCfg {
   static constexpr size_t lds = ((size_t)2 * NA * HW * HW + 49) * C * sizeof(float);
   // one workgroup per CU where the maps take 128 KB (15x15x64), two where they take <= 80 KB
@@ -264,7 +427,10 @@ int dwln_bwd_rows(int HW, int C, int B) {
   if (B <= 0) return 0;
   if (HW == 15 && C == 64) return DwlnCfg<15, 64, 512, 1>::grid(B);
   if (HW == 7 && C == 128) return DwlnCfg<7, 128, 512, 1>::grid(B);
-  if (HW == 3 && C == 256) return DwlnCfg<3, 256, 512, 4>::grid(B);
+  if (HW == 3 && C == 256) {   // (room for either kernel's rows: the deterministic mode runs the general one)
+    const int r0 = DwlnCfg<3, 256, 512, 4>::grid(B), r1 = dw3_grid(B);
+    return r0 > r1 ? r0 : r1;
+  }
   return 0;
 }
 
@@ -280,4 +446,27 @@ int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const floa
   if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
+}
+
+// The 3x3 maps' own kernel (256 channels) unless BTSBOT_AMD_DW3_OLD=1.  launch_dw3ln_bwd recomputes the depthwise output from x_in and the depthwise bias `dwb`;
+// launch_dw3_rows (any stream that has seen the kernel) adds its dw3_rows(B) compact partial rows into the arena at
+// out = gradient of conv_dw.weight, with conv_dw.bias | norm.weight | norm.bias behind it.
+bool dw3_bwd_active(int HW, int C) { return HW == 3 && C == 256 && !dw3_old(); }
+int dw3_rows(int B) { return dw3_grid(B); }
+int launch_dw3ln_bwd(const float* dwb, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
+                     void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes, size_t pstride) {
+  if (B <= 0) return BTSBOT_OK;
+  hipLaunchKernelGGL(dw3ln_bwd_kernel, dim3(dw3_grid(B)), dim3(256), 0, st, dwb, dxn, g, xin, w, dy, out16, prec16, partials,
+                     B, dw3_ga(B), nplanes, pstride);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+int launch_dw3_rows(const float* partials, float* out, int nrows, hipStream_t st) {
+  if (nrows <= 0) return BTSBOT_OK;
+  // (deterministic mode: one slice, i.e. every column is added by one thread group in a fixed order)
+  const int nsl = det_alloc(0) != nullptr ? 1 : nrows >= 256 ? 8 : nrows >= 32 ? 4 : 1, rslice = (nrows + nsl - 1) / nsl;
+  hipLaunchKernelGGL(dw3_rows_kernel, dim3(DW3_ROW * 256 / 64, (nrows + rslice - 1) / rslice), dim3(256), 0, st, partials, out,
+                     nrows, rslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
 }

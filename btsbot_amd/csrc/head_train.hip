@@ -339,6 +339,17 @@ __global__ void logits_kernel(const float* __restrict__ in, float* logits, float
   if (scores != nullptr) scores[i] = 1.0f / (1.0f + expf(-z));
 }
 
+// dst[m][0:cols] = src[m][0:cols]  (rows ldd / lds floats apart).  A kernel, not hipMemcpy2DAsync: the runtime's
+// rectangular device-to-device copy held the calling thread until the stream had drained -- once per step the host lost
+// its whole lead over the GPU, and the backward's first ~25 launches then arrived one host round trip apart.
+__global__ __launch_bounds__(256) void copy_cols_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src,
+                                                        int lds, int cols, int M) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * cols) return;
+  const int m = idx / cols, c = idx - m * cols;
+  dst[(size_t)m * ldd + c] = src[(size_t)m * lds + c];
+}
+
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -508,8 +519,10 @@ int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float
   if (need_image && h->has_image)
     // d(z)[:, 0:F] is the gradient of the (head-normalised) image feature; pulled out of the concat layout
     // (the metadata backward below recycles d(z))
-    HIP_TRY(hipMemcpy2DAsync(dfeat, (size_t)F * 4, dz, (size_t)zd * 4, (size_t)F * 4, M,
-                             hipMemcpyDeviceToDevice, st));
+  {
+    hipLaunchKernelGGL(copy_cols_kernel, g1((long)M * F), dim3(256), 0, st, dfeat, F, dz, zd, F, M);
+    LAUNCH_CHECK();
+  }
   hipStream_t sd = st;
   TRY_RET(side_fork(h, st, &sd));
   if (need_image && h->has_image) {

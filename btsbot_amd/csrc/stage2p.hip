@@ -215,7 +215,10 @@ __device__ __forceinline__ float half_sum(float v) {
   return v + w;
 }
 
-template <typename T, int G, bool TRAIN = false>
+// TRAIN: 0 inference; 1 the keeping form (every tensor the backward reads); 2 the light training forward: the
+// inference kernel plus each block's input map, the stage output and the downsample's patch rows -- what is left
+// (depthwise output, LayerNorm output, fc1 pre-activation, GELU) backbone_train.hip recomputes beside the chain
+template <typename T, int G, int TRAIN = 0>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
   constexpr int KSTEP = MP<T>::KSTEP, VPL = KSTEP / 4, KS1 = C / KSTEP, KS2 = CHUNK / KSTEP, KH = HID / KSTEP;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     b1s[tid + NT] = b1b;
     __syncthreads();
     S2P_STAMP(3 + 8 * j);
-    if (TRAIN) {   // the depthwise output before the LayerNorm (it stays in xl until the next block's map)
+    if (TRAIN == 1) {   // the depthwise output before the LayerNorm (it stays in xl until the next block's map)
       float* dst = a.keep[j].d + (size_t)alert0 * 9 * C;
       for (int i = tid; i < nlive * (C / 4); i += NT) {
         const int p = i / (C / 4), c4 = i - p * (C / 4);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
-    if (TRAIN) {   // the LayerNorm output rows (16-byte pieces: C * ESZ / 16 per row)
+    if (TRAIN == 1) {   // the LayerNorm output rows (16-byte pieces: C * ESZ / 16 per row)
       unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep[j].xn) + (size_t)alert0 * 9 * C * ESZ;
       constexpr int PPR = C * ESZ / 16;
       for (int i = tid; i < nlive * PPR; i += NT) {
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       }
       // (training forward) chunk ch - 1's images are complete and live through this step: their rows leave behind the
       // fc1 products' issue, under their execution
-      if (TRAIN && !first) keep_chunk(ch - 1, 1 - p);
+      if (TRAIN == 1 && !first) keep_chunk(ch - 1, 1 - p);
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
       // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
       unsigned char* hcur = hb + p * H_IMG;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         }
         if (s < NB) {
           float hv[4];
-          if (TRAIN) {
+          if (TRAIN == 1) {
             // the backward differentiates GELU at the ROUNDED pre-activation (as gemm2.hip's GELU_SAVE epilogue does)
             float av[4];
 #pragma unroll
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // the fc2 half of a step of its own: the block's last chunk (the residual must be complete before the next
     // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 0
     auto fc2_tail = [&]() {
-      if (TRAIN) keep_chunk(NCHUNK - 1, 1);
+      if (TRAIN == 1) keep_chunk(NCHUNK - 1, 1);
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const void* src2 = nb.w2p;
       const size_t f2 = (size_t)(2 * wave) * KH;
@@ -749,9 +752,9 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
       (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
-template <typename T, int G = S2P_ALERTS, bool TRAIN = false> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+template <typename T, int G = S2P_ALERTS, int TRAIN = 0> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
   auto kern = stage2p_kernel<T, G, TRAIN>;
-  constexpr int lds_bytes = TRAIN ? Lds<T, G>::BYTES_TRAIN : Lds<T, G>::BYTES;
+  constexpr int lds_bytes = TRAIN == 1 ? Lds<T, G>::BYTES_TRAIN : Lds<T, G>::BYTES;
   static_assert(lds_bytes <= 160 * 1024, "the images fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -823,6 +826,24 @@ int stage2p_alerts_per_workgroup(int B, int hint) {
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
+  if (a.train == 2) {   // the light training forward (16-bit modes; alerts per workgroup as in inference)
+    for (int j = 1; j < a.depth; ++j)
+      if (a.keep[j].xin == nullptr) {
+        btsbot_set_error("stage2p: the light training forward needs the input buffer of block %d", j);
+        return BTSBOT_ERR_INVALID_ARG;
+      }
+    if (a.ds_patches == nullptr || a.tap_stage == nullptr) {
+      btsbot_set_error("stage2p: the training forward needs ds_patches and the stage output (tap_stage)");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    const int gl = stage2p_alerts_per_workgroup(a.B, a.alerts_hint);
+    if (prec == BTSBOT_BF16)
+      return gl == 7 ? launch_stage2p_t<bf16_t, 7, 2>(a, st) : gl == 5 ? launch_stage2p_t<bf16_t, 5, 2>(a, st) : launch_stage2p_t<bf16_t, 4, 2>(a, st);
+    if (prec == BTSBOT_F16)
+      return gl == 7 ? launch_stage2p_t<f16_t, 7, 2>(a, st) : gl == 5 ? launch_stage2p_t<f16_t, 5, 2>(a, st) : launch_stage2p_t<f16_t, 4, 2>(a, st);
+    btsbot_set_error("stage2p: the training forward runs in the bf16 / f16 modes, not %d", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (a.train) {   // the training forward: 16-bit modes, 4 or 5 alerts per workgroup (7 would not leave room for its images)
     for (int j = 0; j < a.depth; ++j)
       if (a.keep[j].d == nullptr || a.keep[j].xn == nullptr || a.keep[j].a == nullptr || a.keep[j].hh == nullptr ||
@@ -835,8 +856,8 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
       return BTSBOT_ERR_INVALID_ARG;
     }
     const bool g4 = stage2p_alerts_per_workgroup(a.B, a.alerts_hint) == 4;
-    if (prec == BTSBOT_BF16) return g4 ? launch_stage2p_t<bf16_t, 4, true>(a, st) : launch_stage2p_t<bf16_t, 5, true>(a, st);
-    if (prec == BTSBOT_F16) return g4 ? launch_stage2p_t<f16_t, 4, true>(a, st) : launch_stage2p_t<f16_t, 5, true>(a, st);
+    if (prec == BTSBOT_BF16) return g4 ? launch_stage2p_t<bf16_t, 4, 1>(a, st) : launch_stage2p_t<bf16_t, 5, 1>(a, st);
+    if (prec == BTSBOT_F16) return g4 ? launch_stage2p_t<f16_t, 4, 1>(a, st) : launch_stage2p_t<f16_t, 5, 1>(a, st);
     btsbot_set_error("stage2p: the training forward runs in the bf16 / f16 modes, not %d", prec);
     return BTSBOT_ERR_INVALID_ARG;
   }
