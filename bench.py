@@ -90,6 +90,8 @@ PER_GPU_BATCH = 1024
 # (fp8 mode: most FLOPs still bf16; f16x2: ALGORITHMIC flop against the f16 peak -- the mode issues two to three
 #  MFMAs per algorithmic product, so its fraction of peak counts useful work only)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "fp8": 2500.0, "f16x2": 2500.0}
+FP8_KERNEL_PEAK_TFLOPS = 5000.0   # MI355X_MICROARCH.md, Matrix cores: block-scaled f8f6f4 with e4m3 operands = 2 x bf16 per clock
+FP8_KERNELS = ("stage2p_kernel", "s3_fc1_kernel", "s3_fc2_kernel")
 HBM_PEAK_GBS = 8000.0
 STAGE_P = (225, 49, 9, 1)
 
@@ -521,21 +523,28 @@ def family_roofline(m, run, batch, precision, steps):
     m.set_profile(False)
     work = family_work(batch, precision)
     peak = MFMA_PEAK_TFLOPS[precision]
-    per_kernel, fam_flop, fam_ms = {}, 0.0, 0.0
+    per_kernel, fam_flop, fam_ms, fam_floor_ms = {}, 0.0, 0.0, 0.0
     for k in POINTWISE:
         ms, n = prof.get(k, (0.0, 0))
         if n == 0 or work[k]["flop"] == 0:
             continue
+        # the peak is the KERNEL's: in the fp8 mode stage2p / s3_* issue v_mfma_scale_f32_*_f8f6f4 (~5 PFLOP/s dense),
+        # stage0b / stage1b stay on the bf16 instructions (~2.5)
+        kpeak = FP8_KERNEL_PEAK_TFLOPS if precision == "fp8" and k in FP8_KERNELS else peak
         ach = work[k]["flop"] * steps / (ms * 1e-3) / 1e12
-        per_kernel[k] = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_call": n // steps,
-                         "ms_per_call": round(ms / steps, 4)}
+        per_kernel[k] = {"achieved": round(ach, 2), "peak": kpeak, "frac": round(ach / kpeak, 4),
+                         "launches_per_call": n // steps, "ms_per_call": round(ms / steps, 4)}
         fam_flop += work[k]["flop"] * steps
         fam_ms += ms
+        fam_floor_ms += work[k]["flop"] * steps / (kpeak * 1e12) * 1e3
     if not per_kernel:
         return None
     ach = fam_flop / (fam_ms * 1e-3) / 1e12
+    # family fraction = time at each kernel's own peak / measured time (equals achieved / peak when every member has
+    # the same peak); `peak` is then the FLOP-weighted harmonic mean of the members' peaks
+    fam_peak = fam_flop / (fam_floor_ms * 1e-3) / 1e12
     return {"kernel": "pointwise-conv kernel family, FLOP-weighted: " + " + ".join(per_kernel), "bound": "mfma",
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "achieved": round(ach, 2), "peak": round(fam_peak, 1), "unit": "TFLOP/s", "frac": round(fam_floor_ms / fam_ms, 4),
             "per_kernel": per_kernel, "alerts_per_call": batch}
 
 
@@ -839,14 +848,16 @@ def main():
         # (sum of algorithmic FLOP / sum of launch time), which cannot flip from box to box the way "the member with
         # the most device time" did when two members are within 1 % of each other.
         per_kernel = {}
-        fam_flop = fam_ms = 0.0
+        fam_flop = fam_ms = fam_floor_ms = 0.0
         for k in POINTWISE:
             ms, n = prof.get(k, (0.0, 0))
             if n == 0 or work[k]["flop"] == 0:
                 continue
             fpl = work[k]["flop"] * prof_steps / n
             ach = fpl / (ms / n * 1e-3) / 1e12
-            per_kernel[k] = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "flop_per_launch": fpl,
+            kpeak = FP8_KERNEL_PEAK_TFLOPS if args.precision == "fp8" and k in FP8_KERNELS else peak   # (family_roofline)
+            fam_floor_ms += work[k]["flop"] * prof_steps / (kpeak * 1e12) * 1e3
+            per_kernel[k] = {"achieved": round(ach, 2), "peak": kpeak, "frac": round(ach / kpeak, 4), "flop_per_launch": fpl,
                              "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // prof_steps,
                              "traffic": pmc_traffic(k, args), "mfma_busy_pmc": pmc_mfma_busy(k, args)}
             fam_flop += work[k]["flop"] * prof_steps
@@ -897,8 +908,9 @@ def main():
             "pipelined_slower_than_serial": bool(pipelined_elapsed is not None and pipelined_elapsed > serial_elapsed),
             "roofline": {
                 "kernel": "pointwise-conv kernel family, FLOP-weighted: " + " + ".join(per_kernel),
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "bound": "mfma", "achieved": round(achieved, 2),
+                "peak": round(fam_flop / (fam_floor_ms * 1e-3) / 1e12, 1),
+                "unit": "TFLOP/s", "frac": round(fam_floor_ms / fam_ms, 4),
                 "traffic": per_kernel[lowest]["traffic"],
                 "lowest_member": lowest,
                 "per_kernel": per_kernel,
@@ -942,6 +954,24 @@ def _newest_profile(pattern):
     return files[-1] if files else None
 
 
+def csrc_sha16():
+    """Digest of the kernel sources the library is built from: a committed PMC summary carries the digest it was
+    collected under (tools/collect_profiles.py), and a summary from other sources is marked stale on the line."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "btsbot_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        with open(f, "rb") as fh:
+            hsh.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def _stale(summary):
+    """True unless the summary says it was collected on the kernels as they are now."""
+    return summary.get("csrc_sha16") != csrc_sha16()
+
+
 def pmc_traffic(kernel, args):
     """HBM-side bytes per launch of `kernel`, NOT measured in this run: PMC counters cannot be sampled from inside
     the process, so the figure comes from the newest committed summary (profiles/r*_pmc_traffic.json: separate
@@ -954,12 +984,12 @@ def pmc_traffic(kernel, args):
     if f is None:
         return None
     with open(f) as fh:
-        ks = json.load(fh)["kernels"]
-    hits = [v for v in ks.values() if v["family"] == kernel]
+        summ = json.load(fh)
+    hits = [v for v in summ["kernels"].values() if v["family"] == kernel]
     if len(hits) != 1:
         return None
     return {"bytes_per_launch": hits[0]["traffic_bytes"], "source": "profiles/" + os.path.basename(f),
-            "measured_in_this_run": False}
+            "measured_in_this_run": False, "stale": _stale(summ)}
 
 
 def depthwise_norm_hbm(args):
@@ -974,7 +1004,7 @@ def depthwise_norm_hbm(args):
     with open(f) as fh:
         d = json.load(fh)
     return {"bound": "hbm", "peak": d["peak_gbs"], "unit": "GB/s", "kernels": d["kernels"],
-            "source": "profiles/" + os.path.basename(f), "measured_in_this_run": False}
+            "source": "profiles/" + os.path.basename(f), "measured_in_this_run": False, "stale": _stale(d)}
 
 
 def pmc_mfma_busy(kernel, args):
@@ -987,13 +1017,13 @@ def pmc_mfma_busy(kernel, args):
     if f is None:
         return None
     with open(f) as fh:
-        ks = json.load(fh)["kernels"]
+        summ = json.load(fh)
     stem = kernel.replace("_kernel", "")
-    hits = [v for v in ks if v["kernel"].split("_kernel")[0] == stem]
+    hits = [v for v in summ["kernels"] if v["kernel"].split("_kernel")[0] == stem]
     if len(hits) != 1:
         return None
     return {"busy_share": hits[0]["mfma_busy"], "source": "profiles/" + os.path.basename(f),
-            "measured_in_this_run": False}
+            "measured_in_this_run": False, "stale": _stale(summ)}
 
 
 if __name__ == "__main__":

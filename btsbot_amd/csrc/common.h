@@ -48,6 +48,21 @@ __device__ __forceinline__ h2x4 split4(const float (&v)[4]) {
   return o;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds for ONE device: a launcher keeps one flag per (kernel, device),
+// so a handle on cuda:1 after one on cuda:0 sets it again (a process-wide bool skipped it: launch failure on the second
+// GPU for every kernel above 64 KB of LDS).  Racing threads may both set the attribute: harmless.
+#include <atomic>
+struct DevOnce {
+  std::atomic<unsigned long long> mask{0};
+  static int dev() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+  }
+  bool need() const { return ((mask.load(std::memory_order_relaxed) >> dev()) & 1ULL) == 0; }
+  void done() { mask.fetch_or(1ULL << dev(), std::memory_order_relaxed); }
+};
+
 // ---------------------------------------------------------------------------------------
 // error plumbing (no exception crosses the ABI)
 // ---------------------------------------------------------------------------------------

@@ -411,11 +411,11 @@ int launch_dw_cfg(const float* x, const float* wdw, const float* bdw, const floa
   constexpr int NV = HW <= 3 ? 4 : (HW <= 7 ? 8 : 16);
   const size_t lds = ((size_t)G * HW * HW * C + 2 * NW * NV) * sizeof(float);
   auto kern = dwconv_ln_kernel<C, HW, G, NW, T>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kern, dim3((B + G - 1) / G), dim3(NW * 64), lds, st, x, wdw, bdw, lnw, lnb,
                      reinterpret_cast<T*>(xn), B, dsave);
@@ -522,11 +522,11 @@ int launch_stem(const float* img, const float* w, const float* bias, const float
     hipLaunchKernelGGL((stem_kernel<64>), dim3(B), dim3(256), lds, st, img, w, bias, lnw, lnb, out,
                        B, pre_out);
   } else if (C0 == 80) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel<80>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.done();
     }
     hipLaunchKernelGGL((stem_kernel<80>), dim3(B), dim3(256), lds, st, img, w, bias, lnw, lnb, out,
                        B, pre_out);

@@ -265,11 +265,11 @@ template <typename T, int C>
 int launch_dw15_t(const float* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, void* xn, int B,
                   hipStream_t st) {
   auto kern = dw15_ln_kernel<T, C>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(L15<C>::BYTES * L15<C>::TEAMS)));
-    attr_set = true;
+    attr_set.done();
   }
   constexpr int TEAMS = L15<C>::TEAMS;
   const int grid = TEAMS == 2 ? (B + 1) / 2 : (B > 512 ? 512 : B);

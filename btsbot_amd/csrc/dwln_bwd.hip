@@ -405,11 +405,11 @@ int dwln_launch(const float* d, const float* dxn, const float* g, const float* x
   using K = DwlnCfg<HW, C, NT, NA>;
   constexpr int G = NT / C;
   static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_bwd_kernel<HW, C, NT, NA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::lds));
-    attr = true;
+    attr.done();
   }
   hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT, NA>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
                      out16, prec16, partials, B, K::ga(B), nplanes, pstride);

@@ -309,11 +309,11 @@ int launch_fused_cfg(const void* xn, const void* wpk, const float* b1, const flo
   using G = FusedGeom<C>;
   const size_t lds = 2 * (size_t)G::CHUNKBYTES + 4 * C * sizeof(float);
   auto kern = fused_mlp_kernel<T, C>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.done();
   }
   const int ntiles = (M + 255) / 256;
   const int maxwg = (C <= 64 ? 2 : 1) * 256;   // workgroups resident on the chip

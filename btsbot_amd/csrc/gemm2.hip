@@ -287,11 +287,11 @@ int launch_tile2p(const T* x, const T* w, const float* bias, const float* gamma,
   constexpr size_t otile = (size_t)TM * (TN * ((EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_BIAS_T || EPI == EPI_GELU_SAVE) ? sizeof(T) : sizeof(float)) + 16);
   constexpr size_t lds = ring > otile ? ring : otile;   // the epilogue tile reuses the ring
   auto kern = gemm2_kernel<T, TM, TN, WM, WN, EPI, NSLOT, PRE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.done();
   }
   dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, bias, gamma, resid, out, M, N, K, bsX, bsW,

@@ -296,11 +296,11 @@ int launch_mv_attn_block(int prec, const void* xn, float* x, void* xn2, const vo
 #define ABLK(TT)                                                                                        \
   do {                                                                                                  \
     auto kern = mv_attn_block64_kernel<TT>;                                                             \
-    static bool attr = false;                                                                           \
-    if (!attr) {                                                                                        \
+    static DevOnce attr;                                                                           \
+    if (attr.need()) {                                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-      attr = true;                                                                                      \
+      attr.done();                                                                                      \
     }                                                                                                   \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, reinterpret_cast<const TT*>(xn), x,        \
                        reinterpret_cast<TT*>(xn2), reinterpret_cast<const TT*>(wqkv), bqkv,             \

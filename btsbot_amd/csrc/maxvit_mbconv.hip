@@ -200,11 +200,11 @@ int launch_front(const void* xn, const void* w1, const float* b1, const float* w
   using G = Geo<STRIDE>;
   constexpr size_t lds = (size_t)G::NPXP * (CIN * 2 + 16) + (size_t)G::NPXP * M1PITCH + 32 * CH * 4;
   auto kern = mv_mbconv_front_kernel<T, STRIDE, CIN>;
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+    attr.done();
   }
   const int Ho = H / STRIDE, tiles = (Ho / G::TO) * (Ho / G::TO);
   hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(256), lds, st, reinterpret_cast<const T*>(xn),

@@ -412,10 +412,10 @@ int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w
                    float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs) {
   using G = BwdGeo<C, NW>;
   auto kern = mlp_bwd_kernel<T, C, NW>;
-  static bool attr = false;
-  if (!attr) {
+  static DevOnce attr;
+  if (attr.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES));
-    attr = true;
+    attr.done();
   }
   const int gx = mlp_bwd_slices(C, R);
   float* partG = part;

@@ -1,12 +1,12 @@
-// Stage-0 megakernel, second layout (gfx950): the same computation as stage0.hip --
+// Stage-0 megakernel (gfx950), one launch for
 //
 //   stem (conv 4x4 s4 + LN)  ->  2 x [ dwconv 7x7 + LN -> fc1 -> GELU -> fc2 -> layer-scale -> +x ]
 //                            ->  downsample (LN + conv 2x2 s2)  ->  [49][128] f32
 //
 // (timm ConvNeXt stem / stages[0] / stages[1].downsample, reached from
-// /root/reference/btsbot/architectures.py:108,132) -- re-cut so that TWO workgroups share a CU:
-// stage0.hip's single 512-thread workgroup per CU runs its phases in lockstep (depthwise = VALU +
-// LDS, MLP = MFMA + VALU, parameter fetches = latency) and nothing overlaps; two independent
+// /root/reference/btsbot/architectures.py:108,132) -- cut so that TWO workgroups share a CU:
+// a single 512-thread workgroup per CU (the first layout of this kernel, rounds 1-2, no longer in the tree) runs its
+// phases in lockstep (depthwise = VALU + LDS, MLP = MFMA + VALU, parameter fetches = latency) and nothing overlaps; two independent
 // 256-thread workgroups drift apart and fill each other's stalls, at the same 2 waves per SIMD
 // that the f32 VALU needs for its full rate (tools/unit/valu_rate.hip).
 //
@@ -760,7 +760,7 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
 
 template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
   auto kern = stage0b_kernel<T, X2, WPS>;
-  static bool attr_set = false;
+  static DevOnce attr_set;
   // (BTSBOT_AMD_S0_ONE_WG=1: developer probe -- the LDS request padded so that ONE workgroup fits a CU: how the kernel's
   //  time scales from one to two waves per SIMD says what two more would buy)
   static const int pad = [] {
@@ -768,10 +768,10 @@ template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const S
     return e != nullptr && e[0] == '1' && !X2 ? 90 * 1024 - S0L<X2>::LDS_BYTES : 0;
   }();
   const int LDS_BYTES = S0L<X2>::LDS_BYTES + pad;
-  if (!attr_set) {
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), LDS_BYTES, st, a);
   LAUNCH_CHECK();

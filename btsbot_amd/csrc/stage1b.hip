@@ -881,16 +881,16 @@ __global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ 
 
 template <typename T, bool X2 = false, int WPS = 2> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
   auto kern = stage1b_kernel<T, X2, WPS>;
-  static bool attr_set = false;
+  static DevOnce attr_set;
   static const int pad = [] {   // (BTSBOT_AMD_S1_ONE_WG=1: the same probe as stage0b.hip's)
     const char* e = getenv("BTSBOT_AMD_S1_ONE_WG");
     return e != nullptr && e[0] == '1' && !X2 ? 90 * 1024 - S1L<X2>::LDS_BYTES : 0;
   }();
   const int LDS_BYTES = S1L<X2>::LDS_BYTES + pad;
-  if (!attr_set) {
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(256), LDS_BYTES, st, a);
   LAUNCH_CHECK();

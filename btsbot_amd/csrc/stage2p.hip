@@ -756,10 +756,10 @@ template <typename T, int G = S2P_ALERTS, int TRAIN = 0> int launch_stage2p_t(co
   auto kern = stage2p_kernel<T, G, TRAIN>;
   constexpr int lds_bytes = TRAIN == 1 ? Lds<T, G>::BYTES_TRAIN : Lds<T, G>::BYTES;
   static_assert(lds_bytes <= 160 * 1024, "the images fit one CU");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), lds_bytes, st, a);
   LAUNCH_CHECK();

@@ -458,19 +458,19 @@ template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase,
   if (phase == 0) {
     auto kern1 = s3_fc1_kernel<T, C>;
     if (LDS1 > 65536) {
-      static bool attr1_set = false;
-      if (!attr1_set) {
+      static DevOnce attr1_set;
+      if (attr1_set.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
-        attr1_set = true;
+        attr1_set.done();
       }
     }
     hipLaunchKernelGGL(kern1, dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
   } else {
     auto kern = s3_fc2_kernel<T, C>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RED_BYTES));
-      attr_set = true;
+      attr_set.done();
     }
     hipLaunchKernelGGL(kern, dim3(((a.B + M2 - 1) / M2) * (C / N2)), dim3(NT), RED_BYTES, st, a, j);
   }

@@ -9,7 +9,7 @@ front of batch n + 1.  Measured on MI355X, mm_ConvNeXt-pico bf16, 1024-alert bat
 0.313 with two batches in flight, 0.301 with three (the default; four: 0.302).
 
 This is the reference's scoring loop (`for triplets, metadata in loader: model(triplets, metadata)`,
-/root/reference/btsbot/validate_model.py and inference_example.py) with the per-batch calls overlapped; a single
+/root/reference/btsbot/val.py:128-157 and inference_example.py:75-91) with the per-batch calls overlapped; a single
 `model(x)` call keeps PyTorch's stream semantics and is not affected.
 
     scorer = ScoreStream(model)                 # depth=3: three batches in flight
@@ -47,7 +47,9 @@ def _replica(model):
     return twin.to(dev).eval()
 
 
-_S2P_HINT = int(__import__("os").environ.get("BTSBOT_AMD_S2P_HINT", "7"))   # (developer A/B: 5 or 7)
+_S2P_HINT = int(__import__("os").environ.get("BTSBOT_AMD_S2P_HINT", "7"))   # (developer A/B: 4, 5 or 7; 0 = by rounds)
+if _S2P_HINT not in (0, 4, 5, 7):   # (the library would reject the value and the hint would silently do nothing)
+    raise ValueError(f"BTSBOT_AMD_S2P_HINT={_S2P_HINT}: stage2p keeps 4, 5 or 7 alerts per workgroup (0: its own choice)")
 
 
 class ScoreStream:
@@ -101,7 +103,7 @@ class ScoreStream:
             # several forwards in flight: the stage-2 kernel keeps 7 alerts per workgroup at every batch size and so
             # leaves ~40 % of the CUs to the other stream's kernels (+6 % through this loop at 1024 alerts; a lone
             # model(...) call is 4 % slower that way, so the hint is taken back right after the launches are queued)
-            _lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", _S2P_HINT)
+            _lib.check(_lib.lib().btsbot_set_option(m._handle.ptr, b"stage2p_alerts", _S2P_HINT), "btsbot_set_option")
         with torch.cuda.stream(side), torch.no_grad():
             try:
                 out = m(*inputs)

@@ -175,7 +175,10 @@ class Trainer:
             m.mark_weights_dirty()
             if _EAGER_REPACK and self.need_image:
                 # the operand images of the NEXT step, queued now: the library packs them on its side stream, under the
-                # next step's mask draws and stem instead of in front of its first consumer (BTSBOT_AMD_EAGER_REPACK=0: A/B)
+                # next step's mask draws and stem instead of in front of its first consumer (BTSBOT_AMD_EAGER_REPACK=0: A/B).
+                # The next training forward trusts this pack while the parameters' tensor versions are unchanged: code
+                # that writes the arena BEHIND torch's back between two steps (a raw C-ABI kernel, `.data` edits, a
+                # custom exchange) must call model.mark_weights_dirty() afterwards, or the step runs on stale images.
                 if getattr(m, "_reserved_image", False):
                     with torch.cuda.device(dev):
                         m._prepare(dev, int(self.last_logits.numel()), train_only=True)   # (one logit per alert)

@@ -261,7 +261,11 @@ int btsbot_op_gemm(int prec, int epi, const void* X, const void* W, const float*
                    void* stream);
 /* K2+K3: depthwise 7x7 p3 + bias + LayerNorm(C, eps 1e-6).  x [B,HW,HW,C] f32 NHWC ->
  * xn [B,HW,HW,C] (prec).  w_tap_major is [49][C] f32.  (C,HW) in {(64,15),(128,7),(256,3),(512,1),
- * (80,15),(160,7),(320,3),(640,1)}. */
+ * (80,15),(160,7),(320,3),(640,1)}.  Arithmetic: fp32 FMAs on the fp32 map, two-pass variance -- EXCEPT the 15x15 maps
+ * in the bf16 / f16 modes, which run the convolution on the matrix pipe: map and taps are rounded to `prec` before
+ * the 49 products (fp32 accumulation) and the variance is single-pass (E[d^2] - mean^2, clamped at 0), so an output
+ * map whose per-pixel mean dwarfs its spread loses bits there; BTSBOT_AMD_NO_DW15=1 (process-wide) keeps the fp32
+ * per-tap kernel. */
 int btsbot_op_dwconv_ln(int prec, const float* x, const float* w_tap_major, const float* bias,
                         const float* ln_w, const float* ln_b, void* xn, int B, int HW, int C,
                         void* stream);

@@ -64,3 +64,22 @@ for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"
 open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])
 for k, v in sorted(out["kernels"].items(), key=lambda x: -x[1]["traffic_bytes"] * x[1]["launches"])[:10]:
     print(f'{v["family"]:24s} launches {v["launches"]:4d}  fetch {v["fetch_bytes"]/1e6:8.2f} MB  write {v["write_bytes"]/1e6:8.2f} MB')
+# every JSON summary bench.py quotes carries the digest of the kernel sources it was collected under (bench.py marks a
+# summary from other sources "stale": true)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob("btsbot_amd/csrc/*.hip") + glob.glob("btsbot_amd/csrc/*.h")):
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    sha = hsh.hexdigest()[:16]
+    for name in ("pmc_traffic", "mfma_util", "depthwise_norm_hbm", "pmc_traffic_train"):
+        path = f"profiles/{tag}_{name}.json"
+        if os.path.exists(path):
+            d = json.load(open(path))
+            d["csrc_sha16"] = sha
+            json.dump(d, open(path, "w"), indent=1)
+    print("csrc_sha16", sha)
+except Exception as e:   # noqa: BLE001
+    print("could not stamp the summaries:", e)
+
