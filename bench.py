@@ -552,6 +552,60 @@ def dev_of(t):
     return t.device
 
 
+def host_fed_leg(model, dev, img, meta, args, n_batches=48):
+    """The scoring loop fed from HOST memory, the way the reference's loops are fed (a DataLoader's CPU tensors:
+    /root/reference/btsbot/inference_example.py:66-82; raw cutouts through make_triplet: alert_utils.py:110-196):
+    pinned host batches -> asynchronous copies on a copy stream -> (btsbot_prep_triplets ->) ScoreStream.  Reported
+    beside `value` (whose inputs are resident in HBM), never as it: 47,628 fp32 bytes per alert cross PCIe here.
+    Forms: fp32 triplets as the reference prepares them; f16 triplets widened on the device (half the bytes on the
+    link, one more pass over HBM); raw fp32 cutouts + shapes normalised and padded on the device (btsbot_prep_triplets)."""
+    from btsbot_amd.alert_utils import prep_triplets
+    B = img.shape[0]
+    nbuf = 4
+    h_img = [img.cpu().pin_memory() for _ in range(nbuf)]
+    h_img16 = [img.cpu().half().pin_memory() for _ in range(nbuf)]
+    h_meta = [meta.cpu().pin_memory() for _ in range(nbuf)]
+    h_shapes = torch.full((B, 3, 2), 63, dtype=torch.int32).pin_memory()
+    copy = torch.cuda.Stream(device=dev)
+    scorer = btsbot_amd.ScoreStream(model, depth=max(2, args.pipeline_depth), inputs_ready=False)
+    cur = torch.cuda.current_stream(dev)
+
+    def batches(n, form):
+        for i in range(n):
+            with torch.cuda.stream(copy):
+                d_meta = h_meta[i % nbuf].to(dev, non_blocking=True)
+                if form == "f16":
+                    d_img = h_img16[i % nbuf].to(dev, non_blocking=True).float()
+                else:
+                    d_img = h_img[i % nbuf].to(dev, non_blocking=True)
+                d_shapes = h_shapes.to(dev, non_blocking=True) if form == "raw+prep" else None
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            cur.wait_event(ev)          # ScoreStream's side streams order themselves behind the caller's stream
+            if form == "raw+prep":
+                d_img, _drop = prep_triplets(d_img, d_shapes, normalize=True)
+            yield d_img, d_meta
+
+    out = {"workload": f"{B} alerts per batch from pinned host memory, {n_batches} batches, ScoreStream depth "
+                       f"{len(scorer.models)}; inputs cross PCIe inside the timed region",
+           "note": "never `value`: the headline's inputs are resident in HBM (BASELINE.json north_star)"}
+    for form, bytes_per_alert in (("fp32", 3 * 63 * 63 * 4 + 25 * 4), ("f16", 3 * 63 * 63 * 2 + 25 * 4),
+                                  ("raw+prep", 3 * 63 * 63 * 4 + 25 * 4 + 24)):
+        for _ in scorer.map(batches(6, form), lag=6):     # warm-up: allocator pools, pinned-copy path
+            pass
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        last = None
+        for last in scorer.map(batches(n_batches, form), lag=8):
+            pass
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out[form] = {"value": round(B * n_batches / el, 1), "unit": "alerts/s", "ms_per_batch": round(1e3 * el / n_batches, 4),
+                     "pcie_gbs": round(B * n_batches * bytes_per_alert / el / 1e9, 2),
+                     "host_bytes_per_alert": bytes_per_alert, "finite": bool(torch.isfinite(last).all().item())}
+    return out
+
+
 def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None, batch=None):
     """BASELINE.json configs[2]: the training step of mm_ConvNeXt, every parameter trainable."""
     from btsbot_amd.train import Trainer
@@ -777,6 +831,11 @@ def main():
             del big_img, big_meta
         except Exception as e:   # noqa: BLE001
             legs["batch8192"] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            try:
+                legs["host_fed"] = host_fed_leg(model, dev, img, meta, args)
+            except Exception as e:   # noqa: BLE001
+                legs["host_fed"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- training leg (BASELINE.json configs[2]): mm_ConvNeXt, every parameter trainable,
     #      BCE(pos_weight) + backward + one all-reduce of the flat gradient arena + AdamW per step

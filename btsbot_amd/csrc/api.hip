@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <algorithm>
 
 #include <string>
 #include <vector>
@@ -626,6 +628,11 @@ extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
       btsbot_set_error("set_option: deterministic = 1 must be set before btsbot_reserve_train() (it sizes a scratch there)");
       return BTSBOT_ERR_STATE;
     }
+    if (value == 1 && h->is_maxvit) {
+      btsbot_set_error("set_option: the deterministic reductions cover the ConvNeXt training step; a MaxViT branch's "
+                       "backward still meets through atomics");
+      return BTSBOT_ERR_STATE;
+    }
     h->deterministic = value == 1;
     return BTSBOT_OK;
   }
@@ -1125,9 +1132,15 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
   // (MaxViT: with_image_grads = 1 trains the branch -- BatchNorm2d batch statistics, maxvit_train.hip; = 0 serves heads
   //  over a frozen, eval-mode branch with the inference kernels)
   const bool want_bb = with_image_grads && h->has_image;
-  if (h->deterministic && h->det_scratch == nullptr) {   // partial rows of the batch reductions (common.h: det_add)
-    h->det_floats = (size_t)16 << 20;
-    HIP_TRY(hipMalloc(&h->det_scratch, h->det_floats * sizeof(float)));
+  if (h->deterministic) {   // partial rows of the batch reductions (common.h: det_add), sized by the batch: 256 KB per alert,
+    const size_t want = std::max((size_t)16 << 20, (size_t)max_batch << 16);   // at least 64 MB (what a step of <= 256 alerts takes)
+    if (h->det_scratch == nullptr || h->det_floats < want) {
+      HIP_TRY(hipDeviceSynchronize());
+      if (h->det_scratch != nullptr) (void)hipFree(h->det_scratch);
+      h->det_scratch = nullptr;
+      h->det_floats = want;
+      HIP_TRY(hipMalloc(&h->det_scratch, h->det_floats * sizeof(float)));
+    }
   }
   if (h->tcache != nullptr && max_batch <= h->tcache_batch &&
       (!want_bb || (h->bbcache != nullptr && max_batch <= h->bbcache_batch)))
@@ -1251,7 +1264,14 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
   for (int i = 0; i < h->n_buckets; ++i)
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
-  if (h->use_side && h->side == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  if (h->use_side && (h->side == nullptr || h->side_for != st)) {
+    if (h->side != nullptr) {   // the caller changed streams: the old side stream may share the new one's hardware queue
+      HIP_TRY(hipStreamSynchronize(h->side));
+      (void)hipStreamDestroy(h->side);
+      h->side = nullptr;
+    }
+    TRY(create_side_stream(h, st));
+  }
   h->side_used = 0;
   // deterministic mode: the launchers below take their partial rows from this scratch (fixed-order reductions)
   struct DetScope {
@@ -1274,6 +1294,67 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
   }
   h->bucket_recorded = true;
   h->last_grad_arena = grad_arena;
+  if (det_fell_short()) {   // (the gradients are complete and correct, but not bit-reproducible: say so instead of OK)
+    btsbot_set_error("backward: the deterministic mode's scratch (%zu floats) was too small for a batch of %d -- some "
+                     "reductions fell back to atomics; call btsbot_reserve_train() with the option already set",
+                     h->det_floats, h->train_batch);
+    return BTSBOT_ERR_STATE;
+  }
+  return BTSBOT_OK;
+}
+
+// The backward's second stream must be served by a DIFFERENT hardware pipe than the caller's stream.  A compute pipe
+// works on one of its hardware queues at a time and changes queue when that one runs dry or after a time quantum; which
+// pipe a new stream's queue gets depends on how many queues the process already has.  When both streams of the backward
+// land on one pipe their kernels are dispatched in turns of ~50 us instead of side by side: measured 4.9-7.0 ms per
+// 1024-alert step against 2.75 ms, in every process that had used exactly THREE other streams before the first
+// btsbot_backward() (bench.py's scoring loop; tools/host_streams_probe2.py: two or four are fine; stream priorities and
+// GPU_MAX_HW_QUEUES do not move it).  The placement cannot be asked, so it is measured: a train of short spinning
+// kernels keeps the caller's stream busy, an empty kernel goes to the candidate, and the host times the candidate's
+// kernel -- a few microseconds beside the train, a quantum or more behind it.  Up to eight candidates, once per handle (and
+// again should the caller come with another stream).
+__global__ void spin_kernel(unsigned long long ticks) {   // s_memrealtime counts at 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void empty_kernel() {}
+
+int create_side_stream(btsbot_ctx* h, hipStream_t caller) {
+  hipEvent_t e_cand = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&e_cand, hipEventDisableTiming));
+  const bool debug = getenv("BTSBOT_AMD_DEBUG_SIDE") != nullptr;
+  hipStream_t rejected[8];
+  int nrej = 0;
+  hipStream_t chosen = nullptr;
+  for (int attempt = 0; attempt < 8 && chosen == nullptr; ++attempt) {
+    hipStream_t cand = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, cand);   // (first use of the stream: its queue exists now)
+    HIP_TRY(hipStreamSynchronize(cand));
+    double worst = 0.0;
+    for (int trial = 0; trial < 3; ++trial) {
+      HIP_TRY(hipStreamSynchronize(caller));
+      for (int i = 0; i < 24; ++i) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, caller, 2500ULL);   // 24 x 25 us
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, cand);
+      HIP_TRY(hipEventRecord(e_cand, cand));
+      HIP_TRY(hipEventSynchronize(e_cand));
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      worst = us > worst ? us : worst;
+    }
+    HIP_TRY(hipStreamSynchronize(caller));
+    const bool apart = worst < 30.0;
+    if (debug)
+      fprintf(stderr, "btsbot: side-stream candidate %d: its kernel took %.1f us beside a busy caller's stream %p -> %s\n",
+              attempt, worst, (void*)caller, apart ? "taken" : "same pipe, rejected");
+    if (apart) chosen = cand;
+    else rejected[nrej++] = cand;
+  }
+  if (chosen == nullptr) chosen = rejected[--nrej];   // (no candidate ran beside the caller's stream: keep one anyway)
+  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+  (void)hipEventDestroy(e_cand);
+  h->side = chosen;
+  h->side_for = caller;
   return BTSBOT_OK;
 }
 

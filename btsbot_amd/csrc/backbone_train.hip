@@ -197,7 +197,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       a.train = 2;
       a.alerts_hint = h->s2p_alerts_hint;
       TRYB(launch_stage2p(c.precision, a, st));
-      if (h->use_side && h->side == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      if (h->use_side && h->side == nullptr) TRYB(create_side_stream(h, st));
       if (h->s2_ready == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->s2_ready, hipEventDisableTiming));
       hipStream_t sd = st;
       TRYB(side_fork(h, st, &sd));

@@ -660,6 +660,7 @@ int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int 
 namespace {
 thread_local float* g_det_base = nullptr;
 thread_local size_t g_det_cap = 0, g_det_used = 0;
+thread_local bool g_det_short = false;   // a request did not fit the scratch: that reduction fell back to atomics
 
 // 32 columns x 8 row groups per workgroup: group q adds rows q, q + 8, ... in order, the groups meet in LDS in order
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nrows, int C, int W,
@@ -689,8 +690,17 @@ void det_begin(float* base, size_t floats) {
   g_det_used = 0;
 }
 void det_end() { det_begin(nullptr, 0); }
+bool det_fell_short() {   // since the last call: did any reduction of this thread's backward not fit the scratch?
+  const bool v = g_det_short;
+  g_det_short = false;
+  return v;
+}
 float* det_alloc(size_t floats) {
-  if (g_det_base == nullptr || g_det_used + floats > g_det_cap) return nullptr;
+  if (g_det_base == nullptr) return nullptr;
+  if (g_det_used + floats > g_det_cap) {
+    g_det_short = true;
+    return nullptr;
+  }
   float* p = g_det_base + g_det_used;
   g_det_used += (floats + 63) / 64 * 64;
   return p;

@@ -222,6 +222,7 @@ __device__ __forceinline__ void det_add(float* out, float v, float* part, size_t
 struct DetOut { float* ptr; int stride; };   // column c of output o goes to ptr[c * stride]
 void det_begin(float* base, size_t floats);  // the scratch of this thread's btsbot_backward() call (base == nullptr: mode off)
 void det_end();
+bool det_fell_short();                       // (and clears the flag) a det_alloc() since the last call found the scratch full
 float* det_alloc(size_t floats);             // nullptr when the mode is off (or the scratch is exhausted: atomics then)
 // outs[o].ptr[c * stride] += sum over rows r (in order) of part[r * nout * C + o * C + c]
 int launch_det_reduce(const float* part, int nrows, int C, int nout, const DetOut* outs, hipStream_t st);

@@ -149,6 +149,7 @@ struct btsbot_ctx {
   hipEvent_t xchg_done = nullptr;
   // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
   hipStream_t side = nullptr;
+  hipStream_t side_for = nullptr;    // the caller's stream h->side was chosen against (create_side_stream)
   std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()
   size_t side_used = 0;
   // btsbot_pack_params_train() queues its packing launches on `side` behind the mirror copy: they then overlap the
@@ -177,6 +178,7 @@ struct btsbot_ctx {
 
 // Fork / join of the backward's second stream.  side_fork: work queued on *sd afterwards sees everything queued on
 // `st` so far (*sd = st when the second stream is off); side_join: `st` waits for everything queued on the side.
+int create_side_stream(btsbot_ctx* h, hipStream_t caller);   // api.hip: h->side, on another hardware queue than `caller`
 int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
 int side_join(btsbot_ctx* h, hipStream_t st);
 
