@@ -253,6 +253,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
   if (cfg->precision == BTSBOT_F16X2) {   // kernels without a split-operand form run the fp32 schedule
     h->x2 = true;
     h->cfg.precision = BTSBOT_F32;
+    const char* tp = getenv("BTSBOT_AMD_X2_TAIL_F16");
+    h->x2_tail_plain = tp != nullptr && tp[0] == '1';
   }
   const int w = cfg->wiring;
   h->has_image = (w != BTSBOT_UM_NN);
@@ -352,6 +354,9 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     const char* nsl = getenv("BTSBOT_AMD_S2P_LIGHT");
     h->s2p_light = !h->s2p_train && h->stage2p && h->use_s2p && !h->x2 && !h->fp8 &&
                    (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nsl != nullptr && nsl[0] == '1';
+    const char* ns0t = getenv("BTSBOT_AMD_NO_S0_TRAIN");
+    h->s0_train = h->stage0 && h->use_stage0 && !h->x2 && !h->fp8 &&
+                  (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && !(ns0t != nullptr && ns0t[0] == '1');
     const char* ns16 = getenv("BTSBOT_AMD_NO_STEM16");
     h->use_stem16 = !(ns16 != nullptr && ns16[0] == '1');
     const char* det = getenv("BTSBOT_AMD_DETERMINISTIC");
@@ -383,6 +388,7 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->side_ev) (void)hipEventDestroy(e);
   if (h->s2_ready) (void)hipEventDestroy(h->s2_ready);
+  if (h->pack_early_ev) (void)hipEventDestroy(h->pack_early_ev);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return BTSBOT_OK;
@@ -419,7 +425,16 @@ int side_join(btsbot_ctx* h, hipStream_t st);
 int pack_sync(btsbot_ctx* h, hipStream_t st) {
   if (!h->pack_on_side) return BTSBOT_OK;
   h->pack_on_side = false;
+  h->pack_early = false;
   return side_join(h, st);
+}
+// `st` waits for the stem / stage-0 operand images only (the re-pack queues them first and records an event behind them);
+// the rest of the re-pack runs on under the stage-0 megakernel and pack_sync() joins it in front of stage 1
+int pack_sync_early(btsbot_ctx* h, hipStream_t st) {
+  if (!h->pack_on_side) return BTSBOT_OK;
+  if (!h->pack_early) return pack_sync(h, st);
+  HIP_TRY(hipStreamWaitEvent(st, h->pack_early_ev, 0));
+  return BTSBOT_OK;
 }
 
 extern "C" int btsbot_pack_params(btsbot_handle h, const float* master, void* stream) {
@@ -463,13 +478,17 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     return e != nullptr && e[0] == '1';
   }();
   const int kind = train_only ? 1 : 0;
-  std::vector<PackJob> jobs;
+  std::vector<PackJob> jobs, jobs_early;
   const bool build = !unbatched && h->pack_jobs[kind] == nullptr;
+  // training re-pack with the stage-0 megakernel in the forward (s0_train): the jobs it reads go into a table of their
+  // own that is launched first ([2]); `early_now` marks them while the tables are built
+  const bool split = train_only && h->s0_train && !unbatched && h->has_image && !h->is_maxvit;
+  bool early_now = false;
   int status = BTSBOT_OK;
   auto job = [&](int op, const float* src, const float* scale, void* dst, int R, int Cc) {
     if (status != BTSBOT_OK) return;
     if (!unbatched) {
-      if (build) jobs.push_back(PackJob{src, scale, dst, R, Cc, op, 0});
+      if (build) (split && early_now ? jobs_early : jobs).push_back(PackJob{src, scale, dst, R, Cc, op, 0});
       return;
     }
     switch (op) {
@@ -482,18 +501,23 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   };
   const bool convnext = h->has_image && !h->is_maxvit;
   if (convnext) {
+    early_now = true;
     if (h->stage0 || h->train_packs)
       job(PACK_CAST, m + h->stem_w, nullptr, h->extra + h->p_stem16, c.dims[0] * 48, 1);
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
+      early_now = i <= 1;
       if (i > 0) {
         job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
+        early_now = false;   // (stage 1's own jobs and the dgrad transposes are not read by the stage-0 kernel)
         if (h->train_packs)
           job(PACK_DOWN_T, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wt, ch, c.dims[i - 1]);
       }
       for (const BlockPk& b : h->blocks[i]) {
+        early_now = i == 0;
         job(PACK_TRANSPOSE_F32, m + b.dw_w, nullptr, h->extra + b.p_dw, ch, 49);
         job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
+        early_now = false;
         job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
         if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
           job(PACK_TRANSPOSE_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch, ch);
@@ -509,17 +533,39 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   for (int i = 0; i < h->n_comb; ++i)
     job(PACK_TRANSPOSE_F32, m + h->comb_w[i], nullptr, h->extra + h->p_comb[i], h->comb_dims[i + 1],
         h->comb_dims[i]);
+  early_now = false;
   TRY(status);
-  if (build && !jobs.empty()) {
+  auto upload = [&](std::vector<PackJob>& v, int slot) -> int {
+    if (v.empty()) return BTSBOT_OK;
     int nb = 0;
-    for (PackJob& j : jobs) {
+    for (PackJob& j : v) {
       j.blk0 = nb;
       nb += pack_job_blocks(j);
     }
-    HIP_TRY(hipMalloc(&h->pack_jobs[kind], jobs.size() * sizeof(PackJob)));
-    HIP_TRY(hipMemcpy(h->pack_jobs[kind], jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
-    h->pack_njobs[kind] = (int)jobs.size();
-    h->pack_blocks[kind] = nb;
+    HIP_TRY(hipMalloc(&h->pack_jobs[slot], v.size() * sizeof(PackJob)));
+    HIP_TRY(hipMemcpy(h->pack_jobs[slot], v.data(), v.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    h->pack_njobs[slot] = (int)v.size();
+    h->pack_blocks[slot] = nb;
+    return BTSBOT_OK;
+  };
+  if (build) {
+    TRY(upload(jobs, kind));
+    if (split) TRY(upload(jobs_early, 2));
+  }
+  h->pack_early = false;
+  if (split && h->pack_jobs[2] != nullptr) {
+    // what the stage-0 megakernel reads, first: its table, then the stage-0 blocks' gamma-scaled fc2 filters and parameter
+    // images (they read the tap-major taps the table wrote), then the event pack_sync_early() waits for
+    TRY(launch_pack_jobs(c.precision, reinterpret_cast<const PackJob*>(h->pack_jobs[2]), h->pack_njobs[2], h->pack_blocks[2], st));
+    for (const BlockPk& b : h->blocks[0]) {
+      const int ch = c.dims[0];
+      TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch, 4 * ch, st));
+      TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b, m + b.ln_w, m + b.ln_b,
+                            m + b.fc1_b, m + b.fc2_b, m + b.gamma, h->extra + b.p_s0par, st));
+    }
+    if (h->pack_early_ev == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->pack_early_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->pack_early_ev, st));
+    h->pack_early = true;
   }
   if (!unbatched)
     TRY(launch_pack_jobs(c.precision, reinterpret_cast<const PackJob*>(h->pack_jobs[kind]), h->pack_njobs[kind],
@@ -531,7 +577,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     for (int i = 0; i < 4; ++i) {
       const int ch = c.dims[i];
       for (const BlockPk& b : h->blocks[i]) {
-        if (!train_only)
+        if (!train_only || (i == 0 && h->s0_train && !h->pack_early))
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
         if (i == 2 && h->stage2p && (!train_only || h->s2p_train || h->s2p_light)) {
@@ -547,7 +593,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (i == 1 && ch == 128 && (c.precision != BTSBOT_F32 || (h->x2 && h->stage1)) && !train_only)
           TRY(launch_pack_s1par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw),
                                 m + b.dw_b, m + b.ln_w, m + b.ln_b, h->extra + b.p_s0par, st));
-        if (i == 0 && ch == 64 && (c.precision != BTSBOT_F32 || (h->x2 && h->stage0)) && !train_only)   // (after the tap-major transpose above: same stream)
+        if (i == 0 && ch == 64 && (c.precision != BTSBOT_F32 || (h->x2 && h->stage0)) && (!train_only || (h->s0_train && !h->pack_early)))   // (after the tap-major transpose above: same stream)
           TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
@@ -1160,7 +1206,7 @@ extern "C" int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_ima
     if (!h->train_packs && !h->is_maxvit) {      // the dgrad transposes must be packed too from now on
       h->train_packs = true;
       h->packed = false;
-      for (int kd = 0; kd < 2; ++kd) {   // the job tables were built without the transposes: rebuild on the next pack
+      for (int kd = 0; kd < 3; ++kd) {   // the job tables were built without the transposes: rebuild on the next pack
         if (h->pack_jobs[kd]) {
           HIP_TRY(hipDeviceSynchronize());
           (void)hipFree(h->pack_jobs[kd]);

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "ctx.h"
+#include "stage0.h"
 #include "stage2p.h"
 
 namespace {
@@ -146,16 +147,56 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   auto stage_in = [&](int i) { return h->blocks[i].empty() ? k.xs[i] : k.blk[i][0].xin; };
   // (the pre-LayerNorm output is kept for the backward; 16-bit modes: the matrix-pipe stem, which like stem_kernel reads
   //  nothing packed -- the operand re-pack of this step runs on the side stream meanwhile)
-  if (h->use_stem16 && stem16_supported(c.precision, c.dims[0]))
+  const bool s0t = h->s0_train && h->blocks[0].size() == 2 && h->mlp_fused(c.dims[0]) && h->use_dwln;
+  if (s0t) {
+    // stem + stage 0 + the first downsample as one launch of the inference megakernel's keeping form: every buffer the
+    // backward reads of them is written on its way (stage0.h).  It needs this step's operand images at once: the
+    // re-pack queued behind the previous optimiser step runs under the mask draws and whatever precedes this call
+    TRYB(pack_sync_early(h, st));
+    Stage0Args a;
+    memset(&a, 0, sizeof(a));
+    a.img = img;
+    a.stem_w = h->extra + h->p_stem16;
+    a.stem_b = m + h->stem_b;
+    a.stem_lnw = m + h->stem_lnw;
+    a.stem_lnb = m + h->stem_lnb;
+    for (int j = 0; j < 2; ++j) {
+      const BlockPk& b = h->blocks[0][j];
+      a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+      a.blk[j].dw_b = m + b.dw_b;
+      a.blk[j].ln_w = m + b.ln_w;
+      a.blk[j].ln_b = m + b.ln_b;
+      a.blk[j].b1 = m + b.fc1_b;
+      a.blk[j].b2 = m + b.fc2_b;
+      a.blk[j].gamma = m + b.gamma;
+      a.blk[j].w1 = h->extra + b.p_fc1;
+      a.blk[j].w2g = h->extra + b.p_fc2g;
+      a.blk[j].par = h->extra + b.p_s0par;
+      a.keep_d[j] = k.blk[0][j].d;
+      a.keep_xn[j] = k.blk[0][j].xn;
+    }
+    a.ds_lnw = m + h->down[1].ln_w;
+    a.ds_lnb = m + h->down[1].ln_b;
+    a.ds_w = h->extra + h->down[1].p_w;
+    a.ds_b = m + h->down[1].b;
+    a.out = stage_in(1);
+    a.keep_stem_pre = k.stem_pre;
+    a.tap_stem = k.blk[0][0].xin;
+    a.keep_xin1 = k.blk[0][1].xin;
+    a.tap_stage = k.xs[0];
+    a.keep_patches = k.patches[1];
+    a.B = B;
+    TRYB(launch_stage0b(c.precision, a, st));
+  } else if (h->use_stem16 && stem16_supported(c.precision, c.dims[0]))
     TRYB(launch_stem16(c.precision, img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0), B,
                        c.dims[0], st, k.stem_pre));
   else
     TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
                      B, c.dims[0], st, k.stem_pre));
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
-  for (int i = 0; i < 4; ++i) {
+  for (int i = s0t ? 1 : 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light))) {
+    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light)) && !(i == 1 && s0t)) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));

@@ -80,8 +80,10 @@ struct btsbot_ctx {
   // device memory
   float* mirror = nullptr;          // fp32 copy of the master arena (same offsets)
   unsigned char* extra = nullptr;   // transformed operands
-  void* pack_jobs[2] = {nullptr, nullptr};   // device tables of PackJob: [0] full pack, [1] training re-pack
-  int pack_njobs[2] = {0, 0}, pack_blocks[2] = {0, 0};
+  void* pack_jobs[3] = {nullptr, nullptr, nullptr};   // device tables of PackJob: [0] full pack, [1] training re-pack,
+  int pack_njobs[3] = {0, 0, 0}, pack_blocks[3] = {0, 0, 0};   // [2] the part of [1] the stage-0 megakernel reads (s0_train)
+  hipEvent_t pack_early_ev = nullptr;   // recorded behind that part and the stage-0 parameter images (pack_sync_early)
+  bool pack_early = false;              // the running re-pack recorded it
   size_t extra_bytes = 0;
   bool packed = false;
   bool packed_full = false;   // false after btsbot_pack_params_train(): inference-only operand images are stale
@@ -104,8 +106,11 @@ struct btsbot_ctx {
   bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
   bool x2 = false;         // created with BTSBOT_F16X2: cfg.precision reads BTSBOT_F32 (the schedule of every kernel without
                            // a split-operand form), the kernels that have one run it
-  int prec_tail() const { return fp8 ? BTSBOT_FP8 : x2 ? BTSBOT_F16X2 : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip
-  int prec_down3() const { return x2 ? BTSBOT_F16X2 : cfg.precision; }   // ... of the last downsample inside stage2p.hip
+  // (x2_tail_plain: developer experiment BTSBOT_AMD_X2_TAIL_F16=1 -- the split mode with stages 2-3 on plain f16 operands:
+  //  what does the mode's error owe to which stage?)
+  bool x2_tail_plain = false;
+  int prec_tail() const { return fp8 ? BTSBOT_FP8 : x2 ? (x2_tail_plain ? BTSBOT_F16 : BTSBOT_F16X2) : cfg.precision; }   // operand mode of stage2p.hip / stage3.hip
+  int prec_down3() const { return x2 ? (x2_tail_plain ? BTSBOT_F16 : BTSBOT_F16X2) : cfg.precision; }   // ... of the last downsample inside stage2p.hip
   bool stage3 = false;     // stage3.hip: the 1x1 stage as two fragment-streaming launches per block
   bool use_s3 = true;      // BTSBOT_AMD_NO_S3=1: dwconv_ln + the generic GEMMs instead
   bool use_fused = true;   // BTSBOT_AMD_NO_FUSED_MLP=1 keeps the two-GEMM path (A/B timing)
@@ -140,6 +145,10 @@ struct btsbot_ctx {
   bool s2p_light = false;
   hipEvent_t s2_ready = nullptr;
   bool s2_pending = false;           // the last training forward queued that recompute: the backward waits for s2_ready
+  // Training forward of stem + stage 0 + first downsample as ONE launch of the inference megakernel's keeping form
+  // (stage0b.hip, KEEP) instead of stem16 + 2 x (dwconv_ln + fused_mlp) + ln_patch + GEMM (16-bit modes).
+  // BTSBOT_AMD_NO_S0_TRAIN=1: the per-op launches (A/B timing, parity tests).
+  bool s0_train = false;
   bool use_stem16 = true;            // BTSBOT_AMD_NO_STEM16=1: the fp32 VALU stem in the 16-bit modes too (A/B, parity)
   bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
   float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)
@@ -183,3 +192,4 @@ int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
 int side_join(btsbot_ctx* h, hipStream_t st);
 
 int pack_sync(btsbot_ctx* h, hipStream_t st);   // api.hip
+int pack_sync_early(btsbot_ctx* h, hipStream_t st);   // api.hip: only what stage0b_kernel reads (else = pack_sync)

@@ -36,6 +36,15 @@ struct Stage0Args {
   unsigned long long* wgt;      // optional: every workgroup's start / end (100 MHz wall clock), [grid][2]
   int diag;               // timing diagnostics only (BTSBOT_AMD_S0_DIAG): bit0 skip depthwise FMAs,
                           // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
+  // Training forward (keep_d[0] != nullptr; bf16 / f16): what the backward reads is written on the way --
+  // backbone_train.hip's buffers: the stem convolution's output before its LayerNorm, block 0's input = tap_stem,
+  // block 1's input, the stage output = tap_stage, per block the depthwise output before the LayerNorm (fp32) and
+  // the LayerNorm output (operand type), and the downsample's LayerNorm'd patch rows [B][49][q = 2 ky + kx][64].
+  float* keep_stem_pre;   // [B][225][64] f32
+  float* keep_xin1;       // [B][225][64] f32
+  float* keep_d[2];       // [B][225][64] f32
+  void* keep_xn[2];       // [B][225][64] operand type
+  void* keep_patches;     // [B][49][256] operand type
 };
 
 

@@ -232,7 +232,8 @@ template <bool SQ> __device__ __forceinline__ void block_reduce64(const float (&
 // (tools/error_budget2.py): 1.4e-5 rms of the 1e-4 score tolerance for the whole network.
 // WPS = waves per SIMD the register allocation leaves room for (2: two workgroups per CU, 256 registers; 1: one
 // workgroup per CU with 512 registers -- the split mode's doubled fragments spill at 256)
-template <typename T, bool X2, int WPS = 2>
+// KEEP: the training forward (Stage0Args::keep_*): the same kernel plus the copies the backward reads
+template <typename T, bool X2, int WPS = 2, bool KEEP = false>
 __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   using frag = typename SBM<T>::frag;
   using frag4 = typename SBM<T>::frag4;
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
           x[t][ct] = SBM<T>::run(af[ci][ct], bf, x[t][ct]);
         }
       }
+      if (KEEP && live[t]) regs_to_tap(x[t], a.keep_stem_pre + ((size_t)alert * P + pix[t]) * C, h);
       ln_regs(x[t], a.stem_lnw, a.stem_lnb, h, x[t]);
       if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
       if (a.tap_stem != nullptr && live[t])
@@ -473,6 +475,20 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[yb * 16 + xb * 4 + i] = acc[yb][xb][i];
     }
+    if (KEEP) {   // the depthwise output before the LayerNorm: lane = (channel, row j of the quad), 60 live values
+      float* dst = a.keep_d[j] + (size_t)alert * P * C + dch;
+#pragma unroll
+      for (int yb = 0; yb < 4; ++yb)
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb)
+          if (yb < 3 || dj < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (xb == 3 && i == 3) continue;
+              dst[((4 * yb + dj) * HW + 4 * xb + i) * C] = v[yb * 16 + xb * 4 + i];
+            }
+          }
+    }
     SB_STAMP(4 + 5 * j);   // depthwise done
     // ---- LayerNorm over the 64 channels of a pixel: 16 blocks of this wave (transposing lane reduction), then
     //      the 4 waves through LDS; single-pass variance
@@ -526,6 +542,13 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
     write_ln(false);
     SB_STAMP(5 + 5 * j);
     __syncthreads();   // LN image complete
+    if (KEEP) {   // the LayerNorm output rows, 16-byte pieces (8 per pixel row), before the image is cleared in the MLP
+      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep_xn[j]) + (size_t)alert * P * C * 2;
+      for (int i = tid; i < P * 8; i += 256) {
+        const int p = i >> 3, c16 = i & 7;
+        *reinterpret_cast<uint4*>(dst + (size_t)p * C * 2 + 16 * c16) = *reinterpret_cast<const uint4*>(map + p * PITCH + 16 * c16);
+      }
+    }
 
     // ---- fc1 -> GELU -> fc2 over 8 chunks; fc2 accumulates into x (gamma is in the filter)
     {
@@ -654,8 +677,10 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
       if (j == 0) {
         load_block_params(1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
           if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
+          if (KEEP && live[t]) regs_to_tap(x[t], a.keep_xin1 + ((size_t)alert * P + pix[t]) * C, h);
+        }
       }
     }
     SB_STAMP(6 + 5 * j);   // MLP done
@@ -690,6 +715,15 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
       for (int ks = 0; ks < 16; ++ks) afl[ks] = *reinterpret_cast<const frag*>(dwl + ks * 16);
     }
     __syncthreads();
+    if (KEEP) {   // the downsample's patch rows [output pixel][q = 2 ky + kx][64] = LayerNorm'd pixels (2 oy + ky, 2 ox + kx)
+      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep_patches) + (size_t)alert * 49 * 4 * C * 2;
+      for (int i = tid; i < 49 * 4 * 8; i += 256) {
+        const int c16 = i & 7, q = (i >> 3) & 3, o = i >> 5;
+        const int pin = (2 * (o / 7) + (q >> 1)) * HW + 2 * (o % 7) + (q & 1);
+        *reinterpret_cast<uint4*>(dst + (size_t)(o * 4 + q) * C * 2 + 16 * c16) =
+            *reinterpret_cast<const uint4*>(map + pin * PITCH + 16 * c16);
+      }
+    }
     SB_STAMP(12);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -758,8 +792,8 @@ __global__ void pack_s0par_kernel(const float* __restrict__ taps, const float* _
   reinterpret_cast<float*>(out + (X2 ? 2 : 1) * TW_BYTES)[f] = v;
 }
 
-template <typename T, bool X2 = false, int WPS = 2> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
-  auto kern = stage0b_kernel<T, X2, WPS>;
+template <typename T, bool X2 = false, int WPS = 2, bool KEEP = false> int launch_stage0b_t(const Stage0Args& a, hipStream_t st) {
+  auto kern = stage0b_kernel<T, X2, WPS, KEEP>;
   static DevOnce attr_set;
   // (BTSBOT_AMD_S0_ONE_WG=1: developer probe -- the LDS request padded so that ONE workgroup fits a CU: how the kernel's
   //  time scales from one to two waves per SIMD says what two more would buy)
@@ -828,6 +862,17 @@ bool stage0_supported(int prec, int c0) {
 // Needs Stage0Blk::par, ::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
+  if (a.keep_d[0] != nullptr) {   // the training forward
+    if (a.keep_stem_pre == nullptr || a.tap_stem == nullptr || a.keep_xin1 == nullptr || a.tap_stage == nullptr ||
+        a.keep_d[1] == nullptr || a.keep_xn[0] == nullptr || a.keep_xn[1] == nullptr || a.keep_patches == nullptr) {
+      btsbot_set_error("stage0b: the training forward needs every kept buffer");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    if (prec == BTSBOT_BF16) return launch_stage0b_t<bf16_t, false, 2, true>(a, st);
+    if (prec == BTSBOT_F16) return launch_stage0b_t<f16_t, false, 2, true>(a, st);
+    btsbot_set_error("stage0b: the training forward runs in the bf16 / f16 modes, not %d", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (prec == BTSBOT_BF16) return launch_stage0b_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage0b_t<f16_t>(a, st);
   if (prec == BTSBOT_F16X2) {
