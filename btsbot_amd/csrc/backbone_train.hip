@@ -171,7 +171,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       a.blk[j].gamma = m + b.gamma;
       a.blk[j].w1 = h->extra + b.p_fc1;
       a.blk[j].w2g = h->extra + b.p_fc2g;
-      a.blk[j].par = h->extra + b.p_s0par;
+      a.blk[j].par = h->extra + b.p_s0par_t;
       a.keep_d[j] = k.blk[0][j].d;
       a.keep_xn[j] = k.blk[0][j].xn;
     }
@@ -194,9 +194,10 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
     TRYB(launch_stem(img, m + h->stem_w, m + h->stem_b, m + h->stem_lnw, m + h->stem_lnb, stage_in(0),
                      B, c.dims[0], st, k.stem_pre));
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
+  const bool s1t = h->s1_train && h->blocks[1].size() == 2 && h->mlp_fused(c.dims[1]) && h->use_dwln;
   for (int i = s0t ? 1 : 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light)) && !(i == 1 && s0t)) {
+    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light)) && !(i == 1 && s0t) && !(i == 2 && s1t)) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
@@ -204,6 +205,39 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
                        m + h->down[i].b, nullptr, nullptr, stage_in(i), rows, ch, 4 * cin, st));
     }
     const size_t nblk = h->blocks[i].size();
+    if (i == 1 && s1t) {
+      // stage 1 + the second downsample as one launch of stage1b's keeping form: block 0's input is its x_in, block 1's
+      // input the residual copy the kernel parks between the blocks anyway
+      Stage1Args a;
+      memset(&a, 0, sizeof(a));
+      a.x_in = stage_in(1);
+      for (int j = 0; j < 2; ++j) {
+        const BlockPk& b = h->blocks[1][j];
+        a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+        a.blk[j].dw_b = m + b.dw_b;
+        a.blk[j].ln_w = m + b.ln_w;
+        a.blk[j].ln_b = m + b.ln_b;
+        a.blk[j].b1 = m + b.fc1_b;
+        a.blk[j].b2 = m + b.fc2_b;
+        a.blk[j].gamma = m + b.gamma;
+        a.blk[j].w1 = h->extra + b.p_fc1;
+        a.blk[j].w2g = h->extra + b.p_fc2g;
+        a.blk[j].par = h->extra + b.p_s0par_t;
+        a.keep_d[j] = k.blk[1][j].d;
+        a.keep_xn[j] = k.blk[1][j].xn;
+      }
+      a.ds_lnw = m + h->down[2].ln_w;
+      a.ds_lnb = m + h->down[2].ln_b;
+      a.ds_w = h->extra + h->down[2].p_wp;
+      a.ds_b = m + h->down[2].b;
+      a.out = stage_in(2);
+      a.scratch = k.blk[1][1].xin;
+      a.tap_stage = k.xs[1];
+      a.keep_patches = k.patches[2];
+      a.B = B;
+      TRYB(launch_stage1b(c.precision, a, st));
+      continue;
+    }
     if (i == 2 && h->s2p_light) {
       // Stage 2 and the last downsample as ONE launch of the inference kernel, which also leaves every block's input map,
       // the stage output and the downsample's patch rows (100 us instead of 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM =

@@ -17,6 +17,7 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   int64_t gamma, dw_w, dw_b, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_dw, p_fc1, p_fc2, p_fused;
   size_t p_s0par;          // stage-0 / stage-1 blocks: parameter image for stage0b.hip / stage1b.hip
+  size_t p_s0par_t = 0;    // ... for their keeping forms (training forward): the same image with f16 taps in every mode
   size_t p_fc2g;           // diag(gamma) W2 in the operand type (megakernels fold the layer scale)
   size_t p_w1p = 0, p_w2p = 0;   // stage2p.hip / stage3.hip: fc1 / gamma * fc2 filters as MFMA A fragments
   size_t p_scales = 0;           // fp8 mode: {S1, 1/S1, S2, 1/S2} of those two
@@ -149,6 +150,8 @@ struct btsbot_ctx {
   // (stage0b.hip, KEEP) instead of stem16 + 2 x (dwconv_ln + fused_mlp) + ln_patch + GEMM (16-bit modes).
   // BTSBOT_AMD_NO_S0_TRAIN=1: the per-op launches (A/B timing, parity tests).
   bool s0_train = false;
+  bool s1_train = false;             // likewise stage 1 + the second downsample (stage1b.hip, KEEP): default in the f16 mode,
+                                     // BTSBOT_AMD_S1_TRAIN=1 in bf16 (api.hip says why), BTSBOT_AMD_NO_S1_TRAIN=1 switches it off
   bool use_stem16 = true;            // BTSBOT_AMD_NO_STEM16=1: the fp32 VALU stem in the 16-bit modes too (A/B, parity)
   bool deterministic = false;        // btsbot_set_option("deterministic") / BTSBOT_AMD_DETERMINISTIC=1: fixed-order batch reductions
   float* det_scratch = nullptr;      // ... their partial rows (sized at btsbot_reserve_train)

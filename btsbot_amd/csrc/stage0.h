@@ -64,4 +64,11 @@ struct Stage1Args {
   unsigned long long* stamps;   // optional phase timestamps (workgroup 0, thread 0)
   unsigned long long* wgt;      // optional per-workgroup start / end, [grid][2]
   int diag;               // timing diagnostics, same bits as Stage0Args::diag
+  // Training forward (keep_d[0] != nullptr; bf16 / f16): block 0's input is x_in itself, block 1's input is what the
+  // kernel parks in `scratch` anyway (point it at that buffer), the stage output is tap_stage; per block the depthwise
+  // output before the LayerNorm (fp32) and the LayerNorm output (operand type), and the downsample's LayerNorm'd patch
+  // rows [B][9][q = 2 ky + kx][128]
+  float* keep_d[2];       // [B][49][128] f32
+  void* keep_xn[2];       // [B][49][128] operand type
+  void* keep_patches;     // [B][9][512] operand type
 };

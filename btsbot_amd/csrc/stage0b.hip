@@ -22,6 +22,8 @@
 //   * layer scale is folded into the fc2 filter (gamma * W2, packed once), so fc2 accumulates
 //     straight into the fp32 residual registers: no second accumulator tile;
 //   * a wave owns 64 pixels (2 column blocks of the 32x32 MFMA): residual = 64 registers.
+#include <type_traits>
+
 #include "common.h"
 #include "stage0.h"
 
@@ -236,7 +238,12 @@ template <bool SQ> __device__ __forceinline__ void block_reduce64(const float (&
 template <typename T, bool X2, int WPS = 2, bool KEEP = false>
 __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
   using frag = typename SBM<T>::frag;
-  using frag4 = typename SBM<T>::frag4;
+  // the depthwise phase's operand type: the training forward reads map and taps as f16 in the bf16 mode too -- the
+  // map is the fp32 residual stream, and its rounding to bf16 in front of 49 products moved a 50-step bf16 training
+  // run ten times further from the fp32 recipe than the per-op forward's fp32 convolution (test_16bit_training_follows_
+  // the_fp32_recipe: worst loss difference 4.0e-2 against 4.0e-3); f16 keeps 11 bits of it
+  using DT = typename std::conditional<KEEP, f16_t, T>::type;
+  using frag4 = typename SBM<DT>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* map = smem;     // [pixel][channel] image (MLP operand, downsample input)
   unsigned char* pl = smem;      // planar image (depthwise operand): same bytes, never live together
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
       }
       if (KEEP && live[t]) regs_to_tap(x[t], a.keep_stem_pre + ((size_t)alert * P + pix[t]) * C, h);
       ln_regs(x[t], a.stem_lnw, a.stem_lnb, h, x[t]);
-      if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
+      if (live[t]) regs_to_planar<DT, PLO>(x[t], pl, pix[t], h);
       if (a.tap_stem != nullptr && live[t])
         regs_to_tap(x[t], a.tap_stem + ((size_t)alert * P + pix[t]) * C, h);
     }
@@ -460,10 +467,10 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
               const int q = xb + rbi - 1;
               if (q < 0 || q > 3) continue;
               if (X2) {   // remainders first (small terms into the accumulator before the large one)
-                acc[yb][xb] = SBM<T>::run4(twl[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
-                acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bql[X2 ? s & 1 : 0][X2 ? q : 0], acc[yb][xb]);
+                acc[yb][xb] = SBM<DT>::run4(twl[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
+                acc[yb][xb] = SBM<DT>::run4(tw[ky * 3 + rbi], bql[X2 ? s & 1 : 0][X2 ? q : 0], acc[yb][xb]);
               }
-              acc[yb][xb] = SBM<T>::run4(tw[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
+              acc[yb][xb] = SBM<DT>::run4(tw[ky * 3 + rbi], bq[s & 1][q], acc[yb][xb]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
         load_block_params(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (live[t]) regs_to_planar<T, PLO>(x[t], pl, pix[t], h);
+          if (live[t]) regs_to_planar<DT, PLO>(x[t], pl, pix[t], h);
           if (KEEP && live[t]) regs_to_tap(x[t], a.keep_xin1 + ((size_t)alert * P + pix[t]) * C, h);
         }
       }

@@ -209,10 +209,16 @@ __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned c
 // (two products per k-step against the f16 filters), the depthwise taps likewise, the downsample with both operands split.
 // WPS = waves per SIMD the register allocation leaves room for (2: two workgroups per CU, 256 registers; 1: one
 // workgroup per CU with 512 registers -- the split mode's doubled fragments spill at 256)
-template <typename T, bool X2, int WPS = 2>
+// KEEP: the training forward (Stage1Args::keep_*): the same kernel plus the copies the backward reads
+template <typename T, bool X2, int WPS = 2, bool KEEP = false>
 __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   using frag = typename SCM<T>::frag;
-  using frag4 = typename SCM<T>::frag4;
+  // the depthwise phase's operand type: the training forward reads map and taps as f16 in the bf16 mode too -- the
+  // map is the fp32 residual stream, and its rounding to bf16 in front of 49 products moved a 50-step bf16 training
+  // run ten times further from the fp32 recipe than the per-op forward's fp32 convolution (test_16bit_training_follows_
+  // the_fp32_recipe: worst loss difference 4.0e-2 against 4.0e-3); f16 keeps 11 bits of it
+  using DT = typename std::conditional<KEEP, f16_t, T>::type;
+  using frag4 = typename SCM<DT>::frag4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* pl = smem + OFF_PL;                 // planar image; its first 16 KB double as ring slot 2
   unsigned char* stg = smem;                         // LN image [98][PITCH] in ring slots 0..1
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   {
     f32x16 x0[CT];
     load_x(xsrc, x0);
-    if (inmap) regs_to_planar<T, PLO>(x0, pl, p, h);
+    if (inmap) regs_to_planar<DT, PLO>(x0, pl, p, h);
   }
   SC_STAMP(1);
 
@@ -446,10 +452,10 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
                 const int q = xb + rbi - 1;
                 if (q < 0 || q > 1) continue;
                 if (X2) {   // remainders first
-                  acc[al][yb][xb] = SCM<T>::run4(twl[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
-                  acc[al][yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bql[X2 ? sx & 1 : 0][al][X2 ? q : 0], acc[al][yb][xb]);
+                  acc[al][yb][xb] = SCM<DT>::run4(twl[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
+                  acc[al][yb][xb] = SCM<DT>::run4(tw[ky * 3 + rbi], bql[X2 ? sx & 1 : 0][al][X2 ? q : 0], acc[al][yb][xb]);
                 }
-                acc[al][yb][xb] = SCM<T>::run4(tw[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
+                acc[al][yb][xb] = SCM<DT>::run4(tw[ky * 3 + rbi], bq[sx & 1][al][q], acc[al][yb][xb]);
               }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -462,6 +468,26 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
           for (int xb = 0; xb < 2; ++xb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[gi][al][yb * 8 + xb * 4 + i] = acc[al][yb][xb][i];
+    }
+    if (KEEP) {   // the depthwise output before the LayerNorm: lane = (channel of the group, row j of the quad)
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int al = 0; al < G; ++al) {
+          if (al >= nal) continue;
+          float* dst = a.keep_d[j] + (size_t)(a0 + al) * PA * C + 16 * (2 * wave + gi) + db;
+#pragma unroll
+          for (int yb = 0; yb < 2; ++yb)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb)
+              if (yb < 1 || dj < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (xb == 1 && i == 3) continue;
+                  dst[((4 * yb + dj) * HW + 4 * xb + i) * C] = v[gi][al][yb * 8 + xb * 4 + i];
+                }
+              }
+        }
     }
     SC_STAMP(4 + 5 * j);   // depthwise done
     // ---- LayerNorm over the 128 channels of a pixel: this wave's 2 groups in the lane, its 16 blocks by the
@@ -529,6 +555,13 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
     };
     write_ln(false);
     __syncthreads();   // LN image complete
+    if (KEEP) {   // the LayerNorm output rows, 16-byte pieces (16 per pixel row), before the ring takes the image's bytes
+      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep_xn[j]) + (size_t)a0 * PA * C * 2;
+      for (int i = tid; i < nal * PA * 16; i += 256) {
+        const int pp = i >> 4, c16 = i & 15;
+        *reinterpret_cast<uint4*>(dst + (size_t)pp * C * 2 + 16 * c16) = *reinterpret_cast<const uint4*>(stg + pp * PITCH + 16 * c16);
+      }
+    }
     issue(0);          // chunk 0 lives in slot 2 = the (dead) planar image's first 16 KB
     SC_STAMP(5 + 5 * j);
 
@@ -729,7 +762,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       if (j == 0) {      // next block's depthwise operand; chunk 15 (slot 2 = the same bytes) must be read out first
         __syncthreads();
         zero_pads();
-        if (inmap) regs_to_planar<T, PLO>(x, pl, p, h);
+        if (inmap) regs_to_planar<DT, PLO>(x, pl, p, h);
         if (live) {
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
@@ -776,6 +809,16 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       if (X2) wql[i] = fsrc(i)[64];
     }
     __syncthreads();
+    if (KEEP) {   // the downsample's patch rows [output pixel][q = 2 ky + kx][128] = LayerNorm'd pixels (2 oy + ky, 2 ox + kx)
+      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep_patches) + (size_t)a0 * PO * 4 * C * 2;
+      for (int i = tid; i < nal * PO * 4 * 16; i += 256) {
+        const int c16 = i & 15, q = (i >> 4) & 3, o2 = i >> 6;
+        const int g2 = o2 / PO, oo2 = o2 - g2 * PO;
+        const int pin2 = g2 * PA + (2 * (oo2 / 3) + (q >> 1)) * HW + 2 * (oo2 % 3) + (q & 1);
+        *reinterpret_cast<uint4*>(dst + (size_t)(o2 * 4 + q) * C * 2 + 16 * c16) =
+            *reinterpret_cast<const uint4*>(stg + pin2 * PITCH + 16 * c16);
+      }
+    }
     SC_STAMP(12);
     const int o = lr;                                // output pixel slot: 18 of 32 used
     const bool olive = o < nal * PO;
@@ -879,8 +922,8 @@ __global__ void pack_frag32_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
-template <typename T, bool X2 = false, int WPS = 2> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
-  auto kern = stage1b_kernel<T, X2, WPS>;
+template <typename T, bool X2 = false, int WPS = 2, bool KEEP = false> int launch_stage1b_t(const Stage1Args& a, hipStream_t st) {
+  auto kern = stage1b_kernel<T, X2, WPS, KEEP>;
   static DevOnce attr_set;
   static const int pad = [] {   // (BTSBOT_AMD_S1_ONE_WG=1: the same probe as stage0b.hip's)
     const char* e = getenv("BTSBOT_AMD_S1_ONE_WG");
@@ -976,6 +1019,17 @@ bool stage1_supported(int prec, int c1, int c2) {
 // and Stage1Args::ds_w as MFMA fragments (launch_pack_frag32).
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
+  if (a.keep_d[0] != nullptr) {   // the training forward
+    if (a.keep_d[1] == nullptr || a.keep_xn[0] == nullptr || a.keep_xn[1] == nullptr || a.keep_patches == nullptr ||
+        a.tap_stage == nullptr || a.scratch == nullptr) {
+      btsbot_set_error("stage1b: the training forward needs every kept buffer");
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    if (prec == BTSBOT_BF16) return launch_stage1b_t<bf16_t, false, 2, true>(a, st);
+    if (prec == BTSBOT_F16) return launch_stage1b_t<f16_t, false, 2, true>(a, st);
+    btsbot_set_error("stage1b: the training forward runs in the bf16 / f16 modes, not %d", prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (prec == BTSBOT_BF16) return launch_stage1b_t<bf16_t>(a, st);
   if (prec == BTSBOT_F16) return launch_stage1b_t<f16_t>(a, st);
   if (prec == BTSBOT_F16X2) return launch_stage1b_x2(a, st);

@@ -325,7 +325,8 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
     assert not torch.equal(want, run_model(kind, build_model(kind, cfg, sd, cuda, "bf16"), img, meta))
 
 
-@pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_keeping_kernel"])
+@pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_keeping_kernel", "stage2_light",
+                                 "per_op_forward", "stage1_keeping_kernel"])
 @pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     """The 16-bit training schedule (LDS-DMA GEMMs with the GELU_SAVE / DGELU / PLAIN epilogues, the MFMA
@@ -341,6 +342,13 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
         monkeypatch.setenv("BTSBOT_AMD_NO_MLP_BWD", "1")
     elif mlp == "stage2_keeping_kernel":   # stage 2's forward as ONE launch of stage2p_kernel's keeping form (opt-in)
         monkeypatch.setenv("BTSBOT_AMD_S2P_TRAIN", "1")
+    elif mlp == "stage2_light":   # ... as the inference kernel + block inputs, the rest recomputed on the side stream (opt-in)
+        monkeypatch.setenv("BTSBOT_AMD_S2P_LIGHT", "1")
+    elif mlp == "per_op_forward":   # stem, stages 0-1 as per-op launches (the default forward runs stage0b's / stage1b's keeping forms)
+        monkeypatch.setenv("BTSBOT_AMD_NO_S0_TRAIN", "1")
+        monkeypatch.setenv("BTSBOT_AMD_NO_S1_TRAIN", "1")
+    elif mlp == "stage1_keeping_kernel":   # stage 1's keeping form in the bf16 mode too (default there: stage 0 only)
+        monkeypatch.setenv("BTSBOT_AMD_S1_TRAIN", "1")
     kind, cfg = CONFIGS["mm_pico"]
     sd = seeded_state(kind, cfg, seed=3)
     B = 24
