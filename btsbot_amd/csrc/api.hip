@@ -1183,7 +1183,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
 float* train_cache_feat(btsbot_ctx* h, float* cache, int M);
 int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* logits,
                        float* scores, int M, const uint8_t* meta_mask, const uint8_t* comb_mask,
-                       float* master, hipStream_t st);
+                       float* master, hipStream_t st, bool meta_done = false);
+int head_train_meta_forward(btsbot_ctx* h, float* cache, const float* meta, int M, const uint8_t* meta_mask, float* master,
+                            hipStream_t st);
 int head_train_backward(btsbot_ctx* h, float* cache, const float* dlogits, float* grads, int M,
                         int need_meta, int need_image, float** dfeat_out,
                         const uint8_t* meta_mask, const uint8_t* comb_mask, hipStream_t st);
@@ -1269,6 +1271,7 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
     return BTSBOT_ERR_INVALID_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
+  bool meta_done = false, meta_on_side = false;
   h->bb_saved = false;
   h->t_img = triplets;
   // (the ConvNeXt training forward waits for the packing launches behind its stem, backbone_train.hip)
@@ -1282,8 +1285,23 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
     if (h->is_maxvit) {
       TRY(maxvit_train_forward(h, triplets, batch, master_arena, st, &feat));
       h->bb_saved = true;
-    } else
+    } else {
+      // the metadata branch reads nothing of the image branch: its three launches go to the side stream (behind the
+      // re-pack queued there) and run beside the backbone instead of in the chain behind it
+      hipStream_t sd = st;
+      static const bool meta_inline = [] {
+        const char* e = getenv("BTSBOT_AMD_NO_META_SIDE");   // 1: the metadata branch in the chain, behind the backbone (A/B)
+        return e != nullptr && e[0] == '1';
+      }();
+      if (h->has_meta && h->side != nullptr && !meta_inline) {
+        TRY(side_fork(h, st, &sd));
+        TRY(head_train_meta_forward(h, h->tcache, meta, batch, meta_mask, master_arena, sd));
+        meta_on_side = sd != st;
+        meta_done = true;
+      }
       TRY(backbone_train_forward(h, triplets, batch, st, &feat));
+      if (meta_on_side) TRY(side_join(h, st));
+    }
     HIP_TRY(hipMemcpyAsync(train_cache_feat(h, h->tcache, batch), feat,
                            (size_t)batch * c.dims[3] * sizeof(float), hipMemcpyDeviceToDevice,
                            st));
@@ -1301,7 +1319,7 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
     }
   }
   TRY(head_train_forward(h, h->tcache, meta, logits, scores, batch, meta_mask, comb_mask,
-                         master_arena, st));
+                         master_arena, st, meta_done));
   h->train_batch = batch;
   h->t_meta_mask = meta_mask;
   h->t_comb_mask = comb_mask;

@@ -415,10 +415,38 @@ static TrainPtrs carve(const btsbot_ctx* h, float* base, int M) {
   return p;
 }
 
+// The metadata branch's training forward (BatchNorm1d batch statistics -> fc1 -> act -> dropout -> fc2 (-> act)) into the
+// cache and columns F.. of the concatenated fusion input z.  It reads nothing of the image branch: btsbot_forward_train
+// queues it on the side stream, beside the backbone, and head_train_forward(meta_done = true) picks up behind a join.
+int head_train_meta_forward(btsbot_ctx* h, float* cache, const float* meta, int M, const uint8_t* meta_mask, float* master,
+                            hipStream_t st) {
+  const btsbot_config& c = h->cfg;
+  const float* m = h->mirror;
+  TrainPtrs p = carve(h, cache, M);
+  const int F = h->has_image ? c.dims[3] : 0;
+  const int zd = h->comb_dims[0];
+  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.n_meta), dim3(256), 0, st, meta, M, c.n_meta,
+                     m + h->bn_w, m + h->bn_b, master ? master + h->bn_rm : nullptr,
+                     master ? master + h->bn_rv : nullptr, p.xhat, p.x1, p.bn_rstd);
+  LAUNCH_CHECK();
+  const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
+  hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, p.x1, c.n_meta,
+                     reinterpret_cast<const float*>(h->extra + h->p_m1), m + h->m1_b, p.a1, p.h1,
+                     c.meta_fc1, M, c.meta_fc1, c.n_meta, h->act,
+                     c.meta_dropout > 0.f ? meta_mask : nullptr, ks1);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, p.h1,
+                     c.meta_fc1, reinterpret_cast<const float*>(h->extra + h->p_m2), m + h->m2_b,
+                     p.a2, p.z + F, zd, M, c.meta_fc2, c.meta_fc1,
+                     h->meta_trailing_act ? h->act : ACT_NONE, nullptr, 1.f);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
 // Forward of the heads in training mode.  feat: [M][F] backbone features (already in the cache).
 int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* logits,
                        float* scores, int M, const uint8_t* meta_mask, const uint8_t* comb_mask,
-                       float* master, hipStream_t st) {
+                       float* master, hipStream_t st, bool meta_done) {
   const btsbot_config& c = h->cfg;
   const float* m = h->mirror;
   TrainPtrs p = carve(h, cache, M);
@@ -430,23 +458,7 @@ int head_train_forward(btsbot_ctx* h, float* cache, const float* meta, float* lo
                        p.z, zd, M);
     LAUNCH_CHECK();
   }
-  if (h->has_meta) {
-    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.n_meta), dim3(256), 0, st, meta, M, c.n_meta,
-                       m + h->bn_w, m + h->bn_b, master ? master + h->bn_rm : nullptr,
-                       master ? master + h->bn_rv : nullptr, p.xhat, p.x1, p.bn_rstd);
-    LAUNCH_CHECK();
-    const float ks1 = c.meta_dropout < 1.f ? 1.f / (1.f - c.meta_dropout) : 0.f;
-    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc1), dim3(256), 0, st, p.x1, c.n_meta,
-                       reinterpret_cast<const float*>(h->extra + h->p_m1), m + h->m1_b, p.a1, p.h1,
-                       c.meta_fc1, M, c.meta_fc1, c.n_meta, h->act,
-                       c.meta_dropout > 0.f ? meta_mask : nullptr, ks1);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(lin_fwd_kernel, g1((long)M * c.meta_fc2), dim3(256), 0, st, p.h1,
-                       c.meta_fc1, reinterpret_cast<const float*>(h->extra + h->p_m2), m + h->m2_b,
-                       p.a2, p.z + F, zd, M, c.meta_fc2, c.meta_fc1,
-                       h->meta_trailing_act ? h->act : ACT_NONE, nullptr, 1.f);
-    LAUNCH_CHECK();
-  }
+  if (h->has_meta && !meta_done) TRY_RET(head_train_meta_forward(h, cache, meta, M, meta_mask, master, st));
   const float* in = p.z;
   int ldi = zd;
   const float ksc = c.comb_dropout < 1.f ? 1.f / (1.f - c.comb_dropout) : 0.f;
