@@ -641,6 +641,8 @@ def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None, b
         "blocks_ms_per_step": [round(1e3 * b / args.train_steps, 3) for b in tblocks],
         "loss_finite": bool(torch.isfinite(tloss).item()),
         "operands": args.precision,
+        "forward": ("stem + stage 0 (+ stage 1 in f16) through the inference megakernels' keeping forms, the rest per-op"
+                    if args.precision in ("bf16", "f16") else "per-op launches"),
     }
     # whole-step roofline: forward + input gradients + filter gradients = 3 x the forward's algorithmic FLOP
     step_flop = 3.0 * (133701376 + 210000) * args.train_batch
@@ -863,6 +865,17 @@ def main():
             except Exception as e:   # noqa: BLE001
                 if isinstance(train, dict):
                     train["f32"] = {"error": f"{type(e).__name__}: {e}"}
+            # f16 operands: the 16-bit mode whose 50-step trajectory stays closest to the fp32 recipe
+            # (tests/test_gpu_train.py::test_16bit_training_follows_the_fp32_recipe) and whose forward runs BOTH
+            # megakernels' keeping forms (stage0b + stage1b); no loss scaling: see DESIGN.md section 6 before using it at
+            # large batches
+            try:
+                t16 = train_leg(dev, rank, world, dist, fence, args, precision="f16", steps=max(5, args.train_steps // 2))
+                if isinstance(train, dict):
+                    train["f16"] = t16
+            except Exception as e:   # noqa: BLE001
+                if isinstance(train, dict):
+                    train["f16"] = {"error": f"{type(e).__name__}: {e}"}
             # the same step on 4 x the alerts per GPU: at 1024 alerts stages 2-3 (9216 / 1024 pixel rows) and the ~260
             # launches of a step leave the chip partly idle; what a user who is free to choose the batch gets
             try:
