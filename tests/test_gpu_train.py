@@ -336,6 +336,8 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     ``mlp``: the blocks of the 64- and 128-channel stages run the fused MLP forward and mlp_bwd_kernel (default; 5400
     rows = 84 row tiles and a ragged one; 1176 rows in four hidden slices whose addend planes of dxn dwln_bwd_kernel
     adds), the 64-channel stage only, or none (the switches are read when the handle is created)."""
+    if prec == "f16" and mlp in ("stage2_light", "per_op_forward", "stage1_keeping_kernel"):
+        pytest.skip("this round's schedule cases run in bf16 (f16's default already runs both keeping forms)")
     if mlp == "stage0_only":
         monkeypatch.setenv("BTSBOT_AMD_MLP_BWD_C", "64")
     elif mlp == "unfused":
