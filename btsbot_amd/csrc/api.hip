@@ -343,6 +343,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     const char* mbc = getenv("BTSBOT_AMD_MLP_BWD_C");
     const char* nmb = getenv("BTSBOT_AMD_NO_MLP_BWD");
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
+    const char* nwb = getenv("BTSBOT_AMD_NO_WGRAD_BATCH");
+    h->wgrad_batch = !(nwb != nullptr && nwb[0] == '1');
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
     // (opt-in: measured 252-259 us per launch with its 360 MB of kept rows against 100 us for the inference form -- the

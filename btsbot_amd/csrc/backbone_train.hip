@@ -31,6 +31,8 @@ struct BlkBuf {
   float* dwpart; // dwln_bwd_kernel's partial rows [dwrows][52 C] (nullptr: the block runs the three-launch form)
   int dwrows;
   float* fS;     // ... and its colsum(dy) [C] (the side stream's fc2_grads_kernel reads and clears it)
+  float* Gb;     // batched filter gradients (ctx.h: wgrad_batch): this block's own G = dy^T h [C][4C] and colsum(dy) [C]
+  float* Sb;     // (nullptr: the block's filter-gradient GEMMs are launched behind it, into the shared G / S)
   float* fpart;  // mlp_bwd_kernel's partial filter-gradient tiles (nullptr: the block runs the unfused MLP backward);
                  // one region per block: the side stream reduces block j's while the chain writes block j-1's
 };
@@ -46,6 +48,8 @@ struct BBCache {
   void* dyT_down[4];        // operand type [rows_i][C_i]: d(loss)/d(downsample i output) (i >= 1)
   void* dyT_stem;           // operand type [B*225][C0]: gradient behind the stem LayerNorm
   float *G, *S;             // fp32 [max C*4C], [max 4C]
+  float* gb0;               // the batched blocks' G / S buffers: one region, cleared with one memset
+  size_t gb_floats;
   float* fS0;               // first of the fused blocks' colsum buffers (they sit directly in front of S), or nullptr
   size_t g_floats;
   float* dpat;              // fp32 [max rows*4Cin]
@@ -91,6 +95,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.fpart = h->mlp_fused((int)ch) ? reinterpret_cast<float*>(take(mlp_bwd_part_floats((int)ch, (int)rows) * 4))
                                       : nullptr;
       b.fS = nullptr;
+      b.Gb = b.Sb = nullptr;
       k.blk[i].push_back(b);
     }
     k.dyT_down[i] = i > 0 ? take(rows * ch * esz) : nullptr;
@@ -116,6 +121,20 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
   k.S = reinterpret_cast<float*>(take((size_t)4 * c.dims[3] * 4));   // S directly in front of G:
   k.G = reinterpret_cast<float*>(take(maxc4c * 4));                   // one memset clears both
   k.g_floats = maxc4c;
+  // per-block G / S of the stages whose filter-gradient GEMMs are batched (unfused blocks, widths that tile by 128)
+  k.gb0 = reinterpret_cast<float*>(take(0));
+  {
+    const size_t start = cur;
+    for (int i = 0; i < 4; ++i) {
+      const size_t ch = c.dims[i];
+      if (!h->wgrad_batch || h->mlp_fused((int)ch) || (ch & 127) != 0 || c.precision == BTSBOT_F32) continue;
+      for (auto& b : k.blk[i]) {
+        b.Gb = reinterpret_cast<float*>(take(4 * ch * ch * 4));
+        b.Sb = reinterpret_cast<float*>(take(ch * 4));
+      }
+    }
+    k.gb_floats = (cur - start) / 4;
+  }
   k.dpat = reinterpret_cast<float*>(take(maxpat * 4));
   k.dwpart = reinterpret_cast<float*>(take((size_t)256 * 50 * c.dims[3] * 4));
   k.wpart = reinterpret_cast<float*>(take(2 * WPART_FLOATS * 4));   // two GEMMs' partial tiles at a time
@@ -410,6 +429,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
     float* z0 = k.fS0 != nullptr ? k.fS0 : k.S;
     HIP_TRY(hipMemsetAsync(z0, 0, (size_t)((k.G + k.g_floats) - z0) * sizeof(float), st));
   }
+  // (deterministic mode: the per-GEMM launches with their fixed-order column sums)
+  const bool batching = k.gb_floats > 0 && det_alloc(0) == nullptr;
+  if (batching) HIP_TRY(hipMemsetAsync(k.gb0, 0, k.gb_floats * sizeof(float), st));
   // operand-type buffer the consumer after block (i, j) reads its dy from: the block before, else the downsample
   auto next_dyT = [&](int i, int j) -> void* {
     if (j > 0) return k.blk[i][j - 1].dyT;
@@ -426,10 +448,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       HIP_TRY(hipStreamWaitEvent(st, h->s2_ready, 0));
       h->s2_pending = false;
     }
+    WgradBatchJob bj[16];
+    int nbj = 0;
     for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
       const BlockPk& b = h->blocks[i][j];
       const BlkBuf& s = k.blk[i][j];
       const float* wdw = reinterpret_cast<const float*>(h->extra + b.p_dw);
+      const bool batched = batching && s.Gb != nullptr && s.fpart == nullptr && nbj + 2 <= 16;
       if (!dyT_ready)
         TRYB(launch_scale_cast(prec, dy, nullptr, s.dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
@@ -483,6 +508,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       //      after the chain's launches above (the fork itself sits behind da), so the host's five launches here never
       //      stand between the chain and its next kernel (measured: no difference, the host runs ahead either way)
       //      (the two GEMMs' slice reductions share one launch: separate halves of the partial-tile scratch)
+      if (batched) {
+        // both filter gradients of this block join the stage's batch (launched behind the stage's last block, below)
+        bj[nbj++] = WgradBatchJob{s.dyT, s.h, s.Gb, s.Sb, rows, ch, H, H};
+        bj[nbj++] = WgradBatchJob{s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch};
+        dyT_ready = nxt != nullptr;
+        continue;
+      }
       if (s.fpart == nullptr) {
       TRYB(wgrad_cs(prec, s.dyT, s.h, k.G, k.S, rows, ch, H, H, sd, k.wpart, &red[0]));
       TRYB(wgrad_cs(prec, s.da, s.xn, grads + b.fc1_w, grads + b.fc1_b, rows, H, ch, ch, sd, k.wpart + WPART_FLOATS,
@@ -492,6 +524,19 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       TRYB(launch_fc2_grads(k.G, s.fpart != nullptr ? s.fS : k.S, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
       dyT_ready = nxt != nullptr;
+    }
+    if (nbj > 0) {
+      // ---- the stage's filter-gradient GEMMs as one launch + one slice reduction, then the fc2 / layer-scale gradients
+      //      of every block from its own G / S (side stream; the chain has passed the stage)
+      TRYB(fork());
+      TRYB(launch_wgrad16_batched(prec, bj, nbj, k.wpart, 2 * WPART_FLOATS, hw >= 3 ? 576 : 256, sd));
+      for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
+        const BlockPk& b = h->blocks[i][j];
+        const BlkBuf& s = k.blk[i][j];
+        if (s.Gb == nullptr) continue;
+        TRYB(launch_fc2_grads(s.Gb, s.Sb, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w, grads + b.fc2_b,
+                              grads + b.gamma, ch, H, sd));
+      }
     }
     if (i > 0) {
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b

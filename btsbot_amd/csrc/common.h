@@ -357,6 +357,17 @@ int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* co
                    int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0,
                    WgradReduceJob* defer = nullptr);   // wgrad.hip: 16-bit modes, colsum optional
 int launch_wgrad_reduce(const WgradReduceJob* jobs, int njobs, hipStream_t st);
+// several filter-gradient GEMMs (N, K multiples of 128; out[n][k] += ..., colsum[n] += ... optional) as one launch + one
+// slice reduction (wgrad.hip); out must be 16-byte aligned with ldo a multiple of 4
+struct WgradBatchJob {
+  const void* D;
+  const void* A;
+  float* out;
+  float* colsum;
+  int M, N, K, ldo;
+};
+int launch_wgrad16_batched(int prec, const WgradBatchJob* jobs, int njobs, float* part, size_t part_floats, int target_wg,
+                           hipStream_t st);
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]

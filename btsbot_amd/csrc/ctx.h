@@ -178,6 +178,9 @@ struct btsbot_ctx {
     return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused && (ch == 64 || use_dwln) &&
            mlp_bwd_supported(cfg.precision, ch) && fused_mlp_supported(cfg.precision, ch);
   }
+  bool wgrad_batch = true; // stages whose blocks run the unfused MLP backward (256 / 512 channels): their 2 x depth filter-gradient
+                           // GEMMs as ONE launch + one slice reduction at the end of the stage's chain (wgrad.hip);
+                           // BTSBOT_AMD_NO_WGRAD_BATCH=1: one launch per GEMM behind each block (A/B timing, parity tests)
   bool use_side = true;    // BTSBOT_AMD_NO_SIDE_STREAM=1: the whole backward on the caller's stream (A/B timing)
 
   unsigned long long* stamps = nullptr;   // 32 phase timestamps: [0..15] stage 0, [16..31] stage 1

@@ -61,13 +61,11 @@ __device__ __forceinline__ s16x8 tr_frag(const unsigned char* tile, int pitchb, 
 
 constexpr int TM = 64;   // reduction rows per LDS tile
 
+// (bx, by, bz) = the workgroup's output tile and slice; (gx, gy) = tiles along n and k
 template <typename T, int TN, int TK>
-__global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
-                                                     const T* __restrict__ A,
-                                                     float* __restrict__ out,
-                                                     float* __restrict__ colsum, int M, int N,
-                                                     int K, int ldo, int mslice,
-                                                     float* __restrict__ part) {
+__device__ __forceinline__ void wgrad2_body(const T* __restrict__ D, const T* __restrict__ A, float* __restrict__ out,
+                                            float* __restrict__ colsum, int M, int N, int K, int ldo, int mslice,
+                                            float* __restrict__ part, int bx, int by, int bz, int gx, int gy) {
   constexpr int PN = TN * 2 + 64, PK = TK * 2 + 64;          // row pitch in bytes
   constexpr int DB = TM * PN, AB = TM * PK;                   // bytes per tile
   constexpr int FN = TN / 64, FK = TK / 64;                   // 32x32 fragments per wave
@@ -75,10 +73,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * (DB + AB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
-  const int mbeg = blockIdx.z * mslice, mend = min(M, mbeg + mslice);
+  const int n0 = bx * TN, k0 = by * TK;
+  const int mbeg = bz * mslice, mend = min(M, mbeg + mslice);
   const int nt = (mend - mbeg + TM - 1) / TM;
-  const bool do_sum = colsum != nullptr && blockIdx.y == 0;
+  const bool do_sum = colsum != nullptr && by == 0;
 
   f32x16 acc[FN][FK];
 #pragma unroll
@@ -165,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
   if (part != nullptr) {
     // slice partial as a dense TN x TK tile (plain coalesced stores; wgrad_reduce_kernel adds the slices in a
     // fixed order): an fp32 atomic per element per slice was the larger half of this kernel's time
-    float* pt = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TN * TK);
+    float* pt = part + ((size_t)(bz * gy + by) * gx + bx) * (TN * TK);
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -199,6 +197,41 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D,
       atomicAdd(colsum + n0 + tid, s);
     }
   }
+}
+
+template <typename T, int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const T* __restrict__ D, const T* __restrict__ A, float* __restrict__ out,
+                                                     float* __restrict__ colsum, int M, int N, int K, int ldo, int mslice,
+                                                     float* __restrict__ part) {
+  wgrad2_body<T, TN, TK>(D, A, out, colsum, M, N, K, ldo, mslice, part, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
+                         gridDim.y);
+}
+
+// Several filter-gradient GEMMs as ONE launch: a stage's blocks each bring two (fc2: dy^T h, fc1: da^T xn) whose
+// operands all exist once the stage's input-gradient chain has passed.  Per GEMM they are 16 output tiles of 128 x 128
+// over 9216 rows (stage 2): launched one by one each needs ~24 reduction slices to fill the chip (24 MB of partial tiles
+// written and read again per GEMM, ~26 us per launch, twelve launches per step); together 192 tiles x 3 slices do.
+constexpr int WB_MAX = 16;
+struct WgradBatch {
+  int njobs;
+  int wg0[WB_MAX + 1];   // first workgroup of job i (prefix sums)
+  struct Job {
+    const void* D;
+    const void* A;
+    float* out;
+    float* colsum;
+    float* part;
+    int M, N, K, ldo, gx, gy, mslice;
+  } j[WB_MAX];
+};
+template <typename T, int TN, int TK> __global__ __launch_bounds__(256) void wgrad2_batched_kernel(WgradBatch a) {
+  int i = 0;
+  while (i + 1 < a.njobs && (int)blockIdx.x >= a.wg0[i + 1]) ++i;
+  const WgradBatch::Job& J = a.j[i];
+  const int w = (int)blockIdx.x - a.wg0[i];
+  const int bx = w % J.gx, by = (w / J.gx) % J.gy, bz = w / (J.gx * J.gy);
+  wgrad2_body<T, TN, TK>(reinterpret_cast<const T*>(J.D), reinterpret_cast<const T*>(J.A), J.out, J.colsum, J.M, J.N, J.K,
+                         J.ldo, J.mslice, J.part, bx, by, bz, J.gx, J.gy);
 }
 
 // out[n][k] += sum over slices of the partial tiles (fixed order: bit-reproducible).  One launch serves up to two
@@ -300,6 +333,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(ReduceJobs a) {
   float4* o = reinterpret_cast<float4*>(J.out + (size_t)n * J.ldo + k);
   float4 cur = *o;
   add(cur, tot);
+  *o = cur;
+}
+
+// the slice reduction of up to WB_MAX GEMMs as one launch (wgrad_reduce4_kernel's walk, per job)
+struct ReduceJobsN {
+  int n;
+  int blk0[WB_MAX + 1];
+  WgradReduceJob j[WB_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce4n_kernel(ReduceJobsN a) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.blk0[i + 1]) ++i;
+  const WgradReduceJob& J = a.j[i];
+  const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const size_t tile = (size_t)J.TN * J.TK, per_slice = (size_t)J.gx * J.gy * tile;
+  const size_t e = ((size_t)((int)blockIdx.x - a.blk0[i]) * 32 + q) * 4;
+  const bool inside = e < per_slice;
+  const int t = inside ? (int)(e / tile) : 0;
+  const int r = inside ? (int)(e - (size_t)t * tile) : 0;
+  const int nl = r / J.TK, kl = r - nl * J.TK;
+  const int tx = t % J.gx, ty = t / J.gx;
+  const int n = tx * J.TN + nl, k = ty * J.TK + kl;
+  const bool live = inside && n < J.N && k < J.K;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* p = J.part + e;
+    for (int s = sg; s < J.nsl; s += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * per_slice);
+      s0.x += v.x;
+      s0.y += v.y;
+      s0.z += v.z;
+      s0.w += v.w;
+    }
+  }
+  __shared__ float4 sh[8][32];
+  sh[sg][q] = s0;
+  __syncthreads();
+  if (sg != 0 || !live) return;
+  float4 tot = sh[0][q];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) {
+    tot.x += sh[g][q].x;
+    tot.y += sh[g][q].y;
+    tot.z += sh[g][q].z;
+    tot.w += sh[g][q].w;
+  }
+  float4* o = reinterpret_cast<float4*>(J.out + (size_t)n * J.ldo + k);
+  float4 cur = *o;
+  cur.x += tot.x;
+  cur.y += tot.y;
+  cur.z += tot.z;
+  cur.w += tot.w;
   *o = cur;
 }
 
@@ -434,4 +519,64 @@ int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* co
       btsbot_set_error("wgrad16: precision %d is not a 16-bit mode", prec);
       return BTSBOT_ERR_INVALID_ARG;
   }
+}
+
+// ---- batched form (backbone_train.hip): up to 16 GEMMs with N, K multiples of 128, one launch + one reduction.
+// part: scratch of part_floats floats shared by the jobs; target_wg: workgroups the launch should have (slices are
+// chosen per job so that the jobs together come to about that many; >= 256 rows per slice).
+int launch_wgrad16_batched(int prec, const WgradBatchJob* jobs, int njobs, float* part, size_t part_floats, int target_wg,
+                           hipStream_t st) {
+  if (njobs <= 0) return BTSBOT_OK;
+  if (njobs > WB_MAX || (prec != BTSBOT_BF16 && prec != BTSBOT_F16)) {
+    btsbot_set_error("wgrad16_batched: %d jobs / precision %d not supported", njobs, prec);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  WgradBatch a;
+  ReduceJobsN r;
+  a.njobs = njobs;
+  r.n = 0;
+  int tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if ((jobs[i].N & 127) || (jobs[i].K & 127) || jobs[i].M <= 0) {
+      btsbot_set_error("wgrad16_batched: job %d: N=%d K=%d must be multiples of 128", i, jobs[i].N, jobs[i].K);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    tiles += (jobs[i].N / 128) * (jobs[i].K / 128);
+  }
+  int wg = 0;
+  size_t pused = 0;
+  r.blk0[0] = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const WgradBatchJob& b = jobs[i];
+    const int gx = b.N / 128, gy = b.K / 128;
+    int nsl = (target_wg + tiles - 1) / tiles;
+    if (nsl > (b.M + 255) / 256) nsl = (b.M + 255) / 256;
+    if (nsl < 1) nsl = 1;
+    int mslice = ((b.M + nsl - 1) / nsl + TM - 1) / TM * TM;
+    nsl = (b.M + mslice - 1) / mslice;
+    const size_t need = (size_t)nsl * gx * gy * 128 * 128;
+    const bool two_pass = nsl > 1 && pused + need <= part_floats;
+    if (nsl > 1 && !two_pass) {   // no room for the partial tiles: one slice (the out += path has a single adder then)
+      nsl = 1;
+      mslice = (b.M + TM - 1) / TM * TM;
+    }
+    a.wg0[i] = wg;
+    a.j[i] = WgradBatch::Job{b.D, b.A, b.out, b.colsum, two_pass ? part + pused : nullptr, b.M, b.N, b.K, b.ldo, gx, gy, mslice};
+    wg += gx * gy * nsl;
+    if (two_pass) {
+      r.j[r.n] = WgradReduceJob{part + pused, b.out, b.N, b.K, b.ldo, gx, gy, nsl, 128, 128};
+      r.blk0[r.n + 1] = r.blk0[r.n] + (int)(((size_t)gx * gy * 128 * 128 + 127) / 128);
+      ++r.n;
+      pused += need;
+    }
+  }
+  a.wg0[njobs] = wg;
+  if (prec == BTSBOT_BF16) hipLaunchKernelGGL((wgrad2_batched_kernel<bf16_t, 128, 128>), dim3(wg), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad2_batched_kernel<f16_t, 128, 128>), dim3(wg), dim3(256), 0, st, a);
+  LAUNCH_CHECK();
+  if (r.n > 0) {
+    hipLaunchKernelGGL(wgrad_reduce4n_kernel, dim3(r.blk0[r.n]), dim3(256), 0, st, r);
+    LAUNCH_CHECK();
+  }
+  return BTSBOT_OK;
 }
