@@ -343,6 +343,10 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     const char* mbc = getenv("BTSBOT_AMD_MLP_BWD_C");
     const char* nmb = getenv("BTSBOT_AMD_NO_MLP_BWD");
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
+    // (opt-in: measured 2.71-2.73 against 2.70-2.71 ms per step -- the third convolution costs the kernel more than the
+    //  59 MB it no longer reads and the 118 MB stage0b no longer writes save: it is not bound by its bytes alone)
+    const char* ndr = getenv("BTSBOT_AMD_DWLN_RECOMP");
+    h->dwln_recomp = ndr != nullptr && ndr[0] == '1';
     const char* nwb = getenv("BTSBOT_AMD_NO_WGRAD_BATCH");
     h->wgrad_batch = !(nwb != nullptr && nwb[0] == '1');
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");

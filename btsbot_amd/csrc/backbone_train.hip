@@ -191,7 +191,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       a.blk[j].w1 = h->extra + b.p_fc1;
       a.blk[j].w2g = h->extra + b.p_fc2g;
       a.blk[j].par = h->extra + b.p_s0par_t;
-      a.keep_d[j] = k.blk[0][j].d;
+      a.keep_d[j] = h->dwln_recomp ? nullptr : k.blk[0][j].d;
       a.keep_xn[j] = k.blk[0][j].xn;
     }
     a.ds_lnw = m + h->down[1].ln_w;
@@ -242,7 +242,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
         a.blk[j].w1 = h->extra + b.p_fc1;
         a.blk[j].w2g = h->extra + b.p_fc2g;
         a.blk[j].par = h->extra + b.p_s0par_t;
-        a.keep_d[j] = k.blk[1][j].d;
+        a.keep_d[j] = h->dwln_recomp ? nullptr : k.blk[1][j].d;
         a.keep_xn[j] = k.blk[1][j].xn;
       }
       a.ds_lnw = m + h->down[2].ln_w;
@@ -489,8 +489,8 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         pend = {s.dwpart, grads + b.dw_w, dw3_rows(B), 0};
       } else if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
-        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
-                             planes, (size_t)rows * ch));
+        TRYB(launch_dwln_bwd(h->dwln_recomp ? nullptr : s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
+                             planes, (size_t)rows * ch, m + b.dw_b));
         pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
       } else if (hw == 1 && h->use_dwln && ch <= 640) {
         // ---- 1x1 maps: the same three steps per (alert, channel) in one launch

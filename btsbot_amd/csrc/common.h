@@ -399,9 +399,10 @@ int launch_ln_dw1_bwd(const float* d, const float* dxn, const float* g, const fl
                       hipStream_t st);
 bool dwln_bwd_supported(int HW, int C);
 int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) one launch writes
+// (d == nullptr: the depthwise output is recomputed from x_in, the taps and the depthwise bias dwb)
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes = 1,
-                    size_t pstride = 0);
+                    size_t pstride = 0, const float* dwb = nullptr);
 // 3x3 maps of 256 channels: their own kernel (d recomputed from x_in, compact partial rows) and its row reduction
 bool dw3_bwd_active(int HW, int C);
 int dw3_rows(int B);

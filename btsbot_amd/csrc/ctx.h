@@ -178,6 +178,9 @@ struct btsbot_ctx {
     return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused && (ch == 64 || use_dwln) &&
            mlp_bwd_supported(cfg.precision, ch) && fused_mlp_supported(cfg.precision, ch);
   }
+  bool dwln_recomp = false; // BTSBOT_AMD_DWLN_RECOMP=1 (opt-in, not faster: api.hip): dwln_bwd_kernel recomputes the depthwise
+                            // output from x_in instead of reading the kept one, and the megakernels' keeping forms do not
+                            // write it
   bool wgrad_batch = true; // stages whose blocks run the unfused MLP backward (256 / 512 channels): their 2 x depth filter-gradient
                            // GEMMs as ONE launch + one slice reduction at the end of the stage's chain (wgrad.hip);
                            // BTSBOT_AMD_NO_WGRAD_BATCH=1: one launch per GEMM behind each block (A/B timing, parity tests)

@@ -36,13 +36,13 @@ struct Stage0Args {
   unsigned long long* wgt;      // optional: every workgroup's start / end (100 MHz wall clock), [grid][2]
   int diag;               // timing diagnostics only (BTSBOT_AMD_S0_DIAG): bit0 skip depthwise FMAs,
                           // bit1 skip fc1/GELU/fc2, bit2 skip LDS-DMA of the filters, bit3 skip GELU
-  // Training forward (keep_d[0] != nullptr; bf16 / f16): what the backward reads is written on the way --
+  // Training forward (keep_xn[0] != nullptr; bf16 / f16): what the backward reads is written on the way --
   // backbone_train.hip's buffers: the stem convolution's output before its LayerNorm, block 0's input = tap_stem,
   // block 1's input, the stage output = tap_stage, per block the depthwise output before the LayerNorm (fp32) and
   // the LayerNorm output (operand type), and the downsample's LayerNorm'd patch rows [B][49][q = 2 ky + kx][64].
   float* keep_stem_pre;   // [B][225][64] f32
   float* keep_xin1;       // [B][225][64] f32
-  float* keep_d[2];       // [B][225][64] f32
+  float* keep_d[2];       // [B][225][64] f32, or both nullptr: the backward recomputes it (dwln_bwd.hip)
   void* keep_xn[2];       // [B][225][64] operand type
   void* keep_patches;     // [B][49][256] operand type
 };
@@ -64,11 +64,11 @@ struct Stage1Args {
   unsigned long long* stamps;   // optional phase timestamps (workgroup 0, thread 0)
   unsigned long long* wgt;      // optional per-workgroup start / end, [grid][2]
   int diag;               // timing diagnostics, same bits as Stage0Args::diag
-  // Training forward (keep_d[0] != nullptr; bf16 / f16): block 0's input is x_in itself, block 1's input is what the
+  // Training forward (keep_xn[0] != nullptr; bf16 / f16): block 0's input is x_in itself, block 1's input is what the
   // kernel parks in `scratch` anyway (point it at that buffer), the stage output is tap_stage; per block the depthwise
   // output before the LayerNorm (fp32) and the LayerNorm output (operand type), and the downsample's LayerNorm'd patch
   // rows [B][9][q = 2 ky + kx][128]
-  float* keep_d[2];       // [B][49][128] f32
+  float* keep_d[2];       // [B][49][128] f32, or both nullptr (as above)
   void* keep_xn[2];       // [B][49][128] operand type
   void* keep_patches;     // [B][9][512] operand type
 };

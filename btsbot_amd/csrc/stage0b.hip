@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[yb * 16 + xb * 4 + i] = acc[yb][xb][i];
     }
-    if (KEEP) {   // the depthwise output before the LayerNorm: lane = (channel, row j of the quad), 60 live values
+    if (KEEP && a.keep_d[j] != nullptr) {   // the depthwise output before the LayerNorm: lane = (channel, row j of the quad), 60 live
+                                             // values (nullptr: the backward recomputes it, dwln_bwd.hip)
       float* dst = a.keep_d[j] + (size_t)alert * P * C + dch;
 #pragma unroll
       for (int yb = 0; yb < 4; ++yb)
@@ -869,9 +870,9 @@ bool stage0_supported(int prec, int c0) {
 // Needs Stage0Blk::par, ::w1 (plain [256][64]) and Stage0Blk::w2g (gamma-scaled [64][256]), 16-bit.
 int launch_stage0b(int prec, const Stage0Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
-  if (a.keep_d[0] != nullptr) {   // the training forward
+  if (a.keep_xn[0] != nullptr) {   // the training forward
     if (a.keep_stem_pre == nullptr || a.tap_stem == nullptr || a.keep_xin1 == nullptr || a.tap_stage == nullptr ||
-        a.keep_d[1] == nullptr || a.keep_xn[0] == nullptr || a.keep_xn[1] == nullptr || a.keep_patches == nullptr) {
+        (a.keep_d[0] == nullptr) != (a.keep_d[1] == nullptr) || a.keep_xn[1] == nullptr || a.keep_patches == nullptr) {
       btsbot_set_error("stage0b: the training forward needs every kept buffer");
       return BTSBOT_ERR_INVALID_ARG;
     }

@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[gi][al][yb * 8 + xb * 4 + i] = acc[al][yb][xb][i];
     }
-    if (KEEP) {   // the depthwise output before the LayerNorm: lane = (channel of the group, row j of the quad)
+    if (KEEP && a.keep_d[j] != nullptr) {   // the depthwise output before the LayerNorm: lane = (channel of the group, row j of
+                                             // the quad) (nullptr: the backward recomputes it, dwln_bwd.hip)
 #pragma unroll
       for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
@@ -1019,8 +1020,8 @@ bool stage1_supported(int prec, int c1, int c2) {
 // and Stage1Args::ds_w as MFMA fragments (launch_pack_frag32).
 int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
-  if (a.keep_d[0] != nullptr) {   // the training forward
-    if (a.keep_d[1] == nullptr || a.keep_xn[0] == nullptr || a.keep_xn[1] == nullptr || a.keep_patches == nullptr ||
+  if (a.keep_xn[0] != nullptr) {   // the training forward
+    if ((a.keep_d[0] == nullptr) != (a.keep_d[1] == nullptr) || a.keep_xn[1] == nullptr || a.keep_patches == nullptr ||
         a.tap_stage == nullptr || a.scratch == nullptr) {
       btsbot_set_error("stage1b: the training forward needs every kept buffer");
       return BTSBOT_ERR_INVALID_ARG;
