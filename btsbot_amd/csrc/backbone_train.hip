@@ -462,6 +462,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
       // (the hidden slices of the 128-channel form hand dxn over as addend planes: dwln_bwd_kernel is their reader)
       const int planes = s.fpart != nullptr ? mlp_bwd_planes(ch) : 1;
+      const int p16 = planes > 1 && prec == BTSBOT_BF16 && h->planes16 ? 1 : 0;   // the addend planes in bf16
       if (planes > 1 && !(s.dwpart != nullptr && adjacent)) {
         btsbot_set_error("backward: the fused MLP backward of a %d-channel block needs dwln_bwd_kernel behind it", ch);
         return BTSBOT_ERR_STATE;
@@ -469,7 +470,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       if (s.fpart != nullptr) {
         // ---- da, dxn = da W1 and both filter gradients of the MLP in one launch (a recomputed from xn; da, g only on chip)
         TRYB(launch_mlp_bwd(prec, ch, s.xn, s.dyT, h->extra + b.p_fc1, h->extra + b.p_fc2t, m + b.fc1_b, dxn, s.fpart,
-                            k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red));
+                            k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red, p16));
         TRYB(fork());
       } else {
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
@@ -490,7 +491,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       } else if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
         TRYB(launch_dwln_bwd(h->dwln_recomp ? nullptr : s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
-                             planes, (size_t)rows * ch, m + b.dw_b));
+                             planes, (size_t)rows * ch, m + b.dw_b, p16));
         pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
       } else if (hw == 1 && h->use_dwln && ch <= 640) {
         // ---- 1x1 maps: the same three steps per (alert, channel) in one launch

@@ -181,6 +181,8 @@ struct btsbot_ctx {
   bool dwln_recomp = false; // BTSBOT_AMD_DWLN_RECOMP=1 (opt-in, not faster: api.hip): dwln_bwd_kernel recomputes the depthwise
                             // output from x_in instead of reading the kept one, and the megakernels' keeping forms do not
                             // write it
+  bool planes16 = false;   // BTSBOT_AMD_PLANES16=1 (opt-in, bf16 mode): mlp_bwd_kernel's four addend planes of dxn (128 channels)
+                           // leave as bf16 and dwln_bwd_kernel reads them so (206 MB less per block; api.hip says why not default)
   bool wgrad_batch = true; // stages whose blocks run the unfused MLP backward (256 / 512 channels): their 2 x depth filter-gradient
                            // GEMMs as ONE launch + one slice reduction at the end of the stage's chain (wgrad.hip);
                            // BTSBOT_AMD_NO_WGRAD_BATCH=1: one launch per GEMM behind each block (A/B timing, parity tests)

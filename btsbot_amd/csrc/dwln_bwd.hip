@@ -28,7 +28,7 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w, float* dy,
                                                       void* __restrict__ out16, int prec16,
                                                       float* __restrict__ partials, int B, int ga, int nplanes,
-                                                      size_t pstride, const float* __restrict__ dwb) {
+                                                      size_t pstride, const float* __restrict__ dwb, int p16) {
   // d == nullptr (opt-in, BTSBOT_AMD_DWLN_RECOMP=1): the depthwise output is RECOMPUTED from x_in (taps, bias dwb) into the
   // LDS map that later holds dd.  The kernel moves 325 MB per launch at 15x15x64 (d, dxn, x_in, dy in; dy out twice: 81 us
   // at 4 TB/s of its 98), but the third convolution costs more than the 59 MB saved: + 10 us per step.
@@ -123,6 +123,18 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
         ok[u] = r < pa;
         const int rr = ok[u] ? r : 0;
         v[u] = *reinterpret_cast<const float4*>(dsrc + (size_t)rr * C + 4 * l);
+        if (p16) {   // bf16 addend planes (mlp_bwd_kernel, several hidden slices in the bf16 mode), pstride ELEMENTS apart
+          const unsigned short* d16 = reinterpret_cast<const unsigned short*>(dxn);
+          dx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int pl = 0; pl < nplanes; ++pl) {
+            const uint2 e = *reinterpret_cast<const uint2*>(d16 + pl * pstride + base + (size_t)rr * C + 4 * l);
+            dx[u].x += __uint_as_float(e.x << 16);
+            dx[u].y += __uint_as_float(e.x & 0xffff0000u);
+            dx[u].z += __uint_as_float(e.y << 16);
+            dx[u].w += __uint_as_float(e.y & 0xffff0000u);
+          }
+          continue;
+        }
         dx[u] = *reinterpret_cast<const float4*>(dxn + base + (size_t)rr * C + 4 * l);
         for (int pl = 1; pl < nplanes; ++pl) {
           const float4 e = *reinterpret_cast<const float4*>(dxn + pl * pstride + base + (size_t)rr * C + 4 * l);
@@ -438,7 +450,7 @@ template <int HW, int C, int NT, int NA> struct DwlnCfg {
 template <int HW, int C, int NT, int NA>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                 void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes, size_t pstride,
-                const float* dwb) {
+                const float* dwb, int p16) {
   using K = DwlnCfg<HW, C, NT, NA>;
   constexpr int G = NT / C;
   static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
@@ -449,7 +461,7 @@ int dwln_launch(const float* d, const float* dxn, const float* g, const float* x
     attr.done();
   }
   hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT, NA>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
-                     out16, prec16, partials, B, K::ga(B), nplanes, pstride, dwb);
+                     out16, prec16, partials, B, K::ga(B), nplanes, pstride, dwb, p16);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -476,15 +488,19 @@ int dwln_bwd_rows(int HW, int C, int B) {
 // tensors, so the caller finishes with ONE column sum of the rows into the arena (launch_colsum, any stream).
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes,
-                    size_t pstride, const float* dwb) {
+                    size_t pstride, const float* dwb, int planes16) {
   if (B <= 0) return BTSBOT_OK;
+  if (planes16 && !(HW == 7 && C == 128)) {
+    btsbot_set_error("dwln_bwd: bf16 addend planes are the 128-channel form's");
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (d == nullptr && dwb == nullptr) {
     btsbot_set_error("dwln_bwd: without the kept depthwise output it needs the depthwise bias to recompute it");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb);
-  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb);
-  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb);
+  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
+  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
+  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
 }
