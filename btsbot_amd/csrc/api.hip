@@ -125,6 +125,10 @@ int build_tables(btsbot_ctx* h) {
         b.p_fc2g = bump(cur, (size_t)4 * ch * ch * esz);
         b.p_s0par = (i == 0 && ch == 64) ? bump(cur, s0par_bytes())
                     : (i == 1 && ch == 128 && (c.precision != BTSBOT_F32 || h->x2)) ? bump(cur, s1par_bytes()) : 0;
+        if (!h->x2 && s2mlp_bwd_supported(c.precision, ch)) {
+          b.p_w1tp = bump(cur, (size_t)4 * ch * ch * 2);
+          b.p_w2tp = bump(cur, (size_t)4 * ch * ch * 2);
+        }
         if (!h->x2 && c.precision != BTSBOT_F32 && ((i == 0 && ch == 64) || (i == 1 && ch == 128)))
           b.p_s0par_t = bump(cur, i == 0 ? s0par_bytes() : s1par_bytes());
         if (h->x2 && ((i == 0 && h->stage0) || (i == 1 && h->stage1))) {
@@ -351,6 +355,12 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     //  its loss band instead of 0.66-0.72: not worth the rounding)
     const char* np16 = getenv("BTSBOT_AMD_PLANES16");
     h->planes16 = np16 != nullptr && np16[0] == '1';
+    // (opt-in: the fused kernel takes 30-35 us where the two tiled GEMMs it replaces take 44, six times per step, yet the step
+    //  measured 2.672 against 2.667 ms on the same box -- the chain is not waiting on these launches)
+    const char* ns2m = getenv("BTSBOT_AMD_S2MLP");
+    h->s2mlp = ns2m != nullptr && ns2m[0] == '1';
+    const char* fpb = getenv("BTSBOT_AMD_FORK_PER_BLOCK");
+    h->fork_per_block = fpb != nullptr && fpb[0] == '1';
     const char* nwb = getenv("BTSBOT_AMD_NO_WGRAD_BATCH");
     h->wgrad_batch = !(nwb != nullptr && nwb[0] == '1');
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
@@ -482,8 +492,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
     HIP_TRY(hipMalloc(&h->extra, h->extra_bytes > 0 ? h->extra_bytes : 256));
   }
   TRY(pack_sync(h, st));   // (a pack nobody consumed yet still reads the mirror on the side stream)
-  HIP_TRY(hipMemcpyAsync(h->mirror, master, (size_t)h->total_floats * 4, hipMemcpyDeviceToDevice,
-                         st));
+  TRY(launch_copy_f32(h->mirror, master, (size_t)h->total_floats, st));
   const float* m = h->mirror;
   if (train_only && h->has_image && !h->is_maxvit && h->use_side && h->side != nullptr) {
     hipStream_t sp = st;
@@ -618,6 +627,11 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
+        // the dgrad transposes (written by the job table above) as MFMA A fragments for s2mlp_bwd_kernel
+        if (b.p_w1tp != 0 && h->train_packs && h->s2mlp) {
+          TRY(launch_pack_frag16(h->extra + b.p_fc2t, h->extra + b.p_w2tp, 4 * ch, ch, st));
+          TRY(launch_pack_frag16(h->extra + b.p_fc1t, h->extra + b.p_w1tp, ch, 4 * ch, st));
+        }
         // the keeping forms' images (f16 taps), in the full pack too: the first training forward follows one
         if (i == 1 && b.p_s0par_t != 0 && h->s1_train && h->train_packs)
           TRY(launch_pack_s1par(BTSBOT_F16, reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b, m + b.ln_w, m + b.ln_b,
@@ -1307,14 +1321,13 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
         TRY(side_fork(h, st, &sd));
         TRY(head_train_meta_forward(h, h->tcache, meta, batch, meta_mask, master_arena, sd));
         meta_on_side = sd != st;
+        h->meta_join_pending = meta_on_side;   // (cleared by the next side_join(): the forward's wait for the re-pack, as a rule)
         meta_done = true;
       }
       TRY(backbone_train_forward(h, triplets, batch, st, &feat));
-      if (meta_on_side) TRY(side_join(h, st));
+      if (meta_on_side && h->meta_join_pending) TRY(side_join(h, st));
     }
-    HIP_TRY(hipMemcpyAsync(train_cache_feat(h, h->tcache, batch), feat,
-                           (size_t)batch * c.dims[3] * sizeof(float), hipMemcpyDeviceToDevice,
-                           st));
+    TRY(launch_copy_f32(train_cache_feat(h, h->tcache, batch), feat, (size_t)batch * c.dims[3], st));
   } else if (h->has_image) {
     // The image branch has no train/eval difference (no BatchNorm, no dropout, drop-path 0):
     // same kernels as inference, chunk by chunk; features are collected in the training cache.
@@ -1353,7 +1366,7 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     return BTSBOT_ERR_STATE;
   }
   if (need_img)   // image-branch gradients are accumulated with atomics
-    HIP_TRY(hipMemsetAsync(grad_arena, 0, (size_t)h->img_floats * sizeof(float), st));
+    TRY(launch_fill0(grad_arena, (size_t)h->img_floats, st));
   for (int i = 0; i < h->n_buckets; ++i)
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
   if (h->use_side && (h->side == nullptr || h->side_for != st)) {
@@ -1370,6 +1383,9 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     explicit DetScope(btsbot_ctx* c) { det_begin(c->deterministic ? c->det_scratch : nullptr, c->det_floats); }
     ~DetScope() { det_end(); }
   } det_scope(h);
+  h->last_bwd_stream = st;
+  // (the paths that record every bucket at their end anyway always do; the ConvNeXt backward forks for them on demand)
+  h->bucket_fine = h->bucket_waits_seen || !need_img || h->is_maxvit;
   float* dfeat = nullptr;
   TRY(head_train_backward(h, h->tcache, dlogits, grad_arena, h->train_batch, need_meta_grads,
                           need_img, &dfeat, h->t_meta_mask, h->t_comb_mask, st));
@@ -1477,6 +1493,7 @@ int side_join(btsbot_ctx* h, hipStream_t st) {
   TRY(side_event(h, &e));
   HIP_TRY(hipEventRecord(e, h->side));
   HIP_TRY(hipStreamWaitEvent(st, e, 0));
+  h->meta_join_pending = false;
   return BTSBOT_OK;
 }
 
@@ -1501,6 +1518,8 @@ extern "C" int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream
     btsbot_set_error("wait_grad_bucket: btsbot_backward() has not run on this handle");
     return BTSBOT_ERR_STATE;
   }
+  h->bucket_waits_seen = true;
+  if (!h->bucket_fine) HIP_TRY(hipEventRecord(h->bucket_ev[bucket], h->last_bwd_stream));   // (ctx.h: bucket_fine)
   HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->bucket_ev[bucket], 0));
   return BTSBOT_OK;
 }
@@ -1576,6 +1595,7 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
                      (void*)h->last_grad_arena);
     return BTSBOT_ERR_INVALID_ARG;
   }
+  h->bucket_waits_seen = true;
   const RcclApi& api = rccl_api();
   if (api.all_reduce == nullptr || (h->exchange_mode == 1 && (api.reduce_scatter == nullptr || api.all_gather == nullptr ||
                                                               api.count == nullptr || api.user_rank == nullptr))) {
@@ -1602,6 +1622,7 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
     }
     // the collective of a span starts as soon as the backward pass has written its bucket, on the library's exchange
     // stream: the rest of the backward keeps the caller's stream
+    if (!h->bucket_fine) HIP_TRY(hipEventRecord(h->bucket_ev[bucket[i]], h->last_bwd_stream));   // (ctx.h: bucket_fine)
     HIP_TRY(hipStreamWaitEvent(h->xchg, h->bucket_ev[bucket[i]], 0));
     float* base = grads + lo[i];
     const size_t n = (size_t)(hi[i] - lo[i]);

@@ -398,7 +398,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   BBCache k = carve_bb(h, h->bbcache, B);
   float* dy = k.dyA;
   float* dxn = k.dyB;
-  HIP_TRY(hipMemcpyAsync(dy, dfeat, (size_t)B * c.dims[3] * 4, hipMemcpyDeviceToDevice, st));
+  TRYB(launch_copy_f32(dy, dfeat, (size_t)B * c.dims[3], st));
   // Two streams.  `st` carries the chain every block waits on (dy -> da -> dxn -> LayerNorm -> depthwise -> dy of the
   // block before); the filter-gradient GEMMs, their slice reductions and the layer-scale / bias gradients hang off
   // that chain (nothing downstream reads them before the optimiser), so they trail it on `h->side`: in stages 2-3
@@ -408,17 +408,29 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   hipStream_t sd = st;
   // dwln_bwd_kernel leaves one partial row per workgroup; the column sum that folds them into the arena is queued on
   // the side stream at the next fork (it then sees the kernel's rows) instead of behind the kernel in the chain
-  struct { const float* part; float* dst; int rows, cols; } pend = {nullptr, nullptr, 0, 0};   // cols == 0: dw3 compact rows
+  // (every block has partial rows of its own, so several may wait for the same fork: the blocks of a stage whose
+  //  filter-gradient GEMMs go out as one batch fork once, behind the stage -- a fork is an event record in the chain's
+  //  queue and costs it ~6 us between two kernels)
+  struct Pend { const float* part; float* dst; int rows, cols; };   // cols == 0: dw3 compact rows
+  Pend pend[8];
+  int npend = 0;
   auto fork = [&]() -> int {
     TRYB(side_fork(h, st, &sd));
-    if (pend.rows > 0 && pend.cols == 0) TRYB(launch_dw3_rows(pend.part, pend.dst, pend.rows, sd));
-    else if (pend.rows > 0) TRYB(launch_colsum(BTSBOT_F32, pend.part, pend.dst, pend.rows, pend.cols, sd));
-    pend.rows = 0;
+    for (int q = 0; q < npend; ++q) {
+      if (pend[q].cols == 0) TRYB(launch_dw3_rows(pend[q].part, pend[q].dst, pend[q].rows, sd));
+      else TRYB(launch_colsum(BTSBOT_F32, pend[q].part, pend[q].dst, pend[q].rows, pend[q].cols, sd));
+    }
+    npend = 0;
     return BTSBOT_OK;
   };
   auto join = [&]() -> int {
-    if (pend.rows > 0) TRYB(fork());
+    if (npend > 0) TRYB(fork());
     return side_join(h, st);
+  };
+  auto add_pend = [&](const float* part, float* dst, int rows, int cols) -> int {
+    if (npend == (int)(sizeof(pend) / sizeof(pend[0]))) TRYB(fork());
+    pend[npend++] = Pend{part, dst, rows, cols};
+    return BTSBOT_OK;
   };
   // 16-bit modes: the depthwise input-gradient kernel that ends a block also writes dy in the operand type (the cast
   // launch in front of the next block is then skipped)
@@ -427,11 +439,11 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   // here, afterwards every consumer (fc2_grads_kernel, unpack_down_grad_kernel) leaves what it read zero
   {
     float* z0 = k.fS0 != nullptr ? k.fS0 : k.S;
-    HIP_TRY(hipMemsetAsync(z0, 0, (size_t)((k.G + k.g_floats) - z0) * sizeof(float), st));
+    TRYB(launch_fill0(z0, (size_t)((k.G + k.g_floats) - z0), st));
   }
   // (deterministic mode: the per-GEMM launches with their fixed-order column sums)
   const bool batching = k.gb_floats > 0 && det_alloc(0) == nullptr;
-  if (batching) HIP_TRY(hipMemsetAsync(k.gb0, 0, k.gb_floats * sizeof(float), st));
+  if (batching) TRYB(launch_fill0(k.gb0, k.gb_floats, st));
   // operand-type buffer the consumer after block (i, j) reads its dy from: the block before, else the downsample
   auto next_dyT = [&](int i, int j) -> void* {
     if (j > 0) return k.blk[i][j - 1].dyT;
@@ -439,7 +451,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   };
   // the stem filter gradient's operand depends on the triplets only: built on the side stream while it is still idle
   // (at the end of the chain it was 36 us of the step's tail)
-  TRYB(fork());
+  // (no fork of its own: it reads the caller's triplets, which the forward already read on this stream, and the side
+  //  stream has the head's backward in front of it, queued behind a fork a few launches ago)
+  if (h->use_side && h->side != nullptr) sd = h->side;
   TRYB(launch_stem_im2col(prec, img, k.stem_patches, B, sd));
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
@@ -472,11 +486,17 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(launch_mlp_bwd(prec, ch, s.xn, s.dyT, h->extra + b.p_fc1, h->extra + b.p_fc2t, m + b.fc1_b, dxn, s.fpart,
                             k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red, p16));
         TRYB(fork());
+      } else if (h->s2mlp && b.p_w1tp != 0 && s2mlp_bwd_supported(prec, ch)) {
+        // ---- 256 channels: da = (dy (diag(gamma) W2)) * gelu'(a) and dxn = da W1 in one launch (s2mlp_bwd.hip)
+        TRYB(launch_s2mlp_bwd(prec, s.dyT, s.a, h->extra + b.p_w2tp, h->extra + b.p_w1tp, s.da, dxn, rows, st));
+        if (!batched || h->fork_per_block) TRYB(fork());
       } else {
       // ---- da = (dy (diag(gamma) W2)) * gelu'(a)     (gamma is folded into the packed W2^T)
       TRYB(launch_gemm(prec, EPI_DGELU, s.dyT, h->extra + b.p_fc2t, nullptr, nullptr,
                        reinterpret_cast<const float*>(s.a), s.da, rows, H, ch, st));
-      TRYB(fork());   // the side stream may start once da exists; its work is queued below, behind the chain's
+      // the side stream may start once da exists; its work is queued below, behind the chain's (a block whose GEMMs wait
+      // for the stage's batch has nothing for it yet)
+      if (!batched || h->fork_per_block) TRYB(fork());
       // ---- dxn = da W1, then the LayerNorm backward on the depthwise output d = dwconv(x_in) + bias the forward kept
       TRYB(launch_gemm(prec, EPI_PLAIN, s.da, h->extra + b.p_fc1t, nullptr, nullptr, nullptr, dxn,
                        rows, ch, H, st));
@@ -487,12 +507,12 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         // ---- 3x3 maps: the same in their own kernel (d recomputed from x_in; compact rows, reduced by launch_dw3_rows)
         TRYB(launch_dw3ln_bwd(m + b.dw_b, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, st, planes,
                               (size_t)rows * ch));
-        pend = {s.dwpart, grads + b.dw_w, dw3_rows(B), 0};
+        TRYB(add_pend(s.dwpart, grads + b.dw_w, dw3_rows(B), 0));
       } else if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
         TRYB(launch_dwln_bwd(h->dwln_recomp ? nullptr : s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
                              planes, (size_t)rows * ch, m + b.dw_b, p16));
-        pend = {s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch};
+        TRYB(add_pend(s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch));
       } else if (hw == 1 && h->use_dwln && ch <= 640) {
         // ---- 1x1 maps: the same three steps per (alert, channel) in one launch
         TRYB(launch_ln_dw1_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, grads + b.ln_w, grads + b.ln_b,
@@ -526,10 +546,9 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                             grads + b.fc2_b, grads + b.gamma, ch, H, sd));
       dyT_ready = nxt != nullptr;
     }
-    if (nbj > 0) {
+    auto stage_batch = [&]() -> int {
       // ---- the stage's filter-gradient GEMMs as one launch + one slice reduction, then the fc2 / layer-scale gradients
       //      of every block from its own G / S (side stream; the chain has passed the stage)
-      TRYB(fork());
       TRYB(launch_wgrad16_batched(prec, bj, nbj, k.wpart, 2 * WPART_FLOATS, hw >= 3 ? 576 : 256, sd));
       for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {
         const BlockPk& b = h->blocks[i][j];
@@ -538,6 +557,13 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(launch_fc2_grads(s.Gb, s.Sb, m + b.fc2_w, m + b.fc2_b, m + b.gamma, grads + b.fc2_w, grads + b.fc2_b,
                               grads + b.gamma, ch, H, sd));
       }
+      nbj = 0;
+      return BTSBOT_OK;
+    };
+    // (with a downsample in front of the stage the batch shares that one's fork)
+    if (nbj > 0 && (i == 0 || h->fork_per_block)) {
+      TRYB(fork());
+      TRYB(stage_batch());
     }
     if (i > 0) {
       // ---- downsample backward: y = patches(LN(x_prev)) Wd^T + b
@@ -548,6 +574,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(launch_scale_cast(prec, dy, nullptr, dyT, (long)rows * ch, ch, st));
       dyT_ready = false;
       TRYB(fork());
+      if (nbj > 0) TRYB(stage_batch());
       TRYB(launch_gemm(prec, EPI_PLAIN, dyT, h->extra + h->down[i].p_wt, nullptr, nullptr,
                        nullptr, k.dpat, rows, 4 * cin, ch, st));
       // LN backward per input pixel (x_prev = stage i-1 output), its incoming gradient gathered from the patch matrix
@@ -564,7 +591,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
     // every gradient of stages.i.* (and, for i = 3, of the heads) is queued: bucket 3 - i is complete once the
     // side stream has drained what it holds AND seen the chain up to here -- so the event is recorded on the side
     // stream behind a fork, and the chain itself does not wait (a join here stalled it ~17 us twice per step)
-    if (i >= 2 && h->n_buckets == 3) {
+    if (i >= 2 && h->n_buckets == 3 && h->bucket_fine) {
       TRYB(fork());
       HIP_TRY(hipEventRecord(h->bucket_ev[3 - i], sd));
     }
@@ -580,6 +607,6 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
                   sd, k.wpart));
   }
   TRYB(join());
-  if (h->n_buckets == 3) HIP_TRY(hipEventRecord(h->bucket_ev[2], st));
+  if (h->n_buckets == 3 && h->bucket_fine) HIP_TRY(hipEventRecord(h->bucket_ev[2], st));
   return BTSBOT_OK;
 }

@@ -409,6 +409,13 @@ int dw3_rows(int B);
 int launch_dw3ln_bwd(const float* dwb, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                      void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes = 1, size_t pstride = 0);
 int launch_dw3_rows(const float* partials, float* out, int nrows, hipStream_t st);
+// the input-gradient half of a 256-channel block's MLP backward as one launch (s2mlp_bwd.hip): da = ((gamma W2)^T dy) *
+// gelu'(a) [R][1024] (operand type) and dxn = W1^T da [R][256] (fp32); w2tp / w1tp = launch_pack_frag16 of the 16-bit
+// dgrad transposes (diag(gamma) W2)^T [1024][256] and W1^T [256][1024]
+bool s2mlp_bwd_supported(int prec, int C);
+int launch_pack_frag16(const void* src, void* dst, int rows, int K, hipStream_t st);
+int launch_s2mlp_bwd(int prec, const void* dy, const void* a, const void* w2tp, const void* w1tp, void* da, float* dxn, int R,
+                     hipStream_t st);
 int launch_stem_im2col(int prec, const float* img, void* patches, int B, hipStream_t st);
 // src fp32 [R][Cc] -> dst prec-typed [Cc][R]
 int launch_transpose_cast(int prec, const float* src, const float* rowscale, void* dst, int R, int Cc,
@@ -451,6 +458,9 @@ int launch_head(const HeadArgs& a, hipStream_t st);
 
 // parameter packing helpers
 int launch_cast(int prec, const float* src, void* dst, int64_t n, hipStream_t st);
+// fills / copies of the training step as plain kernels (train.hip says why not hipMemsetAsync / hipMemcpyAsync)
+int launch_fill0(float* p, size_t n, hipStream_t st);
+int launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t st);
 // One launch for a table of operand-packing jobs (the per-step re-pack of the training loop is ~75 of these,
 // each a 2-5 us kernel: launch-floor bound one by one).  The table lives in device memory; job j owns blocks
 // [blk0_j, blk0_{j+1}).  ops: the element maps of cast / transpose_f32 / transpose_cast / pack_down / pack_down_t.

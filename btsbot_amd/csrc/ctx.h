@@ -24,6 +24,7 @@ struct BlockPk {  // per ConvNeXt block: master offsets + packed offsets (bytes 
   size_t p_x2_w1 = 0, p_x2_w2g = 0;   // split mode, stages 0-1: fc1 / gamma * fc2 filters, f16 heads (stage0b / stage1b)
   size_t p_x2_w1lo = 0, p_x2_w2glo = 0;   // ... and their f16 remainders, same layouts
   size_t p_fc1t, p_fc2t;   // for the dgrad GEMMs: W1^T [C][4C], (diag(gamma) W2)^T [4C][C]
+  size_t p_w1tp = 0, p_w2tp = 0;   // 256-channel blocks, training: the same two as MFMA A fragments (s2mlp_bwd.hip)
   bool fused;
 };
 struct DownPk {
@@ -136,6 +137,13 @@ struct btsbot_ctx {
   int64_t bucket_lo[3] = {0, 0, 0}, bucket_hi[3] = {0, 0, 0};
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   bool bucket_recorded = false;
+  // The per-stage bucket events cost the backward's chain a fork each (an event record between two kernels: ~6 us), so they
+  // are recorded only once somebody has waited for a bucket (btsbot_wait_grad_bucket / btsbot_allreduce_grads: a
+  // multi-GPU run, from its first step on).  bucket_fine: the LAST backward recorded bucket_ev[]; otherwise a waiter gets
+  // an event recorded on that backward's stream at the time it asks (everything the backward queued is in front of it).
+  bool bucket_waits_seen = false, bucket_fine = false;
+  hipStream_t last_bwd_stream = nullptr;
+  bool meta_join_pending = false;   // the metadata branch's training forward sits on the side stream and `st` has not joined it yet
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
   bool s2p_train = false;            // the training forward of stage 2 runs stage2p_kernel's keeping form (16-bit modes;
                                      // BTSBOT_AMD_S2P_TRAIN=1 turns it on: no faster than the per-op launches)
@@ -183,6 +191,10 @@ struct btsbot_ctx {
                             // write it
   bool planes16 = false;   // BTSBOT_AMD_PLANES16=1 (opt-in, bf16 mode): mlp_bwd_kernel's four addend planes of dxn (128 channels)
                            // leave as bf16 and dwln_bwd_kernel reads them so (206 MB less per block; api.hip says why not default)
+  bool s2mlp = false;      // BTSBOT_AMD_S2MLP=1 (opt-in): 256-channel blocks' da and dxn of the MLP backward as one launch
+                           // (s2mlp_bwd.hip) instead of two tiled GEMMs (api.hip says why not default)
+  bool fork_per_block = false;   // BTSBOT_AMD_FORK_PER_BLOCK=1: the blocks of a batched stage fork the side stream one by one, as
+                                 // before the batch existed (A/B timing)
   bool wgrad_batch = true; // stages whose blocks run the unfused MLP backward (256 / 512 channels): their 2 x depth filter-gradient
                            // GEMMs as ONE launch + one slice reduction at the end of the stage's chain (wgrad.hip);
                            // BTSBOT_AMD_NO_WGRAD_BATCH=1: one launch per GEMM behind each block (A/B timing, parity tests)

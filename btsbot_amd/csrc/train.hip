@@ -49,7 +49,58 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p,
   }
 }
 
+// Plain fills and copies of the training step as kernels of our own: the runtime's hipMemsetAsync / hipMemcpyAsync put
+// barrier packets around their blit kernels, which cost the stream 4-6 us of idle time each (five of them per step).
+__global__ __launch_bounds__(256) void fill0_kernel(float4* __restrict__ p, size_t n16, float* __restrict__ tail, int ntail) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+__global__ __launch_bounds__(256) void copy16_kernel(float4* __restrict__ d, const float4* __restrict__ s, size_t n16,
+                                                     float* __restrict__ dt, const float* __restrict__ st, int ntail) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d[i] = s[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dt[threadIdx.x] = st[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void fill0_scalar_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void copy_scalar_kernel(float* __restrict__ d, const float* __restrict__ s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+inline unsigned grid_for(size_t n) {
+  const size_t b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : b > 4096 ? 4096 : b);
+}
+
 }  // namespace
+
+// n floats at p := 0 (p 4-byte aligned)
+int launch_fill0(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return BTSBOT_OK;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) {
+    hipLaunchKernelGGL(fill0_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n);
+  } else {
+    const size_t n16 = n / 4;
+    hipLaunchKernelGGL(fill0_kernel, dim3(grid_for(n16)), dim3(256), 0, st, reinterpret_cast<float4*>(p), n16, p + 4 * n16,
+                       (int)(n - 4 * n16));
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+// n floats from src to dst (non-overlapping, 4-byte aligned)
+int launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t st) {
+  if (n == 0) return BTSBOT_OK;
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) != 0) {
+    hipLaunchKernelGGL(copy_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, src, n);
+  } else {
+    const size_t n16 = n / 4;
+    hipLaunchKernelGGL(copy16_kernel, dim3(grid_for(n16)), dim3(256), 0, st, reinterpret_cast<float4*>(dst),
+                       reinterpret_cast<const float4*>(src), n16, dst + 4 * n16, src + 4 * n16, (int)(n - 4 * n16));
+  }
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
 
 extern "C" int btsbot_bce_fwd_bwd(const float* logits, const float* labels, float pos_weight,
                                   int batch, int n_global, float* loss_sum, float* dlogits,
