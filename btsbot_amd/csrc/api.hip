@@ -368,13 +368,13 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     // (opt-in: measured 252-259 us per launch with its 360 MB of kept rows against 100 us for the inference form -- the
     //  same as the per-op launches it replaces)
     const char* nst = getenv("BTSBOT_AMD_S2P_TRAIN");
-    h->s2p_train = h->stage2p && h->use_s2p && !h->x2 && !h->fp8 &&
+    h->s2p_train = h->stage2p && h->cfg.dims[2] == 256 && h->use_s2p && !h->x2 && !h->fp8 &&
                    (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nst != nullptr && nst[0] == '1';
     // (opt-in: measured 2.85 against 2.78 ms per 1024-alert step.  The chain gets 216 us shorter, but the step is bound
     //  by the chip's total work, not by the chain -- both streams' kernels fill it -- and the keeping stores cost the
     //  kernel 57 us: its counted vmcnt waits for filter fragments also wait for the stores queued in front of them)
     const char* nsl = getenv("BTSBOT_AMD_S2P_LIGHT");
-    h->s2p_light = !h->s2p_train && h->stage2p && h->use_s2p && !h->x2 && !h->fp8 &&
+    h->s2p_light = !h->s2p_train && h->stage2p && h->cfg.dims[2] == 256 && h->use_s2p && !h->x2 && !h->fp8 &&
                    (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nsl != nullptr && nsl[0] == '1';
     const char* ns0t = getenv("BTSBOT_AMD_NO_S0_TRAIN");
     h->s0_train = h->stage0 && h->use_stage0 && !h->x2 && !h->fp8 &&
@@ -1010,6 +1010,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.out = x2;
         a.tap_stage = h->debug ? h->taps[3] : nullptr;
         a.B = nb;
+        a.cw = c.dims[2];
         a.alerts_hint = h->s2p_alerts_hint;
         {
           const char* dg = getenv("BTSBOT_AMD_S2P_DIAG");

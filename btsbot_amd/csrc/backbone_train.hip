@@ -265,6 +265,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       // first, beside the chain's stage 3, heads, loss and their backward; the chain's stage-2 backward waits for it.
       Stage2pArgs a;
       memset(&a, 0, sizeof(a));
+      a.cw = c.dims[2];
       a.x_in = stage_in(2);
       a.depth = (int)nblk;
       for (size_t j = 0; j < nblk; ++j) {
@@ -313,6 +314,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       // the stage output, the downsample's patch rows -- on its way.  Replaces 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM.
       Stage2pArgs a;
       memset(&a, 0, sizeof(a));
+      a.cw = c.dims[2];
       a.x_in = stage_in(2);
       a.depth = (int)nblk;
       for (size_t j = 0; j < nblk; ++j) {

@@ -37,6 +37,7 @@ struct Stage2pArgs {
   float* out;            // [B][512] f32
   float* tap_stage;      // optional [B][9][256] f32 copy of the stage output (validation)
   int B;
+  int cw;                // the stage's width: 256 (pico: dims above) or 320 (convnext_nano: [B][9][320] -> [B][640], 16-bit inference)
   unsigned long long* stamps;   // optional: workgroup 0 / thread 0 stores the shader clock per phase (64 entries)
   int diag;              // developer switches (BTSBOT_AMD_S2P_DIAG): 1 barrier at every chunk start, 2 drain loads there
   int alerts_hint;       // 0: the library picks 5 or 7 alerts per workgroup by rounds; 4 / 5 / 7: the caller's choice

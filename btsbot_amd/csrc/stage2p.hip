@@ -165,7 +165,10 @@ template <> struct MP<fp8_t> {
 template <typename T> struct GeluOf2 { using type = T; };
 template <> struct GeluOf2<fp8_t> { using type = bf16_t; };   // fp8 rides on the bf16 schedule's GELU
 
-constexpr int C = 256, HID = 1024;
+// The stage's width is a template parameter CW: 256 (pico, every mode) or 320 (convnext_nano, 16-bit modes, inference).
+// 320 channels are 20 MFMA row tiles for 8 waves: every wave owns two (as at 256) and the four left over are shared by
+// wave pairs (w, w + 4), each of which runs half of a chunk's fc2 k-steps on its tile -- the residual of those tiles is the
+// SUM of the two waves' accumulators (they meet in the LDS map at every block start).
 // G alerts are resident per workgroup: NPX = 9 G pixel rows in NCOL = 16 NB MFMA columns.  G = 4 (36 of 48 columns,
 // the form for one batch of 1024: one workgroup per CU); G = 7 (63 of 64 columns) for batches large enough that it takes
 // fewer rounds of 256 workgroups: the 1 MB filter stream per block per workgroup, which bounds the kernel, is then
@@ -174,21 +177,29 @@ template <int G> struct Geo {
   static constexpr int NPX = 9 * G, NCOL = (NPX + 15) / 16 * 16, NB = NCOL / 16;
 };
 constexpr int NT = 512, NW = NT / 64;                 // 8 waves: 2 per SIMD
-constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;      // hidden units per fc1 / fc2 step
+constexpr int CHUNK = 128;                            // hidden units per fc1 / fc2 step
 // (k-steps of fc1 / of fc2 per chunk: C / KSTEP and CHUNK / KSTEP of the operand mode: 8 and 4, fp8: 2 and 1)
-constexpr int CO = 512, KD = 4 * C, KSD = KD / 32;    // downsample: 512 outputs, K = 1024
-constexpr int XLP = C;                                // fp32 map: floats per pixel row
+template <int CW> struct Shp {
+  static constexpr int C = CW, HID = 4 * CW, NCHUNK = HID / CHUNK;
+  static constexpr int CO = 2 * CW, KD = 4 * CW, KSD = KD / 32;   // downsample: 512 outputs, K = 1024 (640, 1280)
+  static constexpr int XLP = CW;                                   // fp32 map: floats per pixel row
+  static constexpr int NTILE = CW / 16, MF = NTILE / NW, NX = NTILE - MF * NW;   // row tiles; per wave; shared by wave pairs
+  static_assert(NX == 0 || 2 * NX == NW, "the tiles left over are shared by wave pairs");
+  // 16-bit LN image: bytes per pixel row, 32 (mod 256) -- see below (544; 800)
+  static constexpr int XNP2 = CW == 256 ? 544 : 800;
+  static_assert(XNP2 % 256 == 32 && XNP2 >= 2 * CW + 32, "LN image pitch");
+};
 // Operand images [pixel][k]: a ds_read_b128 is served in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,
 // 28-31} and the same + 32 -- each of which must cover the 16 slots of a 256-byte bank row.  A group holds every
 // pixel column once, at two neighbouring k-groups; with rows 32 bytes (mod 256) apart the slot is 2 col + kg: a
 // bijection.  (Rows 16 bytes apart, the classic padding, made every group 2-way on one slot: half of the kernel's LDS
 // cycles were conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50.)  fp8 reads 8 bytes per lane in two groups
 // of 32 lanes: 16 bytes apart is the bijection there.
-constexpr int XNP2 = C * 2 + 32;                      // 16-bit LN image: bytes per pixel row (544)
 constexpr int HP2 = CHUNK * 2 + 32;                   // hidden image: bytes per pixel row (288)
 constexpr int OFF_XL = 0;                             // [NCOL][256] f32 (rows >= NPX stay zero)
-template <typename T, int G> struct Lds {
+template <typename T, int G, int CW = 256> struct Lds {
   static constexpr int NCOL = Geo<G>::NCOL;
+  static constexpr int XLP = Shp<CW>::XLP, XNP2 = Shp<CW>::XNP2, HID = Shp<CW>::HID;
   static constexpr int OFF_XN = OFF_XL + NCOL * XLP * 4;      // G = 4: 49152
   static constexpr int XN_PLANE = NCOL * XNP2, H_PLANE = NCOL * HP2;   // 26112, 13824 (the split mode has two planes of each)
   static constexpr int NPL = MP<T>::SPLIT ? 2 : 1;
@@ -218,33 +229,43 @@ __device__ __forceinline__ float half_sum(float v) {
 // TRAIN: 0 inference; 1 the keeping form (every tensor the backward reads); 2 the light training forward: the
 // inference kernel plus each block's input map, the stage output and the downsample's patch rows -- what is left
 // (depthwise output, LayerNorm output, fc1 pre-activation, GELU) backbone_train.hip recomputes beside the chain
-template <typename T, int G, int TRAIN = 0>
+template <typename T, int G, int TRAIN = 0, int CW = 256>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
+  using SH = Shp<CW>;
+  constexpr int C = SH::C, HID = SH::HID, NCHUNK = SH::NCHUNK, CO = SH::CO, KSD = SH::KSD, XLP = SH::XLP;
+  constexpr int MF = SH::MF, NX = SH::NX;
+  static_assert(NX == 0 || (TRAIN == 0 && !MP<T>::SPLIT && MP<T>::ESZ == 2), "320 channels: 16-bit inference only");
+  using LD = Lds<T, G, CW>;
   constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
   constexpr int KSTEP = MP<T>::KSTEP, VPL = KSTEP / 4, KS1 = C / KSTEP, KS2 = CHUNK / KSTEP, KH = HID / KSTEP;
-  constexpr int OFF_XN = Lds<T, G>::OFF_XN, XN_PLANE = Lds<T, G>::XN_PLANE, H_PLANE = Lds<T, G>::H_PLANE;
+  constexpr int OFF_XN = LD::OFF_XN, XN_PLANE = LD::XN_PLANE, H_PLANE = LD::H_PLANE;
   using frag = typename MP<T>::frag;
   constexpr int ESZ = MP<T>::ESZ;
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   // operand images: bytes per pixel row (the regions keep their 16-bit sizes)
-  constexpr int XNP = C * ESZ + 16 * ESZ, HP = CHUNK * ESZ + 16 * ESZ;
+  constexpr int XNP = SH::XNP2 * ESZ / 2, HP = CHUNK * ESZ + 16 * ESZ;
   // fc1's B operand (the block's LN image, the same for all 8 chunks): k-steps kept in registers for the whole block;
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
   // (16-bit, 3 column blocks: 5 or 6 spill in the block prologue and lose more than they save; 4 column blocks: 1 -- 2 spill)
-  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? 1 : F8 ? KS1 : 4;
-  constexpr int H_IMG = Lds<T, G>::H_IMG;
+  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 || NX > 0 ? 1 : F8 ? KS1 : 4;
+  constexpr int H_IMG = LD::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
   unsigned char* xn = smem + OFF_XN;
-  unsigned char* hb = smem + Lds<T, G>::OFF_H;   // two hidden images, H_IMG bytes apart
-  float* b1s = reinterpret_cast<float*>(smem + Lds<T, G>::OFF_B1);
-  unsigned char* ab = smem + Lds<T, G>::OFF_A;   // (training forward) two pre-activation images, H_IMG bytes apart
+  unsigned char* hb = smem + LD::OFF_H;   // two hidden images, H_IMG bytes apart
+  float* b1s = reinterpret_cast<float*>(smem + LD::OFF_B1);
+  unsigned char* ab = smem + LD::OFF_A;   // (training forward) two pre-activation images, H_IMG bytes apart
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
   const int alert0 = blockIdx.x * G;
   const int nlive = min(G, a.B - alert0) * 9;        // live pixel rows of this workgroup
+  // 320 channels: the tile this wave shares with wave (wave ^ 4), its first channel for this lane, the half of a chunk's
+  // fc2 k-steps it runs on it; xlead = the wave of the pair that carries the tile's input, bias and layer-scale terms
+  constexpr int KX = KS2 / 2;
+  const int xtile = MF * NW + (NX > 0 ? wave & (NX - 1) : 0), cx0 = 16 * xtile + 4 * kg, xh = NX > 0 ? wave / NX : 0;
+  const bool xlead = xh == 0;
 
   S2P_STAMP(0);
   // pad rows of the operand images: zero once (they are never written again)
@@ -255,16 +276,22 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   for (int i = tid; i < NCOL * XLP; i += NT) xl[i] = 0.f;
 
   // ---- residual stream: this wave's 32 channels x 48 pixels, acc[m][n][r] = x[16 n + col][32 wave + 16 m + 4 kg + r]
-  f32x4 acc[2][NB];
+  f32x4 acc[MF][NB], accx[NB];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const int p = 16 * n + col;
       acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p < nlive)
-        acc[m][n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + 32 * wave + 16 * m + 4 * kg);
+        acc[m][n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + 16 * (MF * wave + m) + 4 * kg);
     }
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int p = 16 * n + col;
+    accx[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (NX > 0 && xlead && p < nlive) accx[n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + cx0);
+  }
   __syncthreads();   // zero fill done before the first map is written
 
   // this wave's fragment streams: fc1 tile (8 ch + wave) of a chunk: 8 KiB contiguous; fc2 tiles 2 wave, 2 wave + 1:
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   // the same k-step of the next chunk, which arrives a whole chunk (~3k cycles) before it is needed (the loads of all
   // 256 CUs hit the same L2 lines at about the same time: ~1.1k cycles of transfer per 64 KB burst per CU on top of
   // the L2 latency).  The registers a second set would take hold the fc1 B operand instead (below).
-  frag a1[KS1], a2[2][KS2];
+  frag a1[KS1], a2[MF][KS2], a2x[KX > 0 ? KX : 1];
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   // (split: the two streams are 128 registers; they are NOT carried through the depthwise / LayerNorm phases -- every
@@ -282,9 +309,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
     for (int s = 0; s < KS1; ++s) a1[s] = MP<T>::gld(a.blk[0].w1p, (size_t)wave * KS1 + s, lane);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MF; ++m) {
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) a2[m][s] = MP<T>::gld(a.blk[0].w2p, (size_t)(2 * wave + m) * KH + s, lane);
+      for (int s = 0; s < KS2; ++s) a2[m][s] = MP<T>::gld(a.blk[0].w2p, (size_t)(MF * wave + m) * KH + s, lane);
+    }
+    if (NX > 0) {
+#pragma unroll
+      for (int s = 0; s < KX; ++s) a2x[s] = MP<T>::gld(a.blk[0].w2p, (size_t)xtile * KH + xh * KX + s, lane);
     }
   }
 
@@ -293,14 +324,22 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     const Stage2pBlk& bk = a.blk[j];
     S2P_STAMP(1 + 8 * j);
     // ---- every small parameter of the block is requested first: the L2 latency passes under the phases below
-    f32x4 g4[2], b4[2];
+    f32x4 g4[MF], b4[MF], gx4 = f32x4{0.f, 0.f, 0.f, 0.f}, bx4 = gx4;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 32 * wave + 16 * m + 4 * kg);
-      b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 32 * wave + 16 * m + 4 * kg);
+    for (int m = 0; m < MF; ++m) {
+      g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
+      b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 16 * (MF * wave + m) + 4 * kg);
     }
-    const float b1a = bk.b1[tid], b1b = bk.b1[tid + NT];
-    const int dc = tid & (C - 1), dhalf = tid >> 8;      // depthwise role: (channel, alert pair)
+    if (NX > 0) {
+      gx4 = *reinterpret_cast<const f32x4*>(bk.gamma + cx0);
+      bx4 = *reinterpret_cast<const f32x4*>(bk.b2 + cx0);
+    }
+    constexpr int NB1 = (HID + NT - 1) / NT;
+    float b1r[NB1];
+#pragma unroll
+    for (int i = 0; i < NB1; ++i) b1r[i] = bk.b1[tid + i * NT < HID ? tid + i * NT : 0];
+    // depthwise role: 256 channels: (channel, alert pair); 320: thread = channel, every alert of the workgroup
+    const int dc = C == 256 ? tid & 255 : tid < C ? tid : 0, dhalf = C == 256 ? tid >> 8 : 0;
     float w[25];
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky)
@@ -311,10 +350,14 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     const f32x4 lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
     const f32x4 lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
     const f32x4 lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
+    // (320 channels: a lane's 9th and 10th channel are 256 + 2 (lane & 31) + {0, 1})
+    constexpr int CXL = C > 256 ? 256 : 0;
+    const float2 lwx = *reinterpret_cast<const float2*>(bk.ln_w + CXL + 2 * (lane & 31));
+    const float2 lbx = *reinterpret_cast<const float2*>(bk.ln_b + CXL + 2 * (lane & 31));
     // ---- the map to LDS in fp32
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int c0 = 32 * wave + 16 * m + 4 * kg;
+    for (int m = 0; m < MF; ++m) {
+      const int c0 = 16 * (MF * wave + m) + 4 * kg;
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         const int p = 16 * n + col;
@@ -323,14 +366,27 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
           *reinterpret_cast<f32x4*>(a.keep[j].xin + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
       }
     }
+    if (NX > 0) {   // the shared tiles: the pair's two partial residuals, one after the other
+      if (xlead) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          if (16 * n + col < NPX) *reinterpret_cast<f32x4*>(xl + (16 * n + col) * XLP + cx0) = accx[n];
+      }
+      __syncthreads();
+      if (!xlead) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          if (16 * n + col < NPX) *reinterpret_cast<f32x4*>(xl + (16 * n + col) * XLP + cx0) += accx[n];
+      }
+    }
     __syncthreads();
     S2P_STAMP(2 + 8 * j);
     // ---- depthwise 7x7 on the 3x3 maps, in place: thread = (channel, alert pair)
     {
-      constexpr int AH = (G + 1) / 2;   // alerts per half of the workgroup (odd G: the second half has one fewer)
+      constexpr int AH = C == 256 ? (G + 1) / 2 : G;   // alerts per half of the workgroup (odd G: the second half has one fewer)
 #pragma unroll
       for (int g = 0; g < AH; ++g) {
-        if (dhalf * AH + g >= G) continue;
+        if (dhalf * AH + g >= G || (C != 256 && tid >= C)) continue;
         float* px = xl + (size_t)((dhalf * AH + g) * 9) * XLP + dc;
         float in[9], o[9];
 #pragma unroll
@@ -350,8 +406,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         for (int i = 0; i < 9; ++i) px[i * XLP] = o[i];
       }
     }
-    b1s[tid] = b1a;            // (last read by the previous block's last fc1, two barriers ago)
-    b1s[tid + NT] = b1b;
+#pragma unroll
+    for (int i = 0; i < NB1; ++i)   // (last read by the previous block's last fc1, two barriers ago)
+      if (tid + i * NT < HID) b1s[tid + i * NT] = b1r[i];
     __syncthreads();
     S2P_STAMP(3 + 8 * j);
     if (TRAIN == 1) {   // the depthwise output before the LayerNorm (it stays in xl until the next block's map)
@@ -365,10 +422,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     for (int p = 2 * wave + (lane >> 5); p < NPX; p += 2 * NW) {
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31));
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31) + 4);
-      const float mean = half_sum(d0[0] + d0[1] + d0[2] + d0[3] + d1[0] + d1[1] + d1[2] + d1[3]) * (1.0f / C);
+      float2 dx = make_float2(0.f, 0.f);
+      if (C > 256) dx = *reinterpret_cast<const float2*>(xl + p * XLP + CXL + 2 * (lane & 31));
+      const float mean = half_sum(d0[0] + d0[1] + d0[2] + d0[3] + d1[0] + d1[1] + d1[2] + d1[3] + dx.x + dx.y) * (1.0f / C);
       const f32x4 e0 = d0 - mean, e1 = d1 - mean;
+      const float ex0 = C > 256 ? dx.x - mean : 0.f, ex1 = C > 256 ? dx.y - mean : 0.f;
       const float var = half_sum(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2] + e0[3] * e0[3] + e1[0] * e1[0] +
-                                 e1[1] * e1[1] + e1[2] * e1[2] + e1[3] * e1[3]) * (1.0f / C);
+                                 e1[1] * e1[1] + e1[2] * e1[2] + e1[3] * e1[3] + ex0 * ex0 + ex1 * ex1) * (1.0f / C);
       const float rstd = rsqrtf(var + LN_EPS);
       float y[8];
 #pragma unroll
@@ -377,6 +437,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         y[4 + i] = e1[i] * rstd * lw2[i] + lb2[i];
       }
       MP<T>::template st8<XN_PLANE>(xn + p * XNP + 8 * ESZ * (lane & 31), y);
+      if constexpr (C > 256) {
+        typedef T pair_t __attribute__((ext_vector_type(2)));
+        pair_t yx;
+        yx[0] = (T)(ex0 * rstd * lwx.x + lbx.x);
+        yx[1] = (T)(ex1 * rstd * lwx.y + lbx.y);
+        *reinterpret_cast<pair_t*>(xn + p * XNP + (CXL + 2 * (lane & 31)) * ESZ) = yx;
+      }
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
@@ -396,16 +463,20 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         xr[s][n] = MP<T>::template ld8<XN_PLANE>(xn + (16 * n + col) * XNP + (KSTEP * s + VPL * kg) * ESZ);
     // residual + gamma * b2 (the bias of the folded fc2)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MF; ++m)
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[m][n] += g4[m] * b4[m];
+    if (NX > 0 && xlead) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) accx[n] += gx4 * bx4;
+    }
     // fp8: gamma * W2 was packed times the power of two S2, so the residual rides through the chunk loop times S2
     // (exact) and comes back times 1/S2 behind the block's last fc2
     const float s1 = F8 ? bk.scales[0] : 1.0f, is1 = F8 ? bk.scales[1] : 1.0f;
     if (F8) {
       const float s2 = bk.scales[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[m][n] *= s2;
     }
@@ -442,7 +513,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const size_t f1 = (size_t)(nch * NW + wave) * KS1;
       // fc2 runs one step behind: its slots are refilled with THIS chunk's fragments (used in the next step)
       const void* src2 = bk.w2p;
-      const size_t f2 = (size_t)(2 * wave) * KH + ch * KS2;
+      const size_t f2 = (size_t)(MF * wave) * KH + ch * KS2;
+      const size_t fx = (size_t)xtile * KH + ch * KS2 + xh * KX;   // (320 channels) this wave's k-steps of the shared tile
       // fc1: hidden tile (8 ch + wave) x 48 pixels, bias in the accumulator; B = [k = channel][n = pixel]: k-steps
       // 0 .. XRES-1 from the registers filled after the LayerNorm, the rest from LDS
       f32x4 hacc[NB];
@@ -507,15 +579,26 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
             for (int n = 0; n < NB; ++n)
               hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * s + VPL * kg) * ESZ);
           }
+          frag hbx[NB];
+          if (NX > 0 && s < KX) {   // the shared tile: this wave's k-step xh KX + s of the chunk, in program step s
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < NB; ++n)
+              hbx[n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * (xh * KX + s) + VPL * kg) * ESZ);
+          }
+#pragma unroll
+          for (int m = 0; m < MF; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
-          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) a2[m][s] = MP<T>::gld(src2, f2 + m * KH + s, lane);
+          if (NX > 0 && s < KX) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) accx[n] = MP<T>::run(a2x[s], hbx[n], accx[n]);
+            a2x[s] = MP<T>::gld(src2, fx + s, lane);
+          }
         } else if (!CARRY) {   // (first step of a block: this chunk's fc2 fragments, used in the next step)
-          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) a2[m][s] = MP<T>::gld(src2, f2 + m * KH + s, lane);
         }
         if (s < NB) {
           float hv[4];
@@ -544,7 +627,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       if (TRAIN == 1) keep_chunk(NCHUNK - 1, 1);
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const void* src2 = nb.w2p;
-      const size_t f2 = (size_t)(2 * wave) * KH;
+      const size_t f2 = (size_t)(MF * wave) * KH;
+      const size_t fx = (size_t)xtile * KH + xh * KX;
       const unsigned char* hprev = hb + 1 * H_IMG;   // chunk NCHUNK - 1 is odd: image 1
       constexpr int DB = MP<T>::SPLIT ? 1 : 2;
       frag hbf[DB][NB];
@@ -564,13 +648,24 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
           for (int n = 0; n < NB; ++n)
             hbf[0][n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * s + VPL * kg) * ESZ);
         }
+        frag hbx[NB];
+        if (NX > 0 && s < KX) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+          for (int n = 0; n < NB; ++n)
+            hbx[n] = MP<T>::template ld8<H_PLANE>(hprev + (16 * n + col) * HP + (KSTEP * (xh * KX + s) + VPL * kg) * ESZ);
+        }
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
 #pragma unroll
           for (int n = 0; n < NB; ++n) acc[m][n] = MP<T>::run(a2[m][s], hbf[s & (DB - 1)][n], acc[m][n]);
         if (CARRY) {
-          a2[0][s] = MP<T>::gld(src2, f2 + s, lane);
-          a2[1][s] = MP<T>::gld(src2, f2 + KH + s, lane);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) a2[m][s] = MP<T>::gld(src2, f2 + m * KH + s, lane);
+        }
+        if (NX > 0 && s < KX) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n) accx[n] = MP<T>::run(a2x[s], hbx[n], accx[n]);
+          a2x[s] = MP<T>::gld(src2, fx + s, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -594,7 +689,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     if (F8) {
       const float is2 = bk.scales[3];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[m][n] *= is2;
     }
@@ -604,8 +699,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   S2P_STAMP(56);
   // ---- stage output (validation copy), then the downsample: LN per pixel + conv 2x2 s2 on pixels 0, 1, 3, 4
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int c0 = 32 * wave + 16 * m + 4 * kg;
+  for (int m = 0; m < MF; ++m) {
+    const int c0 = 16 * (MF * wave + m) + 4 * kg;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const int p = 16 * n + col;
@@ -614,25 +709,50 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
     }
   }
+  if (NX > 0) {   // the shared tiles: sum of the pair's partial residuals (the validation copy leaves from the map)
+    if (xlead) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        if (16 * n + col < NPX) *reinterpret_cast<f32x4*>(xl + (16 * n + col) * XLP + cx0) = accx[n];
+    }
+    __syncthreads();
+    if (!xlead) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int p = 16 * n + col;
+        if (p < NPX) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xl + p * XLP + cx0) + accx[n];
+          *reinterpret_cast<f32x4*>(xl + p * XLP + cx0) = v;
+          if (a.tap_stage != nullptr && p < nlive) *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * 9 + p) * C + cx0) = v;
+        }
+      }
+    }
+  }
   __syncthreads();
   // (the downsample keeps 16-bit operands in the fp8 mode too: it is 5 % of the stage's FLOPs and its LN'd input in
   //  fp8 tripled the mode's score error with trained-like layer scales)
   using TD = typename std::conditional<F8, bf16_t, T>::type;
   using fragd = typename MP<TD>::frag;
-  constexpr int XND = C * MP<TD>::ESZ + 16 * MP<TD>::ESZ;
+  constexpr int XND = SH::XNP2 * MP<TD>::ESZ / 2;
   {
+    // (320 channels: a lane's fifth channel is 256 + lane)
+    constexpr int CXD = C > 256 ? 256 : 0;
     const f32x4 lw = *reinterpret_cast<const f32x4*>(a.ds_lnw + 4 * lane);
     const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ds_lnb + 4 * lane);
+    const float lwx = a.ds_lnw[CXD + lane], lbx = a.ds_lnb[CXD + lane];
     for (int p = wave; p < NPX; p += NW) {
       const f32x4 d = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * lane);
-      const float mean = wave_sum(d[0] + d[1] + d[2] + d[3]) * (1.0f / C);
+      const float dx = C > 256 ? xl[p * XLP + CXD + lane] : 0.f;
+      const float mean = wave_sum(d[0] + d[1] + d[2] + d[3] + dx) * (1.0f / C);
       const f32x4 e = d - mean;
-      const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]) * (1.0f / C);
+      const float ex = C > 256 ? dx - mean : 0.f;
+      const float var = wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3] + ex * ex) * (1.0f / C);
       const float rstd = rsqrtf(var + LN_EPS);
       float y[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = e[i] * rstd * lw[i] + lb[i];
       MP<TD>::template st4<XN_PLANE>(xn + p * XND + 4 * MP<TD>::ESZ * lane, y);
+      if constexpr (C > 256) *reinterpret_cast<TD*>(xn + p * XND + (CXD + lane) * MP<TD>::ESZ) = (TD)(ex * rstd * lwx + lbx);
     }
   }
   __syncthreads();
@@ -651,20 +771,22 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // out[alert][co] = b[co] + sum_k Wd[co][k] patch[alert][k],  k = (2 ky + kx) * 256 + c  ->  pixel 3 ky + kx.
     // Column = alert (4 live of 16); wave w: output tiles 4 w .. 4 w + 3 (16 channels each), 32 k-steps.
     const int al = col < G ? col : 0;
-    // this wave's 4 tiles x 32 k-steps = 128 fragments, contiguous in memory (tile-major): a ring of 16 in flight
-    const size_t fd0 = (size_t)(4 * wave) * KSD;
-    constexpr int RING = MP<TD>::SPLIT ? 8 : 16, NSTEP = 4 * KSD;
+    // this wave's 4 (5) tiles x 32 (40) k-steps = 128 (200) fragments, contiguous in memory (tile-major): a ring of 16 (20) in flight
+    constexpr int TPW = CO / 16 / NW, KSC = C / 32;
+    const size_t fd0 = (size_t)(TPW * wave) * KSD;
+    constexpr int RING = MP<TD>::SPLIT ? 8 : C == 256 ? 16 : 20, NSTEP = TPW * KSD;
+    static_assert(NSTEP % RING == 0, "ring rounds");
     fragd wq[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + i, lane);
-    f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (4 * wave) + 4 * kg);
+    f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (TPW * wave) + 4 * kg);
 #pragma unroll 1
     for (int g = 0; g < NSTEP / RING; ++g) {
 #pragma unroll
       for (int i = 0; i < RING; ++i) {
-        const int st = g * RING + i, s = st & (KSD - 1), tile = 4 * wave + (st >> 5);
-        const int q = s >> 3, pq = 3 * (q >> 1) + (q & 1);
-        const fragd bf = MP<TD>::template ld8<XN_PLANE>(xn + (9 * al + pq) * XND + (32 * (s & 7) + 8 * kg) * MP<TD>::ESZ);
+        const int st = g * RING + i, tq = st / KSD, s = st - tq * KSD, tile = TPW * wave + tq;
+        const int q = s / KSC, pq = 3 * (q >> 1) + (q & 1);
+        const fragd bf = MP<TD>::template ld8<XN_PLANE>(xn + (9 * al + pq) * XND + (32 * (s - q * KSC) + 8 * kg) * MP<TD>::ESZ);
         o = MP<TD>::run(wq[i], bf, o);
         if (st + RING < NSTEP) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + st + RING, lane);
         if (s == KSD - 1) {   // tile finished (every 32 steps = two ring rounds)
@@ -752,9 +874,9 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
       (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
-template <typename T, int G = S2P_ALERTS, int TRAIN = 0> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
-  auto kern = stage2p_kernel<T, G, TRAIN>;
-  constexpr int lds_bytes = TRAIN == 1 ? Lds<T, G>::BYTES_TRAIN : Lds<T, G>::BYTES;
+template <typename T, int G = S2P_ALERTS, int TRAIN = 0, int CW = 256> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+  auto kern = stage2p_kernel<T, G, TRAIN, CW>;
+  constexpr int lds_bytes = TRAIN == 1 ? Lds<T, G, CW>::BYTES_TRAIN : Lds<T, G, CW>::BYTES;
   static_assert(lds_bytes <= 160 * 1024, "the images fit one CU");
   static DevOnce attr_set;
   if (attr_set.need()) {
@@ -769,8 +891,9 @@ template <typename T, int G = S2P_ALERTS, int TRAIN = 0> int launch_stage2p_t(co
 }  // namespace
 
 bool stage2p_supported(int prec, int c2, int c3, int depth) {
-  return (prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8 || prec == BTSBOT_F16X2) && c2 == C && c3 == CO &&
-         depth >= 1 && depth <= S2P_MAX_DEPTH;
+  if (depth < 1 || depth > S2P_MAX_DEPTH || c3 != 2 * c2) return false;
+  if (c2 == 256) return prec == BTSBOT_BF16 || prec == BTSBOT_F16 || prec == BTSBOT_FP8 || prec == BTSBOT_F16X2;
+  return c2 == 320 && (prec == BTSBOT_BF16 || prec == BTSBOT_F16);   // convnext_nano: the 16-bit modes, inference
 }
 
 // src [rows][K] fp32 (row-major; reorder_down: a [Cout][Cin][2][2] downsample filter) -> MFMA A fragments
@@ -826,6 +949,17 @@ int stage2p_alerts_per_workgroup(int B, int hint) {
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
   if (a.B <= 0) return BTSBOT_OK;
+  if (a.cw == 320) {   // convnext_nano: 5 alerts per workgroup (7 would not fit the LDS next to the 320-wide map)
+    if (a.train != 0 || (prec != BTSBOT_BF16 && prec != BTSBOT_F16)) {
+      btsbot_set_error("stage2p: 320 channels run the bf16 / f16 inference form only (precision %d, train %d)", prec, a.train);
+      return BTSBOT_ERR_INVALID_ARG;
+    }
+    return prec == BTSBOT_BF16 ? launch_stage2p_t<bf16_t, 5, 0, 320>(a, st) : launch_stage2p_t<f16_t, 5, 0, 320>(a, st);
+  }
+  if (a.cw != 256) {
+    btsbot_set_error("stage2p: width %d not supported", a.cw);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
   if (a.train == 2) {   // the light training forward (16-bit modes; alerts per workgroup as in inference)
     for (int j = 1; j < a.depth; ++j)
       if (a.keep[j].xin == nullptr) {
