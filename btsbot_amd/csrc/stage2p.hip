@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
   // (16-bit, 3 column blocks: 5 or 6 spill in the block prologue and lose more than they save; 4 column blocks: 1 -- 2 spill)
-  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 || NX > 0 ? 1 : F8 ? KS1 : 4;
+  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? 1 : NX > 0 ? 0 : F8 ? KS1 : 4;
   constexpr int H_IMG = LD::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
@@ -324,15 +324,17 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     const Stage2pBlk& bk = a.blk[j];
     S2P_STAMP(1 + 8 * j);
     // ---- every small parameter of the block is requested first: the L2 latency passes under the phases below
+    // (320 channels: the layer-scale / bias / LayerNorm terms wait until the depthwise phase is over -- 44 registers that
+    //  otherwise pushed filter fragments still in flight out to scratch, whose stores then waited for them: 5k cycles per block)
     f32x4 g4[MF], b4[MF], gx4 = f32x4{0.f, 0.f, 0.f, 0.f}, bx4 = gx4;
+    constexpr int CXL = C > 256 ? 256 : 0;   // (320 channels: a lane's 9th and 10th channel are 256 + 2 (lane & 31) + {0, 1})
+    float2 lwx = make_float2(0.f, 0.f), lbx = lwx;
+    if constexpr (NX == 0) {
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
-      b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 16 * (MF * wave + m) + 4 * kg);
-    }
-    if (NX > 0) {
-      gx4 = *reinterpret_cast<const f32x4*>(bk.gamma + cx0);
-      bx4 = *reinterpret_cast<const f32x4*>(bk.b2 + cx0);
+      for (int m = 0; m < MF; ++m) {
+        g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
+        b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 16 * (MF * wave + m) + 4 * kg);
+      }
     }
     constexpr int NB1 = (HID + NT - 1) / NT;
     float b1r[NB1];
@@ -346,14 +348,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + dc];
     const float dbias = bk.dw_b[dc];
-    const f32x4 lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
-    const f32x4 lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
-    const f32x4 lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
-    const f32x4 lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
-    // (320 channels: a lane's 9th and 10th channel are 256 + 2 (lane & 31) + {0, 1})
-    constexpr int CXL = C > 256 ? 256 : 0;
-    const float2 lwx = *reinterpret_cast<const float2*>(bk.ln_w + CXL + 2 * (lane & 31));
-    const float2 lbx = *reinterpret_cast<const float2*>(bk.ln_b + CXL + 2 * (lane & 31));
+    f32x4 lw, lw2, lb, lb2;
+    if constexpr (NX == 0) {
+      lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
+      lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
+      lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
+      lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
+    }
     // ---- the map to LDS in fp32
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -405,6 +406,21 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) px[i * XLP] = o[i];
       }
+    }
+    if constexpr (NX > 0) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
+        b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 16 * (MF * wave + m) + 4 * kg);
+      }
+      gx4 = *reinterpret_cast<const f32x4*>(bk.gamma + cx0);
+      bx4 = *reinterpret_cast<const f32x4*>(bk.b2 + cx0);
+      lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
+      lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
+      lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
+      lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
+      lwx = *reinterpret_cast<const float2*>(bk.ln_w + CXL + 2 * (lane & 31));
+      lbx = *reinterpret_cast<const float2*>(bk.ln_b + CXL + 2 * (lane & 31));
     }
 #pragma unroll
     for (int i = 0; i < NB1; ++i)   // (last read by the previous block's last fc1, two barriers ago)
@@ -775,7 +791,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     constexpr int TPW = CO / 16 / NW, KSC = C / 32;
     const size_t fd0 = (size_t)(TPW * wave) * KSD;
     constexpr int RING = MP<TD>::SPLIT ? 8 : C == 256 ? 16 : 20, NSTEP = TPW * KSD;
-    static_assert(NSTEP % RING == 0, "ring rounds");
+    static_assert(KSD % RING == 0, "a tile's k-steps are whole ring rounds");
+    constexpr int RPT = KSD / RING;   // ring rounds per tile
     fragd wq[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + i, lane);
@@ -784,12 +801,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     for (int g = 0; g < NSTEP / RING; ++g) {
 #pragma unroll
       for (int i = 0; i < RING; ++i) {
-        const int st = g * RING + i, tq = st / KSD, s = st - tq * KSD, tile = TPW * wave + tq;
+        // (s from the round's position in its tile: `s == KSD - 1` below is then false at compile time for every i but the last)
+        const int st = g * RING + i, tq = g / RPT, s = (g - tq * RPT) * RING + i, tile = TPW * wave + tq;
         const int q = s / KSC, pq = 3 * (q >> 1) + (q & 1);
         const fragd bf = MP<TD>::template ld8<XN_PLANE>(xn + (9 * al + pq) * XND + (32 * (s - q * KSC) + 8 * kg) * MP<TD>::ESZ);
         o = MP<TD>::run(wq[i], bf, o);
         if (st + RING < NSTEP) wq[i] = MP<TD>::gld(a.ds_wp, fd0 + st + RING, lane);
-        if (s == KSD - 1) {   // tile finished (every 32 steps = two ring rounds)
+        if (i == RING - 1 && s == KSD - 1) {   // tile finished (every KSD steps = RPT ring rounds)
           if (col < G && alert0 + col < a.B)
             *reinterpret_cast<f32x4*>(a.out + (size_t)(alert0 + col) * CO + 16 * tile + 4 * kg) = o;
           if (st + 1 < NSTEP) o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * (tile + 1) + 4 * kg);
