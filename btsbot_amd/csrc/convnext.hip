@@ -302,19 +302,19 @@ __global__ __launch_bounds__(256) void ln_patch_kernel(const float* __restrict__
   const int oy = (int)(rest % HO);
   const int b = (int)(rest / HO);
   const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
-  const float* src = x + (((size_t)b * HW + iy) * HW + ix) * Cin + sub * CPL;
+  // a lane's channels: M4 consecutive ones from sub * M4 on (16-byte loads) and, where CPL is no multiple of 4
+  // (convnext_nano: 80 / 160 channels), R more behind the 16 lanes' main part
+  constexpr int M4 = CPL / 4 * 4, R = CPL - M4;
+  const float* src = x + (((size_t)b * HW + iy) * HW + ix) * Cin;
   float v[CPL];
   float sum = 0.f;
-  if (CPL % 4 == 0) {
 #pragma unroll
-    for (int i = 0; i < CPL; i += 4) {
-      const float4 t = *reinterpret_cast<const float4*>(src + i);
-      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) v[i] = src[i];
+  for (int i = 0; i < M4; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(src + sub * M4 + i);
+    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
   }
+#pragma unroll
+  for (int i = 0; i < R; ++i) v[M4 + i] = src[16 * M4 + sub * R + i];
 #pragma unroll
   for (int i = 0; i < CPL; ++i) sum += v[i];
   const float mean = group16_sum(sum) * (1.0f / Cin);
@@ -326,10 +326,23 @@ __global__ __launch_bounds__(256) void ln_patch_kernel(const float* __restrict__
   }
   const float rstd = rsqrtf(group16_sum(sq) * (1.0f / Cin) + LN_EPS);
   if (!live) return;
-  T* dst = patches + ((((size_t)b * HO + oy) * HO + ox) * 4 + q) * Cin + sub * CPL;
+  T* dst = patches + ((((size_t)b * HO + oy) * HO + ox) * 4 + q) * Cin;
+  typedef T T4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int i = 0; i < CPL; ++i)
-    dst[i] = (T)((v[i] - mean) * rstd * lnw[sub * CPL + i] + lnb[sub * CPL + i]);
+  for (int i = 0; i < M4; i += 4) {
+    const float4 w4 = *reinterpret_cast<const float4*>(lnw + sub * M4 + i), b4 = *reinterpret_cast<const float4*>(lnb + sub * M4 + i);
+    T4 o;
+    o[0] = (T)((v[i] - mean) * rstd * w4.x + b4.x);
+    o[1] = (T)((v[i + 1] - mean) * rstd * w4.y + b4.y);
+    o[2] = (T)((v[i + 2] - mean) * rstd * w4.z + b4.z);
+    o[3] = (T)((v[i + 3] - mean) * rstd * w4.w + b4.w);
+    *reinterpret_cast<T4*>(dst + sub * M4 + i) = o;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int c = 16 * M4 + sub * R + i;
+    dst[c] = (T)((v[M4 + i] - mean) * rstd * lnw[c] + lnb[c]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -173,7 +173,9 @@ constexpr int M2 = 64, N2 = 32;   // fc2 tile: alerts x channels
 constexpr float LN_EPS = 1e-6f;
 constexpr int RED_BYTES = 8 * 2 * 4 * 64 * 16;   // fc2: 8 K slices x 2 alert blocks x 4 quads x 64 lanes x float4
 
-template <typename T, int C>
+// MB = 32-alert row blocks per workgroup (1; 2 at C = 640, where 32 x 10 tiles would be 320 workgroups = two rounds of the
+// chip's 256 CUs and 16 x 10 = 160 with twice the rows per filter fragment is one)
+template <typename T, int C, int MB = 1>
 __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& bk, int ab, int nt, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
   constexpr int KSTEP = S3M<T>::KSTEP, VPL = KSTEP / 2;
@@ -186,10 +188,11 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int ht = nt * (N1 / 32) + wave;                 // this wave's tile of 32 hidden units
   // ---- the 32 rows first (4 per wave; lane = channels 128 i + 2 lane + {0, 1}), then the per-channel constants
-  float2 v[4][NV];
+  constexpr int RPW = 4 * MB;   // rows per wave
+  float2 v[RPW][NV];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int al = ab * M1 + 4 * wave + u;
+  for (int u = 0; u < RPW; ++u) {
+    const int al = ab * M1 * MB + RPW * wave + u;
     const float* src = a.x + (size_t)(al < a.B ? al : a.B - 1) * C + 2 * lane;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[u][i] = *reinterpret_cast<const float2*>(src + 128 * i);
@@ -209,9 +212,11 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   frag wq[RING];
   S3_STAMP(9);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < RPW; ++u) {
+    if (u < 4) {
 #pragma unroll
-    for (int i = u * (RING / 4); i < (u + 1) * (RING / 4); ++i) wq[i] = S3M<T>::ldg(bk.w1p, wf0 + i, lane);
+      for (int i = u * (RING / 4); i < (u + 1) * (RING / 4); ++i) wq[i] = S3M<T>::ldg(bk.w1p, wf0 + i, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
@@ -229,7 +234,7 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
       q = fmaf(v[u][i].x, v[u][i].x, fmaf(v[u][i].y, v[u][i].y, q));
     }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + LN_EPS);
-    unsigned char* row = smem + (4 * wave + u) * PITCH;
+    unsigned char* row = smem + (RPW * wave + u) * PITCH;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       S3M<T>::lds_st2(row, 128 * i + 2 * lane, C, fmaf(v[u][i].x * rstd, lw[i].x, lb[i].x),
@@ -242,16 +247,19 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   //      times S1 and the sum comes out times 1/S1; the 16-bit modes have no scales)
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   const float s1 = F8 ? bk.scales[0] : 1.0f, is1 = F8 ? bk.scales[1] : 1.0f;
-  f32x16 acc;
+  f32x16 acc[MB];
   {
     const float* bp = bk.b1 + 32 * ht + 8 * h;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * (qd & 1) + 16 * (qd >> 1));
-      acc[4 * qd + 0] = bv.x * s1;
-      acc[4 * qd + 1] = bv.y * s1;
-      acc[4 * qd + 2] = bv.z * s1;
-      acc[4 * qd + 3] = bv.w * s1;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb][4 * qd + 0] = bv.x * s1;
+        acc[mb][4 * qd + 1] = bv.y * s1;
+        acc[mb][4 * qd + 2] = bv.z * s1;
+        acc[mb][4 * qd + 3] = bv.w * s1;
+      }
     }
   }
   __syncthreads();
@@ -259,33 +267,41 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   const unsigned char* bp = smem + lr * PITCH;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const frag bf = S3M<T>::lds_ld8(bp, ks * KSTEP + h * VPL, C);
-    acc = S3M<T>::run(wq[ks % RING], bf, acc);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const frag bf = S3M<T>::lds_ld8(bp + mb * 32 * PITCH, ks * KSTEP + h * VPL, C);
+      acc[mb] = S3M<T>::run(wq[ks % RING], bf, acc[mb]);
+    }
     if (ks + RING < KS) wq[ks % RING] = S3M<T>::ldg(bk.w1p, wf0 + ks + RING, lane);
   }
   S3_STAMP(12);
   // ---- GELU, out as fc2's B fragments: lane (alert lr, half h) holds k = 16 ks2 + 8 h + 0..7 of k-step ks2 = 2 ht + hh
-  if constexpr (S3M<T>::MX) {
-    // fc2 sums over all hidden units, so their order inside its k-steps is free: this lane's 16 values are bytes
-    // 16 (ht & 1) .. + 15 of its slot in fragment ht >> 1 -- position (S, half h, j) of fc2's k holds hidden unit
-    // 64 S + 32 (j >> 4) + (j & 7) + 8 h + 16 ((j >> 3) & 1), which is how launch_pack_s3 orders gamma * W2 (kperm)
-    float g[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[j] * is1);
-    S3M<T>::stg_half(a.hfrag, (size_t)ab * (HID / 64) + (ht >> 1), ht & 1, lane, g);
-  } else {
+  for (int mb = 0; mb < MB; ++mb) {
+    const size_t ab32 = (size_t)ab * MB + mb;   // the 32-alert block these rows are
+    if constexpr (S3M<T>::MX) {
+      // fc2 sums over all hidden units, so their order inside its k-steps is free: this lane's 16 values are bytes
+      // 16 (ht & 1) .. + 15 of its slot in fragment ht >> 1 -- position (S, half h, j) of fc2's k holds hidden unit
+      // 64 S + 32 (j >> 4) + (j & 7) + 8 h + 16 ((j >> 3) & 1), which is how launch_pack_s3 orders gamma * W2 (kperm)
+      float g[16];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float g[8];
+      for (int j = 0; j < 16; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[mb][j] * is1);
+      S3M<T>::stg_half(a.hfrag, ab32 * (HID / 64) + (ht >> 1), ht & 1, lane, g);
+    } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[8 * hh + j] * is1);
-      S3M<T>::stg(a.hfrag, (size_t)ab * (HID / 16) + 2 * ht + hh, lane, S3M<T>::pack8(g));
+      for (int hh = 0; hh < 2; ++hh) {
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = gelu_for<typename GeluOf<T>::type>(acc[mb][8 * hh + j] * is1);
+        S3M<T>::stg(a.hfrag, ab32 * (HID / 16) + 2 * ht + hh, lane, S3M<T>::pack8(g));
+      }
     }
   }
   __syncthreads();   // the rows in LDS are read out: the next tile may overwrite them
 }
 
-template <typename T, int C>
+// NC = 32-channel tiles per workgroup (1; 2 at C = 640: 16 x 10 = 160 workgroups instead of 320, see fc1_tile)
+template <typename T, int C, int NC = 1>
 __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
   constexpr int HID = 4 * C, KSA = HID / S3M<T>::KSTEP, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
@@ -295,24 +311,31 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = mt * M2;
-  const size_t wf0 = (size_t)ct * KSA + wave * KSW, hf0 = (size_t)(m0 / 32) * KSA + wave * KSW, hf1 = hf0 + KSA;
-  frag wa[RING], ha[RING], hb[RING];
+  const size_t wf0 = (size_t)(ct * NC) * KSA + wave * KSW, hf0 = (size_t)(m0 / 32) * KSA + wave * KSW, hf1 = hf0 + KSA;
+  frag wa[NC][RING], ha[RING], hb[RING];
 #pragma unroll
   for (int i = 0; i < RING; ++i) {
-    wa[i] = S3M<T>::ldg(bk.w2p, wf0 + i, lane);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) wa[nc][i] = S3M<T>::ldg(bk.w2p, wf0 + (size_t)nc * KSA + i, lane);
     ha[i] = S3M<T>::ldg(a.hfrag, hf0 + i, lane);
     hb[i] = S3M<T>::ldg(a.hfrag, hf1 + i, lane);
   }
   __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc sinks the loads to their MFMAs: ~10 in flight instead of 48)
-  f32x16 acc[2];
+  f32x16 acc[NC][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+  for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nc][0][r] = acc[nc][1][r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KSW; ++ks) {
-    acc[0] = S3M<T>::run(wa[ks % RING], ha[ks % RING], acc[0]);
-    acc[1] = S3M<T>::run(wa[ks % RING], hb[ks % RING], acc[1]);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) {
+      acc[nc][0] = S3M<T>::run(wa[nc][ks % RING], ha[ks % RING], acc[nc][0]);
+      acc[nc][1] = S3M<T>::run(wa[nc][ks % RING], hb[ks % RING], acc[nc][1]);
+    }
     if (ks + RING < KSW) {
-      wa[ks % RING] = S3M<T>::ldg(bk.w2p, wf0 + ks + RING, lane);
+#pragma unroll
+      for (int nc = 0; nc < NC; ++nc) wa[nc][ks % RING] = S3M<T>::ldg(bk.w2p, wf0 + (size_t)nc * KSA + ks + RING, lane);
       ha[ks % RING] = S3M<T>::ldg(a.hfrag, hf0 + ks + RING, lane);
       hb[ks % RING] = S3M<T>::ldg(a.hfrag, hf1 + ks + RING, lane);
     }
@@ -320,19 +343,22 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
   S3_STAMP(13);
   // ---- the eight K slices meet in LDS; register r = channel 32 ct + (r & 3) + 8 (r >> 2) + 4 h of alert (lane & 31)
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      red[((wave * 2 + t) * 4 + qd) * 64 + lane] =
-          make_float4(acc[t][4 * qd], acc[t][4 * qd + 1], acc[t][4 * qd + 2], acc[t][4 * qd + 3]);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        red[(((wave * NC + nc) * 2 + t) * 4 + qd) * 64 + lane] =
+            make_float4(acc[nc][t][4 * qd], acc[nc][t][4 * qd + 1], acc[nc][t][4 * qd + 2], acc[nc][t][4 * qd + 3]);
   __syncthreads();
-  {
+#pragma unroll
+  for (int nc = 0; nc < NC; ++nc) {
     const int q = tid, t = q >> 8, qd = (q >> 6) & 3, ln = q & 63;
-    const int al = m0 + 32 * t + (ln & 31), c = 32 * ct + 8 * qd + 4 * (ln >> 5);
-    float4 s = red[q];
+    const int al = m0 + 32 * t + (ln & 31), c = 32 * (ct * NC + nc) + 8 * qd + 4 * (ln >> 5);
+    float4 s = red[nc * 512 + q];
 #pragma unroll
     for (int w = 1; w < 8; ++w) {
-      const float4 p = red[w * 512 + q];
+      const float4 p = red[(w * NC + nc) * 512 + q];
       s.x += p.x;
       s.y += p.y;
       s.z += p.z;
@@ -359,20 +385,20 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
 }
 
 
-template <typename T, int C>
+template <typename T, int C, int MB = 1>
 __global__ __launch_bounds__(NT) void s3_fc1_kernel(Stage3Args a, int j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTL = 4 * C / N1;
   // (blockIdx % 8 = the XCD: consecutive workgroups take different hidden tiles of one alert block, so an XCD's L2
   //  holds 1/8 of the filter)
-  fc1_tile<T, C>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
+  fc1_tile<T, C, MB>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
 }
 
-template <typename T, int C>
+template <typename T, int C, int NC = 1>
 __global__ __launch_bounds__(NT) void s3_fc2_kernel(Stage3Args a, int j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NTL = C / N2;
-  fc2_tile<T, C>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
+  constexpr int NTL = C / (N2 * NC);
+  fc2_tile<T, C, NC>(a, a.blk[j], blockIdx.x / NTL, blockIdx.x % NTL, smem);
 }
 
 // fp32 [rows][K] (x rowscale[row]) -> 32x32x16 A fragments [row tile][k-step][lane][8]: lane l holds tile row (l & 31),
@@ -454,9 +480,11 @@ __global__ void pack_s3_fp8_kernel(const float* __restrict__ w, const float* __r
 }
 
 template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
-  constexpr int LDS1 = M1 * (C * S3M<T>::ESZ + 16);
+  // C = 640, 16-bit modes: 64 alerts per fc1 tile, 64 channels per fc2 tile (160 workgroups each instead of 320: one round)
+  constexpr int MB = C == 640 && S3M<T>::ESZ == 2 ? 2 : 1, NC = MB;
+  constexpr int LDS1 = M1 * MB * (C * S3M<T>::ESZ + 16);
   if (phase == 0) {
-    auto kern1 = s3_fc1_kernel<T, C>;
+    auto kern1 = s3_fc1_kernel<T, C, MB>;
     if (LDS1 > 65536) {
       static DevOnce attr1_set;
       if (attr1_set.need()) {
@@ -464,15 +492,15 @@ template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase,
         attr1_set.done();
       }
     }
-    hipLaunchKernelGGL(kern1, dim3(((a.B + M1 - 1) / M1) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
+    hipLaunchKernelGGL(kern1, dim3(((a.B + M1 * MB - 1) / (M1 * MB)) * (4 * C / N1)), dim3(NT), LDS1, st, a, j);
   } else {
-    auto kern = s3_fc2_kernel<T, C>;
+    auto kern = s3_fc2_kernel<T, C, NC>;
     static DevOnce attr_set;
     if (attr_set.need()) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RED_BYTES));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RED_BYTES * NC));
       attr_set.done();
     }
-    hipLaunchKernelGGL(kern, dim3(((a.B + M2 - 1) / M2) * (C / N2)), dim3(NT), RED_BYTES, st, a, j);
+    hipLaunchKernelGGL(kern, dim3(((a.B + M2 - 1) / M2) * (C / (N2 * NC))), dim3(NT), RED_BYTES * NC, st, a, j);
   }
   LAUNCH_CHECK();
   return BTSBOT_OK;
