@@ -2,7 +2,7 @@
 #pragma once
 
 constexpr int S2P_ALERTS = 4;      // alerts resident per workgroup
-constexpr int S2P_MAX_DEPTH = 8;   // blocks of the stage (pico: 6, nano would be 8 at another width)
+constexpr int S2P_MAX_DEPTH = 8;   // blocks of the stage (pico: 6 at 256 channels, nano: 8 at 320)
 
 struct Stage2pBlk {
   const float* dw_w;     // [49][256] tap-major fp32

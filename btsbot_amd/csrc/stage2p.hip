@@ -1,4 +1,4 @@
-// Stage 2 (3x3 maps, C = 256) as ONE persistent launch (gfx950, 16-bit modes):
+// Stage 2 (3x3 maps, C = 256; convnext_nano: C = 320, template parameter CW below) as ONE persistent launch (gfx950, 16-bit modes):
 //
 //   depth x [ dwconv 7x7 + LN -> fc1 -> GELU -> fc2 -> layer-scale -> +x ]  ->  LN + conv 2x2 s2 (256 -> 512)
 //
