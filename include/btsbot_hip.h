@@ -201,7 +201,11 @@ int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, in
  * completes them -- ConvNeXt wirings: {last image stage + head LayerNorm + metadata branch + fusion head},
  * {stage 2}, {stem + stages 0-1}; every other wiring: one range over the whole arena.  Returns the count.
  * btsbot_wait_grad_bucket: makes `stream` wait (hipStreamWaitEvent) until the kernels of the LAST
- * btsbot_backward() call that write bucket `bucket` have finished; no host synchronisation. */
+ * btsbot_backward() call that write bucket `bucket` have finished; no host synchronisation.  (The per-bucket events
+ * cost the backward a fork of its side stream each, so a handle records them only once it has seen a waiter -- this call
+ * or btsbot_allreduce_grads.  The FIRST wait on a handle therefore orders `stream` behind everything that backward
+ * queued -- correct, but without the overlap; from the next btsbot_backward() on the wait ends with the bucket.
+ * Call it from the thread that called btsbot_backward(), before queuing other work on the backward's stream.) */
 int btsbot_grad_buckets(btsbot_handle h, int capacity, int64_t* lo, int64_t* hi);
 int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
 
