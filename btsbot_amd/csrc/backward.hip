@@ -113,6 +113,97 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ D,
       }
 }
 
+// The same product for fp32 operands at the matrix pipe's fp32 rate (v_mfma_f32_32x32x2_f32: 256 FLOP per clock and CU).
+// The kernel above stages 64 x 64 tiles element by element under a bounds test and ran the fp32 mode's 28 filter-gradient
+// GEMMs per training step at 24 TFLOP/s -- 5.7 ms of a 10.5 ms step, on the side stream that bounds it.  Here: TN x TK
+// output tile (64 or 128 each: one wave per 64 x 64), both operands in 16-row stages through LDS as 16-byte pieces, the
+// next stage's loads in flight under the current stage's products (registers -> the other LDS buffer, one barrier per
+// stage).  Both operands are reduction-major in memory, which is what the 32x32x2 fragments want: lane l reads element
+// [m + (l >> 5)][base + (l & 31)] -- 32 consecutive floats per half wave.  N % TN == K % TK == 0 (the launcher picks).
+typedef __attribute__((ext_vector_type(16))) float f32x16w;
+template <int TN, int TK>
+__global__ __launch_bounds__(64 * (TN / 64) * (TK / 64)) void wgrad_f32_kernel(const float* __restrict__ D,
+                                                                                const float* __restrict__ A,
+                                                                                float* __restrict__ out, int M, int N, int K,
+                                                                                int ldo, int mslice) {
+  constexpr int WK = TK / 64, NTH = 64 * (TN / 64) * WK, TM = 16;
+  constexpr int DV = TM * TN / 4, AV = TM * TK / 4;                 // 16-byte pieces per stage
+  constexpr int DPT = (DV + NTH - 1) / NTH, APT = (AV + NTH - 1) / NTH;
+  static_assert(DV % NTH == 0 && AV % NTH == 0, "whole pieces per thread");
+  __shared__ __attribute__((aligned(16))) float Ds[2][TM * TN];
+  __shared__ __attribute__((aligned(16))) float As[2][TM * TK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WK, wk = wave - wn * WK;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+  const int mbeg = blockIdx.z * mslice, mend = min(M, mbeg + mslice);
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16w acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 dr[DPT], ar[APT];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+      const int i = tid + u * NTH, r = i / (TN / 4), c = i - r * (TN / 4);
+      dr[u] = m0 + r < mend ? *reinterpret_cast<const float4*>(D + (size_t)(m0 + r) * N + n0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+      const int i = tid + u * NTH, r = i / (TK / 4), c = i - r * (TK / 4);
+      ar[u] = m0 + r < mend ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * K + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) reinterpret_cast<float4*>(Ds[buf])[tid + u * NTH] = dr[u];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) reinterpret_cast<float4*>(As[buf])[tid + u * NTH] = ar[u];
+  };
+  if (mbeg < mend) {
+    fetch(mbeg);
+    park(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int m0 = mbeg; m0 < mend; m0 += TM) {
+    const bool more = m0 + TM < mend;   // (uniform)
+    if (more) fetch(m0 + TM);
+    const float* ds = Ds[buf] + wn * 64 + l31;
+    const float* as = As[buf] + wk * 64 + l31;
+#pragma unroll
+    for (int ms = 0; ms < TM; ms += 2) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = ds[(ms + lh) * TN + 32 * t];
+        bf[t] = as[(ms + lh) * TK + 32 * t];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // C/D layout of 32x32: column (lane & 31) -> k, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = k0 + wk * 64 + 32 * j + l31;
+        atomicAdd(out + (size_t)n * ldo + k, acc[i][j][r]);
+      }
+}
+
 // out[n] += sum_m in[m][n].  Block = 64 columns x 4 row groups over one slice of M; the row groups
 // meet in LDS so that every column costs ONE atomic per block (same-address atomics serialise).
 template <typename T>
@@ -614,6 +705,49 @@ int wgrad_t(const void* D, const void* A, float* out, int M, int N, int K, int l
   dim3 grid((N + 63) / 64, (K + 63) / 64, nsl);
   hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(D),
                      reinterpret_cast<const T*>(A), out, M, N, K, ldo, mslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+template <int TN, int TK>
+int wgrad_f32_launch(const float* D, const float* A, float* out, int M, int N, int K, int ldo, hipStream_t st) {
+  // slices of the reduction: ~768 workgroups (two or three per CU), at least 256 rows each
+  const int tiles = (N / TN) * (K / TK);
+  int nsl = (768 + tiles - 1) / tiles;
+  if (nsl > (M + 255) / 256) nsl = (M + 255) / 256;
+  if (nsl < 1) nsl = 1;
+  const int mslice = ((M + nsl - 1) / nsl + 15) / 16 * 16;
+  nsl = (M + mslice - 1) / mslice;
+  hipLaunchKernelGGL((wgrad_f32_kernel<TN, TK>), dim3(N / TN, K / TK, nsl), dim3(64 * (TN / 64) * (TK / 64)), 0, st, D, A, out, M, N,
+                     K, ldo, mslice);
+  LAUNCH_CHECK();
+  return BTSBOT_OK;
+}
+
+template <>
+int wgrad_t<float>(const void* Dv, const void* Av, float* out, int M, int N, int K, int ldo, hipStream_t st) {
+  const float* D = reinterpret_cast<const float*>(Dv);
+  const float* A = reinterpret_cast<const float*>(Av);
+  static const bool old_form = [] {   // BTSBOT_AMD_WGRAD_F32_OLD=1: the 64 x 64 kernel for every shape (A/B timing, parity)
+    const char* e = getenv("BTSBOT_AMD_WGRAD_F32_OLD");
+    return e != nullptr && e[0] == '1';
+  }();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
+  if (!old_form && aligned && N % 64 == 0 && K % 64 == 0) {
+    const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
+    if (n128 && k128) return wgrad_f32_launch<128, 128>(D, A, out, M, N, K, ldo, st);
+    if (n128) return wgrad_f32_launch<128, 64>(D, A, out, M, N, K, ldo, st);
+    if (k128) return wgrad_f32_launch<64, 128>(D, A, out, M, N, K, ldo, st);
+    return wgrad_f32_launch<64, 64>(D, A, out, M, N, K, ldo, st);
+  }
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int nsl = (1024 + tiles - 1) / tiles;
+  if (nsl > (M + 511) / 512) nsl = (M + 511) / 512;
+  if (nsl < 1) nsl = 1;
+  int mslice = ((M + nsl - 1) / nsl + 63) / 64 * 64;
+  nsl = (M + mslice - 1) / mslice;
+  dim3 grid((N + 63) / 64, (K + 63) / 64, nsl);
+  hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, D, A, out, M, N, K, ldo, mslice);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
