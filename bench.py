@@ -441,14 +441,14 @@ def cpu_baseline(sample_batch=256, budget_s=24.0):
                        f"oracle, median per thread count, best of {counts} threads), ~{total_s:.0f}s of CPU work")
 
 
-def parity_vs_oracle(model, img, meta, n=256):
+def parity_vs_oracle(model, img, meta, n=256, cfg=None):
     """max |dlogit| / |dscore| of THIS model (the benchmarked weights and precision) on the first n alerts of the
     benchmarked batch against the fp32 CPU oracle (checker only; outside every timed region)."""
     from oracle import convnext_oracle as O   # checker only
     n = min(n, img.shape[0])
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     with torch.no_grad():
-        ref = O.forward("mm_ConvNeXt", sd, CONFIG, img[:n].cpu(), meta[:n].cpu())
+        ref = O.forward("mm_ConvNeXt", sd, cfg or CONFIG, img[:n].cpu(), meta[:n].cpu())
         out = model(image_input=img[:n].contiguous(), metadata_input=meta[:n].contiguous()).cpu()
     return dict(alerts=n, max_abs_dlogit=float((out - ref).abs().max()),
                 max_abs_dscore=float((torch.sigmoid(out) - torch.sigmoid(ref)).abs().max()),
@@ -492,6 +492,46 @@ def precision_leg(precision, dev, img, meta, steps, warmup, fence, dist, world, 
                ms_per_step=round(1e3 * el / steps, 4), api="drop-in model(...) calls, one stream")
     if with_parity:
         leg["parity"] = parity_vs_oracle(m, img, meta)
+    return leg
+
+
+def nano_leg(precision, dev, img, meta, steps, warmup, fence, dist, world, with_parity=True):
+    """The reference classes' DEFAULT backbone (`convnext_nano.d1h_in1k`, /root/reference/btsbot/architectures.py:107,128)
+    on the benched batch: plain model(...) calls and the three-stream scoring loop.  (Stage 2 + last downsample, stage 3
+    and the head run the fused kernels; the stem and stages 0-1 the per-op schedule: DESIGN.md section 4b / 4c.)"""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cfg = dict(CONFIG, model_kind="convnext_nano.d1h_in1k")
+        m = btsbot_amd.mm_ConvNeXt(cfg, precision=precision)
+    seeded_weights(m)
+    m = m.to(dev).eval()
+
+    def run(n):
+        o = None
+        with torch.no_grad():
+            for _ in range(n):
+                o = m(image_input=img, metadata_input=meta)
+        return o
+
+    el, _, _ = timed_blocks(run, steps, warmup, fence, dist, dev, blocks=5, warm_seconds=0.3)
+    leg = dict(workload="mm_ConvNeXt over convnext_nano.d1h_in1k (dims 80/160/320/640, depths 2/2/8/2), same batch",
+               value=round(img.shape[0] * world * steps / el, 1), unit="alerts/s", steps=steps,
+               ms_per_step=round(1e3 * el / steps, 4), api="drop-in model(...) calls, one stream",
+               flop_per_alert=236811200)
+    leg["whole_net_tflops"] = round(leg["flop_per_alert"] * leg["value"] / 1e12, 2)
+    scorer = btsbot_amd.ScoreStream(m, inputs_ready=True)
+
+    def run_pipelined(n):
+        last = None
+        for out in scorer.map(((img, meta) for _ in range(n)), lag=n):
+            last = out
+        return last
+
+    el2, _, _ = timed_blocks(run_pipelined, steps, warmup, fence, dist, dev, blocks=5, warm_seconds=0.3)
+    leg["streamed"] = dict(value=round(img.shape[0] * world * steps / el2, 1), ms_per_step=round(1e3 * el2 / steps, 4),
+                           api="btsbot_amd.ScoreStream, three batches in flight")
+    if with_parity:
+        leg["parity"] = parity_vs_oracle(m, img, meta, cfg=cfg)
     return leg
 
 
@@ -790,6 +830,11 @@ def main():
                                            3, fence, dist, world, with_parity=(rank == 0))
             except Exception as e:   # noqa: BLE001
                 legs[prec] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            legs["convnext_nano"] = nano_leg(args.precision, dev, img, meta, max(5, args.steps // 2), 3, fence, dist, world,
+                                             with_parity=(rank == 0))
+        except Exception as e:   # noqa: BLE001
+            legs["convnext_nano"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE.json configs[4] (fp8 MFMA inference, batch 8192, streaming throughput): the fp8 mode = stages 2-3's
         # pointwise convolutions on fp8 operands, everything else as in bf16; first this batch size in the
         # benchmarked precision, then the fp8 mode on the benched batch (with its parity) and on 8192 alerts per call
