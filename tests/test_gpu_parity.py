@@ -242,6 +242,19 @@ def test_nano_full_size_batch_matches_oracle(cuda, prec):
     print(f"nano B=1024 {prec}: max|dscore| {ds:.3e}")
 
 
+@pytest.mark.parametrize("B", [1, 6, 11])
+def test_nano_ragged_batches_match_oracle(cuda, B):
+    """stage2p at 320 channels keeps 5 alerts per workgroup: a lone alert, one workgroup and an alert, two and an alert
+    (the shared row tiles' partial residuals must not leak between the live and the padded pixel columns)."""
+    kind, cfg = CONFIGS["mm_nano_ls"]
+    sd = seeded_state(kind, cfg, seed=3)
+    img, meta, _ = synthetic_batch(B, seed=7)
+    ref = _oracle(kind, cfg, sd, img, meta)
+    for prec in ("bf16", "f16"):
+        m = build_model(kind, cfg, sd, cuda, prec)
+        _check(run_model(kind, m, img.to(cuda), meta.to(cuda)), ref, prec)
+
+
 @pytest.mark.timeout(900)
 def test_f16x2_meets_the_north_star_on_five_weight_seeds(cuda):
     """The mode that claims the north star's 1e-4 must not owe it to one draw of the weights: five seeded weight sets
