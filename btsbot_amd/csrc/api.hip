@@ -355,10 +355,10 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     //  its loss band instead of 0.66-0.72: not worth the rounding)
     const char* np16 = getenv("BTSBOT_AMD_PLANES16");
     h->planes16 = np16 != nullptr && np16[0] == '1';
-    // (opt-in: the fused kernel takes 30-35 us where the two tiled GEMMs it replaces take 44, six times per step, yet the step
-    //  measured 2.672 against 2.667 ms on the same box -- the chain is not waiting on these launches)
-    const char* ns2m = getenv("BTSBOT_AMD_S2MLP");
-    h->s2mlp = ns2m != nullptr && ns2m[0] == '1';
+    // (default since its operand images come out of the re-pack's job table: with a dozen launches of their own queued in
+    //  front of the forward's join the kernel LOST 30 us per step; now 2.549-2.560 against 2.565-2.581 ms)
+    const char* ns2m = getenv("BTSBOT_AMD_NO_S2MLP");
+    h->s2mlp = !(ns2m != nullptr && ns2m[0] == '1');
     const char* fpb = getenv("BTSBOT_AMD_FORK_PER_BLOCK");
     h->fork_per_block = fpb != nullptr && fpb[0] == '1';
     const char* nwb = getenv("BTSBOT_AMD_NO_WGRAD_BATCH");
@@ -526,6 +526,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       case PACK_TRANSPOSE_F32: status = launch_transpose_f32(src, reinterpret_cast<float*>(dst), R, Cc, st); break;
       case PACK_TRANSPOSE_CAST: status = launch_transpose_cast(c.precision, src, scale, dst, R, Cc, st); break;
       case PACK_DOWN: status = launch_pack_down(c.precision, src, dst, R, Cc, st); break;
+      case PACK_TFRAG: break;   // (unbatched: launch_pack_frag16 behind the transposes, below)
       default: status = launch_pack_down_t(c.precision, src, dst, R, Cc, st);
     }
   };
@@ -552,6 +553,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
           job(PACK_TRANSPOSE_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch, ch);
           job(PACK_TRANSPOSE_CAST, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch, 4 * ch);
+          if (b.p_w1tp != 0 && h->s2mlp) {   // the same two as MFMA A fragments for s2mlp_bwd_kernel
+            job(PACK_TFRAG, m + b.fc1_w, nullptr, h->extra + b.p_w1tp, 4 * ch, ch);
+            job(PACK_TFRAG, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2tp, ch, 4 * ch);
+          }
         }
       }
     }
@@ -627,8 +632,8 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s0par(h->prec_s01(), reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
                                 m + b.ln_w, m + b.ln_b, m + b.fc1_b, m + b.fc2_b, m + b.gamma,
                                 h->extra + b.p_s0par, st));
-        // the dgrad transposes (written by the job table above) as MFMA A fragments for s2mlp_bwd_kernel
-        if (b.p_w1tp != 0 && h->train_packs && h->s2mlp) {
+        // (the unbatched re-pack only: the job table writes these itself)
+        if (b.p_w1tp != 0 && h->train_packs && h->s2mlp && unbatched) {
           TRY(launch_pack_frag16(h->extra + b.p_fc2t, h->extra + b.p_w2tp, 4 * ch, ch, st));
           TRY(launch_pack_frag16(h->extra + b.p_fc1t, h->extra + b.p_w1tp, ch, 4 * ch, st));
         }

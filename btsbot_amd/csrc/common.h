@@ -464,7 +464,8 @@ int launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t st);
 // One launch for a table of operand-packing jobs (the per-step re-pack of the training loop is ~75 of these,
 // each a 2-5 us kernel: launch-floor bound one by one).  The table lives in device memory; job j owns blocks
 // [blk0_j, blk0_{j+1}).  ops: the element maps of cast / transpose_f32 / transpose_cast / pack_down / pack_down_t.
-enum { PACK_CAST = 0, PACK_TRANSPOSE_F32 = 1, PACK_TRANSPOSE_CAST = 2, PACK_DOWN = 3, PACK_DOWN_T = 4 };
+// PACK_TFRAG: the transpose-cast's result [Cc][R] as 16x16x32 MFMA A fragments [row tile][k-step][lane][8] (s2mlp_bwd.hip)
+enum { PACK_CAST = 0, PACK_TRANSPOSE_F32 = 1, PACK_TRANSPOSE_CAST = 2, PACK_DOWN = 3, PACK_DOWN_T = 4, PACK_TFRAG = 5 };
 struct PackJob {
   const float* src;
   const float* scale;   // PACK_TRANSPOSE_CAST: optional per-source-row scale

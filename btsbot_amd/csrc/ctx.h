@@ -191,8 +191,8 @@ struct btsbot_ctx {
                             // write it
   bool planes16 = false;   // BTSBOT_AMD_PLANES16=1 (opt-in, bf16 mode): mlp_bwd_kernel's four addend planes of dxn (128 channels)
                            // leave as bf16 and dwln_bwd_kernel reads them so (206 MB less per block; api.hip says why not default)
-  bool s2mlp = false;      // BTSBOT_AMD_S2MLP=1 (opt-in): 256-channel blocks' da and dxn of the MLP backward as one launch
-                           // (s2mlp_bwd.hip) instead of two tiled GEMMs (api.hip says why not default)
+  bool s2mlp = true;       // 256-channel blocks: da and dxn of the MLP backward as one launch (s2mlp_bwd.hip) instead of two tiled
+                           // GEMMs; BTSBOT_AMD_NO_S2MLP=1: the GEMMs (A/B timing, parity tests)
   bool fork_per_block = false;   // BTSBOT_AMD_FORK_PER_BLOCK=1: the blocks of a batched stage fork the side stream one by one, as
                                  // before the batch existed (A/B timing)
   bool wgrad_batch = true; // stages whose blocks run the unfused MLP backward (256 / 512 channels): their 2 x depth filter-gradient

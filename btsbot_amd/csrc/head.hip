@@ -329,6 +329,18 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       }
       break;
     }
+    case PACK_TFRAG: {   // d = fragments of t[c][r] = s[r][c] * scale[r]: lane l of fragment (tile, k-step) holds t[16 tile + (l & 15)][32 k-step + 8 (l >> 4) + 0..7]
+      T* d = reinterpret_cast<T*>(jb.dst);
+      const int ksteps = R / 32;
+      for (int64_t i = i0; i < n; i += step) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        const int64_t fs = i >> 9;
+        const int ks = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+        const int c = 16 * tile + (l & 15), r = 32 * ks + 8 * (l >> 4) + j;
+        d[i] = (T)(s[(int64_t)r * Cc + c] * (jb.scale != nullptr ? jb.scale[r] : 1.f));
+      }
+      break;
+    }
     case PACK_DOWN: {   // d[co][q][ci] <- s[co][ci][q]
       T* d = reinterpret_cast<T*>(jb.dst);
       for (int64_t i = i0; i < n; i += step) {

@@ -15,8 +15,9 @@
 //                                dxn += W1^T[:, chunk - 1] . da[chunk - 1]   (one step behind, through a double-buffered
 //                                                                           [pixel][hidden] LDS image: one barrier per step)
 // 205 workgroups for 9216 rows: every CU's share is the same and one round.
-// OPT-IN (BTSBOT_AMD_S2MLP=1): 30-35 us per launch against 44 for the two GEMMs, and no change of the step's wall time
-// (DESIGN.md section 6); held to the gradient bounds by tests/test_gpu_train.py::test_full_backward_16bit[*-stage2_fused_dgrad].
+// 30-35 us per launch against 44 for the two GEMMs; 15 us of a 2.57 ms step (the step is bound by the
+// chip's total work, not by this chain).  BTSBOT_AMD_NO_S2MLP=1: the two GEMMs (tests/test_gpu_train.py::
+// test_full_backward_16bit[*-stage2_two_gemms]; the default cases run this kernel in both 16-bit modes).
 #include <stdlib.h>
 
 #include "common.h"

@@ -326,7 +326,7 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
 
 
 @pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_keeping_kernel", "stage2_light",
-                                 "per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "stage2_fused_dgrad", "fork_per_block"])
+                                 "per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "stage2_two_gemms", "fork_per_block"])
 @pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     """The 16-bit training schedule (LDS-DMA GEMMs with the GELU_SAVE / DGELU / PLAIN epilogues, the MFMA
@@ -352,8 +352,8 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     elif mlp == "depthwise_recompute":   # dwln_bwd_kernel recomputes d from x_in; the keeping forms do not write it (opt-in)
         monkeypatch.setenv("BTSBOT_AMD_DWLN_RECOMP", "1")
         monkeypatch.setenv("BTSBOT_AMD_S1_TRAIN", "1")
-    elif mlp == "stage2_fused_dgrad":   # opt-in: stage 2's da / dxn as one launch of s2mlp_bwd_kernel (default: two tiled GEMMs)
-        monkeypatch.setenv("BTSBOT_AMD_S2MLP", "1")
+    elif mlp == "stage2_two_gemms":   # stage 2's da / dxn as two tiled GEMMs (default: one launch of s2mlp_bwd_kernel)
+        monkeypatch.setenv("BTSBOT_AMD_NO_S2MLP", "1")
     elif mlp == "fork_per_block":   # stages 2-3 fork the side stream behind every block (default: once per stage)
         monkeypatch.setenv("BTSBOT_AMD_FORK_PER_BLOCK", "1")
     elif mlp == "bf16_planes":   # the 128-channel MLP backward's four addend planes of dxn as bf16 (opt-in)
