@@ -2,7 +2,8 @@
 --kernel-trace of tools/train_bench.py.  usage: python tools/train_timeline.py <trace dir> [step index from the end]
 Columns: start (us from the step's first kernel), duration, queue, gap since the previous kernel of the SAME queue, name."""
 import csv, glob, re, sys
-f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'), key=os.path.getmtime)   # (the newest trace: gpurun merges runs into one directory)
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r['Queue_Id']) for r in rows)
