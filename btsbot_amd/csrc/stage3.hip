@@ -17,6 +17,8 @@
 // cycles, behind one MALL round trip (the L2s start every kernel empty); algorithmic FLOPs 2 x 2.1 GFLOP per block.
 // (One cooperative launch for the whole stage was tried: a grid-wide barrier costs 8-20 us on this part -- 256
 //  same-address device-scope atomics, or cooperative_groups' grid.sync() -- against ~3 us for a kernel boundary.)
+#include <stdlib.h>
+
 #include "common.h"
 #include "stage3.h"
 #include <type_traits>
@@ -304,9 +306,11 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
 template <typename T, int C, int NC = 1>
 __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& bk, int mt, int ct, unsigned char* smem) {
   using frag = typename S3M<T>::frag;
-  constexpr int HID = 4 * C, KSA = HID / S3M<T>::KSTEP, KSW = KSA / 8, RING0 = KSW <= 16 ? KSW : KSW / 2;
-  // (split / fp8: a fragment is 8 registers, 3 streams x 8 fragments at most)
-  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : KSW % 8 == 0 ? 8 : KSW % 4 == 0 ? 4 : KSW;
+  constexpr int HID = 4 * C, KSA = HID / S3M<T>::KSTEP, KSW = KSA / 8;
+  // two channel tiles: four fragment streams -- at most 10 fragments each (160 registers), a divisor of the wave's k-steps
+  constexpr int RING0 = NC == 1 ? (KSW <= 16 ? KSW : KSW / 2) : KSW % 10 == 0 ? 10 : KSW % 8 == 0 ? 8 : KSW % 4 == 0 ? 4 : KSW;
+  // (split / fp8: a fragment is 8 registers, 3 streams x 8 fragments at most; two channel tiles: 4 x 4)
+  constexpr int RING = S3M<T>::MAXRING >= 32 ? RING0 : NC == 2 && KSW % 4 == 0 ? 4 : KSW % 8 == 0 ? 8 : KSW % 4 == 0 ? 4 : KSW;
   static_assert(KSW % RING == 0, "k-steps per wave");
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,9 +483,8 @@ __global__ void pack_s3_fp8_kernel(const float* __restrict__ w, const float* __r
       (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
 }
 
-template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
-  // C = 640, 16-bit modes: 64 alerts per fc1 tile, 64 channels per fc2 tile (160 workgroups each instead of 320: one round)
-  constexpr int MB = C == 640 && S3M<T>::ESZ == 2 ? 2 : 1, NC = MB;
+template <typename T, int C, int MB> int launch_tm(const Stage3Args& a, int j, int phase, hipStream_t st) {
+  constexpr int NC = MB;
   constexpr int LDS1 = M1 * MB * (C * S3M<T>::ESZ + 16);
   if (phase == 0) {
     auto kern1 = s3_fc1_kernel<T, C, MB>;
@@ -504,6 +507,23 @@ template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase,
   }
   LAUNCH_CHECK();
   return BTSBOT_OK;
+}
+
+// Tile shapes: 32-alert fc1 tiles / 32-channel fc2 tiles; at 640 channels (16-bit modes) 64 alerts / 64 channels -- 160
+// workgroups instead of 320, one round of the chip's 256 CUs with twice the rows per filter fragment: 19 -> 16.7 / 14.7 us per
+// launch at 1024 alerts.  (Measured and NOT taken at 512 channels for the 2048-alert chunks of a large call, 512 -> 256
+// workgroups: 2.255 against 2.265 ms per 8192 alerts in bf16, 2.09 against 2.07 in fp8.  The split mode's fragments are 8
+// registers each: narrow tiles only.)
+template <typename T, int C> int launch_t(const Stage3Args& a, int j, int phase, hipStream_t st) {
+  if constexpr (S3M<T>::ESZ <= 2) {
+    static const int forced = [] {   // BTSBOT_AMD_S3_TILES=1 / 2: always narrow / always wide (A/B timing, parity)
+      const char* e = getenv("BTSBOT_AMD_S3_TILES");
+      return e != nullptr ? atoi(e) : 0;
+    }();
+    const bool wide = forced == 2 || (forced != 1 && C == 640 && S3M<T>::ESZ == 2);
+    if (wide) return launch_tm<T, C, 2>(a, j, phase, st);
+  }
+  return launch_tm<T, C, 1>(a, j, phase, st);
 }
 
 }  // namespace
