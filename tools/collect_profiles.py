@@ -58,7 +58,8 @@ if glob.glob("gpurun_out/final/pmc_fetch_train/*/*_counter_collection.csv"):   #
 if os.path.exists(f"profiles/{tag}_pmc_traffic_train.json") and os.path.exists(f"profiles/{tag}_kernel_stats_train_bf16_b1024.csv"):
     import subprocess
     subprocess.run([sys.executable, "tools/hbm_kernels.py", tag], check=True, stdout=subprocess.DEVNULL)
-for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt")):   # tools/nano_bench.py; train step default vs
+for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"), ("stamps_nano.log", "stage_stamps_nano.txt"),
+                 ("train_f32_ab.log", "train_f32_ab.txt")):   # tools/nano_bench.py; train step default vs
     if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
         shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")
 open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])

@@ -13,6 +13,9 @@ timeout -k 10 700 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1 &
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 &&
 ( time timeout -k 10 400 python bench.py ) > $O/bench_default.log 2>&1 &&
 timeout -k 10 120 python tools/nano_bench.py 1024 bf16 > $O/nano.log 2>&1 &&
+timeout -k 10 120 python tools/stamps_nano.py > $O/stamps_nano.log 2>&1 &&
+timeout -k 10 120 python tools/train_bench.py 1024 f32 10 > $O/train_f32_ab.log 2>&1 &&
+BTSBOT_AMD_WGRAD_F32_OLD=1 timeout -k 10 120 python tools/train_bench.py 1024 f32 10 >> $O/train_f32_ab.log 2>&1 &&
 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 > $O/train_ab.log 2>&1 &&
 BTSBOT_AMD_NO_SIDE_STREAM=1 BTSBOT_AMD_NO_DWLN=1 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 >> $O/train_ab.log 2>&1
 echo "measure rc=$?" > $O/chain_measure.log
