@@ -83,6 +83,7 @@ int build_tables(btsbot_ctx* h) {
     }
     h->stage1 = stage1_supported(h->prec_s01(), c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
+    h->stage1n = !h->x2 && !h->fp8 && stage1n_supported(c.precision, c.dims[1], c.dims[2], c.depths[1]);
     h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
@@ -97,7 +98,7 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
         h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
-        if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) {
+        if ((i == 3 && h->stage2p) || (i == 2 && (h->stage1 || h->stage1n))) {
           h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
           h->down[i].p_scale = bump(cur, 64);
         }
@@ -137,7 +138,7 @@ int build_tables(btsbot_ctx* h) {
           b.p_x2_w1lo = bump(cur, (size_t)4 * ch * ch * 2);
           b.p_x2_w2glo = bump(cur, (size_t)4 * ch * ch * 2);
         }
-        if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
+        if ((i == 2 && h->stage2p) || (i == 3 && h->stage3) || (i == 1 && h->stage1n)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_scales = bump(cur, 64);
@@ -620,6 +621,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, sc, st));
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, sc + 2, st));
         }
+        if (i == 1 && h->stage1n && !train_only) {   // convnext_nano's stage 1 (stage1n.hip): the same fragment images
+          TRY(launch_pack_s2p(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, nullptr, st));
+          TRY(launch_pack_s2p(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, nullptr, st));
+        }
         if (i == 3 && h->stage3 && !train_only) {
           float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
           TRY(launch_pack_s3(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 1, sc, st));
@@ -665,6 +670,9 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   }
   if (convnext && h->stage1 && (!train_only || h->s1_train))
     TRY(launch_pack_frag32(h->prec_s01(), m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
+  if (convnext && h->stage1n && !train_only)
+    TRY(launch_pack_s2p(c.precision, m + h->down[2].w, nullptr, h->extra + h->down[2].p_wp, c.dims[2], 4 * c.dims[1], 1,
+                        c.dims[1], nullptr, st));
   if (convnext && h->stage2p && (!train_only || h->s2p_train || h->s2p_light))
     TRY(launch_pack_s2p(h->prec_down3(), m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], nullptr, st));
@@ -983,6 +991,40 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         TRY(timed(h, CAT_STAGE1, st, [&] {
           return launch_stage1b(h->prec_s01(), a, st);
         }));
+        float* t = x;
+        x = x2;
+        x2 = t;
+        down_done = true;
+        continue;
+      }
+      if (i == 1 && h->stage1n && h->use_stage1) {
+        // convnext_nano: both blocks of the 7x7 stage and the downsample in front of stage 2 in one launch:
+        // x [nb][49][160] -> x2 [nb][9][320]
+        Stage2pArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x_in = x;
+        a.depth = (int)h->blocks[1].size();
+        for (int j = 0; j < a.depth; ++j) {
+          const BlockPk& b = h->blocks[1][j];
+          a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
+          a.blk[j].dw_b = m + b.dw_b;
+          a.blk[j].ln_w = m + b.ln_w;
+          a.blk[j].ln_b = m + b.ln_b;
+          a.blk[j].b1 = m + b.fc1_b;
+          a.blk[j].b2 = m + b.fc2_b;
+          a.blk[j].gamma = m + b.gamma;
+          a.blk[j].w1p = h->extra + b.p_w1p;
+          a.blk[j].w2p = h->extra + b.p_w2p;
+        }
+        a.ds_lnw = m + h->down[2].ln_w;
+        a.ds_lnb = m + h->down[2].ln_b;
+        a.ds_wp = h->extra + h->down[2].p_wp;
+        a.ds_b = m + h->down[2].b;
+        a.out = x2;
+        a.tap_stage = h->debug ? h->taps[2] : nullptr;
+        a.B = nb;
+        a.cw = c.dims[1];
+        TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1n(c.precision, a, st); }));
         float* t = x;
         x = x2;
         x2 = t;

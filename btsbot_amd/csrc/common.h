@@ -324,6 +324,9 @@ int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.
 struct Stage2pArgs;
 bool stage2p_supported(int prec, int c2, int c3, int depth);
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
+// convnext_nano's stage 1 + the downsample in front of stage 2 as one launch (stage1n.hip; same argument block, depth 2)
+bool stage1n_supported(int prec, int c1, int c2, int depth);
+int launch_stage1n(int prec, const Stage2pArgs& a, hipStream_t st);
 // fp32 [rows][K] (reorder_down: a [Cout][Cin][2][2] downsample filter, K = 4 Cin) -> 16x16x32 A fragments
 // [row tile][k-step][lane][8], optionally scaled per row
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
