@@ -83,7 +83,13 @@ int build_tables(btsbot_ctx* h) {
     }
     h->stage1 = stage1_supported(h->prec_s01(), c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
-    h->stage1n = !h->x2 && !h->fp8 && stage1n_supported(c.precision, c.dims[1], c.dims[2], c.depths[1]);
+    {
+      // (opt-in, BTSBOT_AMD_STAGE1N=1: 150 us per 1024 alerts against 178 for the six launches it replaces, and no
+      //  measurable change of the forward -- the streaming design is LDS-bound at 160 channels)
+      const char* e1n = getenv("BTSBOT_AMD_STAGE1N");
+      h->stage1n = e1n != nullptr && e1n[0] == '1' && !h->x2 && !h->fp8 &&
+                   stage1n_supported(c.precision, c.dims[1], c.dims[2], c.depths[1]);
+    }
     h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
@@ -1024,6 +1030,7 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         a.tap_stage = h->debug ? h->taps[2] : nullptr;
         a.B = nb;
         a.cw = c.dims[1];
+        a.stamps = h->stamps ? h->stamps + 16 : nullptr;   // (stage 1's 16 slots: tools/stamps_nano.py)
         TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1n(c.precision, a, st); }));
         float* t = x;
         x = x2;

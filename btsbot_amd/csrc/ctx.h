@@ -104,7 +104,7 @@ struct btsbot_ctx {
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1: the per-op launches (dwconv_ln + fc1 / fc2 GEMMs) for stage 2
   int s2p_alerts_hint = 0; // btsbot_set_option("stage2p_alerts"): 0 = by rounds, 4 / 7 forced
   bool use_s2p = true;     // (= use_s2: stage2p.hip is the stage-2 kernel)
-  bool stage1n = false;    // convnext_nano, 16-bit modes: stage 1 + the next downsample run stage1n.hip (BTSBOT_AMD_NO_STAGE1=1: per-op)
+  bool stage1n = false;    // BTSBOT_AMD_STAGE1N=1 (opt-in; convnext_nano, 16-bit modes): stage 1 + the next downsample run stage1n.hip
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
   bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
   bool x2 = false;         // created with BTSBOT_F16X2: cfg.precision reads BTSBOT_F32 (the schedule of every kernel without

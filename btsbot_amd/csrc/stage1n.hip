@@ -5,13 +5,21 @@
 //
 // (timm ConvNeXt stages[1].blocks / stages[2].downsample of `convnext_nano`, the reference classes' default model_kind:
 // /root/reference/btsbot/architectures.py:107-108,128,132).  Replaces 2 x (dwconv_ln + fused_mlp) + ln_patch + GEMM of the
-// per-op schedule.  The design is stage2p.hip's: one 512-thread workgroup keeps an alert's 49 pixel rows (four 16-column
-// MFMA blocks) resident for the whole stage, the residual stream is the fc2 accumulator, and the filters stream past
+// per-op schedule.  The design is stage2p.hip's: one 512-thread workgroup keeps TWO alerts' 98 pixel rows (seven 16-column
+// MFMA blocks) resident for the whole stage (one alert per workgroup was the first cut: 149 us per 1024 alerts against 178 for
+// the launches it replaces -- every workgroup streams the stage's 1.2 MB of filters, and the per-workgroup phases around the
+// chunk loop cost as much as the loop), the residual stream is the fc2 accumulator, and the filters stream past
 // as packed MFMA A fragments (launch_pack_s2p: 1 KiB contiguous per wave instruction, straight into registers).
 // 160 channels are ten 16-row tiles for eight waves: wave w owns tile w; tiles 8 and 9 are shared by four waves each
 // (wave & 1 picks the tile, wave >> 1 the one of a chunk's four fc2 k-steps the wave runs on it), so a shared tile's
 // residual is the sum of four accumulators, which meet in the LDS map at every block start.
 // HBM sees [49][160] f32 in and [9][320] f32 out per alert.
+// OPT-IN (BTSBOT_AMD_STAGE1N=1; held to the oracle by tests/test_gpu_parity.py::test_nano_ragged_batches_match_oracle[*-fused_stage1]):
+// 150 us per 1024 alerts against 178 for the launches it replaces and no measurable change of the forward.  In-kernel stamps
+// (tools/stamps_nano.py) per workgroup of two alerts: chunk loop 2 x 30 k cycles (6 k per step: every wave reads all seven
+// 1 KiB B fragments of a k-step from LDS for ONE 16-row tile -- 504 KB of LDS reads per step on a CU: the design is LDS-bound
+// where a wave owns a single row tile; at 256 / 320 channels it owns two / 2.5), downsample 31 k, depthwise 2 x 17 k (60 k
+// with the taps read from L2 inside the loop), residual -> map 2 x 12 k, LayerNorm 2 x 8 k, prologue 13 k.
 #include <stdlib.h>
 
 #include "common.h"
@@ -44,16 +52,22 @@ template <> struct MQ<f16_t> : MQ16<f16_t> {
   }
 };
 
-constexpr int C = 160, HID = 640, HW = 7, NPX = 49, NCOL = 64, NB = 4;
+constexpr int C = 160, HID = 640, HW = 7, G = 2, PA = HW * HW, NPX = G * PA, NCOL = 112, NB = 7;
 constexpr int NT = 512, NW = 8;
 constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;            // 5 chunks of 128 hidden units
 constexpr int KS1 = C / 32, KS2 = CHUNK / 32, KH = HID / 32; // 5, 4, 20 k-steps
 constexpr int CO = 320, KSD = 4 * C / 32;                    // downsample: 320 outputs, K = 640 (20 k-steps)
 constexpr int XLP = C;                                       // fp32 map: floats per pixel row
 constexpr int XNP = 544, HP = CHUNK * 2 + 32;                // LN image / hidden image: bytes per pixel row (32 mod 256)
-constexpr int OFF_XL = 0, OFF_XN = OFF_XL + NCOL * XLP * 4, OFF_H = OFF_XN + NCOL * XNP, H_IMG = NCOL * HP;
-constexpr int OFF_B1 = OFF_H + 2 * H_IMG, LDS_BYTES = OFF_B1 + HID * 4;   // 40960 + 34816 + 36864 + 2560 = 115200
+// the fp32 map (depthwise / LayerNorm phases) and the two hidden images (chunk loop) are never live together: one region
+constexpr int OFF_XN = 0, OFF_XL = OFF_XN + NCOL * XNP, OFF_H = OFF_XL, H_IMG = NCOL * HP;
+constexpr int U_BYTES = NCOL * XLP * 4 > 2 * H_IMG ? NCOL * XLP * 4 : 2 * H_IMG;
+constexpr int OFF_B1 = OFF_XL + U_BYTES, LDS_BYTES = OFF_B1 + HID * 4;   // 60928 + 71680 + 2560 = 135168
 constexpr float LN_EPS = 1e-6f;
+#define S1N_STAMP(i)                                                                      \
+  do {                                                                                    \
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
+  } while (0)
 
 __device__ __forceinline__ float half_sum1(float v) {   // sum over the 32 lanes of a half wave
   v = group16_sum(v);
@@ -105,12 +119,14 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
   float* b1s = reinterpret_cast<float*>(smem + OFF_B1);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
-  const int alert = blockIdx.x;                       // one alert per workgroup (grid = B)
-  const float* xin = a.x_in + (size_t)alert * NPX * C;
+  const int alert0 = blockIdx.x * G;                  // two alerts per workgroup
+  const int nal = min(G, a.B - alert0), nlive = nal * PA;
+  const float* xin = a.x_in + (size_t)alert0 * PA * C;
   // this wave's own tile and the shared one: tile, first channel for this lane, fc2 k-step of a chunk it runs there
   const int c0 = 16 * wave + 4 * kg;
   const int xtile = NW + (wave & 1), cx0 = 16 * xtile + 4 * kg, xq = wave >> 1;
 
+  S1N_STAMP(0);
   for (int i = tid; i < (NCOL - NPX) * XNP / 4; i += NT) reinterpret_cast<unsigned*>(xn + NPX * XNP)[i] = 0u;
   for (int i = tid; i < NCOL * XLP; i += NT) xl[i] = 0.f;
   f32x4 acc[NB], accx[NB];
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
   for (int n = 0; n < NB; ++n) {
     const int p = 16 * n + col;
     acc[n] = accx[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p < NPX) {
+    if (p < nlive) {
       acc[n] = *reinterpret_cast<const f32x4*>(xin + p * C + c0);
       if (xq == 0) accx[n] = *reinterpret_cast<const f32x4*>(xin + p * C + cx0);
     }
@@ -167,33 +183,46 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
 #pragma unroll 1
   for (int j = 0; j < a.depth; ++j) {
     const Stage2pBlk& bk = a.blk[j];
-    residual_to_map();
+    S1N_STAMP(1 + 5 * j);
+    // the block's 49 x 160 taps into the LN image's bytes (dead until this block's LayerNorm): read from HBM / L2 inside
+    // the depthwise loop every tap was an exposed memory round trip -- 60 k cycles per block for 1.1 k FMAs per thread
+    float* taps = reinterpret_cast<float*>(xn);
+    static_assert(49 * C * 4 <= NPX * XNP, "the taps fit the live rows of the LN image");
+    for (int i = tid; i < 49 * C / 4; i += NT)
+      reinterpret_cast<f32x4*>(taps)[i] = reinterpret_cast<const f32x4*>(bk.dw_w)[i];
+    residual_to_map();   // (its barriers also publish the taps)
+    S1N_STAMP(2 + 5 * j);
     // ---- depthwise 7x7 in place: thread = (channel, row group: rows 0-2 / 3-4 / 5-6); 480 of the 512 threads
     {
       const int dc = tid % C, rg = tid / C;
       const float dbias = bk.dw_b[dc];
-      float o[3][HW];
-      int r0 = 0, nr = 0;
-      if (rg == 0) {
-        dw_rows<0, 3>(xl, bk.dw_w, dbias, dc, o);
-        nr = 3;
-      } else if (rg == 1) {
-        dw_rows<3, 5>(xl, bk.dw_w, dbias, dc, o);
-        r0 = 3, nr = 2;
-      } else if (rg == 2) {
-        dw_rows<5, 7>(xl, bk.dw_w, dbias, dc, o);
-        r0 = 5, nr = 2;
-      }
-      __syncthreads();   // every thread holds its outputs: the map may change
-#pragma unroll
-      for (int y = 0; y < 3; ++y)
-        if (y < nr) {
-#pragma unroll
-          for (int x = 0; x < HW; ++x) xl[((r0 + y) * HW + x) * XLP + dc] = o[y][x];
+#pragma unroll 1
+      for (int al = 0; al < G; ++al) {
+        float* xa = xl + al * PA * XLP;
+        float o[3][HW];
+        int r0 = 0, nr = 0;
+        if (rg == 0) {
+          dw_rows<0, 3>(xa, taps, dbias, dc, o);
+          nr = 3;
+        } else if (rg == 1) {
+          dw_rows<3, 5>(xa, taps, dbias, dc, o);
+          r0 = 3, nr = 2;
+        } else if (rg == 2) {
+          dw_rows<5, 7>(xa, taps, dbias, dc, o);
+          r0 = 5, nr = 2;
         }
+        __syncthreads();   // every thread holds its outputs: the map may change
+#pragma unroll
+        for (int y = 0; y < 3; ++y)
+          if (y < nr) {
+#pragma unroll
+            for (int x = 0; x < HW; ++x) xa[((r0 + y) * HW + x) * XLP + dc] = o[y][x];
+          }
+      }
     }
     for (int i = tid; i < HID; i += NT) b1s[i] = bk.b1[i];
     __syncthreads();
+    S1N_STAMP(3 + 5 * j);
     layernorm(bk.ln_w, bk.ln_b);
     // residual + gamma * b2 (the bias of the folded fc2); the shared tiles' lead waves carry theirs
     {
@@ -209,10 +238,12 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
     frag a1[KS1], a2[KS2], a2x;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) a1[s] = MQ<T>::gld(bk.w1p, (size_t)wave * KS1 + s, lane);
+    // (fc2 k-steps in the order xq, xq + 1, ... of a chunk: the shared tile's one k-step is then this wave's program step 0)
 #pragma unroll
-    for (int s = 0; s < KS2; ++s) a2[s] = MQ<T>::gld(bk.w2p, (size_t)wave * KH + s, lane);
+    for (int s = 0; s < KS2; ++s) a2[s] = MQ<T>::gld(bk.w2p, (size_t)wave * KH + ((xq + s) & 3), lane);
     a2x = MQ<T>::gld(bk.w2p, (size_t)xtile * KH + xq, lane);
-    __syncthreads();   // LN image complete
+    __syncthreads();   // LN image complete (and the map is read out: the hidden images take its place)
+    S1N_STAMP(4 + 5 * j);
 
     // One step = fc1 of chunk ch, then GELU of chunk ch between the fc2 products of chunk ch - 1 (stage2p.hip's pipeline);
     // P = the hidden image this chunk writes.  Fragment slots are refilled in place with the next chunk's.
@@ -248,27 +279,23 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
       frag hbf[2][NB];
       if (!first) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (8 * kg) * 2);
+        for (int n = 0; n < NB; ++n) hbf[0][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * xq + 8 * kg) * 2);
       }
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) {
-        if (!first) {
+      for (int s = 0; s < NB; ++s) {   // one GELU column block per iteration, an fc2 k-step in the first four
+        if (!first && s < KS2) {
           if (s + 1 < KS2) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              hbf[(s + 1) & 1][n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * (s + 1) + 8 * kg) * 2);
-          }
-          frag hbx[NB];
-          if (s == 0) {   // the shared tile: k-step xq of the previous chunk
-#pragma unroll
-            for (int n = 0; n < NB; ++n) hbx[n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * xq + 8 * kg) * 2);
+              hbf[(s + 1) & 1][n] =
+                  *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * ((xq + s + 1) & 3) + 8 * kg) * 2);
           }
 #pragma unroll
           for (int n = 0; n < NB; ++n) acc[n] = MQ<T>::run(a2[s], hbf[s & 1][n], acc[n]);
-          a2[s] = MQ<T>::gld(bk.w2p, f2 + s, lane);
-          if (s == 0) {
+          a2[s] = MQ<T>::gld(bk.w2p, f2 + ((xq + s) & 3), lane);
+          if (s == 0) {   // the shared tile: k-step xq of the previous chunk
 #pragma unroll
-            for (int n = 0; n < NB; ++n) accx[n] = MQ<T>::run(a2x, hbx[n], accx[n]);
+            for (int n = 0; n < NB; ++n) accx[n] = MQ<T>::run(a2x, hbf[0][n], accx[n]);
             a2x = MQ<T>::gld(bk.w2p, fx, lane);
           }
         }
@@ -284,9 +311,10 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    static_assert(NCHUNK == 5 && KS2 == NB, "five steps; one GELU column block per fc2 k-step");
+    static_assert(NCHUNK == 5 && KS2 <= NB, "five steps; the fc2 k-steps fit the GELU column blocks' iterations");
     step(P0{}, std::true_type{}, 0);
     step(P1{}, std::false_type{}, 1);
+    S1N_STAMP(5 + 5 * j);
     step(P0{}, std::false_type{}, 2);
     step(P1{}, std::false_type{}, 3);
     step(P0{}, std::false_type{}, 4);
@@ -296,47 +324,65 @@ __global__ __launch_bounds__(NT, 2) void stage1n_kernel(Stage2pArgs a) {
       for (int s = 0; s < KS2; ++s) {
         frag hbf[NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) hbf[n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * s + 8 * kg) * 2);
+        for (int n = 0; n < NB; ++n)
+          hbf[n] = *reinterpret_cast<const frag*>(hprev + (16 * n + col) * HP + (32 * ((xq + s) & 3) + 8 * kg) * 2);
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[n] = MQ<T>::run(a2[s], hbf[n], acc[n]);
-        if (s == xq) {
+        if (s == 0) {
 #pragma unroll
           for (int n = 0; n < NB; ++n) accx[n] = MQ<T>::run(a2x, hbf[n], accx[n]);
         }
       }
     }
-    __syncthreads();   // the images are read out (the next block's GELU writes them again)
+    __syncthreads();   // the images are read out (the map takes their place again)
   }
 
   // ---- stage output, then the downsample: LN per pixel + conv 2x2 s2 -> 3x3 pixels of 320 channels
+  S1N_STAMP(11);
   residual_to_map();
   if (a.tap_stage != nullptr) {
-    for (int i = tid; i < NPX * (C / 4); i += NT) {
+    for (int i = tid; i < nlive * (C / 4); i += NT) {
       const int p = i / (C / 4), c4 = i - p * (C / 4);
-      *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert * NPX + p) * C + 4 * c4) = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * c4);
+      *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * PA + p) * C + 4 * c4) = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * c4);
     }
   }
   layernorm(a.ds_lnw, a.ds_lnb);
   __syncthreads();
+  S1N_STAMP(12);
   {
     // out[opix][co] = b[co] + sum_k Wd[co][k] patch[opix][k],  k = (2 ky + kx) * 160 + c  ->  pixel (2 oy + ky, 2 ox + kx).
-    // Column = output pixel (9 live of 16); wave w: output tiles w, w + 8, w + 16 (20 tiles of 16 channels), 20 k-steps each
-    const int op = col < 9 ? col : 0, oy = op / 3, ox = op - 3 * oy;
+    // Columns = the two alerts' 9 output pixels each (18 live of 32); wave w: output tiles w, w + 8, w + 16 (20 tiles of
+    // 16 channels), 20 k-steps each
+    int pbase[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int o18 = 16 * nb + col, ov = o18 < 9 * G ? o18 : 0, al = ov / 9, op = ov - 9 * al, oy = op / 3, ox = op - 3 * oy;
+      pbase[nb] = al * PA + 2 * oy * HW + 2 * ox;
+    }
 #pragma unroll 1
     for (int t = wave; t < CO / 16; t += NW) {
       frag wq[KSD];
 #pragma unroll
       for (int s = 0; s < KSD; ++s) wq[s] = MQ<T>::gld(a.ds_wp, (size_t)t * KSD + s, lane);
-      f32x4 o = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * t + 4 * kg);
+      f32x4 o[2];
+      o[0] = o[1] = *reinterpret_cast<const f32x4*>(a.ds_b + 16 * t + 4 * kg);
 #pragma unroll
       for (int s = 0; s < KSD; ++s) {
-        const int q = s / KS1, pix = (2 * oy + (q >> 1)) * HW + 2 * ox + (q & 1);
-        const frag bf = *reinterpret_cast<const frag*>(xn + pix * XNP + (32 * (s - q * KS1) + 8 * kg) * 2);
-        o = MQ<T>::run(wq[s], bf, o);
+        const int q = s / KS1, dp = (q >> 1) * HW + (q & 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const frag bf = *reinterpret_cast<const frag*>(xn + (pbase[nb] + dp) * XNP + (32 * (s - q * KS1) + 8 * kg) * 2);
+          o[nb] = MQ<T>::run(wq[s], bf, o[nb]);
+        }
       }
-      if (col < 9) *reinterpret_cast<f32x4*>(a.out + ((size_t)alert * 9 + col) * CO + 16 * t + 4 * kg) = o;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int o18 = 16 * nb + col;
+        if (o18 < 9 * nal) *reinterpret_cast<f32x4*>(a.out + ((size_t)alert0 * 9 + o18) * CO + 16 * t + 4 * kg) = o[nb];
+      }
     }
   }
+  S1N_STAMP(13);
 }
 
 }  // namespace
@@ -358,8 +404,9 @@ int launch_stage1n(int prec, const Stage2pArgs& a, hipStream_t st) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stage1n_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr.done();
   }
-  if (prec == BTSBOT_BF16) hipLaunchKernelGGL(stage1n_kernel<bf16_t>, dim3(a.B), dim3(NT), LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(stage1n_kernel<f16_t>, dim3(a.B), dim3(NT), LDS_BYTES, st, a);
+  const dim3 grid((a.B + G - 1) / G);
+  if (prec == BTSBOT_BF16) hipLaunchKernelGGL(stage1n_kernel<bf16_t>, grid, dim3(NT), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(stage1n_kernel<f16_t>, grid, dim3(NT), LDS_BYTES, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
