@@ -388,8 +388,7 @@ static int wgrad_cs(int prec, const void* D, const void* A, float* out, float* c
     }
     return launch_wgrad16(prec, D, A, out, cs, M, N, K, ldo, st, part, WPART_FLOATS, defer);
   }
-  const int rc = launch_wgrad(prec, D, A, out, M, N, K, ldo, st);
-  return rc != BTSBOT_OK ? rc : launch_colsum(prec, D, cs, M, N, st);
+  return launch_wgrad_cs_f32(reinterpret_cast<const float*>(D), reinterpret_cast<const float*>(A), out, cs, M, N, K, ldo, st);
 }
 
 int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, float* grads,

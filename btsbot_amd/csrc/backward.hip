@@ -125,7 +125,10 @@ template <int TN, int TK>
 __global__ __launch_bounds__(64 * (TN / 64) * (TK / 64)) void wgrad_f32_kernel(const float* __restrict__ D,
                                                                                 const float* __restrict__ A,
                                                                                 float* __restrict__ out, int M, int N, int K,
-                                                                                int ldo, int mslice) {
+                                                                                int ldo, int mslice, float* __restrict__ cs) {
+  // cs != nullptr: cs[n] += sum_m D[m][n] as well (the bias gradient beside the filter gradient): the workgroups of the
+  // first k-tile column add up the D rows they stage anyway -- was a launch of its own reading D once more (fp32 mode:
+  // 32 launches, 1.9 ms of kernel time per training step)
   constexpr int WK = TK / 64, NTH = 64 * (TN / 64) * WK, TM = 16;
   constexpr int DV = TM * TN / 4, AV = TM * TK / 4;                 // 16-byte pieces per stage
   constexpr int DPT = (DV + NTH - 1) / NTH, APT = (AV + NTH - 1) / NTH;
@@ -145,6 +148,9 @@ __global__ __launch_bounds__(64 * (TN / 64) * (TK / 64)) void wgrad_f32_kernel(c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 dr[DPT], ar[APT];
+  const bool do_cs = cs != nullptr && blockIdx.y == 0;   // (uniform)
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);         // this thread's columns 4 (tid % (TN / 4)) .. + 3, its rows
+  static_assert(NTH % (TN / 4) == 0, "a thread's pieces share their columns");
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int u = 0; u < DPT; ++u) {
@@ -159,7 +165,15 @@ __global__ __launch_bounds__(64 * (TN / 64) * (TK / 64)) void wgrad_f32_kernel(c
   };
   auto park = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < DPT; ++u) reinterpret_cast<float4*>(Ds[buf])[tid + u * NTH] = dr[u];
+    for (int u = 0; u < DPT; ++u) {
+      reinterpret_cast<float4*>(Ds[buf])[tid + u * NTH] = dr[u];
+      if (do_cs) {
+        csum.x += dr[u].x;
+        csum.y += dr[u].y;
+        csum.z += dr[u].z;
+        csum.w += dr[u].w;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < APT; ++u) reinterpret_cast<float4*>(As[buf])[tid + u * NTH] = ar[u];
   };
@@ -202,6 +216,29 @@ __global__ __launch_bounds__(64 * (TN / 64) * (TK / 64)) void wgrad_f32_kernel(c
         const int k = k0 + wk * 64 + 32 * j + l31;
         atomicAdd(out + (size_t)n * ldo + k, acc[i][j][r]);
       }
+  if (do_cs) {   // the row groups' column sums meet in LDS (the operand stages are dead: the loop ended on a barrier)
+    constexpr int CG = TN / 4, RG = NTH / CG;
+    float4* red = reinterpret_cast<float4*>(Ds[0]);
+    static_assert(RG * CG * 16 <= (int)sizeof(Ds), "the partial sums fit the D stages");
+    red[tid] = csum;   // [row group = tid / CG][column group = tid % CG]
+    __syncthreads();
+    if (tid < CG) {
+      float4 t = red[tid];
+#pragma unroll
+      for (int g = 1; g < RG; ++g) {
+        const float4 e = red[g * CG + tid];
+        t.x += e.x;
+        t.y += e.y;
+        t.z += e.z;
+        t.w += e.w;
+      }
+      float* d = cs + n0 + 4 * tid;
+      atomicAdd(d, t.x);
+      atomicAdd(d + 1, t.y);
+      atomicAdd(d + 2, t.z);
+      atomicAdd(d + 3, t.w);
+    }
+  }
 }
 
 // out[n] += sum_m in[m][n].  Block = 64 columns x 4 row groups over one slice of M; the row groups
@@ -710,7 +747,7 @@ int wgrad_t(const void* D, const void* A, float* out, int M, int N, int K, int l
 }
 
 template <int TN, int TK>
-int wgrad_f32_launch(const float* D, const float* A, float* out, int M, int N, int K, int ldo, hipStream_t st) {
+int wgrad_f32_launch(const float* D, const float* A, float* out, int M, int N, int K, int ldo, hipStream_t st, float* cs) {
   // slices of the reduction: ~768 workgroups (two or three per CU), at least 256 rows each
   const int tiles = (N / TN) * (K / TK);
   int nsl = (768 + tiles - 1) / tiles;
@@ -719,26 +756,30 @@ int wgrad_f32_launch(const float* D, const float* A, float* out, int M, int N, i
   const int mslice = ((M + nsl - 1) / nsl + 15) / 16 * 16;
   nsl = (M + mslice - 1) / mslice;
   hipLaunchKernelGGL((wgrad_f32_kernel<TN, TK>), dim3(N / TN, K / TK, nsl), dim3(64 * (TN / 64) * (TK / 64)), 0, st, D, A, out, M, N,
-                     K, ldo, mslice);
+                     K, ldo, mslice, cs);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
 
-template <>
-int wgrad_t<float>(const void* Dv, const void* Av, float* out, int M, int N, int K, int ldo, hipStream_t st) {
+// fp32: the matrix-pipe kernel where the shapes allow it; *cs_done says whether the column sums went along
+int wgrad_f32(const void* Dv, const void* Av, float* out, int M, int N, int K, int ldo, hipStream_t st, float* cs, bool* cs_done) {
   const float* D = reinterpret_cast<const float*>(Dv);
   const float* A = reinterpret_cast<const float*>(Av);
+  if (cs_done != nullptr) *cs_done = false;
   static const bool old_form = [] {   // BTSBOT_AMD_WGRAD_F32_OLD=1: the 64 x 64 kernel for every shape (A/B timing, parity)
     const char* e = getenv("BTSBOT_AMD_WGRAD_F32_OLD");
     return e != nullptr && e[0] == '1';
   }();
   const bool aligned = ((reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
   if (!old_form && aligned && N % 64 == 0 && K % 64 == 0) {
+    // (deterministic mode: the column sums keep their own launch with its fixed-order reduction)
+    float* csk = cs != nullptr && cs_done != nullptr && det_alloc(0) == nullptr ? cs : nullptr;
+    if (csk != nullptr) *cs_done = true;
     const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
-    if (n128 && k128) return wgrad_f32_launch<128, 128>(D, A, out, M, N, K, ldo, st);
-    if (n128) return wgrad_f32_launch<128, 64>(D, A, out, M, N, K, ldo, st);
-    if (k128) return wgrad_f32_launch<64, 128>(D, A, out, M, N, K, ldo, st);
-    return wgrad_f32_launch<64, 64>(D, A, out, M, N, K, ldo, st);
+    if (n128 && k128) return wgrad_f32_launch<128, 128>(D, A, out, M, N, K, ldo, st, csk);
+    if (n128) return wgrad_f32_launch<128, 64>(D, A, out, M, N, K, ldo, st, csk);
+    if (k128) return wgrad_f32_launch<64, 128>(D, A, out, M, N, K, ldo, st, csk);
+    return wgrad_f32_launch<64, 64>(D, A, out, M, N, K, ldo, st, csk);
   }
   const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
   int nsl = (1024 + tiles - 1) / tiles;
@@ -750,6 +791,10 @@ int wgrad_t<float>(const void* Dv, const void* Av, float* out, int M, int N, int
   hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, D, A, out, M, N, K, ldo, mslice);
   LAUNCH_CHECK();
   return BTSBOT_OK;
+}
+template <>
+int wgrad_t<float>(const void* D, const void* A, float* out, int M, int N, int K, int ldo, hipStream_t st) {
+  return wgrad_f32(D, A, out, M, N, K, ldo, st, nullptr, nullptr);
 }
 
 template <typename T>
@@ -782,6 +827,15 @@ int colsum_t(const void* in, float* out, int M, int N, hipStream_t st) {
   }                                                             \
   btsbot_set_error("backward: bad precision %d", prec);         \
   return BTSBOT_ERR_INVALID_ARG;
+
+// fp32 operands: filter gradient and (cs != nullptr) the column sums of D, in one launch where the matrix-pipe kernel applies
+int launch_wgrad_cs_f32(const float* D, const float* A, float* out, float* cs, int M, int N, int K, int ldo, hipStream_t st) {
+  if (M <= 0) return BTSBOT_OK;
+  bool done = false;
+  const int rc = wgrad_f32(D, A, out, M, N, K, ldo, st, cs, &done);
+  if (rc != BTSBOT_OK || cs == nullptr || done) return rc;
+  return launch_colsum(BTSBOT_F32, D, cs, M, N, st);
+}
 
 int launch_wgrad(int prec, const void* D, const void* A, float* out, int M, int N, int K, int ldo,
                  hipStream_t st) {

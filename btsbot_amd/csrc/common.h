@@ -372,6 +372,8 @@ struct WgradBatchJob {
 int launch_wgrad16_batched(int prec, const WgradBatchJob* jobs, int njobs, float* part, size_t part_floats, int target_wg,
                            hipStream_t st);
 int launch_colsum(int prec, const void* in, float* out, int M, int N, hipStream_t st);  // out[n] += ...
+// fp32 mode: out[n][k] += sum_m D[m][n] A[m][k] and (cs != nullptr) cs[n] += sum_m D[m][n] (backward.hip)
+int launch_wgrad_cs_f32(const float* D, const float* A, float* out, float* cs, int M, int N, int K, int ldo, hipStream_t st);
 int launch_rowscale_cast(int prec, const float* in, const float* rowscale, void* out, int rows,
                          int cols, hipStream_t st);   // out[r][c] = in[r][c] * rowscale[r]
 // f16 remainder image of launch_rowscale_cast(BTSBOT_F16, ...): out[r][c] = f16(v - f16(v)), v = in[r][c] * rowscale[r] (rowscale

@@ -763,8 +763,7 @@ int maxvit_train_backward(btsbot_ctx* h, const float* img, const float* dfeat, f
       VTRY(launch_cast(prec, X, k.x16, (int64_t)M * K, st));
       return launch_wgrad16(prec, k.d16, k.x16, dW, db, (int)M, N, K, K, st, k.wpart, MVT_WPART_FLOATS);
     }
-    VTRY(launch_wgrad(BTSBOT_F32, dY, X, dW, (int)M, N, K, K, st));
-    return db != nullptr ? launch_colsum(BTSBOT_F32, dY, db, (int)M, N, st) : BTSBOT_OK;
+    return launch_wgrad_cs_f32(dY, X, dW, db, (int)M, N, K, K, st);
   };
   // ---- final LayerNorm2d + global average pool: d(xn)[b][p][c] = dfeat[b][c] / 49
   float* dy = k.dA;         // gradient w.r.t. the current map [rows][C]
