@@ -592,7 +592,11 @@ def test_process_wide_switches_in_a_child_process(cuda):
                BTSBOT_AMD_NO_DW15="1", BTSBOT_AMD_HEAD_NO_GEMM="1", BTSBOT_AMD_WGRAD_REDUCE1="1",
                BTSBOT_AMD_EAGER_REPACK="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+    # (the cases that reach the switched kernels: the default / unfused / stage-0-only backward schedules, and the forward
+    #  of the pico and nano wirings + the frozen fusion -- not every schedule case again: the child was 48 s of the suite)
+    pick = ("(full_backward_16bit and (default or unfused or stage0_only)) or "
+            "(forward_matches_oracle and (mm_pico or mm_nano_ls or frozen_fusion))")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k", pick,
                         "tests/test_gpu_train.py::test_full_backward_16bit",
                         "tests/test_gpu_parity.py::test_forward_matches_oracle"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
