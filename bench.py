@@ -490,6 +490,20 @@ def precision_leg(precision, dev, img, meta, steps, warmup, fence, dist, world, 
     el, _, _ = timed_blocks(run, steps, warmup, fence, dist, dev, blocks=5, warm_seconds=0.3)
     leg = dict(value=round(img.shape[0] * world * steps / el, 1), unit="alerts/s", steps=steps,
                ms_per_step=round(1e3 * el / steps, 4), api="drop-in model(...) calls, one stream")
+    if precision in ("f16", "f16x2"):
+        # the scoring loop of the headline (ScoreStream) in this mode as well
+        scorer = btsbot_amd.ScoreStream(m, inputs_ready=True)
+
+        def run_pipelined(n):
+            last = None
+            for last in scorer.map(((img, meta) for _ in range(n)), lag=n):
+                pass
+            return last
+
+        el2, _, _ = timed_blocks(run_pipelined, steps, warmup, fence, dist, dev, blocks=5, warm_seconds=0.3)
+        leg["streamed"] = dict(value=round(img.shape[0] * world * steps / el2, 1), ms_per_step=round(1e3 * el2 / steps, 4),
+                               api="btsbot_amd.ScoreStream, three batches in flight")
+        del scorer
     if with_parity:
         leg["parity"] = parity_vs_oracle(m, img, meta)
     return leg
@@ -691,6 +705,9 @@ def train_leg(dev, rank, world, dist, fence, args, precision=None, steps=None, b
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4),
                          "flop_per_step": step_flop}
+    tg = pmc_traffic_train(args)
+    if tg is not None:
+        train["roofline"].update(tg)
     if world > 1:
         # what the gradient exchange costs in wall time: the same step with the all-reduce left out (the replicas drift
         # apart from here on: timing only, after the measurement above)
@@ -1059,10 +1076,119 @@ def main():
             line["maxvit_train"] = maxvit_train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        # Two lines: everything measured (one long JSON object, also written to gpurun_out/bench_detail.json where that
+        # directory exists) FIRST, then the contract's ONE line, kept under 7 KB so that a log tail cannot cut it
+        detail = dict(line)
+        detail["bench_detail"] = True
+        print(json.dumps(detail), flush=True)
+        out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        if os.path.isdir(out_dir):
+            try:
+                with open(os.path.join(out_dir, "bench_detail.json"), "w") as fh:
+                    json.dump(detail, fh)
+            except OSError:
+                pass
+        print(json.dumps(compact_line(line)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pick(d, *keys):
+    """The named keys of a leg that ran; its error where it did not."""
+    if not isinstance(d, dict):
+        return None
+    if "error" in d:
+        return {"error": d["error"][:160]}
+    return {k: d[k] for k in keys if k in d}
+
+
+def compact_line(line):
+    """The contract's line: the headline, its roofline (per kernel: fraction and launch time only), the CPU baseline,
+    parity, the tolerance-compliant mode, and one figure per secondary leg.  The long form is the line printed before it."""
+    legs = line.get("precision_legs") or {}
+    roof = dict(line["roofline"])
+    roof["per_kernel"] = {k: {"frac": v["frac"], "us": v["avg_launch_us"], "n": v["launches_per_step"]}
+                          for k, v in roof["per_kernel"].items()}
+    if isinstance(roof.get("traffic"), dict):
+        roof["traffic"] = {k: roof["traffic"][k] for k in ("bytes_per_launch", "source", "measured_in_this_run", "stale")
+                           if k in roof["traffic"]}
+    cfg = dict(line["config"])
+    for k in ("drop_in_api", "api"):
+        cfg.pop(k, None)
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = cfg
+    out["roofline"] = roof
+    if "cpu_baseline" in line:
+        cb = dict(line["cpu_baseline"])
+        cb.pop("thread_sweep", None)
+        out["cpu_baseline"] = cb
+    if "parity" in line:
+        par = dict(line["parity"])
+        for prec in ("bf16", "f16", "fp8"):
+            tl = (legs.get(prec + "_trained_like") or {}).get("parity")
+            if tl:
+                par[prec + "_trained_like_max_abs_dscore"] = tl["max_abs_dscore"]
+        out["parity"] = par
+    # the operand mode that meets the north star's 1e-4 on scores, at speed (tests/test_gpu_parity.py: five weight seeds)
+    x2 = legs.get("f16x2")
+    if isinstance(x2, dict) and "value" in x2:
+        out["parity_compliant"] = {"mode": "f16x2", "value": x2["value"], "ms_per_step": x2["ms_per_step"],
+                                   "max_abs_dscore": (x2.get("parity") or {}).get("max_abs_dscore"),
+                                   "api": "drop-in calls", "streamed_value": (x2.get("streamed") or {}).get("value")}
+    elif isinstance(x2, dict):
+        out["parity_compliant"] = _pick(x2)
+    for name in ("f16", "f32", "fp8"):
+        lg = legs.get(name)
+        if isinstance(lg, dict):
+            c = _pick(lg, "value", "ms_per_step")
+            if "parity" in lg:
+                c["max_abs_dscore"] = lg["parity"]["max_abs_dscore"]
+            if isinstance(lg.get("streamed"), dict):
+                c["streamed_value"] = lg["streamed"]["value"]
+            out[name] = c
+    nano = legs.get("convnext_nano")
+    if isinstance(nano, dict):
+        c = _pick(nano, "value", "ms_per_step", "whole_net_tflops")
+        if isinstance(nano.get("streamed"), dict):
+            c["streamed_value"] = nano["streamed"]["value"]
+        if "parity" in nano:
+            c["max_abs_dlogit"] = nano["parity"]["max_abs_dlogit"]
+        out["nano"] = c
+    for name in ("batch8192", "fp8_batch8192"):
+        lg = legs.get(name)
+        if isinstance(lg, dict):
+            c = _pick(lg, "value", "ms_per_step")
+            if isinstance(lg.get("roofline"), dict):
+                c["frac"] = lg["roofline"].get("frac")
+            out[name] = c
+    hf = legs.get("host_fed")
+    if isinstance(hf, dict):
+        out["host_fed"] = ({"error": hf["error"][:160]} if "error" in hf else
+                           {k: {"value": hf[k]["value"], "pcie_gbs": hf[k]["pcie_gbs"]} for k in ("fp32", "f16", "raw+prep")
+                            if isinstance(hf.get(k), dict)})
+    tr = line.get("train")
+    if isinstance(tr, dict):
+        c = _pick(tr, "value", "unit", "per_gpu_batch", "steps", "ms_per_step", "operands", "kernel_ms_both_queues")
+        if isinstance(tr.get("roofline"), dict):
+            c["frac"] = tr["roofline"]["frac"]
+            c["traffic_gb"] = tr["roofline"].get("traffic_gb")
+        for sub in ("f32", "f16", "batch_x4"):
+            if isinstance(tr.get(sub), dict):
+                c[sub] = _pick(tr[sub], "value", "ms_per_step", "per_gpu_batch")
+        out["train"] = c
+    mv = line.get("maxvit")
+    if isinstance(mv, dict):
+        out["maxvit"] = _pick(mv, "value", "unit", "per_gpu_batch", "ms_per_step", "whole_net_tflops", "frac")
+    mvt = line.get("maxvit_train")
+    if isinstance(mvt, dict):
+        out["maxvit_train"] = _pick(mvt, "value", "unit", "per_gpu_batch", "ms_per_step", "whole_step_tflops")
+    for k in ("rccl_ranks_seen", "allreduce_exposed_ms_per_step", "rehearsal", "collective", "pipelined_slower_than_serial"):
+        if k in line:
+            out[k] = line[k]
+    out["detail"] = "the line printed before this one (bench_detail: true); gpurun_out/bench_detail.json"
+    return out
 
 
 def _newest_profile(pattern):
@@ -1107,6 +1233,22 @@ def pmc_traffic(kernel, args):
         return None
     return {"bytes_per_launch": hits[0]["traffic_bytes"], "source": "profiles/" + os.path.basename(f),
             "measured_in_this_run": False, "stale": _stale(summ)}
+
+
+def pmc_traffic_train(args):
+    """HBM-side GB per training step from the newest committed summary (profiles/r*_pmc_traffic_train.json: two PMC passes
+    over tools/train_bench.py 1024 bf16); not measured in this run, tagged with its file."""
+    if args.precision != "bf16" or args.train_batch != 1024:
+        return None
+    f = _newest_profile("r*_pmc_traffic_train.json")
+    if f is None:
+        return None
+    with open(f) as fh:
+        d = json.load(fh)
+    tb = (d.get("per_step") or {}).get("traffic_bytes")
+    if tb is None:
+        return None
+    return {"traffic_gb": round(tb / 1e9, 3), "traffic_source": "profiles/" + os.path.basename(f), "traffic_stale": _stale(d)}
 
 
 def depthwise_norm_hbm(args):

@@ -62,7 +62,10 @@ for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"
                  ("train_f32_ab.log", "train_f32_ab.txt")):   # tools/nano_bench.py; train step default vs
     if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
         shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")
-open(f"profiles/{tag}_bench.json", "w").write([l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")][0])
+_lines = [l for l in open("gpurun_out/final/bench_default.log") if l.startswith("{")]
+open(f"profiles/{tag}_bench.json", "w").write(_lines[0])          # everything measured (bench_detail: true)
+if len(_lines) > 1:
+    open(f"profiles/{tag}_bench_line.json", "w").write(_lines[-1])   # the contract's line (< 7 KB)
 for k, v in sorted(out["kernels"].items(), key=lambda x: -x[1]["traffic_bytes"] * x[1]["launches"])[:10]:
     print(f'{v["family"]:24s} launches {v["launches"]:4d}  fetch {v["fetch_bytes"]/1e6:8.2f} MB  write {v["write_bytes"]/1e6:8.2f} MB')
 # every JSON summary bench.py quotes carries the digest of the kernel sources it was collected under (bench.py marks a
