@@ -398,7 +398,8 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     const char* ns16 = getenv("BTSBOT_AMD_NO_STEM16");
     h->use_stem16 = !(ns16 != nullptr && ns16[0] == '1');
     const char* det = getenv("BTSBOT_AMD_DETERMINISTIC");
-    h->deterministic = det != nullptr && det[0] == '1';
+    // (the deterministic reductions cover the ConvNeXt training step only: same rule as btsbot_set_option)
+    h->deterministic = det != nullptr && det[0] == '1' && !h->is_maxvit;
   }
   *out = h;
   return BTSBOT_OK;
@@ -418,16 +419,20 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   for (float* t : h->taps)
     if (t) (void)hipFree(t);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
-  if (h->xchg != nullptr) {
-    (void)hipStreamDestroy(h->xchg);
-    (void)hipEventDestroy(h->xchg_done);
-  }
+  if (h->xchg != nullptr) (void)hipStreamDestroy(h->xchg);
+  if (h->xchg_done != nullptr) (void)hipEventDestroy(h->xchg_done);
   for (hipEvent_t e : h->bucket_ev)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->side_ev) (void)hipEventDestroy(e);
   if (h->s2_ready) (void)hipEventDestroy(h->s2_ready);
   if (h->pack_early_ev) (void)hipEventDestroy(h->pack_early_ev);
-  if (h->side) (void)hipStreamDestroy(h->side);
+  bool side_cached = false;
+  for (const SidePick& p : h->side_cache) {
+    side_cached = side_cached || p.side == h->side;
+    (void)hipStreamDestroy(p.side);
+  }
+  if (h->side && !side_cached) (void)hipStreamDestroy(h->side);
+  if (h->bwd_done) (void)hipEventDestroy(h->bwd_done);
   delete h;
   return BTSBOT_OK;
 }
@@ -741,6 +746,19 @@ extern "C" int btsbot_set_option(btsbot_handle h, const char* key, int value) {
       return BTSBOT_ERR_STATE;
     }
     h->deterministic = value == 1;
+    return BTSBOT_OK;
+  }
+  if (strcmp(key, "query_side_apart") == 0) {
+    // a query, not a setting: BTSBOT_OK when the training step's second stream (and, once btsbot_allreduce_grads() has run,
+    // its exchange stream) was measured on a hardware pipe of its own, BTSBOT_ERR_STATE when none of the candidates was
+    if (h->side != nullptr && !h->side_apart) {
+      btsbot_set_error("the backward's side stream shares a hardware pipe with the caller's stream");
+      return BTSBOT_ERR_STATE;
+    }
+    if (h->xchg != nullptr && !h->xchg_apart) {
+      btsbot_set_error("the exchange stream shares a hardware pipe with the caller's or the side stream");
+      return BTSBOT_ERR_STATE;
+    }
     return BTSBOT_OK;
   }
   if (strcmp(key, "exchange") == 0) {
@@ -1352,6 +1370,15 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
   hipStream_t st = (hipStream_t)stream;
   bool meta_done = false, meta_on_side = false;
   h->bb_saved = false;
+  // the pool's events of the previous forward / backward are all recorded and their waits enqueued: start over (a loop of
+  // training-mode forwards without a backward -- BatchNorm recalibration -- would otherwise grow the pool without bound)
+  h->side_used = 0;
+  if (h->s2_pending) {
+    // light stage-2 forward (opt-in): the previous forward's recompute still reads the block inputs on the side stream
+    // and no backward has waited for it -- this forward overwrites them
+    HIP_TRY(hipStreamWaitEvent(st, h->s2_ready, 0));
+    h->s2_pending = false;
+  }
   h->t_img = triplets;
   // (the ConvNeXt training forward waits for the packing launches behind its stem, backbone_train.hip)
   if (!(h->has_image && keep_image_activations && !h->is_maxvit)) TRY(pack_sync(h, st));
@@ -1420,17 +1447,32 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     btsbot_set_error("backward: image-branch gradients need forward_train(keep_image_activations=1)");
     return BTSBOT_ERR_STATE;
   }
+  if (h->deterministic && need_img) {
+    // checked BEFORE anything is launched or any handle state moves: the scratch of the fixed-order reductions is sized
+    // by the batch at btsbot_reserve_train() (256 KB per alert, at least 64 MB)
+    const size_t want = std::max((size_t)16 << 20, (size_t)h->train_batch << 16);
+    if (h->det_scratch == nullptr || h->det_floats < want) {
+      btsbot_set_error("backward: the deterministic mode's scratch (%zu floats) is too small for a batch of %d (%zu): set the "
+                       "option before btsbot_reserve_train(%d, 1)", h->det_floats, h->train_batch, want, h->train_batch);
+      return BTSBOT_ERR_STATE;
+    }
+  }
   if (need_img)   // image-branch gradients are accumulated with atomics
     TRY(launch_fill0(grad_arena, (size_t)h->img_floats, st));
   for (int i = 0; i < h->n_buckets; ++i)
     if (h->bucket_ev[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
   if (h->use_side && (h->side == nullptr || h->side_for != st)) {
-    if (h->side != nullptr) {   // the caller changed streams: the old side stream may share the new one's hardware queue
-      HIP_TRY(hipStreamSynchronize(h->side));
-      (void)hipStreamDestroy(h->side);
-      h->side = nullptr;
-    }
+    // the caller changed streams: the side stream chosen against the old one may share the new one's pipe.  Whatever the
+    // old pair still holds is ordered in front of this call by the join below (the new caller stream waits for it)
+    hipStream_t old = h->side;
     TRY(create_side_stream(h, st));
+    if (old != nullptr && old != h->side) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      hipError_t r1 = hipEventRecord(e, old), r2 = r1 == hipSuccess ? hipStreamWaitEvent(st, e, 0) : r1;
+      (void)hipEventDestroy(e);   // (released once the record has completed)
+      HIP_TRY(r2);
+    }
   }
   h->side_used = 0;
   // deterministic mode: the launchers below take their partial rows from this scratch (fixed-order reductions)
@@ -1438,7 +1480,6 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     explicit DetScope(btsbot_ctx* c) { det_begin(c->deterministic ? c->det_scratch : nullptr, c->det_floats); }
     ~DetScope() { det_end(); }
   } det_scope(h);
-  h->last_bwd_stream = st;
   // (the paths that record every bucket at their end anyway always do; the ConvNeXt backward forks for them on demand)
   h->bucket_fine = h->bucket_waits_seen || !need_img || h->is_maxvit;
   float* dfeat = nullptr;
@@ -1455,12 +1496,19 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
     TRY(side_join(h, st));
     for (int i = 0; i < h->n_buckets; ++i) HIP_TRY(hipEventRecord(h->bucket_ev[i], st));
   }
+  if (!h->bucket_fine) {
+    // nobody has asked for a bucket yet, so the per-stage events were not recorded: ONE event for "everything is there",
+    // which a late btsbot_wait_grad_bucket() / btsbot_allreduce_grads() waits on (no stream handle is kept for later)
+    if (h->bwd_done == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->bwd_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->bwd_done, st));
+  }
   h->bucket_recorded = true;
   h->last_grad_arena = grad_arena;
-  if (det_fell_short()) {   // (the gradients are complete and correct, but not bit-reproducible: say so instead of OK)
-    btsbot_set_error("backward: the deterministic mode's scratch (%zu floats) was too small for a batch of %d -- some "
-                     "reductions fell back to atomics; call btsbot_reserve_train() with the option already set",
-                     h->det_floats, h->train_batch);
+  if (det_fell_short()) {
+    // (cannot happen with the entry check above unless the sizing rule and the launchers disagree: the gradients are
+    //  complete and correct, but some reduction fell back to atomics)
+    btsbot_set_error("backward: the deterministic mode's scratch (%zu floats) ran out inside a batch of %d although the entry "
+                     "check passed -- gradients are valid, not bit-reproducible", h->det_floats, h->train_batch);
     return BTSBOT_ERR_STATE;
   }
   return BTSBOT_OK;
@@ -1472,52 +1520,114 @@ extern "C" int btsbot_backward(btsbot_handle h, const float* dlogits, float* gra
 // land on one pipe their kernels are dispatched in turns of ~50 us instead of side by side: measured 4.9-7.0 ms per
 // 1024-alert step against 2.75 ms, in every process that had used exactly THREE other streams before the first
 // btsbot_backward() (bench.py's scoring loop; tools/host_streams_probe2.py: two or four are fine; stream priorities and
-// GPU_MAX_HW_QUEUES do not move it).  The placement cannot be asked, so it is measured: a train of short spinning
-// kernels keeps the caller's stream busy, an empty kernel goes to the candidate, and the host times the candidate's
-// kernel -- a few microseconds beside the train, a quantum or more behind it.  Up to eight candidates, once per handle (and
-// again should the caller come with another stream).
+// GPU_MAX_HW_QUEUES do not move it).  The placement cannot be asked, so it is measured, RELATIVE to a baseline taken in
+// the same call: the host times an empty kernel on the candidate (launch -> event synchronise) first with the busy
+// streams idle, then while a train of short spinning kernels keeps each of them busy; the minimum over the trials of
+// each (host noise and a profiler's per-launch cost only ever add, and they add to both) differs by a few microseconds
+// when the candidate runs beside the trains and by a quantum (30-40 us) when it shares a pipe with one of them.
+// Up to eight candidates.  The choice is kept per caller stream (ctx.h: side_cache); when no candidate runs apart the
+// last one is kept anyway and the handle says so: once on stderr, in btsbot_last_error() and through
+// btsbot_set_option(h, "query_side_apart", 0) (returns 1 / 0 as BTSBOT_OK / BTSBOT_ERR_STATE).
 __global__ void spin_kernel(unsigned long long ticks) {   // s_memrealtime counts at 100 MHz
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 __global__ void empty_kernel() {}
 
-int create_side_stream(btsbot_ctx* h, hipStream_t caller) {
-  hipEvent_t e_cand = nullptr;
-  HIP_TRY(hipEventCreateWithFlags(&e_cand, hipEventDisableTiming));
+namespace {
+constexpr double SAME_PIPE_EXTRA_US = 20.0;   // beside: +0 .. 9 us over the idle baseline; same pipe: +30 .. 40
+constexpr int PLACEMENT_TRIALS = 4;
+
+struct StreamPile {   // candidates that were not taken (and the event) are released on every path out
+  hipStream_t s[8];
+  int n = 0;
+  hipEvent_t ev = nullptr;
+  ~StreamPile() {
+    for (int i = 0; i < n; ++i) (void)hipStreamDestroy(s[i]);
+    if (ev != nullptr) (void)hipEventDestroy(ev);
+  }
+};
+
+// microseconds from the launch of an empty kernel on `cand` to the host seeing it done (minimum of the trials), with a
+// train of spinning kernels on each of busy[0..nbusy) when `loaded`
+int time_candidate(hipStream_t cand, hipEvent_t ev, const hipStream_t* busy, int nbusy, bool loaded, double* best_us) {
+  double best = 1e30;
+  for (int trial = 0; trial < PLACEMENT_TRIALS; ++trial) {
+    for (int b = 0; b < nbusy; ++b) HIP_TRY(hipStreamSynchronize(busy[b]));
+    if (loaded)
+      for (int i = 0; i < 24; ++i)          // 24 x 25 us per busy stream, interleaved so that every train has started
+        for (int b = 0; b < nbusy; ++b) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, busy[b], 2500ULL);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, cand);
+    HIP_TRY(hipEventRecord(ev, cand));
+    HIP_TRY(hipEventSynchronize(ev));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    best = us < best ? us : best;
+  }
+  for (int b = 0; b < nbusy; ++b) HIP_TRY(hipStreamSynchronize(busy[b]));
+  *best_us = best;
+  return BTSBOT_OK;
+}
+}  // namespace
+
+// a new non-blocking stream whose hardware queue is served by another pipe than every stream in busy[]
+int pick_apart_stream(btsbot_ctx* h, const hipStream_t* busy, int nbusy, const char* role, hipStream_t* out, bool* apart_out) {
+  StreamPile pile;
+  HIP_TRY(hipEventCreateWithFlags(&pile.ev, hipEventDisableTiming));
   const bool debug = getenv("BTSBOT_AMD_DEBUG_SIDE") != nullptr;
-  hipStream_t rejected[8];
-  int nrej = 0;
   hipStream_t chosen = nullptr;
+  bool apart = false;
   for (int attempt = 0; attempt < 8 && chosen == nullptr; ++attempt) {
     hipStream_t cand = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+    pile.s[pile.n++] = cand;
     hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, cand);   // (first use of the stream: its queue exists now)
     HIP_TRY(hipStreamSynchronize(cand));
-    double worst = 0.0;
-    for (int trial = 0; trial < 3; ++trial) {
-      HIP_TRY(hipStreamSynchronize(caller));
-      for (int i = 0; i < 24; ++i) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, caller, 2500ULL);   // 24 x 25 us
-      const auto t0 = std::chrono::steady_clock::now();
-      hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, cand);
-      HIP_TRY(hipEventRecord(e_cand, cand));
-      HIP_TRY(hipEventSynchronize(e_cand));
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      worst = us > worst ? us : worst;
-    }
-    HIP_TRY(hipStreamSynchronize(caller));
-    const bool apart = worst < 30.0;
+    double idle = 0.0, loaded = 0.0;
+    TRY(time_candidate(cand, pile.ev, busy, nbusy, false, &idle));
+    TRY(time_candidate(cand, pile.ev, busy, nbusy, true, &loaded));
+    apart = loaded - idle < SAME_PIPE_EXTRA_US;
     if (debug)
-      fprintf(stderr, "btsbot: side-stream candidate %d: its kernel took %.1f us beside a busy caller's stream %p -> %s\n",
-              attempt, worst, (void*)caller, apart ? "taken" : "same pipe, rejected");
-    if (apart) chosen = cand;
-    else rejected[nrej++] = cand;
+      fprintf(stderr, "btsbot: %s-stream candidate %d: its kernel returns in %.1f us with the %d busy stream(s) idle, %.1f us "
+                      "beside their spinning kernels -> %s\n", role, attempt, idle, nbusy, loaded,
+              apart ? "taken" : "shares a pipe, rejected");
+    if (apart) {
+      chosen = cand;
+      --pile.n;   // (the newest entry: leaves the pile)
+    }
   }
-  if (chosen == nullptr) chosen = rejected[--nrej];   // (no candidate ran beside the caller's stream: keep one anyway)
-  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
-  (void)hipEventDestroy(e_cand);
+  if (chosen == nullptr) {   // no candidate ran beside the busy streams: keep the last one, and say so
+    chosen = pile.s[--pile.n];
+    btsbot_set_error("warning: no %s stream on a hardware pipe of its own was found in 8 candidates; its kernels will take turns "
+                     "with the caller's (expect slower training steps)", role);
+    static bool told = false;
+    if (!told) {
+      told = true;
+      fprintf(stderr, "btsbot_amd: %s\n", btsbot_last_error());
+    }
+  }
+  *out = chosen;
+  *apart_out = apart;
+  (void)h;
+  return BTSBOT_OK;
+}
+
+int create_side_stream(btsbot_ctx* h, hipStream_t caller) {
+  // one choice per caller stream: a caller that alternates streams gets the stream picked for each back, no new probe
+  for (const SidePick& p : h->side_cache)
+    if (p.caller == caller) {
+      h->side = p.side;
+      h->side_for = caller;
+      h->side_apart = p.apart;
+      return BTSBOT_OK;
+    }
+  hipStream_t chosen = nullptr;
+  bool apart = false;
+  TRY(pick_apart_stream(h, &caller, 1, "side", &chosen, &apart));
+  h->side_cache.push_back(SidePick{caller, chosen, apart});
   h->side = chosen;
   h->side_for = caller;
+  h->side_apart = apart;
   return BTSBOT_OK;
 }
 
@@ -1573,9 +1683,8 @@ extern "C" int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream
     btsbot_set_error("wait_grad_bucket: btsbot_backward() has not run on this handle");
     return BTSBOT_ERR_STATE;
   }
-  h->bucket_waits_seen = true;
-  if (!h->bucket_fine) HIP_TRY(hipEventRecord(h->bucket_ev[bucket], h->last_bwd_stream));   // (ctx.h: bucket_fine)
-  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->bucket_ev[bucket], 0));
+  h->bucket_waits_seen = true;   // (the next backward records the per-stage events)
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->bucket_fine ? h->bucket_ev[bucket] : h->bwd_done, 0));
   return BTSBOT_OK;
 }
 
@@ -1665,9 +1774,19 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  if (h->xchg == nullptr) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->xchg, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->xchg_done, hipEventDisableTiming));
+  if (h->xchg == nullptr || h->xchg_for[0] != st || h->xchg_for[1] != h->side) {
+    // The collectives run long kernels: on the caller's pipe (or the side stream's) they would take turns with the
+    // backward exactly as a badly placed side stream does (create_side_stream).  Same measurement, against both.
+    if (h->xchg != nullptr) {
+      HIP_TRY(hipStreamSynchronize(h->xchg));
+      (void)hipStreamDestroy(h->xchg);
+      h->xchg = nullptr;
+    }
+    hipStream_t busy[2] = {st, h->side};
+    TRY(pick_apart_stream(h, busy, h->side != nullptr ? 2 : 1, "exchange", &h->xchg, &h->xchg_apart));
+    h->xchg_for[0] = st;
+    h->xchg_for[1] = h->side;
+    if (h->xchg_done == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->xchg_done, hipEventDisableTiming));
   }
   for (int i = 0; i < nspans; ++i) {
     if (bucket[i] < 0 || bucket[i] >= h->n_buckets || lo[i] < 0 || hi[i] > h->total_floats || lo[i] >= hi[i]) {
@@ -1677,8 +1796,7 @@ extern "C" int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* g
     }
     // the collective of a span starts as soon as the backward pass has written its bucket, on the library's exchange
     // stream: the rest of the backward keeps the caller's stream
-    if (!h->bucket_fine) HIP_TRY(hipEventRecord(h->bucket_ev[bucket[i]], h->last_bwd_stream));   // (ctx.h: bucket_fine)
-    HIP_TRY(hipStreamWaitEvent(h->xchg, h->bucket_ev[bucket[i]], 0));
+    HIP_TRY(hipStreamWaitEvent(h->xchg, h->bucket_fine ? h->bucket_ev[bucket[i]] : h->bwd_done, 0));   // (ctx.h: bucket_fine)
     float* base = grads + lo[i];
     const size_t n = (size_t)(hi[i] - lo[i]);
     int rc = 0;

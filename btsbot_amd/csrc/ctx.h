@@ -51,6 +51,10 @@ const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "g
 constexpr size_t PROF_MAX_LAUNCHES = 16384;
 
 struct MaxVit;   // maxvit.hip
+struct SidePick {
+  hipStream_t caller, side;
+  bool apart;
+};
 
 struct btsbot_ctx {
   btsbot_config cfg;
@@ -143,7 +147,6 @@ struct btsbot_ctx {
   // multi-GPU run, from its first step on).  bucket_fine: the LAST backward recorded bucket_ev[]; otherwise a waiter gets
   // an event recorded on that backward's stream at the time it asks (everything the backward queued is in front of it).
   bool bucket_waits_seen = false, bucket_fine = false;
-  hipStream_t last_bwd_stream = nullptr;
   bool meta_join_pending = false;   // the metadata branch's training forward sits on the side stream and `st` has not joined it yet
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
   bool s2p_train = false;            // the training forward of stage 2 runs stage2p_kernel's keeping form (16-bit modes;
@@ -171,6 +174,11 @@ struct btsbot_ctx {
   // second stream of the image-branch backward (backbone_train.hip): filter-gradient GEMMs trail the dX chain on it
   hipStream_t side = nullptr;
   hipStream_t side_for = nullptr;    // the caller's stream h->side was chosen against (create_side_stream)
+  bool side_apart = true;            // ... and was measured to run on another hardware pipe than it (false: none of 8 did)
+  std::vector<SidePick> side_cache;  // one chosen side stream per caller stream this handle has seen (never re-probed)
+  hipStream_t xchg_for[2] = {nullptr, nullptr};   // the (caller, side) pair h->xchg was placed against
+  bool xchg_apart = true;
+  hipEvent_t bwd_done = nullptr;     // recorded at the end of a backward that did not record the per-bucket events
   std::vector<hipEvent_t> side_ev;   // pool, side_used of them taken by the current btsbot_backward()
   size_t side_used = 0;
   // btsbot_pack_params_train() queues its packing launches on `side` behind the mirror copy: they then overlap the
@@ -212,6 +220,8 @@ struct btsbot_ctx {
 // Fork / join of the backward's second stream.  side_fork: work queued on *sd afterwards sees everything queued on
 // `st` so far (*sd = st when the second stream is off); side_join: `st` waits for everything queued on the side.
 int create_side_stream(btsbot_ctx* h, hipStream_t caller);   // api.hip: h->side, on another hardware queue than `caller`
+// api.hip: a new stream measured to run beside every stream of busy[] (else the last candidate, *apart = false + a warning)
+int pick_apart_stream(btsbot_ctx* h, const hipStream_t* busy, int nbusy, const char* role, hipStream_t* out, bool* apart);
 int side_fork(btsbot_ctx* h, hipStream_t st, hipStream_t* sd);
 int side_join(btsbot_ctx* h, hipStream_t st);
 

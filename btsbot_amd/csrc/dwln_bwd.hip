@@ -476,7 +476,7 @@ int dwln_bwd_rows(int HW, int C, int B) {
   if (B <= 0) return 0;
   if (HW == 15 && C == 64) return DwlnCfg<15, 64, 512, 1>::grid(B);
   if (HW == 7 && C == 128) return DwlnCfg<7, 128, 512, 1>::grid(B);
-  if (HW == 3 && C == 256) {   // (room for either kernel's rows: the deterministic mode runs the general one)
+  if (HW == 3 && C == 256) {   // (room for either kernel's rows: BTSBOT_AMD_DW3_OLD=1 runs the general one; the deterministic mode keeps the 3x3 kernel and adds its rows in one slice)
     const int r0 = DwlnCfg<3, 256, 512, 4>::grid(B), r1 = dw3_grid(B);
     return r0 > r1 ? r0 : r1;
   }

@@ -175,7 +175,9 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
 // this lane's pixel (32 of its 64 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
 // image; the zero padding around the 15x15 map is never touched
 // (LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind -- split mode)
-template <typename T, int LOPLANE = 0>
+// (SAT: the value is clamped to the f16 range first -- the keeping forms run their depthwise phase on f16 operands in
+//  every mode, and a bf16 handle's residual stream may exceed 65504: saturate instead of inf -> NaN through the LayerNorm)
+template <typename T, int LOPLANE = 0, bool SAT = false>
 __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
   const int y = p / HW, xx = p - y * HW;
   unsigned char* dst = pl + (xx >> 2) * PL_XQ + (y + 3) * 8 + (xx & 3) * 2 + h * 4 * PL_CH;
@@ -183,7 +185,7 @@ __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned c
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const T hi = (T)x[ct][r];
+      const T hi = (T)(SAT ? __builtin_amdgcn_fmed3f(x[ct][r], -65504.0f, 65504.0f) : x[ct][r]);
       *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = hi;
       if (LOPLANE > 0)
         *reinterpret_cast<T*>(dst + LOPLANE + (ct * 32 + 8 * (r >> 2) + (r & 3)) * PL_CH) = (T)(x[ct][r] - (float)hi);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
       }
       if (KEEP && live[t]) regs_to_tap(x[t], a.keep_stem_pre + ((size_t)alert * P + pix[t]) * C, h);
       ln_regs(x[t], a.stem_lnw, a.stem_lnb, h, x[t]);
-      if (live[t]) regs_to_planar<DT, PLO>(x[t], pl, pix[t], h);
+      if (live[t]) regs_to_planar<DT, PLO, KEEP && !std::is_same<T, f16_t>::value>(x[t], pl, pix[t], h);
       if (a.tap_stem != nullptr && live[t])
         regs_to_tap(x[t], a.tap_stem + ((size_t)alert * P + pix[t]) * C, h);
     }
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256, WPS) void stage0b_kernel(Stage0Args a) {
         load_block_params(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (live[t]) regs_to_planar<DT, PLO>(x[t], pl, pix[t], h);
+          if (live[t]) regs_to_planar<DT, PLO, KEEP && !std::is_same<T, f16_t>::value>(x[t], pl, pix[t], h);
           if (KEEP && live[t]) regs_to_tap(x[t], a.keep_xin1 + ((size_t)alert * P + pix[t]) * C, h);
         }
       }

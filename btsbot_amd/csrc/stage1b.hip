@@ -190,7 +190,9 @@ __device__ __forceinline__ void regs_to_map(const f32x16 (&x)[CT], unsigned char
 // this lane's pixel (64 of its 128 channels: rows (r & 3) + 8 (r >> 2) + 4 h of column block ct) into the planar
 // image; p = alert * 49 + y * 7 + x
 // (LOPLANE > 0: also the values' f16 remainders, LOPLANE bytes behind -- split mode)
-template <typename T, int LOPLANE = 0>
+// (SAT: the value is clamped to the f16 range first -- the keeping forms run their depthwise phase on f16 operands in
+//  every mode, and a bf16 handle's residual stream may exceed 65504: saturate instead of inf -> NaN through the LayerNorm)
+template <typename T, int LOPLANE = 0, bool SAT = false>
 __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned char* pl, int p, int h) {
   const int al = p >= PA ? 1 : 0, pp = p - al * PA;
   const int y = pp / HW, xx = pp - y * HW;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void regs_to_planar(const f32x16 (&x)[CT], unsigned c
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const T hi = (T)x[ct][r];
+      const T hi = (T)(SAT ? __builtin_amdgcn_fmed3f(x[ct][r], -65504.0f, 65504.0f) : x[ct][r]);
       *reinterpret_cast<T*>(dst + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = hi;
       if (LOPLANE > 0) *reinterpret_cast<T*>(dst + LOPLANE + (ct * 32 + 8 * (r >> 2) + (r & 3)) * 8) = (T)(x[ct][r] - (float)hi);
     }
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
   {
     f32x16 x0[CT];
     load_x(xsrc, x0);
-    if (inmap) regs_to_planar<DT, PLO>(x0, pl, p, h);
+    if (inmap) regs_to_planar<DT, PLO, KEEP && !std::is_same<T, f16_t>::value>(x0, pl, p, h);
   }
   SC_STAMP(1);
 
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256, WPS) void stage1b_kernel(Stage1Args a) {
       if (j == 0) {      // next block's depthwise operand; chunk 15 (slot 2 = the same bytes) must be read out first
         __syncthreads();
         zero_pads();
-        if (inmap) regs_to_planar<DT, PLO>(x, pl, p, h);
+        if (inmap) regs_to_planar<DT, PLO, KEEP && !std::is_same<T, f16_t>::value>(x, pl, p, h);
         if (live) {
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)

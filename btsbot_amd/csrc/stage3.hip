@@ -189,6 +189,7 @@ __device__ __forceinline__ void fc1_tile(const Stage3Args& a, const Stage3Blk& b
   constexpr int PITCH = C * ESZ + 16;   // bytes per LDS row: C operand values + 16 (8 rows cover the 32 banks)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int ht = nt * (N1 / 32) + wave;                 // this wave's tile of 32 hidden units
+  S3_STAMP(0);
   // ---- the 32 rows first (4 per wave; lane = channels 128 i + 2 lane + {0, 1}), then the per-channel constants
   constexpr int RPW = 4 * MB;   // rows per wave
   float2 v[RPW][NV];
@@ -317,6 +318,7 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
   const int m0 = mt * M2;
   const size_t wf0 = (size_t)(ct * NC) * KSA + wave * KSW, hf0 = (size_t)(m0 / 32) * KSA + wave * KSW, hf1 = hf0 + KSA;
   frag wa[NC][RING], ha[RING], hb[RING];
+  S3_STAMP(1);
 #pragma unroll
   for (int i = 0; i < RING; ++i) {
 #pragma unroll

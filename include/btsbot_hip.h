@@ -173,7 +173,13 @@ int btsbot_forward(btsbot_handle h, const float* triplets_nchw, const float* met
  * hidden activation (about 1.2 MB per alert; 2.8 MB with the backward's own per-block buffers) for a later
  * btsbot_backward(need_image_grads=1);
  * otherwise the image branch runs the fused inference kernels.  The MaxViT wirings take only that second form:
- * their BatchNorm2d layers use the running statistics (a frozen, eval-mode branch under trainable heads). */
+ * their BatchNorm2d layers use the running statistics (a frozen, eval-mode branch under trainable heads).
+ * 16-bit modes, pico: stem + stage 0 (+ stage 1 in the f16 mode) run the inference megakernels' keeping forms, whose
+ * depthwise phase reads its map and taps as F16 operands in EVERY mode (bf16 taps moved the 50-step loss curve ten
+ * times further from the fp32 recipe): a bf16 handle's stage-0/1 residual stream therefore has f16 RANGE during
+ * training -- values beyond +-65504 are saturated on their way into that phase (no inf / NaN), and the backward
+ * differentiates the convolution as written.  BTSBOT_AMD_NO_S0_TRAIN=1 (and NO_S1_TRAIN=1) at btsbot_create restores
+ * the per-op forward with its fp32 depthwise operands. */
 int btsbot_reserve_train(btsbot_handle h, int max_batch, int with_image_grads);
 int btsbot_forward_train(btsbot_handle h, const float* triplets_nchw, const float* meta,
                          float* logits, float* scores, int batch, const uint8_t* meta_keep_mask,
@@ -203,9 +209,10 @@ int btsbot_backward(btsbot_handle h, const float* dlogits, float* grad_arena, in
  * btsbot_wait_grad_bucket: makes `stream` wait (hipStreamWaitEvent) until the kernels of the LAST
  * btsbot_backward() call that write bucket `bucket` have finished; no host synchronisation.  (The per-bucket events
  * cost the backward a fork of its side stream each, so a handle records them only once it has seen a waiter -- this call
- * or btsbot_allreduce_grads.  The FIRST wait on a handle therefore orders `stream` behind everything that backward
- * queued -- correct, but without the overlap; from the next btsbot_backward() on the wait ends with the bucket.
- * Call it from the thread that called btsbot_backward(), before queuing other work on the backward's stream.) */
+ * or btsbot_allreduce_grads.  A backward that ran before any waiter records ONE event at its end instead, and the FIRST
+ * wait on a handle waits on that: `stream` is ordered behind everything that backward queued -- correct, but without
+ * the overlap; from the next btsbot_backward() on the wait ends with the bucket.  No stream handle is kept: any thread,
+ * any time after btsbot_backward() has returned.) */
 int btsbot_grad_buckets(btsbot_handle h, int capacity, int64_t* lo, int64_t* hi);
 int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
 
@@ -221,7 +228,10 @@ int btsbot_wait_grad_bucket(btsbot_handle h, int bucket, void* stream);
  * none.  `grads` must be the arena the last btsbot_backward() wrote (the bucket events belong to it;
  * BTSBOT_ERR_INVALID_ARG otherwise).  btsbot_set_option(h, "exchange", 1) switches every span from one ncclAllReduce
  * to the direct form for xGMI's point-to-point links: ncclReduceScatter (each rank owns the sum of its 1 / N slice)
- * + ncclAllGather, in place, plus a small ncclAllReduce for what is left after N equal slices. */
+ * + ncclAllGather, in place, plus a small ncclAllReduce for what is left after N equal slices.
+ * The exchange stream is placed like the backward's side stream: measured (once per caller stream) to run on another
+ * hardware pipe than `stream` AND the side stream, so that a long collective kernel does not take turns with the
+ * backward's kernels; btsbot_set_option(h, "query_side_apart", 0) tells whether that succeeded. */
 int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int nspans, const int* bucket,
                            const int64_t* lo, const int64_t* hi, void* stream);
 
@@ -233,7 +243,13 @@ int btsbot_allreduce_grads(btsbot_handle h, void* nccl_comm, float* grads, int n
  *   "deterministic" (also BTSBOT_AMD_DETERMINISTIC=1 at btsbot_create; set before btsbot_reserve_train): 1 = the batch
  *   reductions of the ConvNeXt training step that meet through fp32 atomics (LayerNorm / depthwise parameter gradients,
  *   column sums, the fused MLP backward's bias gradient) write partial rows and add them in a fixed order instead: two
- *   identical btsbot_backward() calls give bit-identical gradients (16-bit modes; ~25 small extra launches per step). */
+ *   identical btsbot_backward() calls give bit-identical gradients (16-bit modes; ~25 small extra launches per step).
+ *   btsbot_backward() checks the scratch against the batch BEFORE it launches anything (BTSBOT_ERR_STATE, no state
+ *   change); ConvNeXt wirings only (refused for MaxViT, ignored there when it comes from the environment).
+ *   "query_side_apart" (a query; `value` ignored): BTSBOT_OK when the second stream of btsbot_backward() and the
+ *   exchange stream of btsbot_allreduce_grads() were each measured on a hardware pipe of their own, BTSBOT_ERR_STATE
+ *   (and a warning on stderr at the time) when none of eight candidates was: two queues of one pipe take turns of ~50 us,
+ *   a 1024-alert step then takes 5-7 ms instead of 2.6. */
 int btsbot_set_option(btsbot_handle h, const char* key, int value);
 
 /* Validation aid with no reference counterpart: when on, forward() keeps fp32 copies of the stem and

@@ -54,17 +54,12 @@ print(f"   downsample: LN +{s2[57]-s2[56]:6d}  conv +{s2[58]-s2[57]:6d}")
 
 s3 = t[32 + 16384 + 64:32 + 16384 + 64 + 16]
 if any(s3):
-    print("stage3 (workgroup 0) total cycles", s3[8] - s3[0] if s3[8] else s3[7] - s3[0])
-    lab = ["fc1", "sync", "fc2", "sync"]
-    for j in range(2):
-        print("   block", j, "  ".join(f"{lab[i]} +{s3[1 + 4 * j + i] - s3[4 * j + i]:6d}" for i in range(4)))
-    print("   last fc1 tile: loads issued", s3[9] - s3[4], " LN done +", s3[10] - s3[9], " barrier +", s3[11] - s3[10], " MFMA loop +", s3[12] - s3[11],
-          " | last fc2 tile: MFMA loop done", s3[13] - s3[6], " reduced/stored +", s3[14] - s3[13])
-    w = np.array(t[32 + 16384 + 64 + 16:32 + 16384 + 64 + 16 + 5 * 256]).reshape(256, 5)
-    t0 = w[:, 0].min()
-    for k, nm in enumerate(["start", "fc1 done", "sync done", "fc2 done", "sync done"]):
-        d = (w[:, k] - t0) / 100.0
-        print(f"   {nm:10s} us after first start: min {d.min():6.1f} median {np.median(d):6.1f} max {d.max():6.1f}")
+    # the stage is four launches (s3_fc1, s3_fc2 per block): workgroup 0 of the LAST launch of each kernel leaves its stamps
+    print("stage3, workgroup 0 of the last s3_fc1 launch: total cycles", s3[12] - s3[0], "(+ GELU and the h stores)")
+    print(f"   rows + constants requested +{s3[9] - s3[0]:6d}  filter quarters + LayerNorm of 4 rows +{s3[10] - s3[9]:6d}  "
+          f"bias + barrier +{s3[11] - s3[10]:6d}  MFMA loop +{s3[12] - s3[11]:6d}")
+    print("stage3, workgroup 0 of the last s3_fc2 launch: total cycles", s3[14] - s3[1])
+    print(f"   fragments requested + MFMA loop +{s3[13] - s3[1]:6d}  K slices through LDS, + x, stored +{s3[14] - s3[13]:6d}")
 
 hs = t[32 + 16384 + 64 + 1500:32 + 16384 + 64 + 1500 + 10]
 if any(hs):
