@@ -83,13 +83,6 @@ int build_tables(btsbot_ctx* h) {
     }
     h->stage1 = stage1_supported(h->prec_s01(), c.dims[1], c.dims[2]) && c.depths[1] == 2;
     h->stage2p = stage2p_supported(h->prec_tail(), c.dims[2], c.dims[3], c.depths[2]);
-    {
-      // (opt-in, BTSBOT_AMD_STAGE1N=1: 150 us per 1024 alerts against 178 for the six launches it replaces, and no
-      //  measurable change of the forward -- the streaming design is LDS-bound at 160 channels)
-      const char* e1n = getenv("BTSBOT_AMD_STAGE1N");
-      h->stage1n = e1n != nullptr && e1n[0] == '1' && !h->x2 && !h->fp8 &&
-                   stage1n_supported(c.precision, c.dims[1], c.dims[2], c.depths[1]);
-    }
     h->stage3 = stage3_supported(h->prec_tail(), c.dims[3], c.depths[3]);
     h->blocks.resize(4);
     for (int i = 0; i < 4; ++i) {
@@ -104,7 +97,7 @@ int build_tables(btsbot_ctx* h) {
         h->down[i].b = add_param(h, p + "1.bias", {ch});
         h->down[i].p_w = bump(cur, (size_t)ch * cin * 4 * esz);
         h->down[i].p_wt = bump(cur, (size_t)ch * cin * 4 * esz);
-        if ((i == 3 && h->stage2p) || (i == 2 && (h->stage1 || h->stage1n))) {
+        if ((i == 3 && h->stage2p) || (i == 2 && h->stage1)) {
           h->down[i].p_wp = bump(cur, (size_t)ch * cin * 4 * esz);
           h->down[i].p_scale = bump(cur, 64);
         }
@@ -144,7 +137,7 @@ int build_tables(btsbot_ctx* h) {
           b.p_x2_w1lo = bump(cur, (size_t)4 * ch * ch * 2);
           b.p_x2_w2glo = bump(cur, (size_t)4 * ch * ch * 2);
         }
-        if ((i == 2 && h->stage2p) || (i == 3 && h->stage3) || (i == 1 && h->stage1n)) {
+        if ((i == 2 && h->stage2p) || (i == 3 && h->stage3)) {
           b.p_w1p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_w2p = bump(cur, (size_t)4 * ch * ch * esz);
           b.p_scales = bump(cur, 64);
@@ -372,17 +365,11 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     h->wgrad_batch = !(nwb != nullptr && nwb[0] == '1');
     const char* nss = getenv("BTSBOT_AMD_NO_SIDE_STREAM");
     h->use_side = !(nss != nullptr && nss[0] == '1');
-    // (opt-in: measured 252-259 us per launch with its 360 MB of kept rows against 100 us for the inference form -- the
-    //  same as the per-op launches it replaces)
-    const char* nst = getenv("BTSBOT_AMD_S2P_TRAIN");
-    h->s2p_train = h->stage2p && h->cfg.dims[2] == 256 && h->use_s2p && !h->x2 && !h->fp8 &&
-                   (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nst != nullptr && nst[0] == '1';
-    // (opt-in: measured 2.85 against 2.78 ms per 1024-alert step.  The chain gets 216 us shorter, but the step is bound
-    //  by the chip's total work, not by the chain -- both streams' kernels fill it -- and the keeping stores cost the
-    //  kernel 57 us: its counted vmcnt waits for filter fragments also wait for the stores queued in front of them)
-    const char* nsl = getenv("BTSBOT_AMD_S2P_LIGHT");
-    h->s2p_light = !h->s2p_train && h->stage2p && h->cfg.dims[2] == 256 && h->use_s2p && !h->x2 && !h->fp8 &&
-                   (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && nsl != nullptr && nsl[0] == '1';
+    // stage 2's training forward through stage2p_kernel's keeping form (ctx.h): on wherever its backward runs the 3x3
+    // kernel that recomputes the depthwise output (dw3ln_bwd_kernel: use_dwln and not BTSBOT_AMD_DW3_OLD)
+    const char* nst = getenv("BTSBOT_AMD_NO_S2P_TRAIN");
+    h->s2p_train = h->stage2p && h->cfg.dims[2] == 256 && h->use_s2p && !h->x2 && !h->fp8 && h->use_dwln && dw3_bwd_active(3, 256) &&
+                   (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && !(nst != nullptr && nst[0] == '1');
     const char* ns0t = getenv("BTSBOT_AMD_NO_S0_TRAIN");
     h->s0_train = h->stage0 && h->use_stage0 && !h->x2 && !h->fp8 &&
                   (h->cfg.precision == BTSBOT_BF16 || h->cfg.precision == BTSBOT_F16) && !(ns0t != nullptr && ns0t[0] == '1');
@@ -424,7 +411,6 @@ extern "C" int btsbot_destroy(btsbot_handle h) {
   for (hipEvent_t e : h->bucket_ev)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->side_ev) (void)hipEventDestroy(e);
-  if (h->s2_ready) (void)hipEventDestroy(h->s2_ready);
   if (h->pack_early_ev) (void)hipEventDestroy(h->pack_early_ev);
   bool side_cached = false;
   for (const SidePick& p : h->side_cache) {
@@ -539,6 +525,8 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       case PACK_TRANSPOSE_CAST: status = launch_transpose_cast(c.precision, src, scale, dst, R, Cc, st); break;
       case PACK_DOWN: status = launch_pack_down(c.precision, src, dst, R, Cc, st); break;
       case PACK_TFRAG: break;   // (unbatched: launch_pack_frag16 behind the transposes, below)
+      case PACK_FRAG:
+      case PACK_FRAG_DOWN: break;   // (unbatched: launch_pack_s2p, below)
       default: status = launch_pack_down_t(c.precision, src, dst, R, Cc, st);
     }
   };
@@ -551,7 +539,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       const int ch = c.dims[i];
       early_now = i <= 1;
       if (i > 0) {
-        job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
+        if (train_only && i == 3 && h->s2p_train)
+          job(PACK_FRAG_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wp, ch, c.dims[i - 1]);
+        else
+          job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
         early_now = false;   // (stage 1's own jobs and the dgrad transposes are not read by the stage-0 kernel)
         if (h->train_packs)
           job(PACK_DOWN_T, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wt, ch, c.dims[i - 1]);
@@ -559,9 +550,16 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       for (const BlockPk& b : h->blocks[i]) {
         early_now = i == 0;
         job(PACK_TRANSPOSE_F32, m + b.dw_w, nullptr, h->extra + b.p_dw, ch, 49);
-        job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
+        // (training re-pack with stage 2's forward through stage2p_kernel: its filters as MFMA fragments ride in the table;
+        //  the row-major images only the per-op forward reads are left alone)
+        const bool s2frag = train_only && i == 2 && h->s2p_train;
+        if (!s2frag) job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
         early_now = false;
-        job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
+        if (!s2frag) job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
+        if (s2frag) {
+          job(PACK_FRAG, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch);
+          job(PACK_FRAG, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch);
+        }
         if (h->train_packs) {   // W1^T [C][4C] and (diag(gamma) W2)^T [4C][C] for the dgrad GEMMs
           job(PACK_TRANSPOSE_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1t, 4 * ch, ch);
           job(PACK_TRANSPOSE_CAST, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2t, ch, 4 * ch);
@@ -627,14 +625,10 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
         if (!train_only || (i == 0 && h->s0_train && !h->pack_early) || (i == 1 && h->s1_train))
           TRY(launch_rowscale_cast(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_fc2g, ch,
                                    4 * ch, st));
-        if (i == 2 && h->stage2p && (!train_only || h->s2p_train || h->s2p_light)) {
+        if (i == 2 && h->stage2p && (!train_only || (h->s2p_train && unbatched))) {
           float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, sc, st));
           TRY(launch_pack_s2p(h->prec_tail(), m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, sc + 2, st));
-        }
-        if (i == 1 && h->stage1n && !train_only) {   // convnext_nano's stage 1 (stage1n.hip): the same fragment images
-          TRY(launch_pack_s2p(c.precision, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch, 0, 0, nullptr, st));
-          TRY(launch_pack_s2p(c.precision, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch, 0, 0, nullptr, st));
         }
         if (i == 3 && h->stage3 && !train_only) {
           float* sc = reinterpret_cast<float*>(h->extra + b.p_scales);
@@ -681,10 +675,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
   }
   if (convnext && h->stage1 && (!train_only || h->s1_train))
     TRY(launch_pack_frag32(h->prec_s01(), m + h->down[2].w, h->extra + h->down[2].p_wp, c.dims[2], c.dims[1], st));
-  if (convnext && h->stage1n && !train_only)
-    TRY(launch_pack_s2p(c.precision, m + h->down[2].w, nullptr, h->extra + h->down[2].p_wp, c.dims[2], 4 * c.dims[1], 1,
-                        c.dims[1], nullptr, st));
-  if (convnext && h->stage2p && (!train_only || h->s2p_train || h->s2p_light))
+  if (convnext && h->stage2p && (!train_only || (h->s2p_train && unbatched)))
     TRY(launch_pack_s2p(h->prec_down3(), m + h->down[3].w, nullptr, h->extra + h->down[3].p_wp, c.dims[3], 4 * c.dims[2], 1,
                         c.dims[2], nullptr, st));
   if (h->head16 && !train_only) {
@@ -1021,41 +1012,6 @@ static int backbone_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t s
         down_done = true;
         continue;
       }
-      if (i == 1 && h->stage1n && h->use_stage1) {
-        // convnext_nano: both blocks of the 7x7 stage and the downsample in front of stage 2 in one launch:
-        // x [nb][49][160] -> x2 [nb][9][320]
-        Stage2pArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x_in = x;
-        a.depth = (int)h->blocks[1].size();
-        for (int j = 0; j < a.depth; ++j) {
-          const BlockPk& b = h->blocks[1][j];
-          a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
-          a.blk[j].dw_b = m + b.dw_b;
-          a.blk[j].ln_w = m + b.ln_w;
-          a.blk[j].ln_b = m + b.ln_b;
-          a.blk[j].b1 = m + b.fc1_b;
-          a.blk[j].b2 = m + b.fc2_b;
-          a.blk[j].gamma = m + b.gamma;
-          a.blk[j].w1p = h->extra + b.p_w1p;
-          a.blk[j].w2p = h->extra + b.p_w2p;
-        }
-        a.ds_lnw = m + h->down[2].ln_w;
-        a.ds_lnb = m + h->down[2].ln_b;
-        a.ds_wp = h->extra + h->down[2].p_wp;
-        a.ds_b = m + h->down[2].b;
-        a.out = x2;
-        a.tap_stage = h->debug ? h->taps[2] : nullptr;
-        a.B = nb;
-        a.cw = c.dims[1];
-        a.stamps = h->stamps ? h->stamps + 16 : nullptr;   // (stage 1's 16 slots: tools/stamps_nano.py)
-        TRY(timed(h, CAT_STAGE1, st, [&] { return launch_stage1n(c.precision, a, st); }));
-        float* t = x;
-        x = x2;
-        x2 = t;
-        down_done = true;
-        continue;
-      }
       if (i == 2 && h->stage2p && h->use_s2p) {
         // every block of the 3x3 stage and the last downsample in one launch: x [nb][9][256] -> x2 [nb][512]
         Stage2pArgs a;
@@ -1373,12 +1329,6 @@ extern "C" int btsbot_forward_train(btsbot_handle h, const float* triplets, cons
   // the pool's events of the previous forward / backward are all recorded and their waits enqueued: start over (a loop of
   // training-mode forwards without a backward -- BatchNorm recalibration -- would otherwise grow the pool without bound)
   h->side_used = 0;
-  if (h->s2_pending) {
-    // light stage-2 forward (opt-in): the previous forward's recompute still reads the block inputs on the side stream
-    // and no backward has waited for it -- this forward overwrites them
-    HIP_TRY(hipStreamWaitEvent(st, h->s2_ready, 0));
-    h->s2_pending = false;
-  }
   h->t_img = triplets;
   // (the ConvNeXt training forward waits for the packing launches behind its stem, backbone_train.hip)
   if (!(h->has_image && keep_image_activations && !h->is_maxvit)) TRY(pack_sync(h, st));

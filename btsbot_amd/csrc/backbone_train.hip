@@ -80,14 +80,17 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
     k.xs[i] = reinterpret_cast<float*>(take(rows * ch * 4));
     k.patches[i] = i > 0 ? take(rows * 4 * c.dims[i - 1] * esz) : nullptr;
     if (i > 0 && rows * 4 * c.dims[i - 1] > maxpat) maxpat = rows * 4 * c.dims[i - 1];
+    // (stage 2 under stage2p_kernel's keeping form: room for 9 more alerts behind the batch -- the kernel stores the rows
+    //  of a ragged last workgroup and of its pad columns unconditionally, stage2p.hip)
+    const size_t prows = i == 2 && h->s2p_train ? rows + 9 * 9 : rows;
     for (int j = 0; j < c.depths[i]; ++j) {
       BlkBuf b;
-      b.xin = reinterpret_cast<float*>(take(rows * ch * 4));
-      b.d = reinterpret_cast<float*>(take(rows * ch * 4));
-      b.xn = take(rows * ch * esz);
+      b.xin = reinterpret_cast<float*>(take(prows * ch * 4));
+      b.d = reinterpret_cast<float*>(take(prows * ch * 4));
+      b.xn = take(prows * ch * esz);
       const bool keep4c = !h->mlp_fused((int)ch);   // fused blocks keep nothing 4C-wide (mlp_bwd.hip recomputes fc1)
-      b.a = keep4c ? take(rows * 4 * ch * esz) : nullptr;
-      b.h = keep4c ? take(rows * 4 * ch * esz) : nullptr;
+      b.a = keep4c ? take(prows * 4 * ch * esz) : nullptr;
+      b.h = keep4c ? take(prows * 4 * ch * esz) : nullptr;
       b.dyT = take(rows * ch * esz);
       b.da = keep4c ? take(rows * 4 * ch * esz) : nullptr;
       b.dwrows = h->use_dwln && dwln_bwd_supported(STAGE_HW[i], (int)ch) ? dwln_bwd_rows(STAGE_HW[i], (int)ch, B) : 0;
@@ -216,7 +219,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
   const bool s1t = h->s1_train && h->blocks[1].size() == 2 && h->mlp_fused(c.dims[1]) && h->use_dwln;
   for (int i = s0t ? 1 : 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0 && !(i == 3 && (h->s2p_train || h->s2p_light)) && !(i == 1 && s0t) && !(i == 2 && s1t)) {
+    if (i > 0 && !(i == 3 && h->s2p_train) && !(i == 1 && s0t) && !(i == 2 && s1t)) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
@@ -257,61 +260,12 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       TRYB(launch_stage1b(c.precision, a, st));
       continue;
     }
-    if (i == 2 && h->s2p_light) {
-      // Stage 2 and the last downsample as ONE launch of the inference kernel, which also leaves every block's input map,
-      // the stage output and the downsample's patch rows (100 us instead of 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM =
-      // 316 us in the chain).  What else the backward reads -- depthwise output, LayerNorm output, fc1 pre-activation and
-      // GELU of every block -- is recomputed from those inputs by the per-op kernels on the side stream, last block
-      // first, beside the chain's stage 3, heads, loss and their backward; the chain's stage-2 backward waits for it.
-      Stage2pArgs a;
-      memset(&a, 0, sizeof(a));
-      a.cw = c.dims[2];
-      a.x_in = stage_in(2);
-      a.depth = (int)nblk;
-      for (size_t j = 0; j < nblk; ++j) {
-        const BlockPk& b = h->blocks[2][j];
-        a.blk[j].dw_w = reinterpret_cast<const float*>(h->extra + b.p_dw);
-        a.blk[j].dw_b = m + b.dw_b;
-        a.blk[j].ln_w = m + b.ln_w;
-        a.blk[j].ln_b = m + b.ln_b;
-        a.blk[j].b1 = m + b.fc1_b;
-        a.blk[j].b2 = m + b.fc2_b;
-        a.blk[j].gamma = m + b.gamma;
-        a.blk[j].w1p = h->extra + b.p_w1p;
-        a.blk[j].w2p = h->extra + b.p_w2p;
-        a.keep[j].xin = j == 0 ? nullptr : k.blk[2][j].xin;
-      }
-      a.ds_lnw = m + h->down[3].ln_w;
-      a.ds_lnb = m + h->down[3].ln_b;
-      a.ds_wp = h->extra + h->down[3].p_wp;
-      a.ds_b = m + h->down[3].b;
-      a.out = stage_in(3);
-      a.tap_stage = k.xs[2];
-      a.ds_patches = k.patches[3];
-      a.B = B;
-      a.train = 2;
-      a.alerts_hint = h->s2p_alerts_hint;
-      TRYB(launch_stage2p(c.precision, a, st));
-      if (h->use_side && h->side == nullptr) TRYB(create_side_stream(h, st));
-      if (h->s2_ready == nullptr) HIP_TRY(hipEventCreateWithFlags(&h->s2_ready, hipEventDisableTiming));
-      hipStream_t sd = st;
-      TRYB(side_fork(h, st, &sd));
-      for (int j = (int)nblk - 1; j >= 0; --j) {
-        const BlockPk& b = h->blocks[2][j];
-        const BlkBuf& s = k.blk[2][j];
-        TRYB(launch_dwconv_ln(c.precision, s.xin, reinterpret_cast<const float*>(h->extra + b.p_dw), m + b.dw_b,
-                              m + b.ln_w, m + b.ln_b, s.xn, B, hw, ch, sd, s.d));
-        TRYB(launch_gemm(c.precision, EPI_GELU_SAVE, s.xn, h->extra + b.p_fc1, m + b.fc1_b, nullptr,
-                         reinterpret_cast<const float*>(s.a), s.h, rows, 4 * ch, ch, sd));
-      }
-      HIP_TRY(hipEventRecord(h->s2_ready, sd));
-      h->s2_pending = sd != st;
-      continue;
-    }
     if (i == 2 && h->s2p_train) {
       // Stage 2 and the last downsample as ONE launch: the inference kernel's keeping form (stage2p.hip, TRAIN) writes
-      // what the backward reads -- every block's input, depthwise output, LayerNorm output, fc1 pre-activation and GELU,
-      // the stage output, the downsample's patch rows -- on its way.  Replaces 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM.
+      // what the backward reads -- every block's input, LayerNorm output, fc1 pre-activation and GELU, the stage output,
+      // the downsample's patch rows -- on its way.  Replaces 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM.  The depthwise
+      // output is not kept: dw3ln_bwd_kernel recomputes it (block 0's buffer for it takes the copy of the stage input the
+      // kernel writes for every block alike).
       Stage2pArgs a;
       memset(&a, 0, sizeof(a));
       a.cw = c.dims[2];
@@ -329,8 +283,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
         a.blk[j].gamma = m + b.gamma;
         a.blk[j].w1p = h->extra + b.p_w1p;
         a.blk[j].w2p = h->extra + b.p_w2p;
-        a.keep[j].xin = j == 0 ? nullptr : sb.xin;
-        a.keep[j].d = sb.d;
+        a.keep[j].xin = j == 0 ? sb.d : sb.xin;
         a.keep[j].xn = sb.xn;
         a.keep[j].a = sb.a;
         a.keep[j].hh = sb.h;
@@ -344,6 +297,8 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       a.ds_patches = k.patches[3];
       a.B = B;
       a.train = 1;
+      a.alerts_hint = h->s2p_alerts_hint;
+      a.stamps = h->stamps ? h->stamps + 32 + 16384 : nullptr;   // (tools/stamps_train.py)
       TRYB(launch_stage2p(c.precision, a, st));
       continue;
     }
@@ -459,10 +414,6 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
   bool dyT_ready = false;
   for (int i = 3; i >= 0; --i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw, H = 4 * ch;
-    if (i == 2 && h->s2_pending) {   // the light forward's recompute of this stage's kept tensors (side stream)
-      HIP_TRY(hipStreamWaitEvent(st, h->s2_ready, 0));
-      h->s2_pending = false;
-    }
     WgradBatchJob bj[16];
     int nbj = 0;
     for (int j = (int)h->blocks[i].size() - 1; j >= 0; --j) {

@@ -324,9 +324,6 @@ int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.
 struct Stage2pArgs;
 bool stage2p_supported(int prec, int c2, int c3, int depth);
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
-// convnext_nano's stage 1 + the downsample in front of stage 2 as one launch (stage1n.hip; same argument block, depth 2)
-bool stage1n_supported(int prec, int c1, int c2, int depth);
-int launch_stage1n(int prec, const Stage2pArgs& a, hipStream_t st);
 // fp32 [rows][K] (reorder_down: a [Cout][Cin][2][2] downsample filter, K = 4 Cin) -> 16x16x32 A fragments
 // [row tile][k-step][lane][8], optionally scaled per row
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,
@@ -470,7 +467,10 @@ int launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t st);
 // each a 2-5 us kernel: launch-floor bound one by one).  The table lives in device memory; job j owns blocks
 // [blk0_j, blk0_{j+1}).  ops: the element maps of cast / transpose_f32 / transpose_cast / pack_down / pack_down_t.
 // PACK_TFRAG: the transpose-cast's result [Cc][R] as 16x16x32 MFMA A fragments [row tile][k-step][lane][8] (s2mlp_bwd.hip)
-enum { PACK_CAST = 0, PACK_TRANSPOSE_F32 = 1, PACK_TRANSPOSE_CAST = 2, PACK_DOWN = 3, PACK_DOWN_T = 4, PACK_TFRAG = 5 };
+// PACK_FRAG: src [R][Cc] (x scale[row]) as 16x16x32 MFMA A fragments [row tile][k-step][lane][8] (stage2p.hip's filters in the
+// training re-pack); PACK_FRAG_DOWN: a downsample filter [R = Cout][Cc = Cin][2][2] likewise with k = (2 ky + kx) * Cin + c
+enum { PACK_CAST = 0, PACK_TRANSPOSE_F32 = 1, PACK_TRANSPOSE_CAST = 2, PACK_DOWN = 3, PACK_DOWN_T = 4, PACK_TFRAG = 5, PACK_FRAG = 6,
+       PACK_FRAG_DOWN = 7 };
 struct PackJob {
   const float* src;
   const float* scale;   // PACK_TRANSPOSE_CAST: optional per-source-row scale

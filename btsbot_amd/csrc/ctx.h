@@ -108,7 +108,6 @@ struct btsbot_ctx {
   bool use_s2 = true;      // BTSBOT_AMD_NO_STAGE2=1: the per-op launches (dwconv_ln + fc1 / fc2 GEMMs) for stage 2
   int s2p_alerts_hint = 0; // btsbot_set_option("stage2p_alerts"): 0 = by rounds, 4 / 7 forced
   bool use_s2p = true;     // (= use_s2: stage2p.hip is the stage-2 kernel)
-  bool stage1n = false;    // BTSBOT_AMD_STAGE1N=1 (opt-in; convnext_nano, 16-bit modes): stage 1 + the next downsample run stage1n.hip
   bool stage2p = false;    // stage 2 + the last downsample as one persistent kernel
   bool fp8 = false;        // created with BTSBOT_FP8: cfg.precision reads BTSBOT_BF16, stages 2-3 run fp8 operands
   bool x2 = false;         // created with BTSBOT_F16X2: cfg.precision reads BTSBOT_F32 (the schedule of every kernel without
@@ -149,15 +148,10 @@ struct btsbot_ctx {
   bool bucket_waits_seen = false, bucket_fine = false;
   bool meta_join_pending = false;   // the metadata branch's training forward sits on the side stream and `st` has not joined it yet
   hipStream_t xchg = nullptr;        // btsbot_allreduce_grads: the stream its collectives run on
-  bool s2p_train = false;            // the training forward of stage 2 runs stage2p_kernel's keeping form (16-bit modes;
-                                     // BTSBOT_AMD_S2P_TRAIN=1 turns it on: no faster than the per-op launches)
-  // Light training forward of stage 2 (opt-in, BTSBOT_AMD_S2P_LIGHT=1; 16-bit modes): stage2p_kernel's inference form + each block's input
-  // map; the backward's other operands (depthwise output, LayerNorm output, fc1 pre-activation, GELU) are recomputed by
-  // the per-op kernels on the side stream, beside the chain's stage 3 / heads / loss, and `s2_ready` tells the chain's
-  // stage-2 backward that they are there.  Not faster than the per-op forward: see api.hip where the switch is read.
-  bool s2p_light = false;
-  hipEvent_t s2_ready = nullptr;
-  bool s2_pending = false;           // the last training forward queued that recompute: the backward waits for s2_ready
+  // Training forward of stage 2 + the last downsample as ONE launch of stage2p_kernel's keeping form (16-bit modes, 256
+  // channels; needs the 3x3 LayerNorm / depthwise backward kernel, which recomputes the depthwise output the form does
+  // not keep).  BTSBOT_AMD_NO_S2P_TRAIN=1: the per-op launches (A/B timing, parity tests).
+  bool s2p_train = false;
   // Training forward of stem + stage 0 + first downsample as ONE launch of the inference megakernel's keeping form
   // (stage0b.hip, KEEP) instead of stem16 + 2 x (dwconv_ln + fused_mlp) + ln_patch + GEMM (16-bit modes).
   // BTSBOT_AMD_NO_S0_TRAIN=1: the per-op launches (A/B timing, parity tests).

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   const int nblk = (lo + 1 < njobs ? jobs[lo + 1].blk0 : (int)gridDim.x) - jb.blk0;
   const float* __restrict__ s = jb.src;
   const int R = jb.R, Cc = jb.Cc;
-  const int64_t n = jb.op == PACK_DOWN || jb.op == PACK_DOWN_T ? (int64_t)R * Cc * 4 : (int64_t)R * Cc;
+  const int64_t n = jb.op == PACK_DOWN || jb.op == PACK_DOWN_T || jb.op == PACK_FRAG_DOWN ? (int64_t)R * Cc * 4 : (int64_t)R * Cc;
   const int64_t i0 = (int64_t)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x, step = (int64_t)nblk * 256;
   switch (jb.op) {
     case PACK_CAST: {
@@ -338,6 +338,32 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         const int ks = (int)(fs % ksteps), tile = (int)(fs / ksteps);
         const int c = 16 * tile + (l & 15), r = 32 * ks + 8 * (l >> 4) + j;
         d[i] = (T)(s[(int64_t)r * Cc + c] * (jb.scale != nullptr ? jb.scale[r] : 1.f));
+      }
+      break;
+    }
+    case PACK_FRAG:
+    case PACK_FRAG_DOWN: {   // lane l of fragment (tile, k-step) holds w[16 tile + (l & 15)][32 k-step + 8 (l >> 4) + 0..7] (stage2p.hip: pack_frag_kernel)
+      T* d = reinterpret_cast<T*>(jb.dst);
+      const bool down = jb.op == PACK_FRAG_DOWN;
+      const int K = down ? 4 * Cc : Cc, ksteps = K / 32;
+      for (int64_t i = i0; i < n; i += step) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        const int64_t fs = i >> 9;
+        const int ks = (int)(fs % ksteps), tile = (int)(fs / ksteps);
+        const int row = 16 * tile + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+        float v;
+        if (down) {
+          const int q = k / Cc, c = k - q * Cc;
+          v = s[((int64_t)row * Cc + c) * 4 + q];
+        } else {
+          v = s[(int64_t)row * K + k];
+        }
+        // (the product is rounded to fp32 BEFORE the conversion, as in stage2p.hip's pack_frag_kernel, which writes the same
+        //  image in the full pack: left alone hipcc fuses the two into v_fma_mixlo_f16 -- one rounding instead of two, other
+        //  bits in a few entries, and the first training step after a full pack would differ from the ones behind a re-pack)
+        float pr = v * (jb.scale != nullptr ? jb.scale[row] : 1.f);
+        asm volatile("" : "+v"(pr));
+        d[i] = (T)pr;
       }
       break;
     }
@@ -395,7 +421,7 @@ int launch_head(const HeadArgs& a, hipStream_t st) {
 }
 
 int pack_job_blocks(const PackJob& j) {
-  const int64_t n = (j.op == PACK_DOWN || j.op == PACK_DOWN_T ? 4 : 1) * (int64_t)j.R * j.Cc;
+  const int64_t n = (j.op == PACK_DOWN || j.op == PACK_DOWN_T || j.op == PACK_FRAG_DOWN ? 4 : 1) * (int64_t)j.R * j.Cc;
   const int64_t b = (n + 1023) / 1024;   // four elements per thread
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }

@@ -16,12 +16,12 @@ struct Stage2pBlk {
   const void* w2p;       // gamma * fc2 filter as A fragments: [channel tile 16][k-step 32][lane 64][8]
   const float* scales;   // fp8 mode: {S1, 1/S1, S2, 1/S2} (device): the powers of two the two filters were packed with
 };
-// Training forward (stage2p_kernel<T, G, true>): what the backward keeps of block j, written on the way --
-// backbone_train.hip's BlkBuf rows [B * 9][...]: the block's input (nullptr for block 0: x_in is that buffer), the
-// depthwise output before the LayerNorm, the LayerNorm output, the fc1 pre-activation and its GELU (operand type)
+// Training forward (stage2p_kernel<T, G, 1>): what the backward reads of block j, written on the way -- backbone_train.hip's
+// BlkBuf rows [(B + 9) * 9][...] (room for 9 alerts behind the batch: the kernel stores every row unconditionally): the
+// block's input (block 0: any buffer of that size, its input is x_in itself), the LayerNorm output, the rounded fc1
+// pre-activation and its GELU (operand type).  The depthwise output is not kept (dw3ln_bwd_kernel recomputes it).
 struct Stage2pKeep {
   float* xin;
-  float* d;
   void* xn;
   void* a;
   void* hh;
@@ -42,8 +42,8 @@ struct Stage2pArgs {
   int diag;              // developer switches (BTSBOT_AMD_S2P_DIAG): 1 barrier at every chunk start, 2 drain loads there
   int alerts_hint;       // 0: the library picks 5 or 7 alerts per workgroup by rounds; 4 / 5 / 7: the caller's choice
                          // (btsbot_set_option "stage2p_alerts")
-  int train;             // 1: the training forward (16-bit modes): keep[] / ds_patches are written; tap_stage = the stage
-                         // output the backward keeps
+  int train;             // 1: the training forward (16-bit modes, 256 channels): keep[] / ds_patches are written; tap_stage =
+                         // the stage output the backward keeps
   Stage2pKeep keep[S2P_MAX_DEPTH];
   void* ds_patches;      // [B][4 * 256] operand type: the downsample's LayerNorm'd patch rows, k = (2 ky + kx) * 256 + c
 };

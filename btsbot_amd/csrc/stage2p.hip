@@ -207,16 +207,43 @@ template <typename T, int G, int CW = 256> struct Lds {
   static constexpr int OFF_H = OFF_XN + NPL * XN_PLANE;
   static constexpr int OFF_B1 = OFF_H + 2 * H_IMG;            // fc1 bias [1024] f32
   static constexpr int BYTES = OFF_B1 + HID * 4;              // G = 4: 104704 (split: 160768); G = 7: 141312
-  // training forward: two more hidden-sized images (the fc1 pre-activation of a chunk, kept for the backward)
+  // training forward: two more hidden-sized images (the rounded fc1 pre-activation of a chunk, kept for the backward)
   static constexpr int OFF_A = BYTES;
   static constexpr int BYTES_TRAIN = BYTES + 2 * H_IMG;
 };
 static_assert(Lds<f16x2_t, 4>::BYTES <= 160 * 1024 && Lds<bf16_t, 7>::BYTES <= 160 * 1024, "the images fit one CU");
 constexpr float LN_EPS = 1e-6f;
+#ifndef XRES_TRAIN
+#define XRES_TRAIN 1
+#endif
 #define S2P_STAMP(i)                                                                      \
   do {                                                                                    \
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = clock64(); \
   } while (0)
+
+// Kept rows of the training forward leave through buffer stores: the base is a scalar descriptor, the lane's part a
+// 32-bit offset, the chunk's part a scalar offset -- no per-lane 64-bit pointers (six of them, strength-reduced over the
+// chunk loop, were 24 registers the loop does not have)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t keep_rsrc(void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000);
+}
+// cache policy of the kept rows' stores (the aux immediate of buffer_store: 1 sc0, 2 nt, 16 sc1).  Measured at 1024
+// alerts: 227 us default, 227 nt, 220 sc0 | nt | sc1, 222 sc0 | sc1 -- no policy matters; the default stays
+#ifndef KEEP_AUX
+#define KEEP_AUX 0
+#endif
+
+
+template <typename Q> __device__ __forceinline__ void keep_st8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, Q q) {
+  static_assert(sizeof(Q) == 8, "a quad of 16-bit values");
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, q), r, (int)voff, (int)soff, KEEP_AUX);
+}
+template <typename Q> __device__ __forceinline__ void keep_st16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, Q q) {
+  static_assert(sizeof(Q) == 16, "four fp32 values / a 16-byte piece");
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, q), r, (int)voff, (int)soff, KEEP_AUX);
+}
 
 // sum over the 32 lanes of a half wave (lanes 0-31 / 32-63 separately); every lane ends with its half's total
 __device__ __forceinline__ float half_sum(float v) {
@@ -226,9 +253,17 @@ __device__ __forceinline__ float half_sum(float v) {
   return v + w;
 }
 
-// TRAIN: 0 inference; 1 the keeping form (every tensor the backward reads); 2 the light training forward: the
-// inference kernel plus each block's input map, the stage output and the downsample's patch rows -- what is left
-// (depthwise output, LayerNorm output, fc1 pre-activation, GELU) backbone_train.hip recomputes beside the chain
+// TRAIN: 0 inference; 1 the training forward's keeping form: per block the input map (fp32), the LayerNorm output, the
+// ROUNDED fc1 pre-activation and its GELU (operand type) -- what s2mlp_bwd / dw3ln_bwd / the filter-gradient GEMMs read;
+// the depthwise output is not kept (dw3ln_bwd_kernel recomputes it from the input) -- plus the stage output and the
+// downsample's patch rows.  Every kept row leaves by an UNCONDITIONAL store: rows of alerts beyond the batch (a ragged
+// last workgroup) and the pad columns 9 G .. 16 NB - 1 go to padding the caller provides behind the live rows (buffers
+// hold (B + 9) alerts' rows; pad columns land on the rows of alerts B + 7, B + 8) -- with conditional stores or copy loops of
+// data-dependent length in the chunk loop hipcc's counted vmcnt waits for the filter fragments degrade to vmcnt(0):
+// rounds 4-5 measured 252-259 us for a keeping form written that way (and + 57 us for one that kept the block inputs
+// only) against 100 us for the inference form.  Stores are buffer stores (scalar descriptor + 32-bit lane offset + scalar
+// chunk offset): per-lane 64-bit pointers, strength-reduced over the chunk loop, cost the loop 24 registers it does not
+// have, and a spilled value's reload is again a vmcnt(0) in front of the fragments.
 template <typename T, int G, int TRAIN = 0, int CW = 256>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   using SH = Shp<CW>;
@@ -248,7 +283,9 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   // every wave re-reading it from LDS per chunk was 2/3 of the kernel's LDS traffic (196 of 288 KB per chunk)
   // (split: a fragment is 8 registers and the filter streams take 128 of them: nothing stays resident)
   // (16-bit, 3 column blocks: 5 or 6 spill in the block prologue and lose more than they save; 4 column blocks: 1 -- 2 spill)
-  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? 1 : NX > 0 ? 0 : F8 ? KS1 : 4;
+  // (training forward: ONE k-step -- the copy-out of the kept rows needs the registers: with two the chunk loop spills 5-8
+  //  of them, with four 33, and a spilled value's reload puts a vmcnt(0) in front of the filter fragments' counted waits)
+  constexpr int XRES = MP<T>::SPLIT ? 0 : NB > 3 ? 1 : NX > 0 ? 0 : F8 ? KS1 : TRAIN ? XRES_TRAIN : 4;
   constexpr int H_IMG = LD::H_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xl = reinterpret_cast<float*>(smem + OFF_XL);
@@ -266,7 +303,6 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   constexpr int KX = KS2 / 2;
   const int xtile = MF * NW + (NX > 0 ? wave & (NX - 1) : 0), cx0 = 16 * xtile + 4 * kg, xh = NX > 0 ? wave / NX : 0;
   const bool xlead = xh == 0;
-
   S2P_STAMP(0);
   // pad rows of the operand images: zero once (they are never written again)
   for (int i = tid; i < (NCOL - NPX) * XNP / 4; i += NT) {
@@ -329,7 +365,10 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     f32x4 g4[MF], b4[MF], gx4 = f32x4{0.f, 0.f, 0.f, 0.f}, bx4 = gx4;
     constexpr int CXL = C > 256 ? 256 : 0;   // (320 channels: a lane's 9th and 10th channel are 256 + 2 (lane & 31) + {0, 1})
     float2 lwx = make_float2(0.f, 0.f), lbx = lwx;
-    if constexpr (NX == 0) {
+    // (the training forward too: its kept rows' stores take the registers at this point, and a spilled value's reload is a
+    //  vmcnt(0) in front of the filter fragments still in flight)
+    constexpr bool LATE = NX > 0 || TRAIN != 0;
+    if constexpr (!LATE) {
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
         g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + dc];
     const float dbias = bk.dw_b[dc];
     f32x4 lw, lw2, lb, lb2;
-    if constexpr (NX == 0) {
+    if constexpr (!LATE) {
       lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
       lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
       lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
@@ -363,8 +402,11 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       for (int n = 0; n < NB; ++n) {
         const int p = 16 * n + col;
         if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
-        if (TRAIN && a.keep[j].xin != nullptr && p < nlive)
-          *reinterpret_cast<f32x4*>(a.keep[j].xin + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
+        // (training forward: the block's input rows, straight from the accumulators; pad columns: the rows of alerts B + 7,
+        //  B + 8 -- the caller's padding.  A coalesced copy out of the LDS map behind the barrier measured no faster and was
+        //  not reproducible from pass to pass -- 3 of 24 identical passes differed in one block's gradients; not understood)
+        if constexpr (TRAIN != 0)
+          keep_st16(keep_rsrc(a.keep[j].xin), (unsigned)(((p < NPX ? alert0 * 9 + p : (a.B + 7) * 9 + (p - NPX)) * C + c0) * 4), 0u, acc[m][n]);
       }
     }
     if (NX > 0) {   // the shared tiles: the pair's two partial residuals, one after the other
@@ -407,33 +449,28 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         for (int i = 0; i < 9; ++i) px[i * XLP] = o[i];
       }
     }
-    if constexpr (NX > 0) {
+    if constexpr (LATE) {
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
         g4[m] = *reinterpret_cast<const f32x4*>(bk.gamma + 16 * (MF * wave + m) + 4 * kg);
         b4[m] = *reinterpret_cast<const f32x4*>(bk.b2 + 16 * (MF * wave + m) + 4 * kg);
       }
-      gx4 = *reinterpret_cast<const f32x4*>(bk.gamma + cx0);
-      bx4 = *reinterpret_cast<const f32x4*>(bk.b2 + cx0);
       lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
       lw2 = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31) + 4);
       lb = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31));
       lb2 = *reinterpret_cast<const f32x4*>(bk.ln_b + 8 * (lane & 31) + 4);
-      lwx = *reinterpret_cast<const float2*>(bk.ln_w + CXL + 2 * (lane & 31));
-      lbx = *reinterpret_cast<const float2*>(bk.ln_b + CXL + 2 * (lane & 31));
+      if constexpr (NX > 0) {
+        gx4 = *reinterpret_cast<const f32x4*>(bk.gamma + cx0);
+        bx4 = *reinterpret_cast<const f32x4*>(bk.b2 + cx0);
+        lwx = *reinterpret_cast<const float2*>(bk.ln_w + CXL + 2 * (lane & 31));
+        lbx = *reinterpret_cast<const float2*>(bk.ln_b + CXL + 2 * (lane & 31));
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB1; ++i)   // (last read by the previous block's last fc1, two barriers ago)
       if (tid + i * NT < HID) b1s[tid + i * NT] = b1r[i];
     __syncthreads();
     S2P_STAMP(3 + 8 * j);
-    if (TRAIN == 1) {   // the depthwise output before the LayerNorm (it stays in xl until the next block's map)
-      float* dst = a.keep[j].d + (size_t)alert0 * 9 * C;
-      for (int i = tid; i < nlive * (C / 4); i += NT) {
-        const int p = i / (C / 4), c4 = i - p * (C / 4);
-        *reinterpret_cast<f32x4*>(dst + (size_t)p * C + 4 * c4) = *reinterpret_cast<const f32x4*>(xl + p * XLP + 4 * c4);
-      }
-    }
     // ---- LayerNorm over the 256 channels of a pixel: half wave = pixel, lane = 8 channels
     for (int p = 2 * wave + (lane >> 5); p < NPX; p += 2 * NW) {
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(xl + p * XLP + 8 * (lane & 31));
@@ -463,12 +500,15 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     }
     __syncthreads();
     S2P_STAMP(4 + 8 * j);
-    if (TRAIN == 1) {   // the LayerNorm output rows (16-byte pieces: C * ESZ / 16 per row)
-      unsigned char* dst = reinterpret_cast<unsigned char*>(a.keep[j].xn) + (size_t)alert0 * 9 * C * ESZ;
-      constexpr int PPR = C * ESZ / 16;
-      for (int i = tid; i < nlive * PPR; i += NT) {
+    if (TRAIN) {   // the LayerNorm output rows, 16-byte pieces (C * ESZ / 16 per row): a fixed number of trips per thread,
+                   // the last pieces written twice rather than under a condition (rows of absent alerts: the padding)
+      const __amdgpu_buffer_rsrc_t rx = keep_rsrc(a.keep[j].xn);
+      constexpr int PPR = C * ESZ / 16, NPC = NPX * PPR;
+#pragma unroll
+      for (int it = 0; it < (NPC + NT - 1) / NT; ++it) {
+        const int i = min(tid + it * NT, NPC - 1);
         const int p = i / PPR, c = i - p * PPR;
-        *reinterpret_cast<uint4*>(dst + (size_t)p * C * ESZ + 16 * c) = *reinterpret_cast<const uint4*>(xn + p * XNP + 16 * c);
+        keep_st16(rx, (unsigned)(p * C * ESZ + 16 * c), (unsigned)(alert0 * 9 * C * ESZ), *reinterpret_cast<const uint4*>(xn + p * XNP + 16 * c));
       }
     }
     frag xr[XRES > 0 ? XRES : 1][NB];
@@ -504,17 +544,23 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // P = which of the two hidden images this chunk writes (the other one holds chunk ch - 1's).
     // The next chunk's 16 fragment loads are spread over the k-steps: issued in one burst they hold every wave at the
     // CU's one vector-memory port for ~2k cycles before its first product.
-    // training forward: rows of chunk `kc`'s two images (pre-activation, GELU) -> the kept [row][1024] arrays
+    const __amdgpu_buffer_rsrc_t ra = keep_rsrc(TRAIN ? a.keep[j].a : nullptr), rh = keep_rsrc(TRAIN ? a.keep[j].hh : nullptr);
+    // training forward: chunk kc's two images (rounded pre-activation, GELU) -> columns kc of the kept [row][1024] arrays,
+    // 16-byte pieces, 16 per row: a wave instruction writes four whole 256-byte row pieces.  (Quads straight from the
+    // registers -- lane = (row, 4 hidden units), 64 separate 8-byte writes per instruction -- took the kernel from 100 to
+    // 279 us.)  A fixed number of trips per thread, the last pieces written twice; rows of absent alerts: the padding
     auto keep_chunk = [&](int kc, int img) {
-      constexpr int PPR = CHUNK * ESZ / 16;   // 16-byte pieces per pixel row of a chunk
-      unsigned char* da = reinterpret_cast<unsigned char*>(a.keep[j].a) + ((size_t)alert0 * 9 * HID + (size_t)kc * CHUNK) * ESZ;
-      unsigned char* dh = reinterpret_cast<unsigned char*>(a.keep[j].hh) + ((size_t)alert0 * 9 * HID + (size_t)kc * CHUNK) * ESZ;
-      for (int i = tid; i < nlive * PPR; i += NT) {
+      constexpr int PPR = CHUNK * ESZ / 16, NPC = NPX * PPR, TRIPS = (NPC + NT - 1) / NT;
+      const unsigned so = (unsigned)((alert0 * 9 * HID + kc * CHUNK) * ESZ);
+#pragma unroll
+      for (int it = 0; it < TRIPS; ++it) {   // (one trip's two pieces at a time: eight registers, not sixteen)
+        const int i = min(tid + it * NT, NPC - 1);
         const int pr = i / PPR, c = i - pr * PPR;
-        *reinterpret_cast<uint4*>(da + (size_t)pr * HID * ESZ + 16 * c) =
-            *reinterpret_cast<const uint4*>(ab + img * H_IMG + pr * HP + 16 * c);
-        *reinterpret_cast<uint4*>(dh + (size_t)pr * HID * ESZ + 16 * c) =
-            *reinterpret_cast<const uint4*>(hb + img * H_IMG + pr * HP + 16 * c);
+        const uint4 va = *reinterpret_cast<const uint4*>(ab + img * H_IMG + pr * HP + 16 * c);
+        const uint4 vh = *reinterpret_cast<const uint4*>(hb + img * H_IMG + pr * HP + 16 * c);
+        const unsigned vo = (unsigned)(pr * HID * ESZ + 16 * c);
+        keep_st16(ra, vo, so, va);
+        keep_st16(rh, vo, so, vh);
       }
     };
     auto step = [&](auto P, auto FIRST, int ch) {
@@ -568,7 +614,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       }
       // (training forward) chunk ch - 1's images are complete and live through this step: their rows leave behind the
       // fc1 products' issue, under their execution
-      if (TRAIN == 1 && !first) keep_chunk(ch - 1, 1 - p);
+      if constexpr (TRAIN == 1 && !first) keep_chunk(ch - 1, 1 - p);
       // fc2 of the previous chunk: out channels 32 wave .. + 31, K = its 128 hidden units (image hb[1 - p]), into the
       // residual; between its k-steps GELU of this chunk -> image hb[p] [pixel][hidden]; rows 4 kg .. + 3 of tile `wave`
       unsigned char* hcur = hb + p * H_IMG;
@@ -618,7 +664,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         }
         if (s < NB) {
           float hv[4];
-          if (TRAIN == 1) {
+          if constexpr (TRAIN == 1) {
             // the backward differentiates GELU at the ROUNDED pre-activation (as gemm2.hip's GELU_SAVE epilogue does)
             float av[4];
 #pragma unroll
@@ -626,6 +672,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
               av[r] = MP<T>::roundtrip(hacc[s][r]);
               hv[r] = gelu_for<typename GeluOf2<T>::type>(av[r]);
             }
+            // (the rounded pre-activation into its own image; both images leave as whole 256-byte row pieces one step later)
             MP<T>::template st4<H_PLANE>(ab + p * H_IMG + (16 * s + col) * HP + (16 * wave + 4 * kg) * ESZ, av);
           } else {
 #pragma unroll
@@ -640,7 +687,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // the fc2 half of a step of its own: the block's last chunk (the residual must be complete before the next
     // block's depthwise phase); it refills the a2 slots it empties with the next block's chunk 0
     auto fc2_tail = [&]() {
-      if (TRAIN == 1) keep_chunk(NCHUNK - 1, 1);
+      if constexpr (TRAIN == 1) keep_chunk(NCHUNK - 1, 1);
       const Stage2pBlk& nb = a.blk[j + 1 < a.depth ? j + 1 : j];
       const void* src2 = nb.w2p;
       const size_t f2 = (size_t)(MF * wave) * KH;
@@ -978,35 +1025,18 @@ int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
     btsbot_set_error("stage2p: width %d not supported", a.cw);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (a.train == 2) {   // the light training forward (16-bit modes; alerts per workgroup as in inference)
-    for (int j = 1; j < a.depth; ++j)
-      if (a.keep[j].xin == nullptr) {
-        btsbot_set_error("stage2p: the light training forward needs the input buffer of block %d", j);
-        return BTSBOT_ERR_INVALID_ARG;
-      }
-    if (a.ds_patches == nullptr || a.tap_stage == nullptr) {
-      btsbot_set_error("stage2p: the training forward needs ds_patches and the stage output (tap_stage)");
-      return BTSBOT_ERR_INVALID_ARG;
-    }
-    const int gl = stage2p_alerts_per_workgroup(a.B, a.alerts_hint);
-    if (prec == BTSBOT_BF16)
-      return gl == 7 ? launch_stage2p_t<bf16_t, 7, 2>(a, st) : gl == 5 ? launch_stage2p_t<bf16_t, 5, 2>(a, st) : launch_stage2p_t<bf16_t, 4, 2>(a, st);
-    if (prec == BTSBOT_F16)
-      return gl == 7 ? launch_stage2p_t<f16_t, 7, 2>(a, st) : gl == 5 ? launch_stage2p_t<f16_t, 5, 2>(a, st) : launch_stage2p_t<f16_t, 4, 2>(a, st);
-    btsbot_set_error("stage2p: the training forward runs in the bf16 / f16 modes, not %d", prec);
-    return BTSBOT_ERR_INVALID_ARG;
-  }
-  if (a.train) {   // the training forward: 16-bit modes, 4 or 5 alerts per workgroup (7 would not leave room for its images)
+  if (a.train) {   // the training forward: 16-bit modes, alerts per workgroup as in inference (4 / 5 / 7)
     for (int j = 0; j < a.depth; ++j)
-      if (a.keep[j].d == nullptr || a.keep[j].xn == nullptr || a.keep[j].a == nullptr || a.keep[j].hh == nullptr ||
-          (j > 0 && a.keep[j].xin == nullptr)) {
-        btsbot_set_error("stage2p: the training forward needs every kept buffer of block %d", j);
+      if (a.keep[j].xin == nullptr || a.keep[j].xn == nullptr || a.keep[j].a == nullptr || a.keep[j].hh == nullptr) {
+        btsbot_set_error("stage2p: the training forward needs every kept buffer of block %d (each with room for %d + 9 alerts)",
+                         j, a.B);
         return BTSBOT_ERR_INVALID_ARG;
       }
     if (a.ds_patches == nullptr || a.tap_stage == nullptr) {
       btsbot_set_error("stage2p: the training forward needs ds_patches and the stage output (tap_stage)");
       return BTSBOT_ERR_INVALID_ARG;
     }
+    // (4 or 5 alerts per workgroup: with 7 -- four column blocks -- the form spills 22-25 registers in its chunk loop)
     const bool g4 = stage2p_alerts_per_workgroup(a.B, a.alerts_hint) == 4;
     if (prec == BTSBOT_BF16) return g4 ? launch_stage2p_t<bf16_t, 4, 1>(a, st) : launch_stage2p_t<bf16_t, 5, 1>(a, st);
     if (prec == BTSBOT_F16) return g4 ? launch_stage2p_t<f16_t, 4, 1>(a, st) : launch_stage2p_t<f16_t, 5, 1>(a, st);

@@ -242,14 +242,10 @@ def test_nano_full_size_batch_matches_oracle(cuda, prec):
     print(f"nano B=1024 {prec}: max|dscore| {ds:.3e}")
 
 
-@pytest.mark.parametrize("schedule", ["default", "fused_stage1"])
 @pytest.mark.parametrize("B", [1, 6, 11])
-def test_nano_ragged_batches_match_oracle(cuda, monkeypatch, B, schedule):
+def test_nano_ragged_batches_match_oracle(cuda, B):
     """stage2p at 320 channels keeps 5 alerts per workgroup: a lone alert, one workgroup and an alert, two and an alert
-    (the shared row tiles' partial residuals must not leak between the live and the padded pixel columns).
-    fused_stage1: the opt-in stage-1 kernel (stage1n.hip, two alerts per workgroup: odd batches leave its last one half empty)."""
-    if schedule == "fused_stage1":
-        monkeypatch.setenv("BTSBOT_AMD_STAGE1N", "1")
+    (the shared row tiles' partial residuals must not leak between the live and the padded pixel columns)."""
     kind, cfg = CONFIGS["mm_nano_ls"]
     sd = seeded_state(kind, cfg, seed=3)
     img, meta, _ = synthetic_batch(B, seed=7)

@@ -325,7 +325,7 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
     assert not torch.equal(want, run_model(kind, build_model(kind, cfg, sd, cuda, "bf16"), img, meta))
 
 
-@pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_keeping_kernel", "stage2_light",
+@pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_per_op",
                                  "per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "stage2_two_gemms", "fork_per_block"])
 @pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
@@ -336,16 +336,14 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     ``mlp``: the blocks of the 64- and 128-channel stages run the fused MLP forward and mlp_bwd_kernel (default; 5400
     rows = 84 row tiles and a ragged one; 1176 rows in four hidden slices whose addend planes of dxn dwln_bwd_kernel
     adds), the 64-channel stage only, or none (the switches are read when the handle is created)."""
-    if prec == "f16" and mlp in ("stage2_light", "per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "fork_per_block"):
+    if prec == "f16" and mlp in ("per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "fork_per_block"):
         pytest.skip("this round's schedule cases run in bf16 (f16's default already runs both keeping forms)")
     if mlp == "stage0_only":
         monkeypatch.setenv("BTSBOT_AMD_MLP_BWD_C", "64")
     elif mlp == "unfused":
         monkeypatch.setenv("BTSBOT_AMD_NO_MLP_BWD", "1")
-    elif mlp == "stage2_keeping_kernel":   # stage 2's forward as ONE launch of stage2p_kernel's keeping form (opt-in)
-        monkeypatch.setenv("BTSBOT_AMD_S2P_TRAIN", "1")
-    elif mlp == "stage2_light":   # ... as the inference kernel + block inputs, the rest recomputed on the side stream (opt-in)
-        monkeypatch.setenv("BTSBOT_AMD_S2P_LIGHT", "1")
+    elif mlp == "stage2_per_op":   # stage 2's forward as per-op launches (default: ONE launch of stage2p_kernel's keeping form)
+        monkeypatch.setenv("BTSBOT_AMD_NO_S2P_TRAIN", "1")
     elif mlp == "per_op_forward":   # stem, stages 0-1 as per-op launches (the default forward runs stage0b's / stage1b's keeping forms)
         monkeypatch.setenv("BTSBOT_AMD_NO_S0_TRAIN", "1")
         monkeypatch.setenv("BTSBOT_AMD_NO_S1_TRAIN", "1")

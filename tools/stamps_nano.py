@@ -26,12 +26,3 @@ for j in range(6):   # (blocks 6-7 share their slots with the downsample's stamp
     print(f"   block {j}: map->LDS +{s2[b+1]-s2[b]:6d}  depthwise +{s2[b+2]-s2[b+1]:6d}  LN +{s2[b+3]-s2[b+2]:6d}  "
           f"chunks 0-1 +{s2[b+4]-s2[b+3]:6d}  2-9 +{s2[b+6]-s2[b+4]:6d}  (block {s2[b+8] - s2[b]:7d})")
 print(f"   downsample: LN +{s2[57]-s2[56]:6d}  conv +{s2[58]-s2[57]:6d}   whole kernel {s2[58]-s2[0]}")
-s1 = t[16:32]
-if any(s1):
-    print(f"stage1n (workgroup 0): prologue +{s1[1] - s1[0]}")
-    for j in range(2):
-        b = 1 + 5 * j
-        nxt = s1[b + 5] if j == 0 else s1[11]
-        print(f"   block {j}: residual->map +{s1[b+1]-s1[b]:6d}  depthwise +{s1[b+2]-s1[b+1]:6d}  LN +{s1[b+3]-s1[b+2]:6d}  "
-              f"steps 0-1 +{s1[b+4]-s1[b+3]:6d}  steps 2-4 + tail +{nxt-s1[b+4]:6d}  (block {nxt - s1[b]:7d})")
-    print(f"   downsample: map + LN +{s1[12]-s1[11]:6d}  conv +{s1[13]-s1[12]:6d}   whole kernel {s1[13]-s1[0]}")
