@@ -92,7 +92,7 @@ BBCache carve_bb(const btsbot_ctx* h, unsigned char* base, int B) {
       b.a = keep4c ? take(prows * 4 * ch * esz) : nullptr;
       b.h = keep4c ? take(prows * 4 * ch * esz) : nullptr;
       b.dyT = take(rows * ch * esz);
-      b.da = keep4c ? take(rows * 4 * ch * esz) : nullptr;
+      b.da = keep4c ? take((rows + 48) * 4 * ch * esz) : nullptr;   // (+ 48 rows: s2mlp_bwd_kernel's last workgroup stores its dead rows too)
       b.dwrows = h->use_dwln && dwln_bwd_supported(STAGE_HW[i], (int)ch) ? dwln_bwd_rows(STAGE_HW[i], (int)ch, B) : 0;
       b.dwpart = b.dwrows ? reinterpret_cast<float*>(take((size_t)b.dwrows * 52 * ch * 4)) : nullptr;
       b.fpart = h->mlp_fused((int)ch) ? reinterpret_cast<float*>(take(mlp_bwd_part_floats((int)ch, (int)rows) * 4))

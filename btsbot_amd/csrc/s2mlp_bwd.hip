@@ -40,6 +40,15 @@ template <> struct SM<f16_t> {
   }
 };
 
+// da leaves through buffer stores (scalar descriptor, 32-bit lane offset, scalar chunk offset), as whole 256-byte row pieces
+// out of its LDS image one step behind: stage2p.hip's keeping form says why (scattered quads: 64 separate 8-byte writes per
+// wave instruction; conditional copy loops: vmcnt(0) in front of the fragment streams)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s2_rsrc(void* p) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ void s2_st16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, uint4 q) {
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, q), r, (int)voff, (int)soff, 0);
+}
+
 constexpr int C = 256, HID = 1024, NT = 512, NW = 8;
 constexpr int CHUNK = 128, NCHUNK = HID / CHUNK;
 constexpr int KS1 = C / 32, KS2 = CHUNK / 32, KH = HID / 32;   // k-steps: first product (K = 256), second per chunk, second in all
@@ -55,7 +64,7 @@ struct S2MlpBwdArgs {
   const void* a;      // [R][1024] operand type: the fc1 pre-activation the forward kept
   const void* w2tp;   // (gamma W2)^T as A fragments [hidden tile 64][k-step 8][lane 64][8]
   const void* w1tp;   // W1^T as A fragments [channel tile 16][k-step 32][lane 64][8]
-  void* da;           // [R][1024] operand type
+  void* da;           // [R + 48][1024] operand type (the last workgroup stores its dead rows -- zeros -- too)
   float* dxn;         // [R][256] fp32
   int R, rw;          // rows; rows per workgroup (<= 48)
 };
@@ -97,7 +106,19 @@ __global__ __launch_bounds__(NT, 2) void s2mlp_bwd_kernel(S2MlpBwdArgs a) {
   // rows per wave instruction.  Routed through LDS images as whole 256-byte row pieces instead -- pre-activations parked a
   // step ahead, da copied out of its image a step behind -- the kernel took 36-40 us instead of 30-34: measured, not kept)
   const T* ap = reinterpret_cast<const T*>(a.a) + 16 * wave + 4 * kg;
-  T* dap = reinterpret_cast<T*>(a.da) + 16 * wave + 4 * kg;
+  const __amdgpu_buffer_rsrc_t rda = s2_rsrc(a.da);
+  // chunk kc's da image -> columns kc of da [R][1024]: fixed trips per thread, the last pieces written twice
+  auto da_out = [&](int kc, int img) {
+    constexpr int PPR = CHUNK * 2 / 16, TRIPS = (NCOL * PPR + NT - 1) / NT;   // (rw <= 48 rows x 16 pieces: two trips)
+    const int npc = a.rw * PPR;
+    const unsigned so = (unsigned)(((size_t)r0 * HID + (size_t)kc * CHUNK) * 2);
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+      const int i = min(tid + it * NT, npc - 1);
+      const int pr = i / PPR, c = i - pr * PPR;
+      s2_st16(rda, (unsigned)(pr * HID * 2 + 16 * c), so, *reinterpret_cast<const uint4*>(hb + img * H_IMG + pr * HP + 16 * c));
+    }
+  };
   size_t rowoff[NB];
   bool rlive[NB];
 #pragma unroll
@@ -144,6 +165,7 @@ __global__ __launch_bounds__(NT, 2) void s2mlp_bwd_kernel(S2MlpBwdArgs a) {
       a1[s] = w2f[(size_t)((nch * NW + wave) * KS1 + s) * 64];
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (!first) da_out(ch - 1, 1 - p);   // (the previous chunk's image is complete and lives through this step)
     // second product of the previous chunk (dxn += W1^T[:, chunk - 1] . da[chunk - 1]) between the GELU' pieces of this one
     unsigned char* hcur = hb + p * H_IMG;
     const unsigned char* hprev = hb + (1 - p) * H_IMG;
@@ -175,7 +197,6 @@ __global__ __launch_bounds__(NT, 2) void s2mlp_bwd_kernel(S2MlpBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dv[r] = (T)(t[s][r] * gelu_grad_for<T>((float)aq[s][r]));
         *reinterpret_cast<quad*>(hcur + (16 * s + col) * HP + (16 * wave + 4 * kg) * 2) = dv;
-        if (rlive[s]) *reinterpret_cast<quad*>(dap + rowoff[s] + ch * CHUNK) = dv;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -187,6 +208,7 @@ __global__ __launch_bounds__(NT, 2) void s2mlp_bwd_kernel(S2MlpBwdArgs a) {
   {   // the last chunk's second product (chunk NCHUNK - 1 is odd: image 1)
     static_assert(NCHUNK % 2 == 0, "the last chunk writes hidden image 1");
     const unsigned char* hprev = hb + 1 * H_IMG;
+    da_out(NCHUNK - 1, 1);
 #pragma unroll
     for (int s = 0; s < KS2; ++s) {
       frag hbf[NB];
