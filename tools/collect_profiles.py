@@ -58,7 +58,14 @@ if glob.glob("gpurun_out/final/pmc_fetch_train/*/*_counter_collection.csv"):   #
 if os.path.exists(f"profiles/{tag}_pmc_traffic_train.json") and os.path.exists(f"profiles/{tag}_kernel_stats_train_bf16_b1024.csv"):
     import subprocess
     subprocess.run([sys.executable, "tools/hbm_kernels.py", tag], check=True, stdout=subprocess.DEVNULL)
+if glob.glob("gpurun_out/final/mv_fetch/*/*_counter_collection.csv"):   # mm_MaxViT forward: per-kernel statistics + traffic
+    import subprocess
+    shutil.copy(newest("gpurun_out/final/mv_trace/*/*_kernel_stats.csv"), f"profiles/{tag}_maxvit_kernel_stats.csv")
+    subprocess.run([sys.executable, "tools/maxvit_traffic.py", "gpurun_out/final/mv_fetch", "gpurun_out/final/mv_write",
+                    "gpurun_out/final/mv_trace", "4", f"profiles/{tag}_maxvit_traffic.json"], check=True)
 for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"), ("stamps_nano.log", "stage_stamps_nano.txt"),
+                 ("stamps.log", "stage_stamps.txt"), ("stamps_train.log", "stage_stamps_train.txt"),
+                 ("train_s2_ab.log", "train_stage2_forward_ab.txt"), ("train_timeline.txt", "train_timeline.txt"),
                  ("train_f32_ab.log", "train_f32_ab.txt")):   # tools/nano_bench.py; train step default vs
     if os.path.exists(f"gpurun_out/final/{src}"):                                        # one stream + three-launch LN/dw backward
         shutil.copy(f"gpurun_out/final/{src}", f"profiles/{tag}_{dst}")

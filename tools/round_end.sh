@@ -14,6 +14,10 @@ timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smok
 ( time timeout -k 10 400 python bench.py ) > $O/bench_default.log 2>&1 &&
 timeout -k 10 120 python tools/nano_bench.py 1024 bf16 > $O/nano.log 2>&1 &&
 timeout -k 10 120 python tools/stamps_nano.py > $O/stamps_nano.log 2>&1 &&
+timeout -k 10 120 python tools/stamps.py 1024 > $O/stamps.log 2>&1 &&
+timeout -k 10 120 python tools/stamps_train.py 1024 bf16 > $O/stamps_train.log 2>&1 &&
+timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 > $O/train_s2_ab.log 2>&1 &&
+BTSBOT_AMD_NO_S2P_TRAIN=1 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 >> $O/train_s2_ab.log 2>&1 &&
 timeout -k 10 120 python tools/train_bench.py 1024 f32 10 > $O/train_f32_ab.log 2>&1 &&
 BTSBOT_AMD_WGRAD_F32_OLD=1 timeout -k 10 120 python tools/train_bench.py 1024 f32 10 >> $O/train_f32_ab.log 2>&1 &&
 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 > $O/train_ab.log 2>&1 &&
@@ -33,5 +37,14 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_train -- python3 tools/train_bench.py 1024 bf16 5 > $O/pmc_write_train.log 2>&1
 rc=$?
 fi
+if [ $rc = 0 ]; then
+# one training step's two-queue timeline, and the MaxViT forward's per-kernel statistics and HBM-side traffic
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/train_tl -- python3 tools/train_bench.py 1024 bf16 8 > $O/train_tl.log 2>&1 &&
+python3 tools/train_timeline.py $O/train_tl > $O/train_timeline.txt 2>&1 &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mv_trace -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_trace.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/mv_fetch -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_fetch.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/mv_write -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_write.log 2>&1
+rc=$?
+fi
 echo "chain rc=$rc" > $O/chain.log
-cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace pmc_fetch_train pmc_write_train; do tail -n 1 $O/$f.log | cut -c1-200; done
+cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace pmc_fetch_train pmc_write_train train_tl mv_trace mv_fetch mv_write; do tail -n 1 $O/$f.log | cut -c1-200; done

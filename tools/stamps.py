@@ -66,5 +66,6 @@ if any(hs):
     print("head16 (workgroup 0) total cycles", hs[8] - hs[0])
     for i, nm in enumerate(["loads issued", "feature LN", "meta in", "step 0", "step 1", "step 2", "step 3", "step 4"]):
         print(f"   {nm:14s} +{hs[i + 1] - hs[i]:7d}")
-    d = t[32 + 16384 + 64 + 1500 + 10:32 + 16384 + 64 + 1500 + 15]
-    print("   inside meta fc2: ring+bias issued/arrived", d[1] - d[0], " MFMA loop", d[2] - d[1], " barrier", d[3] - d[2], " epilogue", d[4] - d[3], " (entry at +", d[0] - hs[4], ")")
+    d = t[32 + 16384 + 64 + 1500 + 10:32 + 16384 + 64 + 1500 + 15]   # slots 10, 12, 13, 14 (11 is unused)
+    print("   inside meta fc2: entry -> fragments arrived + MFMA loop", d[2] - d[0], " barrier", d[3] - d[2], " epilogue", d[4] - d[3],
+          " (entry at +", d[0] - hs[4], ")")
