@@ -541,8 +541,7 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       if (i > 0) {
         if (train_only && i == 3 && h->s2p_train)
           job(PACK_FRAG_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wp, ch, c.dims[i - 1]);
-        else
-          job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
+        job(PACK_DOWN, m + h->down[i].w, nullptr, h->extra + h->down[i].p_w, ch, c.dims[i - 1]);
         early_now = false;   // (stage 1's own jobs and the dgrad transposes are not read by the stage-0 kernel)
         if (h->train_packs)
           job(PACK_DOWN_T, m + h->down[i].w, nullptr, h->extra + h->down[i].p_wt, ch, c.dims[i - 1]);
@@ -550,12 +549,12 @@ static int pack_impl(btsbot_handle h, const float* master, void* stream, bool tr
       for (const BlockPk& b : h->blocks[i]) {
         early_now = i == 0;
         job(PACK_TRANSPOSE_F32, m + b.dw_w, nullptr, h->extra + b.p_dw, ch, 49);
-        // (training re-pack with stage 2's forward through stage2p_kernel: its filters as MFMA fragments ride in the table;
-        //  the row-major images only the per-op forward reads are left alone)
+        // (training re-pack with stage 2's forward through stage2p_kernel: its filters as MFMA fragments ride in the table,
+        //  beside the row-major images the per-op forward reads -- large batches take that one, backbone_train.hip)
         const bool s2frag = train_only && i == 2 && h->s2p_train;
-        if (!s2frag) job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
+        job(PACK_CAST, m + b.fc1_w, nullptr, h->extra + b.p_fc1, 4 * ch * ch, 1);
         early_now = false;
-        if (!s2frag) job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
+        job(PACK_CAST, m + b.fc2_w, nullptr, h->extra + b.p_fc2, 4 * ch * ch, 1);
         if (s2frag) {
           job(PACK_FRAG, m + b.fc1_w, nullptr, h->extra + b.p_w1p, 4 * ch, ch);
           job(PACK_FRAG, m + b.fc2_w, m + b.gamma, h->extra + b.p_w2p, ch, 4 * ch);

@@ -217,9 +217,13 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
                      B, c.dims[0], st, k.stem_pre));
   TRYB(pack_sync(h, st));   // the operand images of this step (packed on the side stream while the stem ran)
   const bool s1t = h->s1_train && h->blocks[1].size() == 2 && h->mlp_fused(c.dims[1]) && h->use_dwln;
+  // stage 2 through stage2p_kernel's keeping form up to two rounds of one workgroup (5 alerts) per CU: 2.50 against 2.57 ms
+  // per 1024-alert step; at 4096 alerts the per-op GEMMs (36 864 rows: full tiles, full rounds) are as fast or faster
+  // (7.95 against 8.00 ms), so large batches keep them
+  const bool s2t = h->s2p_train && B <= 2560;
   for (int i = s0t ? 1 : 0; i < 4; ++i) {
     const int ch = c.dims[i], hw = STAGE_HW[i], rows = B * hw * hw;
-    if (i > 0 && !(i == 3 && h->s2p_train) && !(i == 1 && s0t) && !(i == 2 && s1t)) {
+    if (i > 0 && !(i == 3 && s2t) && !(i == 1 && s0t) && !(i == 2 && s1t)) {
       const int cin = c.dims[i - 1];
       TRYB(launch_ln_patch(c.precision, k.xs[i - 1], m + h->down[i].ln_w, m + h->down[i].ln_b,
                            k.patches[i], B, STAGE_HW[i - 1], cin, st));
@@ -260,7 +264,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       TRYB(launch_stage1b(c.precision, a, st));
       continue;
     }
-    if (i == 2 && h->s2p_train) {
+    if (i == 2 && s2t) {
       // Stage 2 and the last downsample as ONE launch: the inference kernel's keeping form (stage2p.hip, TRAIN) writes
       // what the backward reads -- every block's input, LayerNorm output, fc1 pre-activation and GELU, the stage output,
       // the downsample's patch rows -- on its way.  Replaces 6 x (dw3_ln + two GEMMs) + ln_patch + GEMM.  The depthwise
