@@ -326,6 +326,18 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
     ha[i] = S3M<T>::ldg(a.hfrag, hf0 + i, lane);
     hb[i] = S3M<T>::ldg(a.hfrag, hf1 + i, lane);
   }
+  // the epilogue's operands (this thread's four residual values, layer scale, bias) are requested behind the fragments:
+  // asked for only after the K slices had met in LDS they were one more exposed memory round trip per launch (~2.5k cycles
+  // of the workgroup's 14.7k).  (One channel tile per workgroup only: with two the fragments leave no registers for them.)
+  constexpr bool EPI_PRE = NC == 1;
+  float4 xv_pre = make_float4(0.f, 0.f, 0.f, 0.f), g_pre = xv_pre, b_pre = xv_pre;
+  if constexpr (EPI_PRE) {
+    const int q = tid, t = q >> 8, qd = (q >> 6) & 3, ln = q & 63;
+    const int al = m0 + 32 * t + (ln & 31), c = 32 * ct + 8 * qd + 4 * (ln >> 5);
+    xv_pre = *reinterpret_cast<const float4*>(a.x + (size_t)(al < a.B ? al : a.B - 1) * C + c);
+    g_pre = *reinterpret_cast<const float4*>(bk.gamma + c);
+    b_pre = *reinterpret_cast<const float4*>(bk.b2 + c);
+  }
   __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc sinks the loads to their MFMAs: ~10 in flight instead of 48)
   f32x16 acc[NC][2];
 #pragma unroll
@@ -379,9 +391,9 @@ __device__ __forceinline__ void fc2_tile(const Stage3Args& a, const Stage3Blk& b
     }
     if (al < a.B) {
       float* xp = a.x + (size_t)al * C + c;
-      const float4 xv = *reinterpret_cast<const float4*>(xp);
-      const float4 g = *reinterpret_cast<const float4*>(bk.gamma + c);
-      const float4 b = *reinterpret_cast<const float4*>(bk.b2 + c);
+      const float4 xv = EPI_PRE ? xv_pre : *reinterpret_cast<const float4*>(xp);
+      const float4 g = EPI_PRE ? g_pre : *reinterpret_cast<const float4*>(bk.gamma + c);
+      const float4 b = EPI_PRE ? b_pre : *reinterpret_cast<const float4*>(bk.b2 + c);
       *reinterpret_cast<float4*>(xp) = make_float4(xv.x + fmaf(g.x, b.x, s.x), xv.y + fmaf(g.y, b.y, s.y),
                                                    xv.z + fmaf(g.z, b.z, s.z), xv.w + fmaf(g.w, b.w, s.w));
     }
