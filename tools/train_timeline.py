@@ -24,4 +24,10 @@ for a, b, n, q in seg:
     last[q] = b
     mark = 'C' if q == mainq else '  s'
     print(f"{(a - t0) / 1e3:8.1f} {(b - a) / 1e3:7.1f} {mark:3s} gap {gap:6.1f}  {short(n)}")
-print(f"step wall {(seg[-1][1] - t0) / 1e3:.1f} us")
+busy = {}
+for a, b, n, q in seg:
+    busy[q] = busy.get(q, 0.0) + (b - a) / 1e3
+chain = busy.get(mainq, 0.0)
+side = sum(v for q, v in busy.items() if q != mainq)
+print(f"step wall {(seg[-1][1] - t0) / 1e3:.1f} us; kernels: {len(seg)} launches, chain queue busy {chain:.1f} us, other queues {side:.1f} us, "
+      f"both {chain + side:.1f} us")
