@@ -347,14 +347,6 @@ extern "C" int btsbot_create(const btsbot_config* cfg, btsbot_handle* out) {
     const char* mbc = getenv("BTSBOT_AMD_MLP_BWD_C");
     const char* nmb = getenv("BTSBOT_AMD_NO_MLP_BWD");
     h->mlp_bwd_only = nmb != nullptr && nmb[0] == '1' ? -1 : mbc != nullptr ? atoi(mbc) : 0;
-    // (opt-in: measured 2.71-2.73 against 2.70-2.71 ms per step -- the third convolution costs the kernel more than the
-    //  59 MB it no longer reads and the 118 MB stage0b no longer writes save: it is not bound by its bytes alone)
-    const char* ndr = getenv("BTSBOT_AMD_DWLN_RECOMP");
-    h->dwln_recomp = ndr != nullptr && ndr[0] == '1';
-    // (opt-in: 0.41 GB less HBM-side traffic per step for 10 us of 2.66 ms, and the 50-step bf16 trajectory uses 0.78-0.80 of
-    //  its loss band instead of 0.66-0.72: not worth the rounding)
-    const char* np16 = getenv("BTSBOT_AMD_PLANES16");
-    h->planes16 = np16 != nullptr && np16[0] == '1';
     // (default since its operand images come out of the re-pack's job table: with a dozen launches of their own queued in
     //  front of the forward's join the kernel LOST 30 us per step; now 2.549-2.560 against 2.565-2.581 ms)
     const char* ns2m = getenv("BTSBOT_AMD_NO_S2MLP");

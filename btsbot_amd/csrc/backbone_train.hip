@@ -194,7 +194,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
       a.blk[j].w1 = h->extra + b.p_fc1;
       a.blk[j].w2g = h->extra + b.p_fc2g;
       a.blk[j].par = h->extra + b.p_s0par_t;
-      a.keep_d[j] = h->dwln_recomp ? nullptr : k.blk[0][j].d;
+      a.keep_d[j] = k.blk[0][j].d;
       a.keep_xn[j] = k.blk[0][j].xn;
     }
     a.ds_lnw = m + h->down[1].ln_w;
@@ -249,7 +249,7 @@ int backbone_train_forward(btsbot_ctx* h, const float* img, int B, hipStream_t s
         a.blk[j].w1 = h->extra + b.p_fc1;
         a.blk[j].w2g = h->extra + b.p_fc2g;
         a.blk[j].par = h->extra + b.p_s0par_t;
-        a.keep_d[j] = h->dwln_recomp ? nullptr : k.blk[1][j].d;
+        a.keep_d[j] = k.blk[1][j].d;
         a.keep_xn[j] = k.blk[1][j].xn;
       }
       a.ds_lnw = m + h->down[2].ln_w;
@@ -432,7 +432,6 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       const bool adjacent = b.dw_b == b.dw_w + 49 * (int64_t)ch && b.ln_w == b.dw_b + ch && b.ln_b == b.ln_w + ch;
       // (the hidden slices of the 128-channel form hand dxn over as addend planes: dwln_bwd_kernel is their reader)
       const int planes = s.fpart != nullptr ? mlp_bwd_planes(ch) : 1;
-      const int p16 = planes > 1 && prec == BTSBOT_BF16 && h->planes16 ? 1 : 0;   // the addend planes in bf16
       if (planes > 1 && !(s.dwpart != nullptr && adjacent)) {
         btsbot_set_error("backward: the fused MLP backward of a %d-channel block needs dwln_bwd_kernel behind it", ch);
         return BTSBOT_ERR_STATE;
@@ -440,7 +439,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
       if (s.fpart != nullptr) {
         // ---- da, dxn = da W1 and both filter gradients of the MLP in one launch (a recomputed from xn; da, g only on chip)
         TRYB(launch_mlp_bwd(prec, ch, s.xn, s.dyT, h->extra + b.p_fc1, h->extra + b.p_fc2t, m + b.fc1_b, dxn, s.fpart,
-                            k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red, p16));
+                            k.G, s.fS, grads + b.fc1_w, grads + b.fc1_b, rows, st, red));
         TRYB(fork());
       } else if (h->s2mlp && b.p_w1tp != 0 && s2mlp_bwd_supported(prec, ch)) {
         // ---- 256 channels: da = (dy (diag(gamma) W2)) * gelu'(a) and dxn = da W1 in one launch (s2mlp_bwd.hip)
@@ -466,8 +465,7 @@ int backbone_train_backward(btsbot_ctx* h, const float* img, const float* dfeat,
         TRYB(add_pend(s.dwpart, grads + b.dw_w, dw3_rows(B), 0));
       } else if (s.dwpart != nullptr && adjacent) {
         // ---- LayerNorm backward, depthwise filter gradient and dx = dy + conv_flipped(dd) in one launch
-        TRYB(launch_dwln_bwd(h->dwln_recomp ? nullptr : s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st,
-                             planes, (size_t)rows * ch, m + b.dw_b, p16));
+        TRYB(launch_dwln_bwd(s.d, dxn, m + b.ln_w, s.xin, wdw, dy, nxt, prec, s.dwpart, B, hw, ch, st, planes, (size_t)rows * ch));
         TRYB(add_pend(s.dwpart, grads + b.dw_w, s.dwrows, 52 * ch));
       } else if (hw == 1 && h->use_dwln && ch <= 640) {
         // ---- 1x1 maps: the same three steps per (alert, channel) in one launch

@@ -352,7 +352,7 @@ size_t mlp_bwd_part_floats(int C, int R);   // scratch for the partial filter-gr
 int mlp_bwd_planes(int C);
 int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
                    float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
-                   WgradReduceJob* jobs, int planes16 = 0);   // planes16 (bf16 mode, several planes): the planes leave as bf16
+                   WgradReduceJob* jobs);
 int launch_wgrad16(int prec, const void* D, const void* A, float* out, float* colsum, int M, int N,
                    int K, int ldo, hipStream_t st, float* part = nullptr, size_t part_floats = 0,
                    WgradReduceJob* defer = nullptr);   // wgrad.hip: 16-bit modes, colsum optional
@@ -404,7 +404,7 @@ int dwln_bwd_rows(int HW, int C, int B);   // partial rows (52 * C floats each) 
 // (d == nullptr: the depthwise output is recomputed from x_in, the taps and the depthwise bias dwb)
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes = 1,
-                    size_t pstride = 0, const float* dwb = nullptr, int planes16 = 0);   // planes16: dxn's addend planes are bf16
+                    size_t pstride = 0);
 // 3x3 maps of 256 channels: their own kernel (d recomputed from x_in, compact partial rows) and its row reduction
 bool dw3_bwd_active(int HW, int C);
 int dw3_rows(int B);

@@ -189,11 +189,6 @@ struct btsbot_ctx {
     return mlp_bwd_only >= 0 && (mlp_bwd_only == 0 || mlp_bwd_only == ch) && use_fused && (ch == 64 || use_dwln) &&
            mlp_bwd_supported(cfg.precision, ch) && fused_mlp_supported(cfg.precision, ch);
   }
-  bool dwln_recomp = false; // BTSBOT_AMD_DWLN_RECOMP=1 (opt-in, not faster: api.hip): dwln_bwd_kernel recomputes the depthwise
-                            // output from x_in instead of reading the kept one, and the megakernels' keeping forms do not
-                            // write it
-  bool planes16 = false;   // BTSBOT_AMD_PLANES16=1 (opt-in, bf16 mode): mlp_bwd_kernel's four addend planes of dxn (128 channels)
-                           // leave as bf16 and dwln_bwd_kernel reads them so (206 MB less per block; api.hip says why not default)
   bool s2mlp = true;       // 256-channel blocks: da and dxn of the MLP backward as one launch (s2mlp_bwd.hip) instead of two tiled
                            // GEMMs; BTSBOT_AMD_NO_S2MLP=1: the GEMMs (A/B timing, parity tests)
   bool fork_per_block = false;   // BTSBOT_AMD_FORK_PER_BLOCK=1: the blocks of a batched stage fork the side stream one by one, as

@@ -28,10 +28,10 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w, float* dy,
                                                       void* __restrict__ out16, int prec16,
                                                       float* __restrict__ partials, int B, int ga, int nplanes,
-                                                      size_t pstride, const float* __restrict__ dwb, int p16) {
-  // d == nullptr (opt-in, BTSBOT_AMD_DWLN_RECOMP=1): the depthwise output is RECOMPUTED from x_in (taps, bias dwb) into the
-  // LDS map that later holds dd.  The kernel moves 325 MB per launch at 15x15x64 (d, dxn, x_in, dy in; dy out twice: 81 us
-  // at 4 TB/s of its 98), but the third convolution costs more than the 59 MB saved: + 10 us per step.
+                                                      size_t pstride) {
+  // The kernel moves 325 MB per launch at 15x15x64 (d, dxn, x_in, dy in; dy out twice: 81 us at 4 TB/s of its 98-113).
+  // (Measured in round 5 and removed in round 6: recomputing d from x_in -- the third convolution cost more than the 59 MB
+  //  saved, + 10 us per step -- and bf16 addend planes of dxn -- 10 us per step for 0.12 of the trajectory test's band.)
   // dxn may arrive as `nplanes` addends, pstride floats apart (mlp_bwd_kernel's hidden slices each write their own)
   extern __shared__ __attribute__((aligned(16))) float sm[];   // xs [NA P][C] | ds [NA P][C] | flipped taps [49][C]
   constexpr int P = HW * HW, PA = NA * P;   // NA alerts share a pass (3x3 maps: their latencies are paid once)
@@ -80,39 +80,7 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
           if (i0 + k * NT < n4) dst[i0 + k * NT] = v[k];
       }
     }
-    if (d == nullptr) {
-      // ---- d = dwconv(x_in) + bias into ds: thread = (channel, row group), the forward tap t is flipped tap 48 - t
-      __syncthreads();   // x_in is staged
-      const float bias = dwb[c];
-      for (int q = rg; q < na * HW; q += G) {
-        const int al = q / HW, y = q - al * HW;
-        const float* xsa = xs + al * P * C;
-        float o[HW];
-#pragma unroll
-        for (int xx = 0; xx < HW; ++xx) o[xx] = bias;
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-          const int iy = y + ky - 3;
-          if (iy < 0 || iy >= HW) continue;
-          float in[HW], wk[7];
-#pragma unroll
-          for (int xx = 0; xx < HW; ++xx) in[xx] = xsa[(iy * HW + xx) * C + c];
-#pragma unroll
-          for (int kx = 0; kx < 7; ++kx) wk[kx] = ws[(48 - (ky * 7 + kx)) * C + c];
-#pragma unroll
-          for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-            for (int xx = 0; xx < HW; ++xx) {
-              const int ix = xx + kx - 3;
-              if (ix >= 0 && ix < HW) o[xx] = fmaf(in[ix], wk[kx], o[xx]);
-            }
-        }
-#pragma unroll
-        for (int xx = 0; xx < HW; ++xx) ds[(al * P + y * HW + xx) * C + c] = o[xx];
-      }
-      __syncthreads();   // d is complete (the LayerNorm phase reads whole pixel rows of it)
-    }
-    const float* dsrc = d != nullptr ? d + base : ds;   // pixel rows of d: global, or the recomputed map in LDS
+    const float* dsrc = d + base;   // pixel rows of the kept depthwise output
     // LayerNorm backward, two row groups per wave pass (4 x 16-byte loads in flight per lane)
     for (int r0 = wv * R * 2; r0 < pa; r0 += NW * R * 2) {
       float4 v[2], dx[2];
@@ -123,18 +91,6 @@ __global__ __launch_bounds__(NT) void dwln_bwd_kernel(const float* __restrict__ 
         ok[u] = r < pa;
         const int rr = ok[u] ? r : 0;
         v[u] = *reinterpret_cast<const float4*>(dsrc + (size_t)rr * C + 4 * l);
-        if (p16) {   // bf16 addend planes (mlp_bwd_kernel, several hidden slices in the bf16 mode), pstride ELEMENTS apart
-          const unsigned short* d16 = reinterpret_cast<const unsigned short*>(dxn);
-          dx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int pl = 0; pl < nplanes; ++pl) {
-            const uint2 e = *reinterpret_cast<const uint2*>(d16 + pl * pstride + base + (size_t)rr * C + 4 * l);
-            dx[u].x += __uint_as_float(e.x << 16);
-            dx[u].y += __uint_as_float(e.x & 0xffff0000u);
-            dx[u].z += __uint_as_float(e.y << 16);
-            dx[u].w += __uint_as_float(e.y & 0xffff0000u);
-          }
-          continue;
-        }
         dx[u] = *reinterpret_cast<const float4*>(dxn + base + (size_t)rr * C + 4 * l);
         for (int pl = 1; pl < nplanes; ++pl) {
           const float4 e = *reinterpret_cast<const float4*>(dxn + pl * pstride + base + (size_t)rr * C + 4 * l);
@@ -449,8 +405,7 @@ template <int HW, int C, int NT, int NA> struct DwlnCfg {
 
 template <int HW, int C, int NT, int NA>
 int dwln_launch(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
-                void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes, size_t pstride,
-                const float* dwb, int p16) {
+                void* out16, int prec16, float* partials, int B, hipStream_t st, int nplanes, size_t pstride) {
   using K = DwlnCfg<HW, C, NT, NA>;
   constexpr int G = NT / C;
   static_assert((size_t)(G / 2) * 50 * C * sizeof(float) <= K::lds, "closing reduction fits the maps' footprint");
@@ -461,7 +416,7 @@ int dwln_launch(const float* d, const float* dxn, const float* g, const float* x
     attr.done();
   }
   hipLaunchKernelGGL((dwln_bwd_kernel<HW, C, NT, NA>), dim3(K::grid(B)), dim3(NT), K::lds, st, d, dxn, g, xin, w, dy,
-                     out16, prec16, partials, B, K::ga(B), nplanes, pstride, dwb, p16);
+                     out16, prec16, partials, B, K::ga(B), nplanes, pstride);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -488,19 +443,15 @@ int dwln_bwd_rows(int HW, int C, int B) {
 // tensors, so the caller finishes with ONE column sum of the rows into the arena (launch_colsum, any stream).
 int launch_dwln_bwd(const float* d, const float* dxn, const float* g, const float* xin, const float* w, float* dy,
                     void* out16, int prec16, float* partials, int B, int HW, int C, hipStream_t st, int nplanes,
-                    size_t pstride, const float* dwb, int planes16) {
+                    size_t pstride) {
   if (B <= 0) return BTSBOT_OK;
-  if (planes16 && !(HW == 7 && C == 128)) {
-    btsbot_set_error("dwln_bwd: bf16 addend planes are the 128-channel form's");
+  if (d == nullptr) {
+    btsbot_set_error("dwln_bwd: the kept depthwise output is missing");
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (d == nullptr && dwb == nullptr) {
-    btsbot_set_error("dwln_bwd: without the kept depthwise output it needs the depthwise bias to recompute it");
-    return BTSBOT_ERR_INVALID_ARG;
-  }
-  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
-  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
-  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride, dwb, planes16);
+  if (HW == 15 && C == 64) return dwln_launch<15, 64, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
+  if (HW == 7 && C == 128) return dwln_launch<7, 128, 512, 1>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
+  if (HW == 3 && C == 256) return dwln_launch<3, 256, 512, 4>(d, dxn, g, xin, w, dy, out16, prec16, partials, B, st, nplanes, pstride);
   btsbot_set_error("dwln_bwd: no kernel for a %dx%d map of %d channels", HW, HW, C);
   return BTSBOT_ERR_INVALID_ARG;
 }

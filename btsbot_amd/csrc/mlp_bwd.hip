@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ b1, float* __restrict__ dxn,
                                                           float* __restrict__ partG, float* __restrict__ partW,
                                                           float* __restrict__ db1, float* __restrict__ Ssum, int R,
-                                                          float* detb, float* dets, int p16) {
+                                                          float* detb, float* dets) {
   using G = BwdGeo<C, NW>;
   using M = MB<T>;
   constexpr int PX = G::PX, PD = G::PD;
@@ -242,15 +242,6 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
     const size_t oi = (size_t)blockIdx.y * R * C + (size_t)(tile * G::TR + 16 * mi + 4 * (lane >> 4)) * C + 16 * ni0 + (lane & 15);
     float* o = dxn + oi;
     if (MLP_BWD_ABL & 8) return;
-    if (p16) {   // the addend planes in bf16 (several hidden slices, bf16 mode): half the bytes out here and in at the reader
-      bf16_t* o16 = reinterpret_cast<bf16_t*>(dxn) + oi;
-#pragma unroll
-      for (int i = 0; i < G::TPW; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (tile * G::TR + 16 * mi + 4 * (lane >> 4) + r < R) o16[r * C + 16 * i] = (bf16_t)dx[i][r];
-      return;
-    }
     if (tile * G::TR + G::TR <= R) {   // whole tile inside the map (workgroup-uniform): no per-row masks
 #pragma unroll
       for (int i = 0; i < G::TPW; ++i)
@@ -419,8 +410,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const T* __restrict__ 
 
 template <typename T, int C, int NW>
 int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1, float* dxn,
-                   float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs,
-                   int p16) {
+                   float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs) {
   using G = BwdGeo<C, NW>;
   auto kern = mlp_bwd_kernel<T, C, NW>;
   static DevOnce attr;
@@ -436,7 +426,7 @@ int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w
   if (dets == nullptr) detb = nullptr;
   hipLaunchKernelGGL(kern, dim3(gx, G::NH), dim3(G::NT), G::BYTES, st, reinterpret_cast<const T*>(xn),
                      reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(w1), reinterpret_cast<const T*>(w2g), b1,
-                     dxn, partG, partW, db1, Ssum, R, detb, dets, G::NH > 1 ? p16 : 0);
+                     dxn, partG, partW, db1, Ssum, R, detb, dets);
   LAUNCH_CHECK();
   if (detb != nullptr) {
     const DetOut ob{db1, 1}, os{Ssum, 1};
@@ -450,9 +440,9 @@ int mlp_bwd_launch(const void* xn, const void* dy, const void* w1, const void* w
 
 template <typename T>
 int mlp_bwd_t(int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1, float* dxn,
-              float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs, int p16) {
-  if (C == 64) return mlp_bwd_launch<T, 64, 8>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs, p16);
-  return mlp_bwd_launch<T, 128, 4>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs, p16);
+              float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st, WgradReduceJob* jobs) {
+  if (C == 64) return mlp_bwd_launch<T, 64, 8>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+  return mlp_bwd_launch<T, 128, 4>(xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
 }
 
 }  // namespace
@@ -477,13 +467,13 @@ size_t mlp_bwd_part_floats(int C, int R) { return (size_t)mlp_bwd_slices(C, R) *
 // R * C floats (C = 128: its four hidden slices; the reader adds them, launch_dwln_bwd's nplanes).
 int launch_mlp_bwd(int prec, int C, const void* xn, const void* dy, const void* w1, const void* w2g, const float* b1,
                    float* dxn, float* part, float* Gacc, float* Ssum, float* dW1, float* db1, int R, hipStream_t st,
-                   WgradReduceJob* jobs, int planes16) {
+                   WgradReduceJob* jobs) {
   jobs[0].nsl = jobs[1].nsl = 0;
   if (R <= 0) return BTSBOT_OK;
   if (!mlp_bwd_supported(prec, C)) {
     btsbot_set_error("mlp_bwd: unsupported (prec %d, C %d)", prec, C);
     return BTSBOT_ERR_INVALID_ARG;
   }
-  if (prec == BTSBOT_BF16) return mlp_bwd_t<bf16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs, planes16);
-  return mlp_bwd_t<f16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs, 0);
+  if (prec == BTSBOT_BF16) return mlp_bwd_t<bf16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
+  return mlp_bwd_t<f16_t>(C, xn, dy, w1, w2g, b1, dxn, part, Gacc, Ssum, dW1, db1, R, st, jobs);
 }

@@ -326,7 +326,7 @@ def test_eval_after_training_step_repacks_inference_images(cuda):
 
 
 @pytest.mark.parametrize("mlp", ["default", "stage0_only", "unfused", "stage2_per_op",
-                                 "per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "stage2_two_gemms", "fork_per_block"])
+                                 "per_op_forward", "stage1_keeping_kernel", "stage2_two_gemms", "fork_per_block"])
 @pytest.mark.parametrize("prec,bound", [("f16", 8e-3), ("bf16", 4.5e-2)])
 def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     """The 16-bit training schedule (LDS-DMA GEMMs with the GELU_SAVE / DGELU / PLAIN epilogues, the MFMA
@@ -336,7 +336,7 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     ``mlp``: the blocks of the 64- and 128-channel stages run the fused MLP forward and mlp_bwd_kernel (default; 5400
     rows = 84 row tiles and a ragged one; 1176 rows in four hidden slices whose addend planes of dxn dwln_bwd_kernel
     adds), the 64-channel stage only, or none (the switches are read when the handle is created)."""
-    if prec == "f16" and mlp in ("per_op_forward", "stage1_keeping_kernel", "depthwise_recompute", "bf16_planes", "fork_per_block"):
+    if prec == "f16" and mlp in ("per_op_forward", "stage1_keeping_kernel", "fork_per_block"):
         pytest.skip("this round's schedule cases run in bf16 (f16's default already runs both keeping forms)")
     if mlp == "stage0_only":
         monkeypatch.setenv("BTSBOT_AMD_MLP_BWD_C", "64")
@@ -347,15 +347,10 @@ def test_full_backward_16bit(cuda, monkeypatch, prec, bound, mlp):
     elif mlp == "per_op_forward":   # stem, stages 0-1 as per-op launches (the default forward runs stage0b's / stage1b's keeping forms)
         monkeypatch.setenv("BTSBOT_AMD_NO_S0_TRAIN", "1")
         monkeypatch.setenv("BTSBOT_AMD_NO_S1_TRAIN", "1")
-    elif mlp == "depthwise_recompute":   # dwln_bwd_kernel recomputes d from x_in; the keeping forms do not write it (opt-in)
-        monkeypatch.setenv("BTSBOT_AMD_DWLN_RECOMP", "1")
-        monkeypatch.setenv("BTSBOT_AMD_S1_TRAIN", "1")
     elif mlp == "stage2_two_gemms":   # stage 2's da / dxn as two tiled GEMMs (default: one launch of s2mlp_bwd_kernel)
         monkeypatch.setenv("BTSBOT_AMD_NO_S2MLP", "1")
     elif mlp == "fork_per_block":   # stages 2-3 fork the side stream behind every block (default: once per stage)
         monkeypatch.setenv("BTSBOT_AMD_FORK_PER_BLOCK", "1")
-    elif mlp == "bf16_planes":   # the 128-channel MLP backward's four addend planes of dxn as bf16 (opt-in)
-        monkeypatch.setenv("BTSBOT_AMD_PLANES16", "1")
     elif mlp == "stage1_keeping_kernel":   # stage 1's keeping form in the bf16 mode too (default there: stage 0 only)
         monkeypatch.setenv("BTSBOT_AMD_S1_TRAIN", "1")
     kind, cfg = CONFIGS["mm_pico"]
