@@ -737,6 +737,11 @@ def test_exchange_step_through_the_c_abi_on_a_one_rank_communicator(cuda):
         assert (gc - gb).abs().max().item() <= 2e-5 * scale
         assert _lib.lib().btsbot_set_option(ma._handle.ptr, b"exchange", 2) != 0
         _lib.check(_lib.lib().btsbot_set_option(ma._handle.ptr, b"exchange", 0), "set_option")
+        # both streams the library made for concurrent work (the backward's side stream, the exchange stream) were placed
+        # by measurement: the query answers OK (each on a hardware pipe of its own) or BTSBOT_ERR_STATE with a message that
+        # names the shared pipe -- never anything else, and training is correct either way (the asserts above)
+        rcq = _lib.lib().btsbot_set_option(ma._handle.ptr, b"query_side_apart", 0)
+        assert rcq == 0 or (rcq == -5 and b"pipe" in _lib.lib().btsbot_last_error()), rcq   # (-5 = BTSBOT_ERR_STATE)
         # an arena other than the one the last backward wrote is refused (its bucket events say nothing about it)
         other = torch.zeros_like(gc)
         one = (C.c_int32 * 1)(0)
