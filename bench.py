@@ -224,8 +224,8 @@ def maxvit_family_work(batch, precision):
     w = {k: dict(flop=0, bytes=0) for k in (
         "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
         "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
-        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel", "mv_se_kernel", "mv_ln_kernel",
-        "mv_attn_kernel", "head_kernel")}
+        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_streamed_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
+        "mv_se_kernel", "mv_ln_kernel", "mv_attn_kernel", "head_kernel")}
 
     def add(k, macs, nbytes):
         w[k]["flop"] += 2 * macs * batch
@@ -259,9 +259,11 @@ def maxvit_family_work(batch, precision):
             add("mv_gemm<shortcut>", po * cin * c, po * (cin * esz + 4 * c))
         ln_fused = precision != "f32" and c in (64, 128) and \
             os.environ.get("BTSBOT_AMD_MV_NO_LN_FUSE", "0") != "1"
+        # C = 256: norm2 + fc1 + GELU + fc2 + residual as one launch of stage2p_kernel's row-tile form (its own LayerNorm)
+        smlp = precision != "f32" and c == 256 and os.environ.get("BTSBOT_AMD_MV_NO_SMLP", "0") != "1"
         for g in range(2):
             # C = 64 / 128: every LayerNorm rides on the epilogue of the kernel that produces its input
-            add("mv_ln_kernel", 0, (0 if ln_fused else 2) * po * c * (4 + esz))
+            add("mv_ln_kernel", 0, (0 if ln_fused else 1 if smlp else 2) * po * c * (4 + esz))
             if precision != "f32" and c == 64 and os.environ.get("BTSBOT_AMD_MV_NO_ATTN_BLOCK", "0") != "1":
                 add("mv_attn_block", po * (4 * c * c + 49 * c * 2), po * c * (2 * esz + 8))
             else:
@@ -271,6 +273,8 @@ def maxvit_family_work(batch, precision):
             if precision != "f32" and c in (64, 128) and \
                     os.environ.get("BTSBOT_AMD_MV_MLP_UNFUSED", "0") != "1":
                 add("mv_fused_mlp", po * 8 * c * c, po * c * (esz + 8))
+            elif smlp:
+                add("mv_streamed_mlp", po * 8 * c * c, po * c * 8)
             else:
                 add("mv_gemm<fc1,GELU>", po * 4 * c * c, po * 5 * c * esz)
                 add("mv_gemm<fc2,RESID>", po * 4 * c * c, po * c * (4 * esz + 8))

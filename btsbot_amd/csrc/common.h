@@ -324,6 +324,12 @@ int launch_stage1b(int prec, const Stage1Args& a, hipStream_t st);   // stage1b.
 struct Stage2pArgs;
 bool stage2p_supported(int prec, int c2, int c3, int depth);
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st);
+// the kernel's row-tile form (stage2p.hip, ROWS): x [rows][256] fp32 += W2 gelu(W1 LN(x) + b1) + b2 in place -- the MLP half
+// of a MaxViT partition-attention layer at 256 channels.  blk: ln_w / ln_b = norm2, b1 / b2 the Linear biases, gamma = ones,
+// w1p / w2p = launch_pack_s2p fragments of fc1 [1024][256] / fc2 [256][1024]; dw_* unused
+struct Stage2pBlk;
+bool stage2p_rows_supported(int prec, int c);
+int launch_stage2p_rows(int prec, float* x, long rows, const Stage2pBlk& blk, hipStream_t st);
 // fp32 [rows][K] (reorder_down: a [Cout][Cin][2][2] downsample filter, K = 4 Cin) -> 16x16x32 A fragments
 // [row tile][k-step][lane][8], optionally scaled per row
 int launch_pack_s2p(int prec, const float* src, const float* rowscale, void* dst, int rows, int K, int reorder_down,

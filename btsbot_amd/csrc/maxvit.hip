@@ -24,6 +24,7 @@
 
 #include "ctx.h"
 #include "maxvit.h"
+#include "stage2p.h"
 
 #include "maxvit_tables.h"
 
@@ -92,6 +93,11 @@ AttnPk add_attn(btsbot_ctx* h, const std::string& p, int c, size_t& cur, int esz
   a.p_bias64 = mv_bump(cur, (size_t)heads * 4096 * 4);
   a.fused = fused_mlp_supported(h->cfg.precision, c);
   a.p_fused = a.fused ? mv_bump(cur, fused_mlp_packed_bytes(c)) : 0;
+  a.smlp = !a.fused && stage2p_rows_supported(h->cfg.precision, c);
+  if (a.smlp) {
+    a.p_w1p = mv_bump(cur, (size_t)4 * c * c * esz);
+    a.p_w2p = mv_bump(cur, (size_t)4 * c * c * esz);
+  }
   return a;
 }
 
@@ -119,6 +125,8 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_attn_block = ab != nullptr && ab[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
+    const char* ns = getenv("BTSBOT_AMD_MV_NO_SMLP");
+    mv->no_smlp = ns != nullptr && ns[0] == '1';
   }
   char buf[96];
   mv->stem1_w = mv_add(h, "stem.conv1.weight", {32, 3, 3, 3});
@@ -228,6 +236,10 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st) {
       MTRY(launch_mv_pack_relbias(m + a.rel, F(a.p_bias), c / 32, st));
       MTRY(launch_mv_pack_relbias64(m + a.rel, F(a.p_bias64), c / 32, st));
       if (a.fused) MTRY(launch_pack_fused_mlp(prec, c, m + a.fc1_w, m + a.fc2_w, ex + a.p_fused, st));
+      if (a.smlp) {
+        MTRY(launch_pack_s2p(prec, m + a.fc1_w, nullptr, ex + a.p_w1p, 4 * c, c, 0, 0, nullptr, st));
+        MTRY(launch_pack_s2p(prec, m + a.fc2_w, nullptr, ex + a.p_w2p, c, 4 * c, 0, 0, nullptr, st));
+      }
     }
   }
   return BTSBOT_OK;
@@ -480,9 +492,10 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         MTRY(mv_timed(h, CAT_MV_G_PROJ, st, [&] {
           return mv_gemm(mv, prec, EPI_RESID, E, ex + a.p_proj, m + a.proj_b, one, x, x, Mo, c, c, st);
         }));
-        MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
-          return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
-        }));
+        if (!(a.smlp && !mv->no_smlp))   // (the streamed MLP below normalises its rows itself)
+          MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
+            return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
+          }));
       }
       }
       if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
@@ -507,6 +520,22 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         }));
         if (post == 1) ln1_grid_done = true;
         if (post == 2) next_xn_ready = true;
+        continue;
+      }
+      if (a.smlp && !mv->no_smlp) {
+        // C = 256: norm2 -> fc1 -> GELU -> fc2 -> + x as ONE launch of stage2p_kernel's row-tile form: 64 rows resident per
+        // workgroup, both filters streamed past them as packed MFMA fragments, the 1024-wide hidden rows never leave the CU
+        // (unfused: a LayerNorm launch and two GEMMs that write and re-read 4 KB per row)
+        Stage2pBlk sb;
+        memset(&sb, 0, sizeof(sb));
+        sb.ln_w = m + a.n2w;
+        sb.ln_b = m + a.n2b;
+        sb.b1 = m + a.fc1_b;
+        sb.b2 = m + a.fc2_b;
+        sb.gamma = one;
+        sb.w1p = ex + a.p_w1p;
+        sb.w2p = ex + a.p_w2p;
+        MTRY(mv_timed(h, CAT_MV_SMLP, st, [&] { return launch_stage2p_rows(prec, x, (long)Mo, sb, st); }));
         continue;
       }
       MTRY(mv_timed(h, CAT_MV_G_FC1, st, [&] {

@@ -12,7 +12,9 @@ struct BnPk {
 struct AttnPk {
   int64_t n1w, n1b, qkv_w, qkv_b, rel, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b;
   size_t p_qkv, p_proj, p_fc1, p_fc2, p_bias, p_bias64, p_fused;
+  size_t p_w1p = 0, p_w2p = 0;   // C = 256, 16-bit modes: fc1 / fc2 as stage2p.hip's MFMA A fragments (the streamed MLP)
   bool fused;
+  bool smlp = false;             // the MLP runs stage2p_kernel's row-tile form (launch_stage2p_rows)
 };
 struct MvBlock {
   int cin, c, mid, rd, stride, hin, hout;
@@ -30,6 +32,7 @@ struct MaxVit {
   std::vector<MvBlock> blocks;
   // workspace offsets (bytes) for the current reservation
   size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr, o_wg;
+  bool no_smlp = false;     // BTSBOT_AMD_MV_NO_SMLP=1: the 256-channel MLPs as LayerNorm + two GEMMs (A/B, parity tests)
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
   bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
                             // (measured slower than gemm2 on these shapes: opt-in, kept as the record)

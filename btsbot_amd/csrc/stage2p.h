@@ -47,3 +47,4 @@ struct Stage2pArgs {
   Stage2pKeep keep[S2P_MAX_DEPTH];
   void* ds_patches;      // [B][4 * 256] operand type: the downsample's LayerNorm'd patch rows, k = (2 ky + kx) * 256 + c
 };
+

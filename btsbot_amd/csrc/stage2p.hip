@@ -28,6 +28,7 @@
 //     5 x 5 taps (all a 3 x 3 map can touch) in place, wave = pixel normalises (two wave reductions);
 //   * the downsample's 4 MB-per-launch GEMM (M = alerts) runs here as 16-column products with 4 live columns:
 //     wasteful on the matrix pipe, free in time -- it is the 1 MB filter stream that bounds it.
+#include <string.h>
 #include <type_traits>
 
 #include "common.h"
@@ -264,14 +265,20 @@ __device__ __forceinline__ float half_sum(float v) {
 // only) against 100 us for the inference form.  Stores are buffer stores (scalar descriptor + 32-bit lane offset + scalar
 // chunk offset): per-lane 64-bit pointers, strength-reduced over the chunk loop, cost the loop 24 registers it does not
 // have, and a spilled value's reload is again a vmcnt(0) in front of the fragments.
-template <typename T, int G, int TRAIN = 0, int CW = 256>
+// ROWS > 0: the row-tile form -- a workgroup owns ROWS consecutive rows of a [rows][CW] fp32 stream instead of G alerts' 3x3
+// maps, every block is  x += W2 gelu(W1 LN(x) + b1) + b2  (no depthwise phase, no downsample): the MLP half of a MaxViT
+// partition-attention layer at 256 channels (timm PartitionAttentionCl.mlp behind norm2, reached from
+// /root/reference/btsbot/architectures.py:51,97), updated in place (x_in == tap_stage); a.B counts rows.
+template <typename T, int G, int TRAIN = 0, int CW = 256, int ROWS = 0>
 __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   using SH = Shp<CW>;
   constexpr int C = SH::C, HID = SH::HID, NCHUNK = SH::NCHUNK, CO = SH::CO, KSD = SH::KSD, XLP = SH::XLP;
   constexpr int MF = SH::MF, NX = SH::NX;
   static_assert(NX == 0 || (TRAIN == 0 && !MP<T>::SPLIT && MP<T>::ESZ == 2), "320 channels: 16-bit inference only");
   using LD = Lds<T, G, CW>;
-  constexpr int NPX = Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
+  constexpr bool RM = ROWS > 0;
+  static_assert(!RM || (TRAIN == 0 && ROWS == Geo<G>::NCOL && CW == 256), "row-tile form: inference, whole column blocks");
+  constexpr int NPX = RM ? ROWS : Geo<G>::NPX, NCOL = Geo<G>::NCOL, NB = Geo<G>::NB;
   constexpr int KSTEP = MP<T>::KSTEP, VPL = KSTEP / 4, KS1 = C / KSTEP, KS2 = CHUNK / KSTEP, KH = HID / KSTEP;
   constexpr int OFF_XN = LD::OFF_XN, XN_PLANE = LD::XN_PLANE, H_PLANE = LD::H_PLANE;
   using frag = typename MP<T>::frag;
@@ -297,7 +304,8 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
   const int alert0 = blockIdx.x * G;
-  const int nlive = min(G, a.B - alert0) * 9;        // live pixel rows of this workgroup
+  const size_t row0 = RM ? (size_t)blockIdx.x * ROWS : (size_t)alert0 * 9;   // first row of this workgroup in x_in / tap_stage
+  const int nlive = RM ? (int)min((long)ROWS, (long)a.B - (long)row0) : min(G, a.B - alert0) * 9;   // its live rows
   // 320 channels: the tile this wave shares with wave (wave ^ 4), its first channel for this lane, the half of a chunk's
   // fc2 k-steps it runs on it; xlead = the wave of the pair that carries the tile's input, bias and layer-scale terms
   constexpr int KX = KS2 / 2;
@@ -320,13 +328,13 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const int p = 16 * n + col;
       acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p < nlive)
-        acc[m][n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + 16 * (MF * wave + m) + 4 * kg);
+        acc[m][n] = *reinterpret_cast<const f32x4*>(a.x_in + (row0 + p) * C + 16 * (MF * wave + m) + 4 * kg);
     }
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
     const int p = 16 * n + col;
     accx[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (NX > 0 && xlead && p < nlive) accx[n] = *reinterpret_cast<const f32x4*>(a.x_in + ((size_t)alert0 * 9 + p) * C + cx0);
+    if (NX > 0 && xlead && p < nlive) accx[n] = *reinterpret_cast<const f32x4*>(a.x_in + (row0 + p) * C + cx0);
   }
   __syncthreads();   // zero fill done before the first map is written
 
@@ -382,11 +390,14 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     // depthwise role: 256 channels: (channel, alert pair); 320: thread = channel, every alert of the workgroup
     const int dc = C == 256 ? tid & 255 : tid < C ? tid : 0, dhalf = C == 256 ? tid >> 8 : 0;
     float w[25];
+    float dbias = 0.f;
+    if constexpr (!RM) {
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky)
+      for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + dc];
-    const float dbias = bk.dw_b[dc];
+        for (int kx = 0; kx < 5; ++kx) w[ky * 5 + kx] = bk.dw_w[((ky + 1) * 7 + kx + 1) * C + dc];
+      dbias = bk.dw_b[dc];
+    }
     f32x4 lw, lw2, lb, lb2;
     if constexpr (!LATE) {
       lw = *reinterpret_cast<const f32x4*>(bk.ln_w + 8 * (lane & 31));
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
     __syncthreads();
     S2P_STAMP(2 + 8 * j);
     // ---- depthwise 7x7 on the 3x3 maps, in place: thread = (channel, alert pair)
-    {
+    if constexpr (!RM) {
       constexpr int AH = C == 256 ? (G + 1) / 2 : G;   // alerts per half of the workgroup (odd G: the second half has one fewer)
 #pragma unroll
       for (int g = 0; g < AH; ++g) {
@@ -769,9 +780,10 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
       const int p = 16 * n + col;
       if (p < NPX) *reinterpret_cast<f32x4*>(xl + p * XLP + c0) = acc[m][n];
       if (a.tap_stage != nullptr && p < nlive)
-        *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * 9 + p) * C + c0) = acc[m][n];
+        *reinterpret_cast<f32x4*>(a.tap_stage + (row0 + p) * C + c0) = acc[m][n];
     }
   }
+  if constexpr (RM) return;   // (the row-tile form ends with its rows written back)
   if (NX > 0) {   // the shared tiles: sum of the pair's partial residuals (the validation copy leaves from the map)
     if (xlead) {
 #pragma unroll
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(NT, 2) void stage2p_kernel(Stage2pArgs a) {
         if (p < NPX) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(xl + p * XLP + cx0) + accx[n];
           *reinterpret_cast<f32x4*>(xl + p * XLP + cx0) = v;
-          if (a.tap_stage != nullptr && p < nlive) *reinterpret_cast<f32x4*>(a.tap_stage + ((size_t)alert0 * 9 + p) * C + cx0) = v;
+          if (a.tap_stage != nullptr && p < nlive) *reinterpret_cast<f32x4*>(a.tap_stage + (row0 + p) * C + cx0) = v;
         }
       }
     }
@@ -939,8 +951,8 @@ __global__ void pack_frag_fp8_kernel(const float* __restrict__ w, const float* _
       (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * scale[0], 0.f, 0, false) & 0xff);
 }
 
-template <typename T, int G = S2P_ALERTS, int TRAIN = 0, int CW = 256> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
-  auto kern = stage2p_kernel<T, G, TRAIN, CW>;
+template <typename T, int G = S2P_ALERTS, int TRAIN = 0, int CW = 256, int ROWS = 0> int launch_stage2p_t(const Stage2pArgs& a, hipStream_t st) {
+  auto kern = stage2p_kernel<T, G, TRAIN, CW, ROWS>;
   constexpr int lds_bytes = TRAIN == 1 ? Lds<T, G, CW>::BYTES_TRAIN : Lds<T, G, CW>::BYTES;
   static_assert(lds_bytes <= 160 * 1024, "the images fit one CU");
   static DevOnce attr_set;
@@ -948,7 +960,7 @@ template <typename T, int G = S2P_ALERTS, int TRAIN = 0, int CW = 256> int launc
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set.done();
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G), dim3(NT), lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3(ROWS > 0 ? (a.B + ROWS - 1) / ROWS : (a.B + G - 1) / G), dim3(NT), lds_bytes, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
 }
@@ -1010,6 +1022,26 @@ int stage2p_alerts_per_workgroup(int B, int hint) {
   // unused) unless 7 take fewer rounds of one workgroup per CU
   const int r5 = ((B + 4) / 5 + 255) / 256, r7 = ((B + 6) / 7 + 255) / 256;
   return r7 < r5 ? 7 : 5;
+}
+
+// The row-tile form: x [rows][256] fp32 += W2 gelu(W1 LN(x) + b1) + b2 in place, 64 rows per workgroup; blk carries the
+// LayerNorm, the two biases, gamma (ones where the layer has no layer scale) and both filters as launch_pack_s2p fragments
+bool stage2p_rows_supported(int prec, int c) { return c == 256 && (prec == BTSBOT_BF16 || prec == BTSBOT_F16); }
+int launch_stage2p_rows(int prec, float* x, long rows, const Stage2pBlk& blk, hipStream_t st) {
+  if (rows <= 0) return BTSBOT_OK;
+  if (!stage2p_rows_supported(prec, 256) || rows > 0x7fffffffL) {
+    btsbot_set_error("stage2p_rows: precision %d / %ld rows not supported", prec, rows);
+    return BTSBOT_ERR_INVALID_ARG;
+  }
+  Stage2pArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x_in = x;
+  a.tap_stage = x;
+  a.blk[0] = blk;
+  a.depth = 1;
+  a.B = (int)rows;
+  a.cw = 256;
+  return prec == BTSBOT_BF16 ? launch_stage2p_t<bf16_t, 7, 0, 256, 64>(a, st) : launch_stage2p_t<f16_t, 7, 0, 256, 64>(a, st);
 }
 
 int launch_stage2p(int prec, const Stage2pArgs& a, hipStream_t st) {
