@@ -224,7 +224,7 @@ def maxvit_family_work(batch, precision):
     w = {k: dict(flop=0, bytes=0) for k in (
         "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
         "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
-        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_streamed_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
+        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_streamed_mlp", "mv_attn256", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
         "mv_se_kernel", "mv_ln_kernel", "mv_attn_kernel", "head_kernel")}
 
     def add(k, macs, nbytes):
@@ -261,11 +261,15 @@ def maxvit_family_work(batch, precision):
             os.environ.get("BTSBOT_AMD_MV_NO_LN_FUSE", "0") != "1"
         # C = 256: norm2 + fc1 + GELU + fc2 + residual as one launch of stage2p_kernel's row-tile form (its own LayerNorm)
         smlp = precision != "f32" and c == 256 and os.environ.get("BTSBOT_AMD_MV_NO_SMLP", "0") != "1"
+        # C = 256: norm1 + qkv + attention + proj + residual as one launch (maxvit_attn256.hip; needs the streamed MLP behind it)
+        a256 = smlp and os.environ.get("BTSBOT_AMD_MV_NO_ATTN256", "0") != "1"
         for g in range(2):
             # C = 64 / 128: every LayerNorm rides on the epilogue of the kernel that produces its input
-            add("mv_ln_kernel", 0, (0 if ln_fused else 1 if smlp else 2) * po * c * (4 + esz))
+            add("mv_ln_kernel", 0, (0 if ln_fused or a256 else 1 if smlp else 2) * po * c * (4 + esz))
             if precision != "f32" and c == 64 and os.environ.get("BTSBOT_AMD_MV_NO_ATTN_BLOCK", "0") != "1":
                 add("mv_attn_block", po * (4 * c * c + 49 * c * 2), po * c * (2 * esz + 8))
+            elif a256:
+                add("mv_attn256", po * (4 * c * c + 49 * c * 2), po * c * 8)
             else:
                 add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
                 add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)

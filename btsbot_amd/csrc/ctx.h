@@ -39,7 +39,7 @@ constexpr int STAGE_HW[4] = {15, 7, 3, 1};
 
 enum { CAT_STEM = 0, CAT_DWLN, CAT_FC1, CAT_FC2, CAT_LNPATCH, CAT_DOWN, CAT_HEAD, CAT_FUSED, CAT_STAGE0, CAT_STAGE1, CAT_STAGE2, CAT_S3FC1, CAT_S3FC2, CAT_HEAD16,
        CAT_MV_STEM, CAT_MV_G_STEM, CAT_MV_G_CONV1, CAT_MV_G_CONV3, CAT_MV_G_SC, CAT_MV_G_QKV, CAT_MV_G_PROJ, CAT_MV_G_FC1,
-       CAT_MV_G_FC2, CAT_MV_FUSED, CAT_MV_FRONT, CAT_MV_ABLK, CAT_MV_ELT, CAT_MV_DW, CAT_MV_SE, CAT_MV_LN, CAT_MV_ATTN, CAT_MV_SMLP, NCAT };
+       CAT_MV_G_FC2, CAT_MV_FUSED, CAT_MV_FRONT, CAT_MV_ABLK, CAT_MV_ELT, CAT_MV_DW, CAT_MV_SE, CAT_MV_LN, CAT_MV_ATTN, CAT_MV_SMLP, CAT_MV_PART, NCAT };
 const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "gemm_kernel<fc1,GELU>",
                                      "gemm_kernel<fc2,RESID>", "ln_patch_kernel", "gemm_kernel<down,BIAS>",
                                      "head_kernel", "fused_mlp_kernel", "stage0b_kernel", "stage1b_kernel",
@@ -47,7 +47,7 @@ const char* const CAT_NAMES[NCAT] = {"stem_kernel",       "dwconv_ln_kernel", "g
                                      "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
                                      "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
                                      "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
-                                     "mv_se_kernel", "mv_ln_kernel", "mv_attn_kernel", "mv_streamed_mlp"};
+                                     "mv_se_kernel", "mv_ln_kernel", "mv_attn_kernel", "mv_streamed_mlp", "mv_partition"};
 constexpr size_t PROF_MAX_LAUNCHES = 16384;
 
 struct MaxVit;   // maxvit.hip

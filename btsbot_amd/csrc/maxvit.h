@@ -88,6 +88,21 @@ int launch_mv_attn_block(int prec, const void* xn, float* x, void* xn2, const vo
                          const float* bqkv, const void* wproj, const float* bproj, const float* bias64,
                          const float* ln_w, const float* ln_b, int B, int H, int C, int grid_mode,
                          hipStream_t st);
+// A partition block in one kernel at C = 128 / 256 (maxvit_part.hip; 16-bit modes): x f32 updated in place by the attention
+// half (norm1, qkv, window/grid attention, proj, residual) and, with w1p set, the MLP half (norm2, fc1, GELU, fc2, residual).
+// The filters are launch_pack_s2p fragments of attn.qkv.weight [3C][C], attn.proj.weight [C][C], mlp.fc1.weight [4C][C],
+// mlp.fc2.weight [C][4C]; biasl is launch_mv_pack_relbias_lanes' image.
+struct MvPartW {
+  const float *ln1w, *ln1b, *bqkv, *bproj, *biasl;
+  const void *wqkvp, *wprojp;
+  const float *ln2w, *ln2b, *b1, *b2;
+  const void *w1p, *w2p;
+  unsigned long long* stamps;   // developer diagnostic: 32 phase clocks of workgroup 0 (nullptr: none)
+};
+bool mv_part_supported(int prec, int C);
+int launch_mv_part(int prec, float* x, const MvPartW& p, int B, int H, int C, int grid_mode, hipStream_t st);
+// biasl [heads][4][4][64][4] f32: the relative-position bias (+ key mask) in the order the attention wave's lanes add it
+int launch_mv_pack_relbias_lanes(const float* table, float* out, int heads, hipStream_t st);
 // final LayerNorm2d + global average pool: x [B,49,C] f32 -> feat [B,C] f32
 int launch_mv_final(const float* x, const float* w, const float* b, float* feat, int B, int P, int C,
                     hipStream_t st);

@@ -94,9 +94,15 @@ AttnPk add_attn(btsbot_ctx* h, const std::string& p, int c, size_t& cur, int esz
   a.fused = fused_mlp_supported(h->cfg.precision, c);
   a.p_fused = a.fused ? mv_bump(cur, fused_mlp_packed_bytes(c)) : 0;
   a.smlp = !a.fused && stage2p_rows_supported(h->cfg.precision, c);
-  if (a.smlp) {
+  a.part = mv_part_supported(h->cfg.precision, c);
+  if (a.smlp || a.part) {
     a.p_w1p = mv_bump(cur, (size_t)4 * c * c * esz);
     a.p_w2p = mv_bump(cur, (size_t)4 * c * c * esz);
+  }
+  if (a.part) {
+    a.p_qkvp = mv_bump(cur, (size_t)3 * c * c * esz);
+    a.p_projp = mv_bump(cur, (size_t)c * c * esz);
+    a.p_biasl = mv_bump(cur, (size_t)heads * 4096 * 4);
   }
   return a;
 }
@@ -125,6 +131,10 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->no_attn_block = ab != nullptr && ab[0] == '1';
     const char* u = getenv("BTSBOT_AMD_MV_MLP_UNFUSED");
     mv->mlp_unfused = u != nullptr && u[0] == '1';
+    const char* na = getenv("BTSBOT_AMD_MV_NO_PART");
+    mv->no_part = na != nullptr && na[0] == '1';
+    const char* pa = getenv("BTSBOT_AMD_MV_PART_ATTN_ONLY");
+    mv->part_attn_only = pa != nullptr && pa[0] == '1';
     const char* ns = getenv("BTSBOT_AMD_MV_NO_SMLP");
     mv->no_smlp = ns != nullptr && ns[0] == '1';
   }
@@ -236,7 +246,12 @@ int maxvit_pack(btsbot_ctx* h, hipStream_t st) {
       MTRY(launch_mv_pack_relbias(m + a.rel, F(a.p_bias), c / 32, st));
       MTRY(launch_mv_pack_relbias64(m + a.rel, F(a.p_bias64), c / 32, st));
       if (a.fused) MTRY(launch_pack_fused_mlp(prec, c, m + a.fc1_w, m + a.fc2_w, ex + a.p_fused, st));
-      if (a.smlp) {
+      if (a.part) {
+        MTRY(launch_pack_s2p(prec, m + a.qkv_w, nullptr, ex + a.p_qkvp, 3 * c, c, 0, 0, nullptr, st));
+        MTRY(launch_pack_s2p(prec, m + a.proj_w, nullptr, ex + a.p_projp, c, c, 0, 0, nullptr, st));
+        MTRY(launch_mv_pack_relbias_lanes(m + a.rel, F(a.p_biasl), c / 32, st));
+      }
+      if (a.smlp || a.part) {
         MTRY(launch_pack_s2p(prec, m + a.fc1_w, nullptr, ex + a.p_w1p, 4 * c, c, 0, 0, nullptr, st));
         MTRY(launch_pack_s2p(prec, m + a.fc2_w, nullptr, ex + a.p_w2p, c, 4 * c, 0, 0, nullptr, st));
       }
@@ -429,7 +444,9 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     const int hw2 = b.hout * b.hout;
     // wide stages (C = 64 / 128): the LayerNorm that follows a residual GEMM is computed in that GEMM's
     // epilogue (the staged output tile holds whole rows)
-    const bool ln_fuse = prec != BTSBOT_F32 && !mv->no_ln_fuse && (b.c == 64 || b.c == 128);
+    // (a block whose partition halves run as mv_part_kernel normalises its rows there: nobody reads a fused LayerNorm copy)
+    const bool part_blk = b.attn[0].part && !mv->no_part;
+    const bool ln_fuse = prec != BTSBOT_F32 && !mv->no_ln_fuse && (b.c == 64 || b.c == 128) && !part_blk;
     bool ln1_done = false, ln1_grid_done = false;
     if (prec != BTSBOT_F32 && !mv->gated_gemm && (size_t)b.c * b.mid * 4 <= (size_t)hw2 * b.mid) {
       // wide stages: per-alert filters W3 diag(g_b) (a fraction of the map's size) + batched LDS-DMA GEMM
@@ -462,6 +479,33 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     for (int g = 0; g < 2; ++g) {
       const AttnPk& a = b.attn[g];
       const int c = b.c;
+      // C = 128 / 256: norm1, qkv, attention, proj, residual, norm2, fc1, GELU, fc2, residual as ONE launch (maxvit_part.hip)
+      if (part_blk) {
+        MvPartW pw;
+        memset(&pw, 0, sizeof(pw));
+        pw.ln1w = m + a.n1w;
+        pw.ln1b = m + a.n1b;
+        pw.wqkvp = ex + a.p_qkvp;
+        pw.bqkv = m + a.qkv_b;
+        pw.wprojp = ex + a.p_projp;
+        pw.bproj = m + a.proj_b;
+        pw.biasl = F(a.p_biasl);
+        pw.stamps = h->stamps ? h->stamps + 20000 + (c == 256 ? 0 : 32) : nullptr;
+        if (!mv->part_attn_only) {
+          pw.ln2w = m + a.n2w;
+          pw.ln2b = m + a.n2b;
+          pw.w1p = ex + a.p_w1p;
+          pw.b1 = m + a.fc1_b;
+          pw.w2p = ex + a.p_w2p;
+          pw.b2 = m + a.fc2_b;
+        }
+        MTRY(mv_timed(h, CAT_MV_PART, st, [&] { return launch_mv_part(prec, x, pw, nb, b.hout, c, g, st); }));
+        if (!mv->part_attn_only) continue;
+        if (!(a.smlp && !mv->no_smlp))   // (the streamed MLP normalises its rows itself)
+          MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
+            return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
+          }));
+      } else {
       if (!(g == 0 && ln1_done) && !(g == 1 && ln1_grid_done)) {
         MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
           return launch_mv_ln(prec, x, m + a.n1w, m + a.n1b, Cc, (long)Mo, c, st);
@@ -498,6 +542,7 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           }));
       }
       }
+      }   // (part_blk)
       if (a.fused && !mv->mlp_unfused) {   // C = 64 / 128: fc1 -> GELU -> fc2 -> +x with the hidden on-chip
         // ... and the next consumer's normalised copy of x from the same registers: the grid attention's
         // LN1 after the window attention's MLP, the next block's pre-norm BatchNorm after the grid one's.

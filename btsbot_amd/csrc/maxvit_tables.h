@@ -15,6 +15,8 @@ struct AttnPk {
   size_t p_w1p = 0, p_w2p = 0;   // C = 256, 16-bit modes: fc1 / fc2 as stage2p.hip's MFMA A fragments (the streamed MLP)
   bool fused;
   bool smlp = false;             // the MLP runs stage2p_kernel's row-tile form (launch_stage2p_rows)
+  size_t p_qkvp = 0, p_projp = 0, p_biasl = 0;   // C = 128 / 256, 16-bit modes: attn.qkv / attn.proj as MFMA A fragments, the bias in lane order (maxvit_part.hip)
+  bool part = false;             // the partition block (attention half + MLP half) runs as one launch
 };
 struct MvBlock {
   int cin, c, mid, rd, stride, hin, hout;
@@ -32,6 +34,8 @@ struct MaxVit {
   std::vector<MvBlock> blocks;
   // workspace offsets (bytes) for the current reservation
   size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr, o_wg;
+  bool no_part = false;     // BTSBOT_AMD_MV_NO_PART=1: the partition blocks of C = 128 / 256 launch by launch (A/B, parity tests)
+  bool part_attn_only = false;
   bool no_smlp = false;     // BTSBOT_AMD_MV_NO_SMLP=1: the 256-channel MLPs as LayerNorm + two GEMMs (A/B, parity tests)
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
   bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
