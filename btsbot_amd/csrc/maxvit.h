@@ -97,6 +97,8 @@ struct MvPartW {
   const void *wqkvp, *wprojp;
   const float *ln2w, *ln2b, *b1, *b2;
   const void *w1p, *w2p;
+  const float *post_s, *post_b;   // with post_out (a 16-bit map shaped like x): also out = x * post_s[c] + post_b[c], the next
+  void* post_out;                 // block's pre-norm BatchNorm copy
   unsigned long long* stamps;   // developer diagnostic: 32 phase clocks of workgroup 0 (nullptr: none)
 };
 bool mv_part_supported(int prec, int C);

@@ -498,8 +498,14 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
           pw.b1 = m + a.fc1_b;
           pw.w2p = ex + a.p_w2p;
           pw.b2 = m + a.fc2_b;
+          if (g == 1 && bi + 1 < mv->blocks.size()) {   // ... and the next block's pre-norm copy of the finished rows
+            pw.post_s = F(mv->blocks[bi + 1].pre.p_scale);
+            pw.post_b = F(mv->blocks[bi + 1].pre.p_shift);
+            pw.post_out = Cc;
+          }
         }
         MTRY(mv_timed(h, CAT_MV_PART, st, [&] { return launch_mv_part(prec, x, pw, nb, b.hout, c, g, st); }));
+        if (pw.post_out != nullptr) next_xn_ready = true;
         if (!mv->part_attn_only) continue;
         if (!(a.smlp && !mv->no_smlp))   // (the streamed MLP normalises its rows itself)
           MTRY(mv_timed(h, CAT_MV_LN, st, [&] {

@@ -255,10 +255,14 @@ __global__ __launch_bounds__(256, 2) void mv_stem2_kernel(const T* __restrict__ 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
       wf[mt][tap] = *reinterpret_cast<const frag*>(w + (mt * 16 + l15) * 288 + tap * 32 + g * 8);
-  frag zero;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
   typedef T __attribute__((ext_vector_type(4))) T4;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  // the pre-norm constants, staged once (a load from L2 inside the epilogue costs its whole latency per tile)
+  __shared__ float4 ss[32];
+  if (xn != nullptr && threadIdx.x < 32)
+    ss[threadIdx.x] = threadIdx.x < 16 ? reinterpret_cast<const float4*>(scale)[threadIdx.x]
+                                       : reinterpret_cast<const float4*>(shift)[threadIdx.x - 16];
+  __syncthreads();
   for (int pp = 0; pp < pairs_per_wave; ++pp) {
     const int pair = wid * pairs_per_wave + pp;
     if (pair >= pairs_total) break;                    // wave-uniform
@@ -266,28 +270,37 @@ __global__ __launch_bounds__(256, 2) void mv_stem2_kernel(const T* __restrict__ 
     const int yp = pair - (int)b * 56;
     for (int xt = 0; xt < 7; ++xt) {
       const int x = xt * 16 + l15;
+      // the four input rows 2 yp - 1 .. 2 yp + 2 serve both output rows of the pair: all twelve B fragments are
+      // requested in one batch (one wait per tile; rows and columns off the image are clamped on the address and
+      // zeroed by a select -- a branch per row would serialise the requests, each paying the L2 round trip)
+      frag xf[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * yp - 1 + r;
+        const bool rok = iy >= 0 && iy < 112;          // wave-uniform
+        const T* rowp = in + ((b * 112 + (rok ? iy : 2 * yp)) * 112) * 32 + g * 8;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = x + kx - 1;
+          const bool cok = ix >= 0 && ix < 112;
+          i32x4 v = *reinterpret_cast<const i32x4*>(rowp + (long)(cok ? ix : x) * 32);
+          if (!(rok && cok)) v = i32x4{0, 0, 0, 0};
+          xf[r][kx] = __builtin_bit_cast(frag, v);
+        }
+      }
       float top[4][4];                                 // POOL: a + b of the pair's first row
-#pragma unroll 1
+#pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const int y = 2 * yp + sub;
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = y + ky - 1;
-          if (iy < 0 || iy >= 112) continue;           // wave-uniform
-          const T* rowp = in + ((b * 112 + iy) * 112) * 32 + g * 8;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = x + kx - 1;
-            const bool ok = ix >= 0 && ix < 112;
-            frag xf = *reinterpret_cast<const frag*>(rowp + (long)(ok ? ix : x) * 32);
-            if (!ok) xf = zero;
+          for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf, acc[mt]);
-          }
-        }
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = AM<T>::run(wf[mt][ky * 3 + kx], xf[sub + ky][kx], acc[mt]);
         const long po = ((b * 112 + y) * 112 + x) * 64 + 4 * g;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -295,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void mv_stem2_kernel(const T* __restrict__ 
             *reinterpret_cast<float4*>(out + po + mt * 16) =
                 make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
           if (xn != nullptr) {   // the first MBConv block's pre-norm BatchNorm + cast, while the values are here
-            const float4 sc = *reinterpret_cast<const float4*>(scale + mt * 16 + 4 * g);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + mt * 16 + 4 * g);
+            const float4 sc = ss[mt * 4 + g];
+            const float4 sh = ss[16 + mt * 4 + g];
             T4 v;
             v[0] = (T)(acc[mt][0] * sc.x + sh.x);
             v[1] = (T)(acc[mt][1] * sc.y + sh.y);
