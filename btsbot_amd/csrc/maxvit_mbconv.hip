@@ -71,14 +71,31 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
 
   // ---- stage the input halo (zeros outside the image and in the padding rows)
   constexpr int CPR = CIN / 8;                                // 16-byte chunks per pixel
-  for (int i = tid; i < G::NPXP * CPR; i += 256) {
-    const int px = i / CPR, ck = i - px * CPR;
-    const int hy = px / G::HALO, hx = px - hy * G::HALO;
-    const int iy = iy0 + hy, ix = ix0 + hx;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (px < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < H)
-      v = *reinterpret_cast<const uint4*>(xn + ((b * H + iy) * H + ix) * CIN + ck * 8);
-    *reinterpret_cast<uint4*>(xs + px * XPITCH + ck * 16) = v;
+  {
+    // all of a thread's pieces are requested before the first is stored (a load under a branch, or one per trip of a
+    // rolled loop, is waited for on the spot: eight HBM round trips in a row instead of one): the address is clamped
+    // into the image, the value zeroed by a select
+    constexpr int TRIPS = (G::NPXP * CPR + 255) / 256;
+    uint4 hv[TRIPS];
+    bool ok[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int i = tid + 256 * t;
+      const int px = i / CPR, ck = i - px * CPR;
+      const int hy = px / G::HALO, hx = px - hy * G::HALO;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      ok[t] = px < G::NPX && iy >= 0 && iy < H && ix >= 0 && ix < H;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), H - 1);
+      hv[t] = *reinterpret_cast<const uint4*>(xn + ((b * H + cy) * H + cx) * CIN + ck * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      asm volatile("" : "+v"(hv[t].x), "+v"(hv[t].y), "+v"(hv[t].z), "+v"(hv[t].w));   // (keeps the load unconditional)
+      if (!ok[t]) hv[t] = make_uint4(0, 0, 0, 0);
+      const int i = tid + 256 * t;
+      const int px = i / CPR, ck = i - px * CPR;
+      if (i < G::NPXP * CPR) *reinterpret_cast<uint4*>(xs + px * XPITCH + ck * 16) = hv[t];
+    }
   }
   __syncthreads();
 
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         xf[ks] = *reinterpret_cast<const frag*>(xs + (pt * 16 + l15) * XPITCH + ks * 64 + g * 16);
-      const bool in = (inside >> pt) & 1u;
+      const float inf = ((inside >> pt) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -137,13 +154,22 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
         for (int ks = 0; ks < KS; ++ks) acc = FM<T>::run(wf[mt][ks], xf[ks], acc);
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
-        v[0] = (T)(in ? silu_fast(acc[0] + bv[mt].x) : 0.f);
-        v[1] = (T)(in ? silu_fast(acc[1] + bv[mt].y) : 0.f);
-        v[2] = (T)(in ? silu_fast(acc[2] + bv[mt].z) : 0.f);
-        v[3] = (T)(in ? silu_fast(acc[3] + bv[mt].w) : 0.f);
+        // (a factor, not a branch: straight-line code lets the next tile's MFMAs issue under this one's SiLU)
+        v[0] = (T)(silu_fast(acc[0] + bv[mt].x) * inf);
+        v[1] = (T)(silu_fast(acc[1] + bv[mt].y) * inf);
+        v[2] = (T)(silu_fast(acc[2] + bv[mt].z) * inf);
+        v[3] = (T)(silu_fast(acc[3] + bv[mt].w) * inf);
         *reinterpret_cast<T4*>(m1s + (pt * 16 + l15) * M1PITCH + (mt * 16 + 4 * g) * 2) = v;
       }
     }
+    // phase 2's taps arrived long ago; naming them here puts their wait BEFORE the next chunk's requests -- behind them
+    // it would be a wait for everything (loads and this kernel's stores share one counter, which then cannot count)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      asm volatile("" ::"v"(wq[t][0].x), "v"(wq[t][0].y), "v"(wq[t][0].z), "v"(wq[t][0].w), "v"(wq[t][1].x), "v"(wq[t][1].y),
+                   "v"(wq[t][1].z), "v"(wq[t][1].w));
+    asm volatile("" ::"v"(bq[0].x), "v"(bq[0].y), "v"(bq[0].z), "v"(bq[0].w), "v"(bq[1].x), "v"(bq[1].y), "v"(bq[1].z),
+                 "v"(bq[1].w));
     if (cc + 1 < nchunk) load_p1(ch0 + CH);      // in flight during phase 2
     __syncthreads();
     // ---- phase 2: depthwise 3x3 + BN2 + SiLU on the chunk; items = (output pixel, 8-channel group)
@@ -151,7 +177,13 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
       float psum[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) psum[e] = 0.f;
-      for (int op = tid >> 3; op < G::NOUT; op += 32) {
+      // (fixed trips, the last one ragged and predicated: a rolled loop's header waits for every load in flight -- the
+      //  next chunk's filter fragments, requested just above to arrive DURING this phase)
+      constexpr int P2T = (G::NOUT + 31) / 32;
+#pragma unroll
+      for (int t2 = 0; t2 < P2T; ++t2) {
+        const int op = (tid >> 3) + 32 * t2;
+        if (op >= G::NOUT) break;
         const int oy = op / G::TO, ox = op - oy * G::TO;
         float acc[8] = {bq[0].x, bq[0].y, bq[0].z, bq[0].w, bq[1].x, bq[1].y, bq[1].z, bq[1].w};
 #pragma unroll
