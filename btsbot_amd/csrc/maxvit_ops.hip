@@ -234,10 +234,18 @@ __global__ __launch_bounds__(256) void mv_dw3s_kernel(const T* __restrict__ in,
       }
     }
     const int ix0 = ox0 * STRIDE - 1;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = oy * STRIDE - 1 + ky;
-      if (iy < 0 || iy >= H) continue;
+      const bool rok = iy >= 0 && iy < H;
+      // a row's input columns are requested as one batch: the address is clamped into the image and the value zeroed
+      // by a select (a load under a lane-varying branch is waited for on the spot -- one L2 round trip per column)
+      const T* rowp = in + ((b * H + min(max(iy, 0), H - 1)) * H) * C + c;
+      i32x4 vi[NIN];
+#pragma unroll
+      for (int j = 0; j < NIN; ++j)
+        vi[j] = *reinterpret_cast<const i32x4*>(rowp + (long)min(max(ix0 + j, 0), H - 1) * C);
       float w[3][8];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
@@ -246,12 +254,12 @@ __global__ __launch_bounds__(256) void mv_dw3s_kernel(const T* __restrict__ in,
         w[kx][0] = w0.x; w[kx][1] = w0.y; w[kx][2] = w0.z; w[kx][3] = w0.w;
         w[kx][4] = w1.x; w[kx][5] = w1.y; w[kx][6] = w1.z; w[kx][7] = w1.w;
       }
-      const T* rowp = in + ((b * H + iy) * H) * C + c;
 #pragma unroll
       for (int j = 0; j < NIN; ++j) {
+        asm volatile("" : "+v"(vi[j]));               // (keeps the load unconditional)
         const int ix = ix0 + j;
-        if (ix < 0 || ix >= H) continue;
-        const T8 v = *reinterpret_cast<const T8*>(rowp + (long)ix * C);
+        if (!(rok && ix >= 0 && ix < H)) vi[j] = i32x4{0, 0, 0, 0};
+        const T8 v = __builtin_bit_cast(T8, vi[j]);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           // input column j feeds output p when j == p*STRIDE + kx
