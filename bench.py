@@ -224,7 +224,7 @@ def maxvit_family_work(batch, precision):
     w = {k: dict(flop=0, bytes=0) for k in (
         "mv_stem_im2col", "mv_gemm<stem>", "mv_gemm<conv1,SILU>", "mv_gemm<conv3,gated>",
         "mv_gemm<shortcut>", "mv_gemm<qkv>", "mv_gemm<proj,RESID>", "mv_gemm<fc1,GELU>",
-        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_streamed_mlp", "mv_attn256", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
+        "mv_gemm<fc2,RESID>", "mv_fused_mlp", "mv_streamed_mlp", "mv_partition", "mv_mbconv_front", "mv_attn_block", "mv_elementwise", "mv_dw3_kernel",
         "mv_se_kernel", "mv_ln_kernel", "mv_attn_kernel", "head_kernel")}
 
     def add(k, macs, nbytes):
@@ -242,7 +242,11 @@ def maxvit_family_work(batch, precision):
         pi, po = hi * hi, ho * ho
         # 16-bit modes: block 0's pre-norm and pooled shortcut come out of the stem kernel, and a block that
         # follows a C = 64 / 128 block gets its pre-norm from that block's last fused MLP
-        pre_fused = precision != "f32" and (bi == 0 or prev_c in (64, 128))
+        # (or, with the partition blocks as one kernel, from that kernel's post-op: every block but the first)
+        part_on = precision in ("bf16", "f16") and os.environ.get("BTSBOT_AMD_MV_NO_PART", "0") != "1"
+        part_full = part_on
+        part_prev = part_full and prev_c in (64, 128, 256)
+        pre_fused = precision != "f32" and (bi == 0 or prev_c in (64, 128) or part_prev)
         pool_fused = precision != "f32" and bi == 0
         add("mv_elementwise", 0, (0 if pre_fused else pi * cin * (4 + esz)) +
             (po * cin * (4 + esz) if s == 2 and not pool_fused else 0))
@@ -257,19 +261,23 @@ def maxvit_family_work(batch, precision):
         add("mv_gemm<conv3,gated>", po * mid * c, po * (mid * esz + 8 * c))
         if s == 2 and cin != c:
             add("mv_gemm<shortcut>", po * cin * c, po * (cin * esz + 4 * c))
-        ln_fused = precision != "f32" and c in (64, 128) and \
+        part = part_on and c in (64, 128, 256)   # maxvit_part.hip: a partition block (attention half + MLP half) per launch
+        ln_fused = precision != "f32" and c in (64, 128) and not part and \
             os.environ.get("BTSBOT_AMD_MV_NO_LN_FUSE", "0") != "1"
         # C = 256: norm2 + fc1 + GELU + fc2 + residual as one launch of stage2p_kernel's row-tile form (its own LayerNorm)
         smlp = precision != "f32" and c == 256 and os.environ.get("BTSBOT_AMD_MV_NO_SMLP", "0") != "1"
-        # C = 256: norm1 + qkv + attention + proj + residual as one launch (maxvit_attn256.hip; needs the streamed MLP behind it)
-        a256 = smlp and os.environ.get("BTSBOT_AMD_MV_NO_ATTN256", "0") != "1"
         for g in range(2):
+            if part and part_full:
+                # rows read once and written once (+ the next block's pre-norm copy behind the grid half)
+                post = po * c * esz if g == 1 and bi + 1 < len(maxvit_blocks()) else 0
+                add("mv_partition", po * (4 * c * c + 49 * c * 2 + 8 * c * c), po * c * 8 + post)
+                continue
             # C = 64 / 128: every LayerNorm rides on the epilogue of the kernel that produces its input
-            add("mv_ln_kernel", 0, (0 if ln_fused or a256 else 1 if smlp else 2) * po * c * (4 + esz))
-            if precision != "f32" and c == 64 and os.environ.get("BTSBOT_AMD_MV_NO_ATTN_BLOCK", "0") != "1":
+            add("mv_ln_kernel", 0, (0 if ln_fused else (0 if smlp else 1) if part else 1 if smlp else 2) * po * c * (4 + esz))
+            if part:
+                add("mv_partition", po * (4 * c * c + 49 * c * 2), po * c * 8)
+            elif precision != "f32" and c == 64 and os.environ.get("BTSBOT_AMD_MV_NO_ATTN_BLOCK", "0") != "1":
                 add("mv_attn_block", po * (4 * c * c + 49 * c * 2), po * c * (2 * esz + 8))
-            elif a256:
-                add("mv_attn256", po * (4 * c * c + 49 * c * 2), po * c * 8)
             else:
                 add("mv_gemm<qkv>", po * c * 3 * c, po * 4 * c * esz)
                 add("mv_attn_kernel", po * 49 * c * 2, po * 4 * c * esz)

@@ -133,8 +133,6 @@ int maxvit_build_tables(btsbot_ctx* h, size_t* extra_cursor) {
     mv->mlp_unfused = u != nullptr && u[0] == '1';
     const char* na = getenv("BTSBOT_AMD_MV_NO_PART");
     mv->no_part = na != nullptr && na[0] == '1';
-    const char* pa = getenv("BTSBOT_AMD_MV_PART_ATTN_ONLY");
-    mv->part_attn_only = pa != nullptr && pa[0] == '1';
     const char* ns = getenv("BTSBOT_AMD_MV_NO_SMLP");
     mv->no_smlp = ns != nullptr && ns[0] == '1';
   }
@@ -479,7 +477,8 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
     for (int g = 0; g < 2; ++g) {
       const AttnPk& a = b.attn[g];
       const int c = b.c;
-      // C = 128 / 256: norm1, qkv, attention, proj, residual, norm2, fc1, GELU, fc2, residual as ONE launch (maxvit_part.hip)
+      // C = 64 / 128 / 256 (every block but stage 3's): norm1, qkv, attention, proj, residual, norm2, fc1, GELU, fc2,
+      // residual as ONE launch (maxvit_part.hip)
       if (part_blk) {
         MvPartW pw;
         memset(&pw, 0, sizeof(pw));
@@ -491,26 +490,20 @@ int maxvit_chunk(btsbot_ctx* h, const float* img, int nb, hipStream_t st, float*
         pw.bproj = m + a.proj_b;
         pw.biasl = F(a.p_biasl);
         pw.stamps = h->stamps ? h->stamps + 20000 + (c == 256 ? 0 : 32) : nullptr;
-        if (!mv->part_attn_only) {
-          pw.ln2w = m + a.n2w;
-          pw.ln2b = m + a.n2b;
-          pw.w1p = ex + a.p_w1p;
-          pw.b1 = m + a.fc1_b;
-          pw.w2p = ex + a.p_w2p;
-          pw.b2 = m + a.fc2_b;
-          if (g == 1 && bi + 1 < mv->blocks.size()) {   // ... and the next block's pre-norm copy of the finished rows
-            pw.post_s = F(mv->blocks[bi + 1].pre.p_scale);
-            pw.post_b = F(mv->blocks[bi + 1].pre.p_shift);
-            pw.post_out = Cc;
-          }
+        pw.ln2w = m + a.n2w;
+        pw.ln2b = m + a.n2b;
+        pw.w1p = ex + a.p_w1p;
+        pw.b1 = m + a.fc1_b;
+        pw.w2p = ex + a.p_w2p;
+        pw.b2 = m + a.fc2_b;
+        if (g == 1 && bi + 1 < mv->blocks.size()) {   // ... and the next block's pre-norm copy of the finished rows
+          pw.post_s = F(mv->blocks[bi + 1].pre.p_scale);
+          pw.post_b = F(mv->blocks[bi + 1].pre.p_shift);
+          pw.post_out = Cc;
         }
         MTRY(mv_timed(h, CAT_MV_PART, st, [&] { return launch_mv_part(prec, x, pw, nb, b.hout, c, g, st); }));
         if (pw.post_out != nullptr) next_xn_ready = true;
-        if (!mv->part_attn_only) continue;
-        if (!(a.smlp && !mv->no_smlp))   // (the streamed MLP normalises its rows itself)
-          MTRY(mv_timed(h, CAT_MV_LN, st, [&] {
-            return launch_mv_ln(prec, x, m + a.n2w, m + a.n2b, Cc, (long)Mo, c, st);
-          }));
+        continue;
       } else {
       if (!(g == 0 && ln1_done) && !(g == 1 && ln1_grid_done)) {
         MTRY(mv_timed(h, CAT_MV_LN, st, [&] {

@@ -495,7 +495,7 @@ def test_maxvit_chunking_independence_and_modes(cuda):
 @pytest.mark.parametrize("env", ["BTSBOT_AMD_MV_ATTN_VALU", "BTSBOT_AMD_MV_DW_PLAIN",
                                  "BTSBOT_AMD_MV_MLP_UNFUSED", "BTSBOT_AMD_MV_STEM_IM2COL",
                                  "BTSBOT_AMD_MV_GATED_GEMM", "BTSBOT_AMD_MV_NO_FRONT", "BTSBOT_AMD_MV_NO_LN_FUSE",
-                                 "BTSBOT_AMD_MV_NO_ATTN_BLOCK", "BTSBOT_AMD_MV_NO_SMLP", "BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_PART_ATTN_ONLY"])
+                                 "BTSBOT_AMD_MV_NO_ATTN_BLOCK", "BTSBOT_AMD_MV_NO_SMLP", "BTSBOT_AMD_MV_NO_PART"])
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_maxvit_alternative_kernels_match_oracle(cuda, monkeypatch, env, prec):
     """16-bit modes default to the MFMA attention kernel and the strip depthwise kernel with the fused
