@@ -414,9 +414,9 @@ def maxvit_train_leg(dev, rank, world, dist, fence, args):
         "steps": args.maxvit_train_steps, "ms_per_step": round(1e3 * el / args.maxvit_train_steps, 2),
         "loss_finite": bool(torch.isfinite(loss).item()),
         "whole_step_tflops": round(step_flop / (el / args.maxvit_train_steps) / 1e12, 2),
-        "note": "correctness-first: one launch per layer, every intermediate through HBM (GEMMs are ~15 % of the step; "
-                "attention / depthwise / BatchNorm backward kernels the rest); the training benchmark of BASELINE.json "
-                "(configs[2]) is the ConvNeXt `train` leg",
+        "note": "an fp32 per-layer engine: one launch per layer, every intermediate through HBM (~2,100 launches of 10-20 us per "
+                "64-alert step: the GEMMs are ~20 % of it, operand casts 10 %, the attention backward 10 %); the training "
+                "benchmark of BASELINE.json (configs[2]) is the ConvNeXt `train` leg",
     }
 
 
