@@ -492,16 +492,26 @@ def test_maxvit_chunking_independence_and_modes(cuda):
         m(image_input=img, metadata_input=meta)
 
 
-@pytest.mark.parametrize("env", ["BTSBOT_AMD_MV_ATTN_VALU", "BTSBOT_AMD_MV_DW_PLAIN",
-                                 "BTSBOT_AMD_MV_MLP_UNFUSED", "BTSBOT_AMD_MV_STEM_IM2COL",
-                                 "BTSBOT_AMD_MV_GATED_GEMM", "BTSBOT_AMD_MV_NO_FRONT", "BTSBOT_AMD_MV_NO_LN_FUSE",
-                                 "BTSBOT_AMD_MV_NO_ATTN_BLOCK", "BTSBOT_AMD_MV_NO_SMLP", "BTSBOT_AMD_MV_NO_PART"])
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
-def test_maxvit_alternative_kernels_match_oracle(cuda, monkeypatch, env, prec):
-    """16-bit modes default to the MFMA attention kernel and the strip depthwise kernel with the fused
-    squeeze-excite pool; the switches select the one-query-per-lane / per-pixel kernels the f32 mode
-    uses.  Both must hold the same bound."""
-    monkeypatch.setenv(env, "1")
+# (the partition blocks of stages 0-2 run as one kernel each by default: the per-op kernels behind them -- LayerNorm fused into a
+#  GEMM epilogue, the C = 64 attention block, the register-chained and the streamed MLP -- are reached with NO_PART; those
+#  combinations run in bf16 only, the f16 instantiations of the same templates are covered by the NO_PART case)
+_MV_SWITCHES = [("BTSBOT_AMD_MV_ATTN_VALU",), ("BTSBOT_AMD_MV_DW_PLAIN",), ("BTSBOT_AMD_MV_STEM_IM2COL",),
+                ("BTSBOT_AMD_MV_GATED_GEMM",), ("BTSBOT_AMD_MV_NO_FRONT",), ("BTSBOT_AMD_MV_NO_PART",),
+                ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_MLP_UNFUSED"), ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_LN_FUSE"),
+                ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_ATTN_BLOCK"), ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_SMLP")]
+
+
+_MV_CASES = [(p, e) for p in ("bf16", "f16") for e in _MV_SWITCHES if len(e) == 1 or p == "bf16"]
+
+
+@pytest.mark.parametrize("prec,envs", _MV_CASES,
+                         ids=[p + "-" + "+".join(e.replace("BTSBOT_AMD_MV_", "") for e in t) for p, t in _MV_CASES])
+def test_maxvit_alternative_kernels_match_oracle(cuda, monkeypatch, envs, prec):
+    """16-bit modes default to the partition-block kernels, the MFMA attention kernel (stage 3) and the strip depthwise
+    kernel with the fused squeeze-excite pool; the switches select the per-op kernels behind them and the
+    one-query-per-lane / per-pixel kernels the f32 mode uses.  All must hold the same bound."""
+    for env in envs:
+        monkeypatch.setenv(env, "1")
     kind, cfg, sd = _mv("mm_maxvit")
     img, meta, _ = synthetic_batch(3, seed=2)
     ref = _mv_oracle(kind, cfg, sd, img, meta)
