@@ -21,9 +21,17 @@ def load(d, name):
 
 
 def family(k):
+    # mangled (_ZN12_GLOBAL__N_1<len><name>...) or demangled (...::<name><...>(...)) symbols; names may hold digits (mv_part64_kernel)
+    m = re.search(r"_GLOBAL__N_1(\d+)", k)
+    if m:
+        n = int(m.group(1))
+        for cut in (2, 1, 3):   # the length prefix is 1-3 digits: take the split whose length matches a *_kernel name
+            pre = m.group(1)[:cut]
+            name = k[m.start(1) + cut:m.start(1) + cut + int(pre)] if pre.isdigit() else ""
+            if name.endswith("_kernel") and len(name) == int(pre):
+                return name
     k = k.replace("(anonymous namespace)::", "")
-    m = re.search(r"\d+([a-z_0-9]+_kernel)", k)
-    return m.group(1) if m else re.sub(r"^void ", "", k).split("(")[0].split("<")[0][:48]
+    return re.sub(r"^void ", "", k).split("(")[0].split("<")[0][:48]
 
 
 fa, wa = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
