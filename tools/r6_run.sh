@@ -1,5 +1,5 @@
 O=gpurun_out/r6; mkdir -p $O; export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_train.py -q -x -k "maxvit" > $O/pt43.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pt43.log
-timeout -k 10 300 python tools/mv_train_bench.py 64 bf16 5 2>&1 | grep -v amdgpu
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvt43 -- python3 tools/mv_train_bench.py 64 bf16 3 > $O/mvt43.log 2>&1
-python3 tools/kstats.py $O/mvt43 4 16
+timeout -k 10 200 python tools/mv_bench.py 1024 f16 5 2>&1 | grep -v amdgpu
+timeout -k 10 200 python tools/mv_bench.py 1024 bf16 5 2>&1 | grep -v amdgpu
+timeout -k 10 200 python tools/stamps_maxvit.py 1024 2>&1 | grep -v amdgpu
+BTSBOT_BENCH_REHEARSAL=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench2.log 2>&1; echo "bench2 rc=$?"; tail -c 700 $O/bench2.log
