@@ -33,7 +33,7 @@ for base, tag in ((20000, "C=256"), (20032, "C=128")):
     s = t[base:base + 32]
     if not any(s):
         continue
-    print(tag, "unit total, shader clocks", s[16] - s[0])
+    print(tag, "unit total, shader clocks:", s[16] - s[0])
     for i in range(16):
         if s[idx[i + 1]] and s[idx[i]]:
             print(f"   {names[i]:40s} +{s[idx[i + 1]] - s[idx[i]]:6d}")
