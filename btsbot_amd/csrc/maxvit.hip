@@ -16,6 +16,8 @@
 //   2 x partition attention (windows, then grid):
 //            x += proj(attn(qkv(LN1(x))))                         mv_ln, GEMM EPI_BIAS_T, mv_attn, GEMM EPI_RESID
 //            x += fc2(gelu(fc1(LN2(x))))                          mv_ln, GEMM EPI_GELU, GEMM EPI_RESID
+//            16-bit modes, C = 64 / 128 / 256 (stages 0-2): both lines of a partition attention as ONE launch
+//            (maxvit_part.hip: mv_part_kernel / mv_part64_kernel), the next block's BN_pre copy as its post-op
 #include <stdlib.h>
 #include <string.h>
 

@@ -37,7 +37,7 @@ struct MaxVit {
   size_t o_x, o_x2, o_a, o_b, o_c, o_d, o_e, o_gate, o_feat, o_part, o_sescr, o_wg;
   // training, 16-bit modes: (fp32 GEMM input of the forward, its kept 16-bit copy) in call order (maxvit_train.hip)
   std::vector<std::pair<const float*, void*>> xkept;
-  bool no_part = false;     // BTSBOT_AMD_MV_NO_PART=1: the partition blocks of C = 128 / 256 launch by launch (A/B, parity tests)
+  bool no_part = false;     // BTSBOT_AMD_MV_NO_PART=1: the partition blocks of C = 64 / 128 / 256 launch by launch (A/B, parity tests)
   bool no_smlp = false;     // BTSBOT_AMD_MV_NO_SMLP=1: the 256-channel MLPs as LayerNorm + two GEMMs (A/B, parity tests)
   bool mlp_unfused = false; // BTSBOT_AMD_MV_MLP_UNFUSED=1: fc1 / fc2 GEMM pair also where the fused MLP kernel applies
   bool stem_im2col = false; // BTSBOT_AMD_MV_STEM_IM2COL=1: im2col + GEMM for the second stem conv in the 16-bit modes too
