@@ -63,7 +63,9 @@ if glob.glob("gpurun_out/final/mv_fetch/*/*_counter_collection.csv"):   # mm_Max
     shutil.copy(newest("gpurun_out/final/mv_trace/*/*_kernel_stats.csv"), f"profiles/{tag}_maxvit_kernel_stats.csv")
     subprocess.run([sys.executable, "tools/maxvit_traffic.py", "gpurun_out/final/mv_fetch", "gpurun_out/final/mv_write",
                     "gpurun_out/final/mv_trace", "4", f"profiles/{tag}_maxvit_traffic.json"], check=True)
-for src, dst in (("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"), ("stamps_nano.log", "stage_stamps_nano.txt"),
+if glob.glob("gpurun_out/final/mvt_trace/*/*_kernel_stats.csv"):   # mm_MaxViT training step (64 alerts): per-kernel statistics
+    shutil.copy(newest("gpurun_out/final/mvt_trace/*/*_kernel_stats.csv"), f"profiles/{tag}_maxvit_train_kernel_stats.csv")
+for src, dst in (("stamps_maxvit.log", "maxvit_part_stamps.txt"), ("nano.log", "nano_bench.txt"), ("train_ab.log", "train_ab.txt"), ("stamps_nano.log", "stage_stamps_nano.txt"),
                  ("stamps.log", "stage_stamps.txt"), ("stamps_train.log", "stage_stamps_train.txt"),
                  ("train_s2_ab.log", "train_stage2_forward_ab.txt"), ("train_timeline.txt", "train_timeline.txt"),
                  ("train_f32_ab.log", "train_f32_ab.txt")):   # tools/nano_bench.py; train step default vs

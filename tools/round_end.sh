@@ -16,6 +16,7 @@ timeout -k 10 120 python tools/nano_bench.py 1024 bf16 > $O/nano.log 2>&1 &&
 timeout -k 10 120 python tools/stamps_nano.py > $O/stamps_nano.log 2>&1 &&
 timeout -k 10 120 python tools/stamps.py 1024 > $O/stamps.log 2>&1 &&
 timeout -k 10 120 python tools/stamps_train.py 1024 bf16 > $O/stamps_train.log 2>&1 &&
+timeout -k 10 200 python tools/stamps_maxvit.py 1024 > $O/stamps_maxvit.log 2>&1 &&
 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 > $O/train_s2_ab.log 2>&1 &&
 BTSBOT_AMD_NO_S2P_TRAIN=1 timeout -k 10 120 python tools/train_bench.py 1024 bf16 40 >> $O/train_s2_ab.log 2>&1 &&
 timeout -k 10 120 python tools/train_bench.py 1024 f32 10 > $O/train_f32_ab.log 2>&1 &&
@@ -43,8 +44,9 @@ timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/train_tl --
 python3 tools/train_timeline.py $O/train_tl > $O/train_timeline.txt 2>&1 &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mv_trace -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_trace.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/mv_fetch -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_fetch.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/mv_write -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_write.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/mv_write -- python3 tools/mv_bench.py 1024 bf16 3 > $O/mv_write.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvt_trace -- python3 tools/mv_train_bench.py 64 bf16 3 > $O/mvt_trace.log 2>&1
 rc=$?
 fi
 echo "chain rc=$rc" > $O/chain.log
-cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace pmc_fetch_train pmc_write_train train_tl mv_trace mv_fetch mv_write; do tail -n 1 $O/$f.log | cut -c1-200; done
+cat $O/chain.log; for f in trace pmc_fetch pmc_write mfma train_trace pmc_fetch_train pmc_write_train train_tl mv_trace mv_fetch mv_write mvt_trace; do tail -n 1 $O/$f.log | cut -c1-200; done
