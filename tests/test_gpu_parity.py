@@ -492,6 +492,25 @@ def test_maxvit_chunking_independence_and_modes(cuda):
         m(image_input=img, metadata_input=meta)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_maxvit_full_size_batch_is_batch_independent(cuda, prec):
+    """BASELINE.json configs[3] size (1100 alerts = an internal chunk of 1024 + one of 76) through a size-independent
+    property: an alert's logit does not depend on the batch it came in.  At 1024 alerts per chunk the partition kernels
+    walk several units per workgroup (C = 64: persistent workgroups, 128 units each with the next unit's rows in flight;
+    C = 128: a grid-stride loop of two), which the oracle-sized batches never reach; the first and last alerts of the big
+    batch must equal the same alerts scored on their own, bit for bit (no atomics, no cross-alert arithmetic in the
+    forward)."""
+    kind, cfg, sd = _mv("mm_maxvit")
+    img, meta, _ = synthetic_batch(1100, seed=6)
+    img, meta = img.to(cuda), meta.to(cuda)
+    m = build_model(kind, cfg, sd, cuda, prec)
+    big = run_model(kind, m, img, meta)
+    assert torch.isfinite(big).all()
+    for sl in (slice(0, 5), slice(1093, 1100)):
+        small = run_model(kind, m, img[sl].contiguous(), meta[sl].contiguous())
+        assert torch.equal(small, big[sl]), (prec, sl, (small - big[sl]).abs().max().item())
+
+
 # (the partition blocks of stages 0-2 run as one kernel each by default: the per-op kernels behind them -- LayerNorm fused into a
 #  GEMM epilogue, the C = 64 attention block, the register-chained and the streamed MLP -- are reached with NO_PART; those
 #  combinations run in bf16 only, the f16 instantiations of the same templates are covered by the NO_PART case)
