@@ -1,4 +1,4 @@
-// A MaxViT partition block as ONE kernel (gfx950, 16-bit modes, C = 128 / 256):
+// A MaxViT partition block as ONE kernel (gfx950, 16-bit modes; C = 128 / 256 here, C = 64 in the second half of the file):
 //
 //   x += proj( MHSA_7x7( qkv( LN1(x) ) ) )            the attention half
 //   x += fc2( gelu( fc1( LN2(x) ) ) )                  the MLP half (MLP = true)
@@ -12,14 +12,15 @@
 // The design is stage2p.hip's: the rows stay on the CU, the filters stream past them from L2 as packed MFMA A fragments
 // (1 KiB contiguous per wave instruction, launch_pack_s2p), the residual stream IS the accumulator of proj and fc2.
 // A workgroup of HEADS = C / 32 waves owns one partition (49 tokens, padded to 64 = four 16-column MFMA blocks); wave wo
-// owns its residual rows' channels 32 wo .. 32 wo + 31 and its head wo.  C = 256: 8 waves, 137 KB of LDS, one workgroup
-// per CU; C = 128: 4 waves, 72 KB, two per CU, which run into each other's barriers and load latencies.  (PARTS > 1 puts
+// owns its residual rows' channels 32 wo .. 32 wo + 31 and its head wo.  C = 256: 8 waves, 155 KB of LDS, one workgroup
+// per CU; C = 128: 4 waves, 80 KB, two per CU, which run into each other's barriers and load latencies.  (PARTS > 1 puts
 // PARTS neighbouring partitions of one alert into a workgroup: wave (wt, wo) = (wave / HEADS, wave % HEADS).)
 //   phase 0  the rows (an index map on the row address: window or grid) -> residual registers
 //            acc[m][n][r] = x[partition wt, token 16 n + col][channel 32 wo + 16 m + 4 kg + r]
-//   phase 1  LayerNorm in registers: per-token sums over the lane's 8 channels, over kg by lane shuffles, over the
-//            partition's HEADS waves through a small LDS table (two rounds: mean, then centred squares) -> 16-bit image xn
-//   phase 2  qkv^T = Wqkv . xn^T + b in chunks of QT output tiles per wave, 8 fragments per chunk, the next chunk's
+//   phase 1  LayerNorm in registers: a wave reduces its 32 channels of a token to (mean, centred squares) -- over the lane's
+//            8 channels, then over kg by permlane swaps --, the HEADS pairs meet in a small LDS table and combine exactly
+//            (one exchange, one barrier) -> 16-bit image xn
+//   phase 2  qkv^T = Wqkv . xn^T + b in three chunks of QT = 2 output tiles per wave, the next chunk's fragments
 //            requested as the current ones are used -> 16-bit image IMG [token][3C]
 //   phase 3  attention of head wo: S^T = K Q^T (16 MFMAs), softmax over the keys in registers (bias and key mask in lane
 //            order), O^T = V^T P^T (16 MFMAs, V^T by ds_read_b64_tr_b16); O overwrites the head's own Q columns -- two
@@ -27,7 +28,8 @@
 //   phase 4  residual += Wproj . O + b: k-step = head (its 32 O columns are contiguous in IMG)
 //   phase 5  (MLP) LayerNorm (norm2) as phase 1 -> xn; 128 hidden units per step: fc1 (HT tiles per wave) + GELU -> one
 //            of two hidden images (they overlay IMG), one barrier, fc2 into the residual
-//   phase 6  rows back to x (tokens 49..63 of the padded tile repeat token 48, are masked as keys and never stored)
+//   phase 6  rows back to x (tokens 49..63 of the padded tile repeat token 48, are masked as keys and never stored); behind
+//            a block's grid half also the next block's pre-norm copy (T)(x * s + t) (post_out)
 #include "maxvit.h"
 
 namespace {
