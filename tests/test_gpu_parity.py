@@ -513,14 +513,14 @@ def test_maxvit_full_size_batch_is_batch_independent(cuda, prec):
 
 # (the partition blocks of stages 0-2 run as one kernel each by default: the per-op kernels behind them -- LayerNorm fused into a
 #  GEMM epilogue, the C = 64 attention block, the register-chained and the streamed MLP -- are reached with NO_PART; those
-#  combinations run in bf16 only, the f16 instantiations of the same templates are covered by the NO_PART case)
+#  combinations, and the single switches, run in bf16; f16 runs the NO_PART case, which instantiates the same templates)
 _MV_SWITCHES = [("BTSBOT_AMD_MV_ATTN_VALU",), ("BTSBOT_AMD_MV_DW_PLAIN",), ("BTSBOT_AMD_MV_STEM_IM2COL",),
                 ("BTSBOT_AMD_MV_GATED_GEMM",), ("BTSBOT_AMD_MV_NO_FRONT",), ("BTSBOT_AMD_MV_NO_PART",),
                 ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_MLP_UNFUSED"), ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_LN_FUSE"),
                 ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_ATTN_BLOCK"), ("BTSBOT_AMD_MV_NO_PART", "BTSBOT_AMD_MV_NO_SMLP")]
 
 
-_MV_CASES = [(p, e) for p in ("bf16", "f16") for e in _MV_SWITCHES if len(e) == 1 or p == "bf16"]
+_MV_CASES = [(p, e) for p in ("bf16", "f16") for e in _MV_SWITCHES if p == "bf16" or e == ("BTSBOT_AMD_MV_NO_PART",)]
 
 
 @pytest.mark.parametrize("prec,envs", _MV_CASES,
