@@ -154,11 +154,21 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
         for (int ks = 0; ks < KS; ++ks) acc = FM<T>::run(wf[mt][ks], xf[ks], acc);
         typedef T __attribute__((ext_vector_type(4))) T4;
         T4 v;
-        // (a factor, not a branch: straight-line code lets the next tile's MFMAs issue under this one's SiLU)
-        v[0] = (T)(silu_fast(acc[0] + bv[mt].x) * inf);
-        v[1] = (T)(silu_fast(acc[1] + bv[mt].y) * inf);
-        v[2] = (T)(silu_fast(acc[2] + bv[mt].z) * inf);
-        v[3] = (T)(silu_fast(acc[3] + bv[mt].w) * inf);
+        // (a factor, not a branch: straight-line code lets the next tile's MFMAs issue under this one's SiLU; the
+        //  adds and multiplies of silu_fast as packed fp32 pairs -- the same operations in the same order)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 inf2 = f2{inf, inf};
+        auto silu2 = [&](f2 x) {
+          const f2 t = x * f2{-1.4426950408889634f, -1.4426950408889634f};
+          const f2 d = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f2{1.0f, 1.0f};
+          return x * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)} * inf2;
+        };
+        const f2 s01 = silu2(f2{acc[0], acc[1]} + f2{bv[mt].x, bv[mt].y});
+        const f2 s23 = silu2(f2{acc[2], acc[3]} + f2{bv[mt].z, bv[mt].w});
+        v[0] = (T)s01.x;
+        v[1] = (T)s01.y;
+        v[2] = (T)s23.x;
+        v[3] = (T)s23.y;
         *reinterpret_cast<T4*>(m1s + (pt * 16 + l15) * M1PITCH + (mt * 16 + 4 * g) * 2) = v;
       }
     }
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
         const int op = (tid >> 3) + 32 * t2;
         if (op >= G::NOUT) break;
         const int oy = op / G::TO, ox = op - oy * G::TO;
-        float acc[8] = {bq[0].x, bq[0].y, bq[0].z, bq[0].w, bq[1].x, bq[1].y, bq[1].z, bq[1].w};
+        // (the 9 x 8 products as packed fp32 FMAs, two channels per instruction)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 acc[4] = {f2{bq[0].x, bq[0].y}, f2{bq[0].z, bq[0].w}, f2{bq[1].x, bq[1].y}, f2{bq[1].z, bq[1].w}};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -193,19 +205,15 @@ __global__ __launch_bounds__(256) void mv_mbconv_front_kernel(const T* __restric
             const int px = (oy * STRIDE + ky) * G::HALO + ox * STRIDE + kx;
             const T8 v = *reinterpret_cast<const T8*>(m1s + px * M1PITCH + cg * 16);
             const float4 wa = wq[ky * 3 + kx][0], wb = wq[ky * 3 + kx][1];
-            acc[0] = fmaf((float)v[0], wa.x, acc[0]);
-            acc[1] = fmaf((float)v[1], wa.y, acc[1]);
-            acc[2] = fmaf((float)v[2], wa.z, acc[2]);
-            acc[3] = fmaf((float)v[3], wa.w, acc[3]);
-            acc[4] = fmaf((float)v[4], wb.x, acc[4]);
-            acc[5] = fmaf((float)v[5], wb.y, acc[5]);
-            acc[6] = fmaf((float)v[6], wb.z, acc[6]);
-            acc[7] = fmaf((float)v[7], wb.w, acc[7]);
+            acc[0] = f2{(float)v[0], (float)v[1]} * f2{wa.x, wa.y} + acc[0];
+            acc[1] = f2{(float)v[2], (float)v[3]} * f2{wa.z, wa.w} + acc[1];
+            acc[2] = f2{(float)v[4], (float)v[5]} * f2{wb.x, wb.y} + acc[2];
+            acc[3] = f2{(float)v[6], (float)v[7]} * f2{wb.z, wb.w} + acc[3];
           }
         T8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          o[e] = (T)silu_fast(acc[e]);
+          o[e] = (T)silu_fast(acc[e / 2][e & 1]);
           psum[e] += (float)o[e];
         }
         const long orow = (b * Ho + ty * G::TO + oy) * Ho + tx * G::TO + ox;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void mv_stem1_kernel(const float* __restrict__
                                                        const T* __restrict__ w,
                                                        const float* __restrict__ shift,
                                                        T* __restrict__ out, long total) {
-  __shared__ float ws[27][32];
+  __shared__ __attribute__((aligned(8))) float ws[27][32];
   __shared__ float sh[32];
   for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i / 32][i % 32] = (float)w[(i % 32) * 32 + i / 32];
   if (threadIdx.x < 32) sh[threadIdx.x] = shift[threadIdx.x];
@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void mv_stem1_kernel(const float* __restrict__
   const int b = (int)(idx / 12544), p = (int)(idx % 12544), oy = p / 112, ox = p % 112;
   const float* im = img + (size_t)b * 3 * 3969;
   const float scale = 63.0f / 224.0f;
-  float acc[32];
+  // (the 27 x 32 products as packed fp32 FMAs -- v_pk_fma_f32, two outputs per instruction: this kernel is bound by them)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 acc[16];
 #pragma unroll
-  for (int o = 0; o < 32; ++o) acc[o] = sh[o];
+  for (int o = 0; o < 16; ++o) acc[o] = f2{sh[2 * o], sh[2 * o + 1]};
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = 2 * oy - 1 + ky;
@@ -103,9 +105,10 @@ __global__ __launch_bounds__(256) void mv_stem1_kernel(const float* __restrict__
         const float bot = (1.f - lx) * pc[y1 * 63 + x0] + lx * pc[y1 * 63 + x1];
         // the GEMM path rounds the sample to T before the product: keep that (same numbers either way)
         const float v = (float)(T)((1.f - ly) * top + ly * bot);
-        const float* wr = ws[(ky * 3 + kx) * 3 + c];
+        const f2* wr = reinterpret_cast<const f2*>(ws[(ky * 3 + kx) * 3 + c]);
+        const f2 v2 = f2{v, v};
 #pragma unroll
-        for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+        for (int o = 0; o < 16; ++o) acc[o] = v2 * wr[o] + acc[o];
       }
     }
   }
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void mv_stem1_kernel(const float* __restrict__
   for (int q = 0; q < 4; ++q) {
     T8 r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (T)silu_fast(acc[q * 8 + e]);
+    for (int e = 0; e < 8; ++e) r[e] = (T)silu_fast(acc[q * 4 + e / 2][e & 1]);
     op[q] = r;
   }
 }
