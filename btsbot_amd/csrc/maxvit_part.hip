@@ -918,7 +918,11 @@ template <typename T, int C_, bool MLP> int launch_part_t(const PartArgs& a, int
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
     attr.done();
   }
-  const int grid = units < 4096 * P::WGS ? units : 4096 * P::WGS;
+  // C = 256 (one workgroup per CU): persistent, 256 workgroups walk 16 units each at 1024 alerts -- the constants are
+  // staged and the workgroup launched once (622 -> 578 us); C = 128 (two per CU) measured better with a unit or two per
+  // workgroup (770 against 785 us)
+  const int cap = P::WGS == 1 ? 256 : 4096 * P::WGS;
+  const int grid = units < cap ? units : cap;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(P::NT), P::LDS_BYTES, st, a);
   LAUNCH_CHECK();
   return BTSBOT_OK;
